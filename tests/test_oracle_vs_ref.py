@@ -1,0 +1,81 @@
+"""CPU, build container only: the oracle restatement against the reference itself (oracle/_ref) on inputs beyond
+the committed fixtures.  Skipped where oracle/_ref is absent."""
+import numpy as np
+import pytest
+
+import util
+from pyoracle import ElasParams
+
+pytestmark = pytest.mark.ref
+
+
+def _compare(ref, oracle, p, L, R):
+    n1 = ref.run_stages(p, L, R)
+    n2 = oracle.run_stages(p, L, R)
+    assert n1 == n2
+    bad = [k for k in util.STAGES if not np.array_equal(ref.stage(k).view(np.uint8), oracle.stage(k).view(np.uint8))]
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("seed,H,W,D", [(11, 140, 400, 64), (12, 90, 333, 48), (13, 200, 640, 128), (14, 64, 128, 32)])
+@pytest.mark.parametrize("preset", ["driver", "robotics", "middlebury"])
+def test_synthetic_pairs(ref, oracle, seed, H, W, D, preset):
+    L, R = util.pkg("synth").make_pair(seed, H, W, D)
+    p = ElasParams.driver(D - 1) if preset == "driver" else ElasParams.preset(preset)
+    p.disp_max = D - 1
+    _compare(ref, oracle, p, L, R)
+
+
+def test_noise_images(ref, oracle):
+    """Pure noise: few, scattered support points, many invalid pixels, heavy speckle removal."""
+    rng = np.random.default_rng(3)
+    L = rng.integers(0, 256, (100, 260), dtype=np.uint8)
+    R = np.roll(L, -7, axis=1)
+    R[::3] = rng.integers(0, 256, R[::3].shape, dtype=np.uint8)
+    for preset in ("robotics", "middlebury"):
+        p = ElasParams.preset(preset)
+        p.disp_max = 31
+        _compare(ref, oracle, p, L, R)
+
+
+def test_textureless_images(ref, oracle):
+    """The reference's own smoke test feeds all-zero images (tests/test_demo.py:8-10): no lattice point passes the
+    texture gate, the driver preset still triangulates its six corner points; ROBOTICS returns early."""
+    L = np.zeros((80, 200), np.uint8)
+    _compare(ref, oracle, ElasParams.driver(63), L, L)
+    p = ElasParams.preset("robotics")
+    p.disp_max = 63
+    D1r, D2r, _ = ref.process(p, L, L)
+    D1o, D2o, _ = oracle.process(p, L, L)
+    assert np.array_equal(D1r, D1o) and np.array_equal(D2r, D2o) and not D1r.any()
+
+
+def test_delaunay_random_sets(ref, oracle):
+    """Lattice points (co-circular quadruples everywhere), duplicates (right-image collisions), strips."""
+    rng = np.random.default_rng(0)
+    done = 0
+    for it in range(600):
+        mode = it % 5
+        n = int(rng.integers(3, 300)) if it % 10 else int(rng.integers(3, 10))
+        if mode == 0:
+            pts = rng.integers(0, 60, (n, 2)) * 5
+        elif mode == 1:
+            pts = np.stack([rng.integers(-50, 300, n), rng.integers(0, 75, n) * 5], 1)
+        elif mode == 2:
+            pts = rng.integers(0, 4000, (n, 2))
+        elif mode == 3:
+            pts = np.stack([rng.integers(0, 8, n) * 5, rng.integers(0, 8, n) * 5], 1)
+        else:
+            pts = np.stack([np.arange(n) * 5, (np.arange(n) % 3) * 5], 1)
+        u = np.unique(pts, axis=0)
+        if len(u) < 3:
+            continue
+        d = u - u[0]
+        k = np.flatnonzero((d != 0).any(1))[0]
+        if np.all(d[:, 0] * d[k, 1] == d[:, 1] * d[k, 0]):
+            continue  # all collinear: Triangle yields no triangles; ELAS never feeds that
+        xy = pts.astype(np.float32)
+        a, b = ref.delaunay(xy), oracle.delaunay(xy)
+        assert a.shape == b.shape and np.array_equal(a, b), (it, mode, n)
+        done += 1
+    assert done > 400
