@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native ELAS stereo hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole hot path (gray pair -> final left disparity map + L/R-checked right map) over one
+batch of KITTI-shaped synthetic stereo pairs that is already resident in HBM.  Metric = BASELINE.json's
+"stereo pairs/sec" at 1242x375, D=128 (throughput configuration, batch 256 per GPU); the batch-1 latency
+("ms/frame") is reported beside it.  One process per GPU (torch.distributed / RCCL for the barrier and the
+max-over-ranks time only: pairs are independent, there is no data-path collective), weak scaling.
+
+Also on the JSON line:
+  roofline      the dominant kernel's achieved algorithmic HBM bytes/s (HIP events on the launching streams,
+                measured inside the timed region) against the 8 TB/s HBM3E peak
+  cpu_baseline  the reference's own serial LIBELAS (oracle/_ref, compiled from /root/reference in the build
+                container) or, if that artefact is absent, our CPU restatement, timed on this host, 1 thread
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = "low-cost-hardware-accelerated-vision-based-depth-perception-for-real-time-applications_amd"
+sys.path.insert(0, ROOT)
+
+W, H, D = 1242, 375, 128
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_pair(N, Wc, Hc, Wimg, MW, ncell):
+    """Minimal HBM bytes each kernel must move for ONE pair given its interface (one read of its inputs, one write of
+    its outputs; no credit for re-reads).  N = W*H.  See DESIGN.md §Kernels."""
+    desc = 16 * N
+    return {
+        "descriptor": 2 * N + 2 * desc,                       # gray L,R in; 16 B/px descriptors out (both images)
+        "support_match": 2 * (2 * (Hc - 1)) * Wimg * 16 + 2 * Wc * Hc,  # descriptor rows v+-2 of every lattice row, both images; lattice out
+        "grid_mark": 0, "grid_dilate": 2 * 2 * ncell * MW * 4,
+        "triangles_raster": 2 * 4 * N,                        # one tri_id write per covered pixel, both sides
+        "dense_match": 2 * desc + 2 * 4 * N + 2 * 4 * N,      # both descriptor images, tri_id in, WTA out (both sides)
+        "lr_check": 2 * 4 * N + 2 * 4 * N,
+        "ccl_init": 4 * N + 8 * N, "ccl_merge": 4 * N, "ccl_count": 4 * N + 4 * N, "ccl_apply": 8 * N + 4 * N,
+        "gap_rows": 8 * N, "gap_cols": 8 * N, "amean_h": 8 * N, "amean_v": 8 * N, "median_h": 8 * N, "median_v": 8 * N,
+        "output": 2 * 8 * N,
+    }
+
+
+def cpu_baseline(sample_pairs, synth):
+    """Reference serial path (or our port of it) on this host's cores, 1 thread, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+
+    if pyoracle.RefElas.available():
+        lib, kind = pyoracle.RefElas(), "reference"
+    else:
+        lib, kind = pyoracle.Oracle(), "port"
+    p = pyoracle.ElasParams.driver(D - 1)
+    t = 0.0
+    for i in range(sample_pairs):
+        L, R = synth.make_pair(1000 + i, H, W, D)
+        _, _, sec = lib.process(p, L, R, canonical=False, reps=1)
+        t += sec
+    return {"value": round(sample_pairs / t, 3), "unit": "pairs/s", "cores": 1, "kind": kind,
+            "sample": "%d synthetic KITTI-shaped pairs (seeds 1000..%d), 1242x375, D=128, Elas::process only, %.1f s" % (sample_pairs, 1000 + sample_pairs - 1, t),
+            "ms_per_pair": round(1e3 * t / sample_pairs, 2), "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU per step")
+    ap.add_argument("--workers", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=64, help="pairs timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    eng = importlib.import_module(PKG + ".engine")
+    synth = importlib.import_module(PKG + ".synth")
+    B = args.batch
+    # distinct pairs per rank: seeds 1000 + rank*B + i
+    batch = synth.make_batch(1000 + rank * B, B, H, W, D)
+    left = torch.from_numpy(np.ascontiguousarray(batch[:, 0])).cuda()
+    right = torch.from_numpy(np.ascontiguousarray(batch[:, 1])).cuda()
+    d1 = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
+    d2 = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
+    params = eng.SvParams.driver(D - 1)
+    engine = eng.StereoEngine(W, H, params, device=local_rank, n_workers=args.workers, chunk=args.chunk)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        engine.process_device(left, right, d1, d2)
+    if not args.no_kernel_timing:
+        engine.timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        engine.process_device(left, right, d1, d2)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ktimes = engine.kernel_times() if not args.no_kernel_timing else {}
+    engine.timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    valid_frac = float((d1 >= 0).float().mean().item())
+    checksum = float(d1.double().sum().item())
+
+    # batch-1 latency on rank 0 (ms/frame): one pair per call, one worker
+    lat_ms = None
+    if rank == 0:
+        e1 = eng.StereoEngine(W, H, params, device=local_rank, n_workers=1, chunk=1)
+        l1, r1 = left[:1].contiguous(), right[:1].contiguous()
+        o1, o2 = d1[:1].clone(), d2[:1].clone()
+        for _ in range(5):
+            e1.process_device(l1, r1, o1, o2)
+        ts = []
+        for _ in range(50):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            e1.process_device(l1, r1, o1, o2)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - a)
+        e1.close()
+        lat_ms = {"median": round(1e3 * float(np.median(ts)), 3), "p99": round(1e3 * float(np.percentile(ts, 99)), 3)}
+    engine.close()
+
+    if rank == 0:
+        total_pairs = B * world * args.steps
+        out = {
+            "metric": "stereo pairs/sec, KITTI 1242x375 D=128 (ms/frame at batch 1 in latency_ms_batch1)",
+            "value": round(total_pairs / elapsed, 2),
+            "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "kitti_1242x375_D128_batch%d_per_gpu_streamed" % B, "width": W, "height": H, "disp_max": D - 1,
+                       "preset": "driver(MIDDLEBURY+only_left+adaptive_mean+median)", "pairs_per_gpu_per_step": B,
+                       "parallelism": "batch-sharded x%d, no data-path collective" % world},
+            "latency_ms_batch1": lat_ms,
+            "valid_fraction": round(valid_frac, 4), "checksum_rank0": checksum,
+        }
+        if ktimes:
+            N = W * H
+            step = params.candidate_stepsize
+            Wc, Hc = (W + step - 1) // step, (H + step - 1) // step
+            gw, gh = -(-W // params.grid_size), -(-H // params.grid_size)
+            alg = algorithmic_bytes_per_pair(N, Wc, Hc, W, (D + 31) // 32, gw * gh)
+            tot = {k: v[0] for k, v in ktimes.items() if v[1] > 0}
+            dom = max(tot, key=tot.get)
+            ms, calls = ktimes[dom]
+            pairs_per_launch = B * args.steps / calls  # rank 0's launches of this kernel each cover one chunk
+            avg_s = 1e-3 * ms / calls
+            achieved = alg[dom] * pairs_per_launch / avg_s / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                               "avg_launch_us": round(1e6 * avg_s, 2), "pairs_per_launch": pairs_per_launch,
+                               "algorithmic_bytes_per_pair": alg[dom]}
+            gpu_ms_total = sum(tot.values())
+            out["kernel_ms_per_pair"] = {k: round(v / (B * args.steps), 5) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
+            out["kernel_ms_per_pair"]["_sum"] = round(gpu_ms_total / (B * args.steps), 5)
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, synth)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

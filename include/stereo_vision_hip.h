@@ -1,0 +1,156 @@
+/*
+ * libstereo_vision_hip.so — C ABI of the MI355X-native stereo disparity engine.
+ *
+ * Plain C: pointers and sizes only, no torch / C++ types.  Two groups of entry points:
+ *
+ *  (A) The reference's own exported symbols, kept signature-for-signature so that the reference's
+ *      ctypes binding (stereo_vision/sv.py:164-192) drives this library unchanged:
+ *        generatePointCloud   reference: src/serial_includes/main/stereo_vision.cpp:565-623
+ *        clean                reference: src/serial_includes/main/stereo_vision.cpp:105-114
+ *        getColor             reference: src/serial_includes/main/stereo_vision.cpp:625-627
+ *
+ *  (B) The operator seam the reference's driver calls once per frame,
+ *        Elas::process(I1, I2, D1, D2, dims)   reference: src/serial_includes/elas/elas.h:162,
+ *                                               called from stereo_vision.cpp:296-318
+ *      exposed as a handle-based, batched API (sv_*): the reference keeps all state in file-scope
+ *      globals and function statics (stereo_vision.cpp:50-89, 307-314, 582) and processes one pair
+ *      per call; here state lives in an sv_handle and one call takes B independent pairs.
+ *
+ * All sv_* functions return SV_OK (0) or a negative sv_status; sv_last_error() gives the text.
+ * Nothing in this library calls exit().
+ */
+#ifndef STEREO_VISION_HIP_H
+#define STEREO_VISION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#ifndef __cplusplus
+#include <stdbool.h>
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- (B) batched Elas::process ------------------------------------------------------------------------ */
+
+/* Field-for-field mirror of Elas::parameters (reference: src/serial_includes/elas/elas.h:60-145);
+ * every bool is an int32 so the block is 23 four-byte words. */
+typedef struct sv_params {
+    int32_t disp_min;              /* elas.h:61  only 0 is supported (both reference presets use 0) */
+    int32_t disp_max;              /* elas.h:62  D = disp_max + 1, 10 <= disp_max <= 1023 */
+    float support_threshold;       /* elas.h:63 */
+    int32_t support_texture;       /* elas.h:64 */
+    int32_t candidate_stepsize;    /* elas.h:65 */
+    int32_t incon_window_size;     /* elas.h:66 */
+    int32_t incon_threshold;       /* elas.h:67 */
+    int32_t incon_min_support;     /* elas.h:68 */
+    int32_t add_corners;           /* elas.h:69 */
+    int32_t grid_size;             /* elas.h:70 */
+    float beta;                    /* elas.h:71 */
+    float gamma;                   /* elas.h:72 */
+    float sigma;                   /* elas.h:73 */
+    float sradius;                 /* elas.h:74 */
+    int32_t match_texture;         /* elas.h:75 */
+    int32_t lr_threshold;          /* elas.h:76 */
+    float speckle_sim_threshold;   /* elas.h:77 */
+    int32_t speckle_size;          /* elas.h:78 */
+    int32_t ipol_gap_width;        /* elas.h:79 */
+    int32_t filter_median;         /* elas.h:80 */
+    int32_t filter_adaptive_mean;  /* elas.h:81 */
+    int32_t postprocess_only_left; /* elas.h:82 */
+    int32_t subsampling;           /* elas.h:83  must be 0 (half-resolution mode: SURVEY.md §8f rank 3) */
+} sv_params;
+
+enum sv_setting { SV_ROBOTICS = 0, SV_MIDDLEBURY = 1, SV_DRIVER = 2 };
+
+/* SV_ROBOTICS / SV_MIDDLEBURY: the two presets of elas.h:92-143.
+ * SV_DRIVER: what the reference driver actually runs (stereo_vision.cpp:307-311):
+ *            MIDDLEBURY + postprocess_only_left + filter_adaptive_mean. */
+void sv_params_init(sv_params *p, int setting);
+
+typedef enum sv_status {
+    SV_OK = 0,
+    SV_ERR_ARG = -1,         /* bad argument / unsupported parameter value */
+    SV_ERR_HIP = -2,         /* a HIP runtime call failed */
+    SV_ERR_NO_DEVICE = -3,   /* no usable GPU */
+    SV_ERR_UNSUPPORTED = -4, /* e.g. subsampling != 0 */
+    SV_ERR_STATE = -5
+} sv_status;
+
+typedef struct sv_handle sv_handle;
+
+/* Engine configuration beyond the ELAS parameters. */
+typedef struct sv_config {
+    int32_t width;      /* image width  (>= 32) */
+    int32_t height;     /* image height (>= 32) */
+    int32_t device;     /* HIP device ordinal */
+    int32_t n_workers;  /* host worker threads, each owning one HIP stream (0 = default) */
+    int32_t chunk;      /* pairs a worker keeps in flight per pipeline step (0 = default) */
+    int32_t keep_debug; /* != 0: keep per-stage intermediates of the LAST processed pair for sv_debug_get */
+} sv_config;
+
+int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out);
+int sv_destroy(sv_handle *h);
+const char *sv_last_error(const sv_handle *h); /* h may be NULL: error of the last failed sv_create */
+
+/* B independent pairs, images and maps in DEVICE memory (HBM):
+ *   left/right : uint8  [B][height][stride]   rectified gray rows (what Elas::process receives as I1/I2)
+ *   d1 / d2    : float  [B][height][width]    disparity maps (what Elas::process writes to D1/D2);
+ *                                             d2 may be NULL.  Invalid pixels are -10 (elas.cpp:823-824, 987-991).
+ *   status     : int32  [B] host array, may be NULL; per pair: number of support points, or <3 when the
+ *                reference would have printed "ERROR: Need at least 3 support points!" (elas.cpp:63-69) — the
+ *                maps of such a pair are left untouched, as the reference leaves them.
+ * The call returns when all B pairs are complete (outputs visible to every stream of the device). */
+int sv_process_batch_device(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status);
+
+/* Same, host memory in and out (stages through pinned buffers; PCIe-inclusive). */
+int sv_process_batch_host(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status);
+
+/* Single pair with the exact argument meaning of Elas::process (elas.h:153-162): dims = {width, height, bytes per line}. */
+int sv_elas_process(sv_handle *h, const uint8_t *I1, const uint8_t *I2, float *D1, float *D2, const int32_t *dims);
+
+/* Per-stage intermediates of the last pair processed (cfg.keep_debug != 0).  Names and layouts follow
+ * oracle/elas_oracle.h: desc1 desc2 dcan_raw support tri1 tri2 planes1 planes2 grid1 grid2 wta1 wta2 lr1 lr2
+ * speckle1 gap1 amean1 final1 ...  Returns the byte count, -1 unknown name, -2 cap too small. */
+long sv_debug_size(sv_handle *h, const char *name);
+long sv_debug_get(sv_handle *h, const char *name, void *out, long cap);
+
+/* Per-kernel device timings (HIP events on the worker streams) accumulated since the last reset.
+ * names/ms/calls are parallel arrays written up to cap entries; returns the number of kernels known. */
+int sv_kernel_times(sv_handle *h, const char **names, double *total_ms, int64_t *calls, int cap);
+void sv_kernel_times_reset(sv_handle *h);
+void sv_kernel_timing_enable(sv_handle *h, int on);
+
+/* Host-side stages exposed for tests (they run on the CPU in the product as well, between the two GPU phases):
+ * the in-place support-point filters + corner points (elas.cpp:152-264, 413-433) and the Delaunay
+ * triangulation (elas.cpp:442-501 -> Triangle "zQB"). */
+int sv_host_support_filter(const sv_params *p, int16_t *dcan, int width, int height, int32_t *support, int cap);
+int sv_host_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap);
+
+/* ---- (A) the reference's exported symbols ------------------------------------------------------------- */
+
+typedef struct {
+    double x, y, z;
+} Double3; /* reference: src/common_includes/structs.h:14-16 */
+
+typedef struct {
+    unsigned char x, y, z, w;
+} Uchar4; /* reference: src/common_includes/structs.h:18-20 */
+
+/* reference: stereo_vision.cpp:565-623.  left/right: BGRA uint8 [height][width][4].  Returns the library-owned
+ * point array [width*height] (valid until the next call / clean()).  State is frozen at the first call, like the
+ * reference's function-static init (stereo_vision.cpp:582). */
+Double3 *generatePointCloud(unsigned char *left, unsigned char *right, char *CAMERA_CALIBRATION_YAML, int width, int height, bool kittiCalibration,
+                            bool objectTracking, bool graphics, bool display, int scale, int pc_extrapolation, const char *YOLO_CFG,
+                            const char *YOLO_WEIGHTS, const char *YOLO_CLASSES, bool removeSky, bool subsampling);
+void clean(void);       /* reference: stereo_vision.cpp:105-114 (without the reference's exit(0)) */
+Uchar4 *getColor(void); /* reference: stereo_vision.cpp:625-627 */
+
+/* Last disparity image of the legacy path as the reference's `dmap` (u8 = saturate(round(4*d)), stereo_vision.cpp:316). */
+const unsigned char *sv_legacy_last_dmap(int *width, int *height);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

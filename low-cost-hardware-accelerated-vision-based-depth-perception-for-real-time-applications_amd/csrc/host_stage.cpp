@@ -1,0 +1,529 @@
+// Host-side stages between the two GPU phases (see host_stage.h).  Built with -ffp-contract=off like everything else,
+// although this file is integer-only.
+#include "host_stage.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace sv {
+
+// ------------------------------------------------------------------------------------------------------------
+// support lattice filters
+// ------------------------------------------------------------------------------------------------------------
+
+static void lattice_dims(const sv_params &p, int W, int H, int &Wc, int &Hc) {  // elas.cpp:376-386
+    const int step = p.candidate_stepsize;
+    Wc = (W + step - 1) / step;
+    Hc = (H + step - 1) / step;
+}
+
+// elas.cpp:152-176.  In place and order dependent: a point invalidated earlier in the (u outer, v inner) scan no longer
+// supports later points.  Counting stops as soon as incon_min_support is reached (the reference only tests `<`).
+static void drop_inconsistent(const sv_params &p, int16_t *D, int Wc, int Hc) {
+    const int win = p.incon_window_size, thr = p.incon_threshold, need = p.incon_min_support;
+    for (int uc = 0; uc < Wc; uc++) {
+        const int u_lo = std::max(uc - win, 0), u_hi = std::min(uc + win, Wc - 1);
+        for (int vc = 0; vc < Hc; vc++) {
+            const int d = D[vc * Wc + uc];
+            if (d < 0) continue;
+            const int v_lo = std::max(vc - win, 0), v_hi = std::min(vc + win, Hc - 1);
+            int support = 0;
+            for (int v2 = v_lo; v2 <= v_hi && support < need; v2++) {
+                const int16_t *row = D + v2 * Wc;
+                for (int u2 = u_lo; u2 <= u_hi; u2++) {
+                    const int d2 = row[u2];
+                    support += (d2 >= 0) & (abs(d - d2) <= thr);
+                }
+            }
+            if (support < need) D[vc * Wc + uc] = -1;
+        }
+    }
+}
+
+// elas.cpp:178-233 with redun_max_dist = 5, redun_threshold = 1 (:419-420); in place.
+static void drop_redundant(int16_t *D, int Wc, int Hc, int max_dist, int thr, bool vertical) {
+    const int stride = vertical ? Wc : 1;
+    for (int uc = 0; uc < Wc; uc++)
+        for (int vc = 0; vc < Hc; vc++) {
+            const int d = D[vc * Wc + uc];
+            if (d < 0) continue;
+            const int pos = vertical ? vc : uc, len = vertical ? Hc : Wc;
+            const int16_t *q = D + vc * Wc + uc;
+            bool both = true;
+            for (int dir = -1; dir <= 1 && both; dir += 2) {
+                bool found = false;
+                for (int j = 1; j <= max_dist; j++) {
+                    const int pp = pos + dir * j;
+                    if (pp < 0 || pp >= len) break;
+                    const int d2 = q[dir * j * stride];
+                    if (d2 >= 0 && abs(d - d2) <= thr) {
+                        found = true;
+                        break;
+                    }
+                }
+                both = found;
+            }
+            if (both) D[vc * Wc + uc] = -1;
+        }
+}
+
+int support_filter(const sv_params &p, int16_t *dcan, int W, int H, int32_t *out, int cap) {
+    int Wc, Hc;
+    lattice_dims(p, W, H, Wc, Hc);
+    drop_inconsistent(p, dcan, Wc, Hc);
+    drop_redundant(dcan, Wc, Hc, 5, 1, true);
+    drop_redundant(dcan, Wc, Hc, 5, 1, false);
+    const int step = p.candidate_stepsize;
+    int n = 0;
+    for (int uc = 1; uc < Wc; uc++)  // elas.cpp:424-428: u outer, v inner
+        for (int vc = 1; vc < Hc; vc++) {
+            const int d = dcan[vc * Wc + uc];
+            if (d < 0) continue;
+            if (n < cap) {
+                out[3 * n] = uc * step;
+                out[3 * n + 1] = vc * step;
+                out[3 * n + 2] = d;
+            }
+            n++;
+        }
+    if (p.add_corners) {  // elas.cpp:235-264
+        if (n + 6 > cap) return -(n + 6);
+        const int bu[4] = {0, 0, W - 1, W - 1}, bv[4] = {0, H - 1, 0, H - 1};
+        int bd[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 4; i++) {
+            int best = 10000000;
+            for (int j = 0; j < n; j++) {
+                const int du = bu[i] - out[3 * j], dv = bv[i] - out[3 * j + 1];
+                const int dist = du * du + dv * dv;
+                if (dist < best) {
+                    best = dist;
+                    bd[i] = out[3 * j + 2];
+                }
+            }
+        }
+        const int base = n;
+        for (int i = 0; i < 4; i++) {
+            out[3 * n] = bu[i];
+            out[3 * n + 1] = bv[i];
+            out[3 * n + 2] = bd[i];
+            n++;
+        }
+        for (int i = 2; i < 4; i++) {  // the two right-image corners (:258-259)
+            out[3 * n] = out[3 * (base + i)] + out[3 * (base + i) + 2];
+            out[3 * n + 1] = out[3 * (base + i) + 1];
+            out[3 * n + 2] = out[3 * (base + i) + 2];
+            n++;
+        }
+    } else if (n > cap) {
+        return -n;
+    }
+    return n;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Delaunay
+// ------------------------------------------------------------------------------------------------------------
+
+namespace {
+constexpr int NEXT3[3] = {1, 2, 0}, PREV3[3] = {2, 0, 1};
+inline int32_t hnext(int32_t h) { return (h & ~3) | NEXT3[h & 3]; }
+inline int32_t hprev(int32_t h) { return (h & ~3) | PREV3[h & 3]; }
+}  // namespace
+
+#define SYM(h) (T[(h) >> 2].nbr[(h)&3])
+#define ORG(h) (T[(h) >> 2].vtx[NEXT3[(h)&3]])
+#define DEST(h) (T[(h) >> 2].vtx[PREV3[(h)&3]])
+#define APEX(h) (T[(h) >> 2].vtx[(h)&3])
+#define BOND(a, b)                       \
+    do {                                 \
+        const int32_t a_ = (a), b_ = (b); \
+        T[a_ >> 2].nbr[a_ & 3] = b_;     \
+        T[b_ >> 2].nbr[b_ & 3] = a_;     \
+    } while (0)
+#define PX(v) ((int64_t)xy_[2 * (v)])
+#define PY(v) ((int64_t)xy_[2 * (v) + 1])
+
+static inline int64_t orient(const int32_t *xy, int a, int b, int c) {
+    return ((int64_t)xy[2 * a] - xy[2 * c]) * ((int64_t)xy[2 * b + 1] - xy[2 * c + 1]) - ((int64_t)xy[2 * a + 1] - xy[2 * c + 1]) * ((int64_t)xy[2 * b] - xy[2 * c]);
+}
+
+static inline int64_t incirc(const int32_t *xy, int a, int b, int c, int d) {
+    const int64_t adx = (int64_t)xy[2 * a] - xy[2 * d], ady = (int64_t)xy[2 * a + 1] - xy[2 * d + 1];
+    const int64_t bdx = (int64_t)xy[2 * b] - xy[2 * d], bdy = (int64_t)xy[2 * b + 1] - xy[2 * d + 1];
+    const int64_t cdx = (int64_t)xy[2 * c] - xy[2 * d], cdy = (int64_t)xy[2 * c + 1] - xy[2 * d + 1];
+    return (adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) + (bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy) + (cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
+}
+
+uint32_t Delaunay::rnd(uint32_t choices) {  // triangle.cpp:3833-3836
+    seed_ = (seed_ * 1366u + 150889u) % 714025u;
+    return (uint32_t)(seed_ / (714025u / choices + 1));
+}
+
+Delaunay::H Delaunay::make() {  // triangle.cpp:2068-2101; slot 0 stands for "outer space"
+    Tri &t = tris_[n_slots_];
+    t.nbr[0] = t.nbr[1] = t.nbr[2] = 0;
+    t.vtx[0] = t.vtx[1] = t.vtx[2] = -1;
+    return (H)(n_slots_++) << 2;
+}
+
+// Randomised quicksort by (x, y) with the reference's pivot sequence (triangle.cpp:5183-5229): which of two coincident
+// points survives the duplicate scan depends on it.
+void Delaunay::sort_xy(int32_t *a, int n) {
+    if (n == 2) {
+        if (PX(a[0]) > PX(a[1]) || (PX(a[0]) == PX(a[1]) && PY(a[0]) > PY(a[1]))) std::swap(a[0], a[1]);
+        return;
+    }
+    const int pivot = (int)rnd((uint32_t)n);
+    const int64_t px = PX(a[pivot]), py = PY(a[pivot]);
+    int left = -1, right = n;
+    while (left < right) {
+        do {
+            left++;
+        } while (left <= right && (PX(a[left]) < px || (PX(a[left]) == px && PY(a[left]) < py)));
+        do {
+            right--;
+        } while (left <= right && (PX(a[right]) > px || (PX(a[right]) == px && PY(a[right]) > py)));
+        if (left < right) std::swap(a[left], a[right]);
+    }
+    if (left > 1) sort_xy(a, left);
+    if (right < n - 2) sort_xy(a + right + 1, n - right - 1);
+}
+
+// Randomised partial partition around the median (triangle.cpp:5243-5294); the arrangement it leaves inside each half
+// decides the leaf order of the recursion, hence the diagonals chosen in co-circular quadruples.
+void Delaunay::median_split(int32_t *a, int n, int median, int axis) {
+    const int k1 = axis, k2 = 1 - axis;
+#define K1(v) ((int64_t)xy_[2 * (v) + k1])
+#define K2(v) ((int64_t)xy_[2 * (v) + k2])
+    if (n == 2) {
+        if (K1(a[0]) > K1(a[1]) || (K1(a[0]) == K1(a[1]) && K2(a[0]) > K2(a[1]))) std::swap(a[0], a[1]);
+        return;
+    }
+    const int pivot = (int)rnd((uint32_t)n);
+    const int64_t p1 = K1(a[pivot]), p2 = K2(a[pivot]);
+    int left = -1, right = n;
+    while (left < right) {
+        do {
+            left++;
+        } while (left <= right && (K1(a[left]) < p1 || (K1(a[left]) == p1 && K2(a[left]) < p2)));
+        do {
+            right--;
+        } while (left <= right && (K1(a[right]) > p1 || (K1(a[right]) == p1 && K2(a[right]) > p2)));
+        if (left < right) std::swap(a[left], a[right]);
+    }
+#undef K1
+#undef K2
+    if (left > median) median_split(a, left, median, axis);
+    if (right < median - 1) median_split(a + right + 1, n - right - 1, median - right - 1, axis);
+}
+
+void Delaunay::alternate(int32_t *a, int n, int axis) {  // triangle.cpp:5307-5325
+    const int divider = n >> 1;
+    if (n <= 3) axis = 0;
+    median_split(a, n, divider, axis);
+    if (n - divider >= 2) {
+        if (divider >= 2) alternate(a, divider, 1 - axis);
+        alternate(a + divider, n - divider, 1 - axis);
+    }
+}
+
+// triangle.cpp:5362-5651
+void Delaunay::merge(H &farleft, H &innerleft, H &innerright, H &farright, int axis) {
+    Tri *T = tris_.data();
+    const int32_t *xy = xy_;
+    int ild = DEST(innerleft), ila = APEX(innerleft);
+    int iro = ORG(innerright), ira = APEX(innerright);
+    if (axis == 1) {  // horizontal cut: walk the four extreme handles to the bottom-/top-most hull vertices
+        int flp = ORG(farleft), fla = APEX(farleft);
+        int frp = DEST(farright);
+        while (PY(fla) < PY(flp)) {
+            farleft = SYM(hnext(farleft));
+            flp = fla;
+            fla = APEX(farleft);
+        }
+        H chk = SYM(innerleft);
+        int cv = APEX(chk);
+        while (PY(cv) > PY(ild)) {
+            innerleft = hnext(chk);
+            ila = ild;
+            ild = cv;
+            chk = SYM(innerleft);
+            cv = APEX(chk);
+        }
+        while (PY(ira) < PY(iro)) {
+            innerright = SYM(hnext(innerright));
+            iro = ira;
+            ira = APEX(innerright);
+        }
+        chk = SYM(farright);
+        cv = APEX(chk);
+        while (PY(cv) > PY(frp)) {
+            farright = hnext(chk);
+            frp = cv;
+            chk = SYM(farright);
+            cv = APEX(chk);
+        }
+    }
+    for (bool changed = true; changed;) {  // lower common tangent
+        changed = false;
+        if (orient(xy, ild, ila, iro) > 0) {
+            innerleft = SYM(hprev(innerleft));
+            ild = ila;
+            ila = APEX(innerleft);
+            changed = true;
+        }
+        if (orient(xy, ira, iro, ild) > 0) {
+            innerright = SYM(hnext(innerright));
+            iro = ira;
+            ira = APEX(innerright);
+            changed = true;
+        }
+    }
+    H leftcand = SYM(innerleft), rightcand = SYM(innerright);
+    H base = make();
+    T = tris_.data();
+    BOND(base, innerleft);
+    base = hnext(base);
+    BOND(base, innerright);
+    base = hnext(base);
+    ORG(base) = iro;
+    DEST(base) = ild;
+    if (ild == ORG(farleft)) farleft = hnext(base);
+    if (iro == DEST(farright)) farright = hprev(base);
+    int ll = ild, lr = iro;
+    int ul = APEX(leftcand), ur = APEX(rightcand);
+    for (;;) {
+        const bool leftdone = orient(xy, ul, ll, lr) <= 0, rightdone = orient(xy, ur, ll, lr) <= 0;
+        if (leftdone && rightdone) {
+            H top = make();
+            T = tris_.data();
+            ORG(top) = ll;
+            DEST(top) = lr;
+            BOND(top, base);
+            top = hnext(top);
+            BOND(top, rightcand);
+            top = hnext(top);
+            BOND(top, leftcand);
+            if (axis == 1) {  // back to left-/right-most handles
+                int flp = ORG(farleft);
+                int frp = DEST(farright), fra = APEX(farright);
+                H chk = SYM(farleft);
+                int cv = APEX(chk);
+                while (PX(cv) < PX(flp)) {
+                    farleft = hprev(chk);
+                    flp = cv;
+                    chk = SYM(farleft);
+                    cv = APEX(chk);
+                }
+                while (PX(fra) > PX(frp)) {
+                    farright = SYM(hprev(farright));
+                    frp = fra;
+                    fra = APEX(farright);
+                }
+            }
+            return;
+        }
+        if (!leftdone) {  // flip away left edges that the circle through ll, lr, ul invalidates
+            H nx = SYM(hprev(leftcand));
+            int na = APEX(nx);
+            if (na != -1) {
+                bool bad = incirc(xy, ll, lr, ul, na) > 0;
+                while (bad) {
+                    nx = hnext(nx);
+                    const H topc = SYM(nx);
+                    nx = hnext(nx);
+                    const H sidec = SYM(nx);
+                    BOND(nx, topc);
+                    BOND(leftcand, sidec);
+                    leftcand = hnext(leftcand);
+                    const H outerc = SYM(leftcand);
+                    nx = hprev(nx);
+                    BOND(nx, outerc);
+                    ORG(leftcand) = ll;
+                    DEST(leftcand) = -1;
+                    APEX(leftcand) = na;
+                    ORG(nx) = -1;
+                    DEST(nx) = ul;
+                    APEX(nx) = na;
+                    ul = na;
+                    nx = sidec;
+                    na = APEX(nx);
+                    bad = na != -1 && incirc(xy, ll, lr, ul, na) > 0;
+                }
+            }
+        }
+        if (!rightdone) {
+            H nx = SYM(hnext(rightcand));
+            int na = APEX(nx);
+            if (na != -1) {
+                bool bad = incirc(xy, ll, lr, ur, na) > 0;
+                while (bad) {
+                    nx = hprev(nx);
+                    const H topc = SYM(nx);
+                    nx = hprev(nx);
+                    const H sidec = SYM(nx);
+                    BOND(nx, topc);
+                    BOND(rightcand, sidec);
+                    rightcand = hprev(rightcand);
+                    const H outerc = SYM(rightcand);
+                    nx = hnext(nx);
+                    BOND(nx, outerc);
+                    ORG(rightcand) = -1;
+                    DEST(rightcand) = lr;
+                    APEX(rightcand) = na;
+                    ORG(nx) = ur;
+                    DEST(nx) = -1;
+                    APEX(nx) = na;
+                    ur = na;
+                    nx = sidec;
+                    na = APEX(nx);
+                    bad = na != -1 && incirc(xy, ll, lr, ur, na) > 0;
+                }
+            }
+        }
+        if (leftdone || (!rightdone && incirc(xy, ul, ll, lr, ur) > 0)) {
+            BOND(base, rightcand);
+            base = hprev(rightcand);
+            DEST(base) = ll;
+            lr = ur;
+            rightcand = SYM(base);
+            ur = APEX(rightcand);
+        } else {
+            BOND(base, leftcand);
+            base = hnext(leftcand);
+            ORG(base) = lr;
+            ll = ul;
+            leftcand = SYM(base);
+            ul = APEX(leftcand);
+        }
+    }
+}
+
+// triangle.cpp:5670-5815
+void Delaunay::build(int32_t *a, int n, int axis, H &farleft, H &farright) {
+    if (n == 2) {
+        H l = make(), r = make();
+        Tri *T = tris_.data();
+        ORG(l) = a[0];
+        DEST(l) = a[1];
+        ORG(r) = a[1];
+        DEST(r) = a[0];
+        BOND(l, r);
+        l = hprev(l);
+        r = hnext(r);
+        BOND(l, r);
+        l = hprev(l);
+        r = hnext(r);
+        BOND(l, r);
+        farright = r;
+        farleft = hprev(r);
+    } else if (n == 3) {
+        H mid = make(), t1 = make(), t2 = make(), t3 = make();
+        Tri *T = tris_.data();
+        const int64_t area = orient(xy_, a[0], a[1], a[2]);
+        if (area == 0) {
+            ORG(mid) = a[0];
+            DEST(mid) = a[1];
+            ORG(t1) = a[1];
+            DEST(t1) = a[0];
+            ORG(t2) = a[2];
+            DEST(t2) = a[1];
+            ORG(t3) = a[1];
+            DEST(t3) = a[2];
+            BOND(mid, t1);
+            BOND(t2, t3);
+            mid = hnext(mid);
+            t1 = hprev(t1);
+            t2 = hnext(t2);
+            t3 = hprev(t3);
+            BOND(mid, t3);
+            BOND(t1, t2);
+            mid = hnext(mid);
+            t1 = hprev(t1);
+            t2 = hnext(t2);
+            t3 = hprev(t3);
+            BOND(mid, t1);
+            BOND(t2, t3);
+            farleft = t1;
+            farright = t2;
+        } else {
+            const int second = area > 0 ? a[1] : a[2], third = area > 0 ? a[2] : a[1];
+            ORG(mid) = a[0];
+            DEST(t1) = a[0];
+            ORG(t3) = a[0];
+            DEST(mid) = second;
+            ORG(t1) = second;
+            DEST(t2) = second;
+            APEX(mid) = third;
+            ORG(t2) = third;
+            DEST(t3) = third;
+            BOND(mid, t1);
+            mid = hnext(mid);
+            BOND(mid, t2);
+            mid = hnext(mid);
+            BOND(mid, t3);
+            t1 = hprev(t1);
+            t2 = hnext(t2);
+            BOND(t1, t2);
+            t1 = hprev(t1);
+            t3 = hprev(t3);
+            BOND(t1, t3);
+            t2 = hnext(t2);
+            t3 = hprev(t3);
+            BOND(t2, t3);
+            farleft = t1;
+            farright = area > 0 ? t2 : hnext(farleft);
+        }
+    } else {
+        const int divider = n >> 1;
+        H innerleft, innerright;
+        build(a, divider, 1 - axis, farleft, innerleft);
+        build(a + divider, n - divider, 1 - axis, innerright, farright);
+        merge(farleft, innerleft, innerright, farright, axis);
+    }
+}
+
+int Delaunay::triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap) {
+    if (n < 3) return 0;
+    xy_ = xy;
+    seed_ = 1;  // triangle.cpp:3818: reseeded on every call
+    if ((int)order_.size() < n) order_.resize(n);
+    // leaves allocate <= 4 slots per 3 points (2 per 2), every merge 2 more: < 3n in total, + the outer-space slot
+    if ((int)tris_.size() < 3 * n + 8) tris_.resize(3 * n + 8);
+    n_slots_ = 0;
+    make();
+    int32_t *a = order_.data();
+    for (int i = 0; i < n; i++) a[i] = i;
+    sort_xy(a, n);
+    int m = 0;
+    for (int j = 1; j < n; j++) {  // triangle.cpp:5890-5903: the first of a group of coincident points is kept
+        if (xy[2 * a[m]] == xy[2 * a[j]] && xy[2 * a[m] + 1] == xy[2 * a[j] + 1]) continue;
+        a[++m] = a[j];
+    }
+    m++;
+    if (m < 2) return 0;
+    const int divider = m >> 1;
+    if (m - divider >= 2) {  // :5904-5913
+        if (divider >= 2) alternate(a, divider, 1);
+        alternate(a + divider, m - divider, 1);
+    }
+    H hl, hr;
+    build(a, m, 0, hl, hr);
+    // Output in slot order (= pool order, triangle.cpp:7449-7500) skipping bounding triangles (what removeghosts,
+    // :5817-5859, deletes): corners are org/dest/apex at orientation 0.
+    int count = 0;
+    const Tri *T = tris_.data();
+    for (int t = 1; t < n_slots_; t++) {
+        if (T[t].vtx[0] < 0 || T[t].vtx[1] < 0 || T[t].vtx[2] < 0) continue;
+        if (count >= cap) return -1;
+        tri_out[3 * count] = T[t].vtx[1];
+        tri_out[3 * count + 1] = T[t].vtx[2];
+        tri_out[3 * count + 2] = T[t].vtx[0];
+        count++;
+    }
+    return count;
+}
+
+}  // namespace sv

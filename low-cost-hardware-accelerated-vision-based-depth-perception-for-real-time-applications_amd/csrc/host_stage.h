@@ -1,0 +1,55 @@
+// Host-side stages that sit between the two GPU phases of a pair: the order-dependent in-place filters of the
+// support lattice and the Delaunay triangulations.  They run on the worker threads of the engine, one pair per
+// thread, while other workers' kernels occupy the GPU.
+#pragma once
+
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/stereo_vision_hip.h"
+
+namespace sv {
+
+// Support lattice -> support point list.
+//   reference: serial_includes/elas/elas.cpp:152-176 (removeInconsistentSupportPoints, in place, u outer / v inner)
+//              :178-233 (removeRedundantSupportPoints, vertical then horizontal, :419-420)
+//              :422-433 (collect, u outer / v inner) and :235-264 (addCornerSupportPoints)
+// `dcan` is [Hc][Wc] (row/col 0 hold 0 = "valid d=0", elas.cpp:387) and is modified in place.
+// Writes (u,v,d) triples to `out` (capacity cap points); returns the point count (or -needed if cap is too small).
+int support_filter(const sv_params &p, int16_t *dcan, int W, int H, int32_t *out, int cap);
+
+// Divide-and-conquer Delaunay triangulation with alternating cuts that reproduces, triangle for triangle and
+// corner for corner, what the reference obtains from Triangle 1.6 with switches "zQB" (elas.cpp:483-484;
+// common_includes/elas/triangle.cpp:5183-5924, :7449-7500).  Coordinates are integers (support points live on a
+// pixel lattice), so orientation and in-circle signs are evaluated exactly in 64-bit integer arithmetic.
+// The object owns its scratch memory and is reused from pair to pair (no allocation in steady state).
+class Delaunay {
+   public:
+    // xy: n points (x0,y0,x1,y1,...).  tri_out receives 3*count vertex indices; returns count (<= 2n), or -1 if cap
+    // (in triangles) is too small.
+    int triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap);
+
+   private:
+    struct Tri {
+        int32_t nbr[3];  // neighbour handle across edge o: (slot << 2) | orientation
+        int32_t vtx[3];  // vertex ids, -1 = the vertex at infinity of a bounding ("ghost") triangle
+    };
+    typedef int32_t H;  // oriented-triangle handle: (slot << 2) | orientation
+
+    const int32_t *xy_ = nullptr;
+    std::vector<Tri> tris_;
+    std::vector<int32_t> order_;
+    int n_slots_ = 0;
+    uint64_t seed_ = 1;
+
+    H make();
+    void sort_xy(int32_t *a, int n);
+    void median_split(int32_t *a, int n, int median, int axis);
+    void alternate(int32_t *a, int n, int axis);
+    void build(int32_t *a, int n, int axis, H &farleft, H &farright);
+    void merge(H &farleft, H &innerleft, H &innerright, H &farright, int axis);
+    uint32_t rnd(uint32_t choices);
+};
+
+}  // namespace sv

@@ -1,0 +1,953 @@
+// gfx950 (MI355X / CDNA4) kernels of the ELAS stereo hot path.
+//
+// Every kernel is written for 64-wide wavefronts and compiled with -ffp-contract=off: the reference's
+// serial path is plain IEEE arithmetic without fused multiply-add, and the disparity maps
+// must match it bit for bit.  Reference citations are relative to /root/reference/src.
+//
+// Integer byte work (descriptors, SAD) uses v_sad_u8 on 4-byte words; there is no matrix contraction here and
+// therefore no MFMA.  Batch dimension: blockIdx.z (or .y) walks the pairs of a launch.
+#include "sv_kernels.h"
+
+namespace sv {
+
+thread_local LaunchHook g_launch_hook = {nullptr, nullptr};
+
+const char *kernel_name(int id) {
+    static const char *names[K_COUNT] = {"descriptor", "support_match", "grid_mark", "grid_dilate", "triangles_raster", "dense_match", "lr_check",
+                                         "ccl_init", "ccl_merge", "ccl_count", "ccl_apply", "gap_rows", "gap_cols", "amean_h", "amean_v",
+                                         "median_h", "median_v", "output"};
+    return (id >= 0 && id < K_COUNT) ? names[id] : "?";
+}
+
+#define SV_LAUNCH(id, kernel, grid, block, shmem, st, ...)                         \
+    do {                                                                           \
+        if (g_launch_hook.fn) g_launch_hook.fn(g_launch_hook.ctx, id, true, st);   \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);           \
+        if (g_launch_hook.fn) g_launch_hook.fn(g_launch_hook.ctx, id, false, st);  \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t sad4(uint32_t a, uint32_t b, uint32_t acc) { return __builtin_amdgcn_sad_u8(a, b, acc); }
+
+__device__ __forceinline__ uint32_t sad16(const uint4 &a, const uint4 &b) {
+    uint32_t s = sad4(a.x, b.x, 0u);
+    s = sad4(a.y, b.y, s);
+    s = sad4(a.z, b.z, s);
+    return sad4(a.w, b.w, s);
+}
+
+// sum |byte - 128| over the 16 descriptor bytes (elas.cpp:296-298, 732-734)
+__device__ __forceinline__ uint32_t texture16(const uint4 &a) {
+    const uint4 mid = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+    return sad16(a, mid);
+}
+
+__device__ __forceinline__ uint4 ld16(const uint8_t *p) { return *reinterpret_cast<const uint4 *>(p); }
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int sat_u8(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
+
+// ------------------------------------------------------------------------------------------------------------
+// K1  Sobel + 16-byte descriptors
+//     reference: common_includes/elas/filter.cpp:416-424 (sobel3x3 = :380-413 + :235-275 + :183-229)
+//                common_includes/elas/descriptor.cpp:96-124
+//     One workgroup = 64x8 output pixels.  Gray tile (+3 halo) -> LDS, du/dv tile (+2 halo) -> LDS,
+//     then one 16-byte store per pixel (1 KiB per wavefront store instruction).  Pixels outside
+//     [3,W-3)x[3,H-3) get the canonical zero descriptor (the reference leaves them uninitialised).
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_descriptor(const uint8_t *__restrict__ left, const uint8_t *__restrict__ right, size_t in_pair_stride, int stride,
+                                                    uint8_t *__restrict__ desc, Dims d) {
+    const int img = blockIdx.z & 1, pair = blockIdx.z >> 1;
+    const uint8_t *I = (img ? right : left) + (size_t)pair * in_pair_stride;
+    uint8_t *out = desc + ((size_t)(pair * 2 + img) * d.N) * 16;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 8;
+    __shared__ uint8_t g[14][72];
+    __shared__ uint8_t sdu[12][68];
+    __shared__ uint8_t sdv[12][68];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 14 * 70; i += 256) {
+        int r = i / 70, c = i - r * 70;
+        int y = y0 - 3 + r, x = x0 - 3 + c;
+        g[r][c] = (x >= 0 && x < d.W && y >= 0 && y < d.H) ? I[(size_t)y * stride + x] : (uint8_t)0;
+    }
+    __syncthreads();
+    for (int i = tid; i < 12 * 68; i += 256) {
+        int r = i / 68, c = i - r * 68;
+        // du/dv at (x0-2+c, y0-2+r); gray rows r..r+2 are y-1..y+1, gray cols c..c+2 are x-1..x+1
+        int a0 = g[r][c], a1 = g[r + 1][c], a2 = g[r + 2][c];
+        int b0 = g[r][c + 1], b2 = g[r + 2][c + 1];
+        int c0 = g[r][c + 2], c1 = g[r + 1][c + 2], c2 = g[r + 2][c + 2];
+        int Sl = a0 + 2 * a1 + a2, Sr = c0 + 2 * c1 + c2;  // vertical (1,2,1) at x-1, x+1
+        int Tl = a0 - a2, Tc = b0 - b2, Tr = c0 - c2;       // vertical (1,0,-1) at x-1, x, x+1
+        sdu[r][c] = (uint8_t)sat_u8(((Sl - Sr) >> 2) + 128);
+        sdv[r][c] = (uint8_t)sat_u8(((Tl + 2 * Tc + Tr) >> 2) + 128);
+    }
+    __syncthreads();
+    const int tx = tid & 63, ty = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int rr = ty + 4 * k;
+        const int x = x0 + tx, y = y0 + rr;
+        if (x >= d.W || y >= d.H) continue;
+        uint4 o = make_uint4(0, 0, 0, 0);
+        if (x >= 3 && x < d.W - 3 && y >= 3 && y < d.H - 3) {
+            const int cx = tx + 2;  // column of x in the du/dv tile; row of y is rr+2
+            uint32_t b0 = sdu[rr][cx], b1 = sdu[rr + 1][cx - 2], b2 = sdu[rr + 1][cx], b3 = sdu[rr + 1][cx + 2];
+            uint32_t b4 = sdu[rr + 2][cx - 1], b5 = sdu[rr + 2][cx], b7 = sdu[rr + 2][cx + 1];
+            uint32_t b8 = sdu[rr + 3][cx - 2], b9 = sdu[rr + 3][cx], b10 = sdu[rr + 3][cx + 2], b11 = sdu[rr + 4][cx];
+            uint32_t b12 = sdv[rr + 1][cx], b13 = sdv[rr + 2][cx - 1], b14 = sdv[rr + 2][cx + 1], b15 = sdv[rr + 3][cx];
+            o.x = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+            o.y = b4 | (b5 << 8) | (b5 << 16) | (b7 << 24);
+            o.z = b8 | (b9 << 8) | (b10 << 16) | (b11 << 24);
+            o.w = b12 | (b13 << 8) | (b14 << 16) | (b15 << 24);
+        }
+        *reinterpret_cast<uint4 *>(out + ((size_t)y * d.W + x) * 16) = o;
+    }
+}
+
+void launch_descriptor(const KParams &k, const uint8_t *left, const uint8_t *right, size_t in_pair_stride, int stride, const SlotDev &s, int n, hipStream_t st) {
+    dim3 grid((k.d.W + 63) / 64, (k.d.H + 7) / 8, n * 2);
+    SV_LAUNCH(K_DESCRIPTOR, k_descriptor, grid, dim3(256), 0, st, left, right, in_pair_stride, stride, s.desc, k.d);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K2  support matching on the lattice: the only full-range disparity search
+//     reference: serial_includes/elas/elas.cpp:266-371 (computeMatchingDisparity), :387-411 (loop + L/R check)
+//     One wavefront per lattice point; lanes stride over the disparity range; energy = 4-corner SAD (64 bytes);
+//     per-wavefront reduction of (best energy, lowest best d) and the second order statistic.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int support_match(const KParams &k, const uint8_t *__restrict__ A, const uint8_t *__restrict__ B, int u, int v, bool right_image, int lane) {
+    const int W = k.d.W, H = k.d.H;
+    if (!(u >= 5 && u <= W - 6 && v >= 5 && v <= H - 6)) return -1;  // elas.cpp:279
+    const uint4 centre = ld16(A + ((size_t)v * W + u) * 16);
+    if ((int)texture16(centre) < k.support_texture) return -1;  // :296-300
+    const int dmax = right_image ? min(k.d.disp_max, W - u - 5) : min(k.d.disp_max, u - 5);  // :318-323 (disp_min = 0)
+    if (dmax < 10) return -1;                                                                // :326
+    const size_t r0 = ((size_t)(v - 2) * W) * 16, r1 = ((size_t)(v + 2) * W) * 16;
+    const uint4 a0 = ld16(A + r0 + (size_t)(u - 2) * 16), a1 = ld16(A + r0 + (size_t)(u + 2) * 16);
+    const uint4 a2 = ld16(A + r1 + (size_t)(u - 2) * 16), a3 = ld16(A + r1 + (size_t)(u + 2) * 16);
+    uint32_t e1 = 0x7FFFu, d1 = 0xFFFFu, e2 = 0x7FFFu;
+    for (int dd = lane; dd <= dmax; dd += 64) {
+        const int uw = right_image ? u + dd : u - dd;
+        const uint8_t *p0 = B + r0 + (size_t)uw * 16, *p1 = B + r1 + (size_t)uw * 16;
+        uint32_t e = sad16(a0, ld16(p0 - 32)) + sad16(a1, ld16(p0 + 32)) + sad16(a2, ld16(p1 - 32)) + sad16(a3, ld16(p1 + 32));  // :341-349
+        if (e < e1) {  // :352-360, ascending d within a lane
+            e2 = e1;
+            e1 = e;
+            d1 = (uint32_t)dd;
+        } else if (e < e2) {
+            e2 = e;
+        }
+    }
+    const uint32_t key = (e1 << 16) | d1;      // min over keys = lowest energy, then lowest d (first-wins under strict <)
+    const uint32_t best = wave_min_u32(key);
+    const uint32_t contrib = (key == best) ? e2 : e1;  // second order statistic of the energy multiset
+    const uint32_t second = wave_min_u32(contrib);
+    const float E1 = (float)(best >> 16), E2 = (float)second;
+    if (E1 < k.support_threshold * E2) return (int)(best & 0xFFFFu);  // :364
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void k_support(KParams k, const uint8_t *__restrict__ desc, int16_t *__restrict__ dcan) {
+    const Dims &d = k.d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cand = blockIdx.x * 4 + wave;
+    if (cand >= d.Wc * d.Hc) return;
+    const int pair = blockIdx.y;
+    const int uc = cand % d.Wc, vc = cand / d.Wc;
+    const uint8_t *d1 = desc + ((size_t)(pair * 2) * d.N) * 16, *d2 = d1 + (size_t)d.N * 16;
+    int res;
+    if (uc == 0 || vc == 0) {
+        res = 0;  // calloc'd border of the lattice (elas.cpp:387): counts as a valid d=0 neighbour in the filters
+    } else {
+        const int u = uc * d.step, v = vc * d.step;
+        res = -1;
+        int dd = support_match(k, d1, d2, u, v, false, lane);
+        if (dd >= 0) {
+            int d2v = support_match(k, d2, d1, u - dd, v, true, lane);
+            if (d2v >= 0 && abs(dd - d2v) <= k.lr_threshold) res = dd;  // :404-409
+        }
+    }
+    if (lane == 0) dcan[(size_t)pair * d.Wc * d.Hc + cand] = (int16_t)res;
+}
+
+void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
+    dim3 grid((k.d.Wc * k.d.Hc + 3) / 4, n);
+    SV_LAUNCH(K_SUPPORT, k_support, grid, dim3(256), 0, st, k, s.desc, s.dcan);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K3  candidate grid as per-cell disparity bit masks
+//     reference: elas.cpp:577-653 (createGrid); the 3x3 dilation runs over the FLAT cell array (:613-628)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_grid_mark(KParams k, const int32_t *__restrict__ blob, uint32_t *__restrict__ gA) {
+    const Dims &d = k.d;
+    const int pair = blockIdx.z, side = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = blob[pair * META_WORDS];
+    if (n < 3 || i >= n) return;
+    const int32_t *p = blob + blob[pair * META_WORDS + 1] + (size_t)i * 3;
+    const int x_curr = p[0], y_curr = p[1], d_curr = p[2];
+    const int d_min = max(d_curr - 1, 0), d_max = min(d_curr + 1, d.disp_max);
+    int x;
+    if (side == 0)
+        x = (int)floorf((float)(x_curr / d.grid_size));  // integer division first (:599)
+    else
+        x = (int)floorf((float)(x_curr - d_curr) / (float)d.grid_size);
+    const int y = (int)floorf((float)y_curr / (float)d.grid_size);
+    if (x < 0 || x >= d.gw || y < 0 || y >= d.gh) return;
+    uint32_t *cell = gA + (((size_t)(pair * 2 + side) * d.ncell) + (size_t)y * d.gw + x) * d.MW;
+    for (int dd = d_min; dd <= d_max; dd++) atomicOr(&cell[dd >> 5], 1u << (dd & 31));
+}
+
+__global__ __launch_bounds__(256) void k_grid_dilate(KParams k, const uint32_t *__restrict__ gA, uint32_t *__restrict__ gB) {
+    const Dims &d = k.d;
+    const int ps = blockIdx.y;  // pair*2 + side
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.ncell * d.MW) return;
+    const int c = i / d.MW, w = i - c * d.MW;
+    const uint32_t *in = gA + (size_t)ps * d.ncell * d.MW;
+    uint32_t r = 0;
+    if (c >= d.gw + 1 && c <= d.ncell - d.gw - 2) {
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+            for (int dx = -1; dx <= 1; dx++) r |= in[(size_t)(c + dy * d.gw + dx) * d.MW + w];
+    }
+    gB[(size_t)ps * d.ncell * d.MW + i] = r;
+}
+
+void launch_grid(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
+    hipMemsetAsync(s.gmaskA, 0, sizeof(uint32_t) * (size_t)n * 2 * k.d.ncell * k.d.MW, st);
+    SV_LAUNCH(K_GRID_MARK, k_grid_mark, dim3((k.d.max_pts + 255) / 256, 2, n), dim3(256), 0, st, k, s.blob, s.gmaskA);
+    SV_LAUNCH(K_GRID_DILATE, k_grid_dilate, dim3((k.d.ncell * k.d.MW + 255) / 256, n * 2), dim3(256), 0, st, k, s.gmaskA, s.gmaskB);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K4  per-triangle plane fit + scan conversion
+//     reference: elas.cpp:503-575 (computeDisparityPlanes) -> common_includes/elas/matrix.cpp:418-510 (Gauss-Jordan,
+//                full pivoting, double); elas.cpp:839-941 (corner sort, edge lines, scan conversion order)
+//     One wavefront per triangle: every lane solves the two 3x3 systems (uniform work), then lanes stride over the
+//     triangle's columns and mark covered pixels with atomicMax(triangle index) so that, as in the reference's
+//     sequential loop, the LAST triangle covering a pixel decides it.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool solve3(double A[3][3], double B[3]) {
+    int ipiv[3] = {0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double big = 0.0;
+        int irow = 0, icol = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (ipiv[j] != 1)
+#pragma unroll
+                for (int kk = 0; kk < 3; kk++)
+                    if (ipiv[kk] == 0)
+                        if (fabs(A[j][kk]) >= big) {
+                            big = fabs(A[j][kk]);
+                            irow = j;
+                            icol = kk;
+                        }
+        // ++ipiv[icol], row swap and elimination with runtime row indices, written with selects so the 3x3 stays in registers
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (j == icol) ipiv[j]++;
+        if (irow != icol) {
+#pragma unroll
+            for (int l = 0; l < 3; l++) {
+                double x = 0, y = 0;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    if (j == irow) x = A[j][l];
+                    if (j == icol) y = A[j][l];
+                }
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    if (j == irow) A[j][l] = y;
+                    if (j == icol) A[j][l] = x;
+                }
+            }
+            double x = 0, y = 0;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                if (j == irow) x = B[j];
+                if (j == icol) y = B[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                if (j == irow) B[j] = y;
+                if (j == icol) B[j] = x;
+            }
+        }
+        double piv = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (j == icol) piv = A[j][j];
+        if (fabs(piv) < 1e-20) return false;
+        const double pivinv = 1.0 / piv;
+        double prow[3] = {0, 0, 0}, pb = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if (j == icol) {
+                A[j][j] = 1.0;
+#pragma unroll
+                for (int l = 0; l < 3; l++) {
+                    A[j][l] *= pivinv;
+                    prow[l] = A[j][l];
+                }
+                B[j] *= pivinv;
+                pb = B[j];
+            }
+#pragma unroll
+        for (int ll = 0; ll < 3; ll++)
+            if (ll != icol) {
+                double dum = 0;
+#pragma unroll
+                for (int l = 0; l < 3; l++)
+                    if (l == icol) {
+                        dum = A[ll][l];
+                        A[ll][l] = 0.0;
+                    }
+#pragma unroll
+                for (int l = 0; l < 3; l++) A[ll][l] -= prow[l] * dum;
+                B[ll] -= pb * dum;
+            }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_triangles(KParams k, const int32_t *__restrict__ blob, float4 *__restrict__ trirec, float *__restrict__ planes,
+                                                   int32_t *__restrict__ tri_id) {
+    const Dims &d = k.d;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pair = blockIdx.z, side = blockIdx.y;
+    const int t = blockIdx.x * 4 + wave;
+    const int32_t *meta = blob + pair * META_WORDS;
+    if (meta[0] < 3 || t >= meta[2 + 2 * side]) return;
+    const size_t tbase = ((size_t)(pair * 2 + side) * d.max_tri + t);
+    const int32_t *tc = blob + meta[3 + 2 * side] + (size_t)t * 3;
+    const int32_t *support = blob + meta[1];
+    int pu[3], pv[3], pd[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int32_t *p = support + (size_t)tc[c] * 3;
+        pu[c] = p[0];
+        pv[c] = p[1];
+        pd[c] = p[2];
+    }
+    float pl[6];
+#pragma unroll
+    for (int sd = 0; sd < 2; sd++) {  // sd 0: left-image plane (t1*), sd 1: right-image plane (t2*)
+        double A[3][3], B[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            A[r][0] = sd == 0 ? (double)pu[r] : (double)(pu[r] - pd[r]);
+            A[r][1] = (double)pv[r];
+            A[r][2] = 1.0;
+            B[r] = (double)pd[r];
+        }
+        const bool ok = solve3(A, B);
+        pl[3 * sd + 0] = ok ? (float)B[0] : 0.f;
+        pl[3 * sd + 1] = ok ? (float)B[1] : 0.f;
+        pl[3 * sd + 2] = ok ? (float)B[2] : 0.f;
+    }
+    const float plane_a = side == 0 ? pl[0] : pl[3], plane_b = side == 0 ? pl[1] : pl[4], plane_c = side == 0 ? pl[2] : pl[5];
+    const float plane_d = side == 0 ? pl[3] : pl[0];
+    const bool valid = (double)fabsf(plane_a) < 0.7 && (double)fabsf(plane_d) < 0.7;  // elas.cpp:910
+    if (lane == 0) {
+        trirec[tbase] = make_float4(plane_a, plane_b, plane_c, valid ? 1.0f : 0.0f);
+#pragma unroll
+        for (int j = 0; j < 6; j++) planes[tbase * 6 + j] = pl[j];
+    }
+    // corner sort wrt u, ascending (elas.cpp:859-884)
+    float tu[3], tv[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        tu[c] = side == 0 ? (float)pu[c] : (float)(pu[c] - pd[c]);
+        tv[c] = (float)pv[c];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int kk = 0; kk < j; kk++)
+            if (tu[kk] > tu[j]) {
+                float x = tu[j];
+                tu[j] = tu[kk];
+                tu[kk] = x;
+                x = tv[j];
+                tv[j] = tv[kk];
+                tv[kk] = x;
+            }
+    const float A_u = tu[0], A_v = tv[0], B_u = tu[1], B_v = tv[1], C_u = tu[2], C_v = tv[2];
+    float AB_a = 0, AC_a = 0, BC_a = 0;  // :894-906
+    if ((int)A_u != (int)B_u) AB_a = (A_v - B_v) / (A_u - B_u);
+    if ((int)A_u != (int)C_u) AC_a = (A_v - C_v) / (A_u - C_u);
+    if ((int)B_u != (int)C_u) BC_a = (B_v - C_v) / (B_u - C_u);
+    const float AB_b = A_v - AB_a * A_u, AC_b = A_v - AC_a * A_u, BC_b = B_v - BC_a * B_u;
+    int32_t *ids = tri_id + (size_t)(pair * 2 + side) * d.N;
+    if ((int)A_u != (int)B_u) {  // :913-925
+        for (int u = max((int)A_u, 0) + lane; u < min((int)B_u, d.W); u += 64) {
+            const int v_1 = (int)(AC_a * (float)u + AC_b), v_2 = (int)(AB_a * (float)u + AB_b);
+            const int lo = max(min(v_1, v_2), 0), hi = min(max(v_1, v_2), d.H);
+            for (int v = lo; v < hi; v++) atomicMax(&ids[(size_t)v * d.W + u], t);
+        }
+    }
+    if ((int)B_u != (int)C_u) {  // :928-940
+        for (int u = max((int)B_u, 0) + lane; u < min((int)C_u, d.W); u += 64) {
+            const int v_1 = (int)(AC_a * (float)u + AC_b), v_2 = (int)(BC_a * (float)u + BC_b);
+            const int lo = max(min(v_1, v_2), 0), hi = min(max(v_1, v_2), d.H);
+            for (int v = lo; v < hi; v++) atomicMax(&ids[(size_t)v * d.W + u], t);
+        }
+    }
+}
+
+void launch_triangles(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
+    hipMemsetAsync(s.tri_id, 0xFF, sizeof(int32_t) * (size_t)n * 2 * k.d.N, st);
+    SV_LAUNCH(K_TRIANGLES, k_triangles, dim3((k.d.max_tri + 3) / 4, 2, n), dim3(256), 0, st, k, s.blob, s.trirec, s.planes, s.tri_id);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K5  dense matching (MAP over ~17 candidate disparities per pixel), both sides in one launch
+//     reference: elas.cpp:688-801 (findMatch) + :655-686 (updatePosteriorMinimum), pixel set from :912-940
+//     One lane per pixel; candidates = cell's grid mask outside the plane band (ascending), then the band
+//     (ascending, + prior); strict '<' keeps the first minimum, exactly like the sequential reference.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restrict__ desc, const int32_t *__restrict__ blob, const int32_t *__restrict__ tri_id,
+                                               const float4 *__restrict__ trirec, const uint32_t *__restrict__ gB, float *__restrict__ wta) {
+    const Dims &d = k.d;
+    const int ps = blockIdx.z, pair = ps >> 1, side = ps & 1;
+    if (blob[pair * META_WORDS] < 3) return;
+    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    if (u >= d.W) return;
+    const size_t pix = (size_t)v * d.W + u;
+    const int t = tri_id[(size_t)ps * d.N + pix];
+    float out = -10.0f;  // elas.cpp:823-824
+    if (t >= 0 && u >= 2 && u < d.W - 2) {
+        const uint8_t *d1 = desc + ((size_t)(pair * 2) * d.N) * 16, *d2 = d1 + (size_t)d.N * 16;
+        const size_t line = (size_t)d.W * max(min(v, d.H - 3), 2) * 16;  // :718
+        const uint8_t *A = (side ? d2 : d1) + line, *B = (side ? d1 : d2) + line;
+        const uint4 own = ld16(A + (size_t)u * 16);
+        if ((int)texture16(own) >= k.match_texture) {  // :732-736
+            const float4 rec = trirec[(size_t)ps * d.max_tri + t];
+            const int d_plane = (int)(rec.x * (float)u + rec.y * (float)v + rec.z);  // :739, ((a*u)+(b*v))+c without contraction
+            const int d_plane_min = max(d_plane - k.plane_radius, 0);
+            const int d_plane_max = min(d_plane + k.plane_radius, d.D - 1);
+            const bool valid = rec.w != 0.0f;
+            const int gx = (int)floorf((float)u / (float)d.grid_size), gy = (int)floorf((float)v / (float)d.grid_size);
+            const uint32_t *cell = gB + ((size_t)ps * d.ncell + (size_t)gy * d.gw + gx) * d.MW;
+            int min_val = 10000, min_d = -1;
+            for (int w = 0; w < d.MW; w++) {  // grid candidates outside the band (:759-767 / :778-786)
+                uint32_t m = cell[w];
+                const int lo = d_plane_min - 32 * w, hi = d_plane_max - 32 * w;
+                if (lo <= 31 && hi >= 0 && lo <= hi) {
+                    const int l = max(lo, 0), h = min(hi, 31);
+                    const uint32_t upto_h = h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u);
+                    m &= ~(upto_h & ~((1u << l) - 1u));
+                }
+                while (m) {
+                    const int b = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    const int dc = 32 * w + b;
+                    const int uw = side ? u + dc : u - dc;
+                    if (uw < 2 || uw >= d.W - 2) continue;
+                    const int val = (int)sad16(own, ld16(B + (size_t)uw * 16));
+                    if (val < min_val) {
+                        min_val = val;
+                        min_d = dc;
+                    }
+                }
+            }
+            for (int dc = d_plane_min; dc <= d_plane_max; dc++) {  // the band, with the plane prior (:768-774 / :787-793)
+                const int uw = side ? u + dc : u - dc;
+                if (uw < 2 || uw >= d.W - 2) continue;
+                const int val = (int)sad16(own, ld16(B + (size_t)uw * 16)) + (valid ? k.prior[abs(dc - d_plane)] : 0);
+                if (val < min_val) {
+                    min_val = val;
+                    min_d = dc;
+                }
+            }
+            out = min_d >= 0 ? (float)min_d : -1.0f;  // :797-800
+        }
+    }
+    wta[(size_t)ps * d.N + pix] = out;
+}
+
+void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
+    SV_LAUNCH(K_DENSE, k_dense, dim3((k.d.W + 255) / 256, k.d.H, n * 2), dim3(256), 0, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K6  left/right consistency check      reference: elas.cpp:946-1011
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lr(KParams k, const int32_t *__restrict__ blob, const float *__restrict__ wta, float *__restrict__ disp) {
+    const Dims &d = k.d;
+    const int pair = blockIdx.z;
+    if (blob[pair * META_WORDS] < 3) return;
+    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    if (u >= d.W) return;
+    const float *W1 = wta + (size_t)(pair * 2) * d.N, *W2 = W1 + d.N;
+    const size_t row = (size_t)v * d.W;
+    const float d1 = W1[row + u], d2 = W2[row + u];
+    const float thr = (float)k.lr_threshold;
+    float o1 = -10.0f, o2 = -10.0f;
+    const float uw1 = (float)u - d1, uw2 = (float)u + d2;
+    if (d1 >= 0 && uw1 >= 0 && uw1 < (float)d.W) o1 = (fabsf(W2[row + (int)uw1] - d1) > thr) ? -10.0f : d1;
+    if (d2 >= 0 && uw2 >= 0 && uw2 < (float)d.W) o2 = (fabsf(W1[row + (int)uw2] - d2) > thr) ? -10.0f : d2;
+    disp[(size_t)(pair * 2) * d.N + row + u] = o1;
+    disp[(size_t)(pair * 2 + 1) * d.N + row + u] = o2;
+}
+
+void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
+    SV_LAUNCH(K_LR, k_lr, dim3((k.d.W + 255) / 256, k.d.H, n), dim3(256), 0, st, k, s.blob, s.wta, s.disp);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K7  speckle removal = connected components of valid pixels under |dD| <= speckle_sim_threshold, 4-adjacency
+//     reference: elas.cpp:1013-1124 (BFS flood fill).  After the L/R stage every invalid pixel is exactly -10, so the
+//     reference's order-dependent BFS reduces to plain component labelling.
+//     Union-find on global memory: row runs give the initial labels, vertical links are merged with atomicMin,
+//     component sizes are counted (saturating at speckle_size) at the root pixel.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t map_offset(const Dims &d, int m, int nproc) {  // m = pair*nproc + side
+    const int pair = m / nproc, side = m - pair * nproc;
+    return (size_t)(pair * 2 + side) * d.N;
+}
+
+__global__ __launch_bounds__(64) void k_ccl_init(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ disp, int32_t *__restrict__ label,
+                                                 int32_t *__restrict__ csize) {
+    const Dims &d = k.d;
+    const int m = blockIdx.y;
+    if (blob[(m / nproc) * META_WORDS] < 3) return;
+    const size_t off = map_offset(d, m, nproc);
+    const int v = blockIdx.x, lane = threadIdx.x;
+    const float *D = disp + off + (size_t)v * d.W;
+    int32_t *L = label + off + (size_t)v * d.W, *S = csize + off + (size_t)v * d.W;
+    int carry_start = -1;
+    float carry_val = -10.0f;
+    for (int u0 = 0; u0 < d.W; u0 += 64) {
+        const int u = u0 + lane;
+        const float val = u < d.W ? D[u] : -10.0f;
+        const bool valid = val >= 0;
+        float left = __shfl_up(val, 1, 64);
+        if (lane == 0) left = carry_val;
+        const bool link = valid && left >= 0 && fabsf(val - left) <= k.speckle_sim;
+        const unsigned long long brk = __ballot(!link);  // bit set: this pixel starts a run (or is invalid)
+        const unsigned long long upto = brk & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+        int start = upto ? (u0 + 63 - __clzll((long long)upto)) : carry_start;
+        if (u < d.W) {
+            L[u] = valid ? (int)(v * d.W + start) : -1;
+            S[u] = 0;
+        }
+        carry_start = __shfl(valid ? start : -1, 63, 64);
+        carry_val = __shfl(val, 63, 64);
+    }
+}
+
+__device__ __forceinline__ int ccl_find(const int32_t *L, int x) {
+    int p = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) {
+        x = p;
+        p = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return x;
+}
+
+__device__ __forceinline__ void ccl_union(int32_t *L, int a, int b) {
+    for (;;) {
+        a = ccl_find(L, a);
+        b = ccl_find(L, b);
+        if (a == b) return;
+        if (a < b) {
+            int x = a;
+            a = b;
+            b = x;
+        }
+        const int old = atomicMin(&L[a], b);  // a > b: hang the larger root under the smaller
+        if (old == a) return;
+        a = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_merge(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ disp, int32_t *__restrict__ label) {
+    const Dims &d = k.d;
+    const int m = blockIdx.z;
+    if (blob[(m / nproc) * META_WORDS] < 3) return;
+    const size_t off = map_offset(d, m, nproc);
+    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y + 1;
+    if (u >= d.W || v >= d.H) return;
+    const float *D = disp + off;
+    const float thr = k.speckle_sim;
+    const float c = D[(size_t)v * d.W + u], up = D[(size_t)(v - 1) * d.W + u];
+    if (!(c >= 0 && up >= 0 && fabsf(c - up) <= thr)) return;
+    if (u > 0) {  // the same vertical link already exists one pixel to the left inside both runs: nothing new to merge
+        const float cl = D[(size_t)v * d.W + u - 1], ul = D[(size_t)(v - 1) * d.W + u - 1];
+        if (cl >= 0 && ul >= 0 && fabsf(c - cl) <= thr && fabsf(up - ul) <= thr && fabsf(cl - ul) <= thr) return;
+    }
+    ccl_union(label + off, v * d.W + u, (v - 1) * d.W + u);
+}
+
+__global__ __launch_bounds__(256) void k_ccl_count(KParams k, int nproc, const int32_t *__restrict__ blob, int32_t *__restrict__ label, int32_t *__restrict__ csize) {
+    const Dims &d = k.d;
+    const int m = blockIdx.y;
+    if (blob[(m / nproc) * META_WORDS] < 3) return;
+    const size_t off = map_offset(d, m, nproc);
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    int32_t *L = label + off, *S = csize + off;
+    int root = -1;
+    if (p < d.N && L[p] >= 0) {
+        root = ccl_find(L, p);
+        L[p] = root;
+    }
+    // wavefront-level aggregation of equal roots, and no more adds once a component is known to be large enough
+    const int lane = threadIdx.x & 63;
+    bool pending = root >= 0;
+    unsigned long long todo = __ballot(pending);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int r = __shfl(root, leader, 64);
+        const bool same = pending && root == r;
+        const unsigned long long grp = __ballot(same);
+        if (lane == leader) {
+            if (__hip_atomic_load(&S[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k.speckle_size) atomicAdd(&S[r], (int)__popcll(grp));
+        }
+        pending = pending && !same;
+        todo &= ~grp;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_apply(KParams k, int nproc, const int32_t *__restrict__ blob, const int32_t *__restrict__ label,
+                                                   const int32_t *__restrict__ csize, float *__restrict__ disp) {
+    const Dims &d = k.d;
+    const int m = blockIdx.y;
+    if (blob[(m / nproc) * META_WORDS] < 3) return;
+    const size_t off = map_offset(d, m, nproc);
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= d.N) return;
+    const int r = label[off + p];
+    if (r >= 0 && csize[off + r] < k.speckle_size) disp[off + p] = -10.0f;  // elas.cpp:1109-1114
+}
+
+void launch_speckle(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st) {
+    const int maps = n * nproc;
+    SV_LAUNCH(K_CCL_INIT, k_ccl_init, dim3(k.d.H, maps), dim3(64), 0, st, k, nproc, s.blob, s.disp, s.tri_id, s.csize);
+    SV_LAUNCH(K_CCL_MERGE, k_ccl_merge, dim3((k.d.W + 255) / 256, k.d.H - 1, maps), dim3(256), 0, st, k, nproc, s.blob, s.disp, s.tri_id);
+    SV_LAUNCH(K_CCL_COUNT, k_ccl_count, dim3((k.d.N + 255) / 256, maps), dim3(256), 0, st, k, nproc, s.blob, s.tri_id, s.csize);
+    SV_LAUNCH(K_CCL_APPLY, k_ccl_apply, dim3((k.d.N + 255) / 256, maps), dim3(256), 0, st, k, nproc, s.blob, s.tri_id, s.csize, s.disp);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K8  gap interpolation, rows then columns      reference: elas.cpp:1126-1294
+//     Filled pixels never serve as interpolation end points (those are always original valid pixels), so each
+//     line can be resolved from its validity bit mask: previous / next valid position by bit scans.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float gap_value(float d1, float d2) {
+    return fabsf(d1 - d2) < 3.0f ? (d1 + d2) / 2 : (d2 < d1 ? d2 : d1);  // :1168-1171 (discon_threshold 3.0)
+}
+
+#define SV_MAX_LINE_WORDS 128  // lines up to 8192 pixels
+
+__global__ __launch_bounds__(64) void k_gap_rows(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp) {
+    const Dims &d = k.d;
+    const int m = blockIdx.y;
+    if (blob[(m / nproc) * META_WORDS] < 3) return;
+    float *D = disp + map_offset(d, m, nproc) + (size_t)blockIdx.x * d.W;
+    const int lane = threadIdx.x;
+    const int nch = (d.W + 63) / 64;
+    __shared__ unsigned long long mw[SV_MAX_LINE_WORDS];
+    __shared__ int prevb[SV_MAX_LINE_WORDS], nextb[SV_MAX_LINE_WORDS];
+    for (int c = 0; c < nch; c++) {
+        const int u = c * 64 + lane;
+        const float val = u < d.W ? D[u] : -1.0f;
+        const unsigned long long b = __ballot(val >= 0);
+        if (lane == 0) mw[c] = b;
+    }
+    __syncthreads();
+    if (lane == 0) {
+        int pb = -1;
+        for (int c = 0; c < nch; c++) {
+            prevb[c] = pb;
+            if (mw[c]) pb = c * 64 + 63 - __clzll((long long)mw[c]);
+        }
+        int nb = -1;
+        for (int c = nch - 1; c >= 0; c--) {
+            nextb[c] = nb;
+            if (mw[c]) nb = c * 64 + __ffsll((long long)mw[c]) - 1;
+        }
+    }
+    __syncthreads();
+    const int gw = k.gap_width;
+    for (int c = 0; c < nch; c++) {
+        const int u = c * 64 + lane;
+        const unsigned long long w = mw[c];
+        if (u >= d.W || ((w >> lane) & 1ull)) continue;
+        const unsigned long long below = w & ((1ull << lane) - 1ull);
+        const unsigned long long above = lane == 63 ? 0ull : (w >> (lane + 1));
+        const int pl = below ? c * 64 + 63 - __clzll((long long)below) : prevb[c];
+        const int nr = above ? u + __ffsll((long long)above) : nextb[c];
+        if (pl >= 0 && nr >= 0) {
+            if (nr - pl - 1 <= gw) D[u] = gap_value(D[pl], D[nr]);  // :1158-1176
+        } else if (k.add_corners) {
+            if (pl < 0 && nr >= 0) {
+                if (u >= nr - gw) D[u] = D[nr];  // :1191-1201
+            } else if (nr < 0 && pl >= 0) {
+                if (u <= pl + gw) D[u] = D[pl];  // :1204-1214
+            }
+        }
+    }
+}
+
+void launch_gap_rows(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st) {
+    SV_LAUNCH(K_GAP_ROWS, k_gap_rows, dim3(k.d.H, n * nproc), dim3(64), 0, st, k, nproc, s.blob, s.disp);
+}
+
+__global__ __launch_bounds__(64) void k_gap_cols(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp) {
+    const Dims &d = k.d;
+    const int m = blockIdx.y;
+    if (blob[(m / nproc) * META_WORDS] < 3) return;
+    float *D = disp + map_offset(d, m, nproc);
+    const int lane = threadIdx.x;
+    const int u = blockIdx.x * 64 + lane;
+    extern __shared__ unsigned long long cmask[];  // [nw][64]
+    const int nw = (d.H + 63) / 64;
+    const bool live = u < d.W;
+    for (int w = 0; w < nw; w++) {
+        unsigned long long word = 0;
+        const int vend = min(64, d.H - w * 64);
+        for (int b = 0; b < vend; b++) {
+            const float val = live ? D[(size_t)(w * 64 + b) * d.W + u] : -1.0f;
+            word |= (unsigned long long)(val >= 0) << b;
+        }
+        cmask[w * 64 + lane] = word;
+    }
+    if (!live) return;
+    const int gw = k.gap_width;
+    int v = 0, pv = -1;
+    while (v < d.H) {
+        const unsigned long long word = cmask[(v >> 6) * 64 + lane];
+        if ((word >> (v & 63)) & 1ull) {
+            pv = v;
+            v++;
+            continue;
+        }
+        // rows v.. are invalid: find the next valid row
+        int nv = -1;
+        {
+            int w = v >> 6;
+            unsigned long long rest = (word >> (v & 63)) << (v & 63);
+            for (;;) {
+                if (rest) {
+                    nv = w * 64 + __ffsll((long long)rest) - 1;
+                    break;
+                }
+                if (++w >= nw) break;
+                rest = cmask[w * 64 + lane];
+            }
+        }
+        if (pv >= 0 && nv >= 0) {
+            if (nv - pv - 1 <= gw) {  // :1232-1251
+                const float val = gap_value(D[(size_t)pv * d.W + u], D[(size_t)nv * d.W + u]);
+                for (int vv = v; vv < nv; vv++) D[(size_t)vv * d.W + u] = val;
+            }
+        } else if (k.add_corners) {
+            if (pv < 0 && nv >= 0) {  // :1268-1278
+                const float val = D[(size_t)nv * d.W + u];
+                for (int vv = max(nv - gw, 0); vv < nv; vv++) D[(size_t)vv * d.W + u] = val;
+            } else if (nv < 0 && pv >= 0) {  // :1281-1291
+                const float val = D[(size_t)pv * d.W + u];
+                for (int vv = pv + 1; vv <= min(pv + gw, d.H - 1); vv++) D[(size_t)vv * d.W + u] = val;
+            }
+        }
+        if (nv < 0) break;
+        v = nv;
+    }
+}
+
+void launch_gap_cols(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st) {
+    const size_t shmem = (size_t)((k.d.H + 63) / 64) * 64 * sizeof(unsigned long long);
+    SV_LAUNCH(K_GAP_COLS, k_gap_cols, dim3((k.d.W + 63) / 64, n * nproc), dim3(64), shmem, st, k, nproc, s.blob, s.disp);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K9  adaptive mean (8-tap "bilateral" approximation), horizontal then vertical   reference: elas.cpp:1297-1494
+//     Bit-exactness needs (a) the reference's broken absolute-value mask (:1329, _mm_set1_ps(0x7FFFFFFF) is the
+//     float 2^31 = 0x4F000000) and (b) its summation order: ring slot = pixel index mod 8, SSE lanes pair slot j
+//     with j+4, then ((s0+s1)+s2)+s3 (:1427-1434).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float absq(float x) { return __uint_as_float(__float_as_uint(x) & 0x4F000000u); }
+
+// x[i] = window value of pixel (first + i), i = 0..7; returns true and the filtered value when the reference would store it
+__device__ __forceinline__ bool amean8(const float x[8], float xc, int first, float &out) {
+    float wsum[4], fsum[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float t0 = 4.0f - absq(x[i] - xc), t1 = 4.0f - absq(x[i + 4] - xc);
+        float w0 = 0.0f > t0 ? 0.0f : t0, w1 = 0.0f > t1 ? 0.0f : t1;  // _mm_max_ps(xconst0, t)
+        float f0 = x[i] * w0, f1 = x[i + 4] * w1;
+        wsum[i] = w0 + w1;  // pixels i and i+4 share an SSE lane (slots s and s+4); the add is commutative
+        fsum[i] = f0 + f1;
+    }
+    // lane of pixel i is (first + i) & 3: rotate so that index j is SSE lane j
+    const int r = first & 3;
+    float ws0, ws1, ws2, ws3, fs0, fs1, fs2, fs3;
+    if (r == 0) {
+        ws0 = wsum[0], ws1 = wsum[1], ws2 = wsum[2], ws3 = wsum[3];
+        fs0 = fsum[0], fs1 = fsum[1], fs2 = fsum[2], fs3 = fsum[3];
+    } else if (r == 1) {
+        ws0 = wsum[3], ws1 = wsum[0], ws2 = wsum[1], ws3 = wsum[2];
+        fs0 = fsum[3], fs1 = fsum[0], fs2 = fsum[1], fs3 = fsum[2];
+    } else if (r == 2) {
+        ws0 = wsum[2], ws1 = wsum[3], ws2 = wsum[0], ws3 = wsum[1];
+        fs0 = fsum[2], fs1 = fsum[3], fs2 = fsum[0], fs3 = fsum[1];
+    } else {
+        ws0 = wsum[1], ws1 = wsum[2], ws2 = wsum[3], ws3 = wsum[0];
+        fs0 = fsum[1], fs1 = fsum[2], fs2 = fsum[3], fs3 = fsum[0];
+    }
+    const float weight_sum = ws0 + ws1 + ws2 + ws3;
+    const float factor_sum = fs0 + fs1 + fs2 + fs3;
+    if (weight_sum > 0) {
+        const float dd = factor_sum / weight_sum;
+        if (dd >= 0) {
+            out = dd;
+            return true;
+        }
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void k_amean_h(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ disp, float *__restrict__ tmp) {
+    const Dims &d = k.d;
+    const int m = blockIdx.z;
+    if (blob[(m / nproc) * META_WORDS] < 3) return;
+    const size_t off = map_offset(d, m, nproc);
+    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    if (u >= d.W) return;
+    const float *D = disp + off + (size_t)v * d.W;
+    const float self = D[u];
+    float out = self < 0 ? -10.0f : 0.0f;  // D_tmp: -10 where invalid (:1313-1318), canonical 0 elsewhere (:1308)
+    if (v >= 3 && v < d.H - 3 && u >= 4 && u <= d.W - 4) {  // centre u of window u-4..u+3 (:1402-1441)
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float t = D[u - 4 + i];
+            x[i] = t < 0 ? -10.0f : t;
+        }
+        float r;
+        if (amean8(x, x[4], u - 4, r)) out = r;
+    }
+    tmp[off + (size_t)v * d.W + u] = out;
+}
+
+__global__ __launch_bounds__(256) void k_amean_v(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ tmp, float *__restrict__ disp) {
+    const Dims &d = k.d;
+    const int m = blockIdx.z;
+    if (blob[(m / nproc) * META_WORDS] < 3) return;
+    const size_t off = map_offset(d, m, nproc);
+    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    if (u < 3 || u >= d.W - 3 || v < 4 || v > d.H - 4) return;  // :1445-1484
+    const float *T = tmp + off;
+    float x[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) x[i] = T[(size_t)(v - 4 + i) * d.W + u];
+    float r;
+    if (amean8(x, x[4], v - 4, r)) disp[off + (size_t)v * d.W + u] = r;
+}
+
+void launch_amean(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st) {
+    dim3 grid((k.d.W + 255) / 256, k.d.H, n * nproc);
+    SV_LAUNCH(K_AMEAN_H, k_amean_h, grid, dim3(256), 0, st, k, nproc, s.blob, s.disp, s.tmp);
+    SV_LAUNCH(K_AMEAN_V, k_amean_v, grid, dim3(256), 0, st, k, nproc, s.blob, s.tmp, s.disp);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K10 separable 7-tap median      reference: elas.cpp:1496-1560
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cswap(float &a, float &b) {
+    const float lo = b < a ? b : a, hi = b < a ? a : b;
+    a = lo;
+    b = hi;
+}
+
+__device__ __forceinline__ float median7(float v0, float v1, float v2, float v3, float v4, float v5, float v6) {
+    // 7-input sorting network (16 compare-exchanges); the median of a multiset does not depend on the sort used
+    cswap(v0, v6); cswap(v2, v3); cswap(v4, v5);
+    cswap(v0, v2); cswap(v1, v4); cswap(v3, v6);
+    cswap(v0, v1); cswap(v2, v5); cswap(v3, v4);
+    cswap(v1, v2); cswap(v4, v6);
+    cswap(v2, v3); cswap(v4, v5);
+    cswap(v1, v2); cswap(v3, v4); cswap(v5, v6);
+    return v3;
+}
+
+__global__ __launch_bounds__(256) void k_median_h(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ disp, float *__restrict__ tmp) {
+    const Dims &d = k.d;
+    const int m = blockIdx.z;
+    if (blob[(m / nproc) * META_WORDS] < 3) return;
+    const size_t off = map_offset(d, m, nproc);
+    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    if (u >= d.W) return;
+    const float *D = disp + off + (size_t)v * d.W;
+    float out = 0.0f;  // calloc'd D_temp (:1506)
+    if (u >= 3 && u < d.W - 3 && v >= 3 && v < d.H - 3) {
+        const float c = D[u];
+        out = c >= 0 ? median7(D[u - 3], D[u - 2], D[u - 1], c, D[u + 1], D[u + 2], D[u + 3]) : c;
+    }
+    tmp[off + (size_t)v * d.W + u] = out;
+}
+
+__global__ __launch_bounds__(256) void k_median_v(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ tmp, float *__restrict__ disp) {
+    const Dims &d = k.d;
+    const int m = blockIdx.z;
+    if (blob[(m / nproc) * META_WORDS] < 3) return;
+    const size_t off = map_offset(d, m, nproc);
+    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    if (u < 3 || u >= d.W - 3 || v < 3 || v >= d.H - 3) return;
+    const size_t p = off + (size_t)v * d.W + u;
+    if (!(disp[p] >= 0)) return;
+    const float *T = tmp + p;
+    const size_t W = d.W;
+    disp[p] = median7(T[-3 * (long)W], T[-2 * (long)W], T[-(long)W], T[0], T[W], T[2 * W], T[3 * W]);
+}
+
+void launch_median(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st) {
+    dim3 grid((k.d.W + 255) / 256, k.d.H, n * nproc);
+    SV_LAUNCH(K_MEDIAN_H, k_median_h, grid, dim3(256), 0, st, k, nproc, s.blob, s.disp, s.tmp);
+    SV_LAUNCH(K_MEDIAN_V, k_median_v, grid, dim3(256), 0, st, k, nproc, s.blob, s.tmp, s.disp);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// final copy into the caller's maps (pairs with < 3 support points are left untouched, as elas.cpp:63-69 does)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_output(KParams k, const int32_t *__restrict__ blob, const float *__restrict__ disp, float *__restrict__ d1, float *__restrict__ d2) {
+    const Dims &d = k.d;
+    const int pair = blockIdx.y;
+    if (blob[pair * META_WORDS] < 3) return;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= d.N) return;
+    const float *s1 = disp + (size_t)(pair * 2) * d.N, *s2 = s1 + d.N;
+    if (i + 3 < d.N && (d.N & 3) == 0) {
+        *reinterpret_cast<float4 *>(d1 + (size_t)pair * d.N + i) = *reinterpret_cast<const float4 *>(s1 + i);
+        if (d2) *reinterpret_cast<float4 *>(d2 + (size_t)pair * d.N + i) = *reinterpret_cast<const float4 *>(s2 + i);
+    } else {
+        for (int j = i; j < min(i + 4, d.N); j++) {
+            d1[(size_t)pair * d.N + j] = s1[j];
+            if (d2) d2[(size_t)pair * d.N + j] = s2[j];
+        }
+    }
+}
+
+void launch_output(const KParams &k, const SlotDev &s, int n, float *d1, float *d2, hipStream_t st) {
+    SV_LAUNCH(K_OUTPUT, k_output, dim3((k.d.N / 4 + 256) / 256, n), dim3(256), 0, st, k, s.blob, s.disp, d1, d2);
+}
+
+}  // namespace sv

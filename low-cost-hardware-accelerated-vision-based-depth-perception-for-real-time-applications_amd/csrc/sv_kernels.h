@@ -1,0 +1,86 @@
+// Internal interface between the host engine (engine.cpp) and the gfx950 kernels (kernels.hip).
+// Not part of the C ABI (that is include/stereo_vision_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sv {
+
+// Geometry of one stereo pair as the kernels see it.  All maps are dense row-major [H][W].
+struct Dims {
+    int W, H, N;             // N = W*H
+    int step, Wc, Hc;        // support lattice (elas.cpp:376-386): Wc x Hc candidates, `step` px apart
+    int grid_size, gw, gh;   // candidate grid cells (elas.cpp:88-90)
+    int ncell, MW;           // gw*gh cells, MW 32-bit mask words per cell (bit d set <=> disparity d is a candidate)
+    int D, disp_max;         // D = disp_max + 1
+    int max_pts, max_tri;    // capacities of the per-pair support / triangle arrays
+};
+
+// Everything a kernel needs besides buffers; passed by value.
+struct KParams {
+    Dims d;
+    float support_threshold;
+    int support_texture;
+    int lr_threshold;
+    int match_texture;
+    int plane_radius;
+    int prior[16];           // P[delta] for delta <= plane_radius (elas.cpp:828-831), computed on the host
+    float speckle_sim;
+    int speckle_size;
+    int gap_width;
+    int add_corners;
+};
+
+// Device buffers of one worker slot, each holding `cap` pairs back to back.
+constexpr int META_WORDS = 8;
+
+struct SlotDev {
+    int cap;
+    uint8_t *desc;      // [cap][2][N][16]   descriptors, image 0 = left, 1 = right
+    int16_t *dcan;      // [cap][Hc*Wc]      raw support lattice
+    int32_t *blob;      // host-stage results of the chunk, one H2D copy: [cap][8] meta words, then tightly packed data.
+                        //   meta of pair p: [0] #support points  [1] offset of its (u,v,d) triples
+                        //                   [2] #triangles left  [3] offset of their corner indices
+                        //                   [4] #triangles right [5] offset           (offsets in int32 units from blob)
+    float4 *trirec;     // [cap][2][max_tri]  (a, b, c, valid) of the side's own plane
+    float *planes;      // [cap][2][max_tri][6] t1a t1b t1c t2a t2b t2c (kept for parity tests)
+    uint32_t *gmaskA;   // [cap][2][ncell][MW] support marks
+    uint32_t *gmaskB;   // [cap][2][ncell][MW] after the 3x3 flat dilation
+    int32_t *tri_id;    // [cap][2][N]  last triangle covering a pixel, -1 = none; reused as CCL labels
+    float *wta;         // [cap][2][N]  integer WTA disparity (-1 / -10 invalid)
+    float *disp;        // [cap][2][N]  L/R-checked maps, post-processed in place
+    float *tmp;         // [cap][2][N]  scratch of the separable filters
+    int32_t *csize;     // [cap][2][N]  CCL component sizes (at root pixels)
+};
+
+// ---- launch wrappers (kernels.hip).  `n` = pairs in this launch; `nproc` = maps per pair to post-process (1 or 2).
+void launch_descriptor(const KParams &k, const uint8_t *left, const uint8_t *right, size_t in_pair_stride, int stride, const SlotDev &s, int n, hipStream_t st);
+void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st);
+void launch_grid(const KParams &k, const SlotDev &s, int n, hipStream_t st);
+void launch_triangles(const KParams &k, const SlotDev &s, int n, hipStream_t st);
+void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st);
+void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st);
+void launch_speckle(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
+void launch_gap_rows(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
+void launch_gap_cols(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
+void launch_amean(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
+void launch_median(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
+void launch_output(const KParams &k, const SlotDev &s, int n, float *d1, float *d2, hipStream_t st);
+
+// names of the kernels behind each wrapper, in launch order, for timing reports
+enum KernelId {
+    K_DESCRIPTOR = 0, K_SUPPORT, K_GRID_MARK, K_GRID_DILATE, K_TRIANGLES, K_DENSE, K_LR,
+    K_CCL_INIT, K_CCL_MERGE, K_CCL_COUNT, K_CCL_APPLY, K_GAP_ROWS, K_GAP_COLS, K_AMEAN_H, K_AMEAN_V,
+    K_MEDIAN_H, K_MEDIAN_V, K_OUTPUT, K_COUNT
+};
+const char *kernel_name(int id);
+
+// Optional per-launch timing hook: when set, each kernel launch is bracketed by the callback (before=true/false).
+struct LaunchHook {
+    void (*fn)(void *ctx, int kernel_id, bool before, hipStream_t st);
+    void *ctx;
+};
+extern thread_local LaunchHook g_launch_hook;
+
+}  // namespace sv

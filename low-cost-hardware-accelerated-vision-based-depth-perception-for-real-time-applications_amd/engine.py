@@ -1,0 +1,224 @@
+"""Python front-end of libstereo_vision_hip.so (ctypes over the C ABI of include/stereo_vision_hip.h).
+
+PyTorch is used only as plumbing: device memory (tensors), the current device and torch.distributed in bench.py.
+All compute is in the hand-written HIP kernels behind the C ABI; there is no eager/CPU fallback — if the
+library is missing or no GPU is present, calls fail loudly.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libstereo_vision_hip.so")
+
+SV_ROBOTICS, SV_MIDDLEBURY, SV_DRIVER = 0, 1, 2
+
+
+class SvParams(ctypes.Structure):
+    """sv_params == Elas::parameters (reference: src/serial_includes/elas/elas.h:60-145)."""
+
+    _fields_ = [
+        ("disp_min", ctypes.c_int32), ("disp_max", ctypes.c_int32), ("support_threshold", ctypes.c_float),
+        ("support_texture", ctypes.c_int32), ("candidate_stepsize", ctypes.c_int32), ("incon_window_size", ctypes.c_int32),
+        ("incon_threshold", ctypes.c_int32), ("incon_min_support", ctypes.c_int32), ("add_corners", ctypes.c_int32),
+        ("grid_size", ctypes.c_int32), ("beta", ctypes.c_float), ("gamma", ctypes.c_float), ("sigma", ctypes.c_float),
+        ("sradius", ctypes.c_float), ("match_texture", ctypes.c_int32), ("lr_threshold", ctypes.c_int32),
+        ("speckle_sim_threshold", ctypes.c_float), ("speckle_size", ctypes.c_int32), ("ipol_gap_width", ctypes.c_int32),
+        ("filter_median", ctypes.c_int32), ("filter_adaptive_mean", ctypes.c_int32), ("postprocess_only_left", ctypes.c_int32),
+        ("subsampling", ctypes.c_int32),
+    ]
+
+    @classmethod
+    def preset(cls, setting):
+        p = cls()
+        code = {"robotics": SV_ROBOTICS, "middlebury": SV_MIDDLEBURY, "driver": SV_DRIVER}[setting]
+        lib().sv_params_init(ctypes.byref(p), code)
+        return p
+
+    @classmethod
+    def driver(cls, disp_max=255):
+        """MIDDLEBURY + postprocess_only_left + adaptive mean: what the reference driver runs (stereo_vision.cpp:307-311)."""
+        p = cls.preset("driver")
+        p.disp_max = disp_max
+        return p
+
+
+class SvConfig(ctypes.Structure):
+    _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("device", ctypes.c_int32), ("n_workers", ctypes.c_int32),
+                ("chunk", ctypes.c_int32), ("keep_debug", ctypes.c_int32)]
+
+
+_lib = None
+
+_STAGE_DTYPES = {"desc1": np.uint8, "desc2": np.uint8, "dcan_raw": np.int16, "dcan_dims": np.int32, "support": np.int32,
+                 "tri1": np.int32, "tri2": np.int32, "grid1": np.int32, "grid2": np.int32, "grid_dims": np.int32,
+                 "tri_id1": np.int32, "tri_id2": np.int32}
+
+
+def lib():
+    """Loads the shared library (building it in-tree with hipcc if it is not there yet)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build
+        _build.build()
+    L = ctypes.CDLL(LIB_PATH)
+    u8p, f32p, i32p = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p
+    L.sv_params_init.argtypes = [ctypes.POINTER(SvParams), ctypes.c_int]
+    L.sv_params_init.restype = None
+    L.sv_create.argtypes = [ctypes.POINTER(SvParams), ctypes.POINTER(SvConfig), ctypes.POINTER(ctypes.c_void_p)]
+    L.sv_create.restype = ctypes.c_int
+    L.sv_destroy.argtypes = [ctypes.c_void_p]
+    L.sv_destroy.restype = ctypes.c_int
+    L.sv_last_error.argtypes = [ctypes.c_void_p]
+    L.sv_last_error.restype = ctypes.c_char_p
+    for name in ("sv_process_batch_device", "sv_process_batch_host"):
+        f = getattr(L, name)
+        f.argtypes = [ctypes.c_void_p, u8p, u8p, ctypes.c_int, ctypes.c_int, f32p, f32p, i32p]
+        f.restype = ctypes.c_int
+    L.sv_elas_process.argtypes = [ctypes.c_void_p, u8p, u8p, f32p, f32p, ctypes.POINTER(ctypes.c_int32)]
+    L.sv_elas_process.restype = ctypes.c_int
+    L.sv_debug_size.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    L.sv_debug_size.restype = ctypes.c_long
+    L.sv_debug_get.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_void_p, ctypes.c_long]
+    L.sv_debug_get.restype = ctypes.c_long
+    L.sv_kernel_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
+    L.sv_kernel_times.restype = ctypes.c_int
+    L.sv_kernel_times_reset.argtypes = [ctypes.c_void_p]
+    L.sv_kernel_times_reset.restype = None
+    L.sv_kernel_timing_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sv_kernel_timing_enable.restype = None
+    L.sv_host_support_filter.argtypes = [ctypes.POINTER(SvParams), ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    L.sv_host_support_filter.restype = ctypes.c_int
+    L.sv_host_delaunay.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    L.sv_host_delaunay.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+class StereoError(RuntimeError):
+    pass
+
+
+class StereoEngine:
+    """Batched Elas::process on one MI355X.
+
+    engine = StereoEngine(1242, 375, SvParams.driver(127))
+    d1, d2 = engine.process_device(left_u8_cuda, right_u8_cuda)     # torch tensors [B,H,W] -> float32 [B,H,W]
+    """
+
+    def __init__(self, width, height, params=None, device=0, n_workers=0, chunk=0, keep_debug=False):
+        L = lib()
+        self.params = params if params is not None else SvParams.driver(127)
+        self.width, self.height, self.device = int(width), int(height), int(device)
+        cfg = SvConfig(self.width, self.height, self.device, int(n_workers), int(chunk), int(bool(keep_debug)))
+        h = ctypes.c_void_p()
+        rc = L.sv_create(ctypes.byref(self.params), ctypes.byref(cfg), ctypes.byref(h))
+        if rc != 0:
+            raise StereoError("sv_create failed (%d): %s" % (rc, L.sv_last_error(None).decode()))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().sv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise StereoError("libstereo_vision_hip error %d: %s" % (rc, lib().sv_last_error(self._h).decode()))
+
+    # ---- device path (inputs resident in HBM)
+    def process_device(self, left, right, d1=None, d2=None, want_d2=True, status=None):
+        import torch
+        assert left.is_cuda and right.is_cuda and left.dtype == torch.uint8 and right.dtype == torch.uint8
+        assert left.dim() == 3 and left.shape == right.shape and left.shape[1] == self.height and left.shape[2] == self.width
+        left, right = left.contiguous(), right.contiguous()
+        B = left.shape[0]
+        if d1 is None:
+            d1 = torch.zeros((B, self.height, self.width), dtype=torch.float32, device=left.device)
+        if d2 is None and want_d2:
+            d2 = torch.zeros((B, self.height, self.width), dtype=torch.float32, device=left.device)
+        torch.cuda.current_stream(left.device).synchronize()  # inputs/outputs are handed to the engine's own streams
+        st = status.ctypes.data_as(ctypes.c_void_p) if status is not None else None
+        self._check(lib().sv_process_batch_device(self._h, left.data_ptr(), right.data_ptr(), B, self.width, d1.data_ptr(),
+                                                  d2.data_ptr() if d2 is not None else None, st))
+        return d1, d2
+
+    # ---- host path (numpy in / out, PCIe inclusive)
+    def process_host(self, left, right, want_d2=True):
+        left = np.ascontiguousarray(left, dtype=np.uint8)
+        right = np.ascontiguousarray(right, dtype=np.uint8)
+        if left.ndim == 2:
+            left, right = left[None], right[None]
+        B, H, W = left.shape
+        assert (H, W) == (self.height, self.width) and right.shape == left.shape
+        d1 = np.zeros((B, H, W), np.float32)
+        d2 = np.zeros((B, H, W), np.float32) if want_d2 else None
+        status = np.zeros(B, np.int32)
+        self._check(lib().sv_process_batch_host(self._h, left.ctypes.data, right.ctypes.data, B, W, d1.ctypes.data,
+                                                d2.ctypes.data if d2 is not None else None, status.ctypes.data))
+        return d1, d2, status
+
+    def elas_process(self, I1, I2):
+        """Elas::process(I1, I2, D1, D2, dims) for one pair (elas.h:153-162)."""
+        I1 = np.ascontiguousarray(I1, dtype=np.uint8)
+        I2 = np.ascontiguousarray(I2, dtype=np.uint8)
+        H, W = I1.shape
+        D1 = np.zeros((H, W), np.float32)
+        D2 = np.zeros((H, W), np.float32)
+        dims = (ctypes.c_int32 * 3)(W, H, W)
+        self._check(lib().sv_elas_process(self._h, I1.ctypes.data, I2.ctypes.data, D1.ctypes.data, D2.ctypes.data, dims))
+        return D1, D2
+
+    def debug(self, name):
+        n = lib().sv_debug_size(self._h, name.encode())
+        if n < 0:
+            raise KeyError(name)
+        dt = np.dtype(_STAGE_DTYPES.get(name, np.float32))
+        out = np.empty(n // dt.itemsize, dtype=dt)
+        got = lib().sv_debug_get(self._h, name.encode(), out.ctypes.data, n)
+        assert got == n
+        return out
+
+    def timing(self, on=True):
+        lib().sv_kernel_timing_enable(self._h, int(on))
+        lib().sv_kernel_times_reset(self._h)
+
+    def kernel_times(self):
+        """{kernel: (total_ms, calls)} accumulated since timing(True)."""
+        cap = 64
+        names = (ctypes.c_char_p * cap)()
+        ms = (ctypes.c_double * cap)()
+        calls = (ctypes.c_int64 * cap)()
+        n = lib().sv_kernel_times(self._h, names, ms, calls, cap)
+        return {names[i].decode(): (ms[i], calls[i]) for i in range(n)}
+
+
+def host_support_filter(params, dcan, width, height):
+    """Product host stage: lattice filters + corner points (CPU by design; see csrc/host_stage.h)."""
+    d = np.ascontiguousarray(dcan, dtype=np.int16).copy()
+    cap = d.size + 6
+    out = np.empty((cap, 3), np.int32)
+    n = lib().sv_host_support_filter(ctypes.byref(params), d.ctypes.data, width, height, out.ctypes.data, cap)
+    if n < 0:
+        raise StereoError("support capacity")
+    return out[:n].copy()
+
+
+def host_delaunay(xy):
+    """Product host stage: Delaunay triangulation of integer points (n,2) -> (nt,3) int32."""
+    xy = np.ascontiguousarray(xy, dtype=np.int32)
+    n = xy.shape[0]
+    out = np.empty((2 * n + 8, 3), np.int32)
+    nt = lib().sv_host_delaunay(xy.ctypes.data, n, out.ctypes.data, 2 * n + 8)
+    if nt < 0:
+        raise StereoError("triangle capacity")
+    return out[:nt].copy()

@@ -1,0 +1,86 @@
+"""CPU: the C-ABI library loads and exports every symbol include/stereo_vision_hip.h declares; the product's
+host-side stages (which run on the CPU by design) match the oracle; argument validation fails loudly."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import util
+from pyoracle import ElasParams
+
+HEADER = os.path.join(util.ROOT, "include", "stereo_vision_hip.h")
+
+
+@pytest.fixture(scope="module")
+def eng():
+    util.pkg("build").build()
+    return util.pkg("engine")
+
+
+def test_header_symbols_exported(eng):
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(sv_[a-z_]+|generatePointCloud|clean|getColor)\s*\(", src))
+    assert {"sv_create", "sv_process_batch_device", "generatePointCloud", "clean", "getColor"} <= names
+    L = ctypes.CDLL(eng.LIB_PATH)
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, missing
+
+
+def test_params_presets_match_reference_values(eng):
+    for setting in ("robotics", "middlebury", "driver"):
+        a = eng.SvParams.preset(setting)
+        b = ElasParams.driver(255) if setting == "driver" else ElasParams.preset(setting)
+        for f, _ in eng.SvParams._fields_:
+            assert getattr(a, f) == getattr(b, f), (setting, f)
+
+
+def test_create_rejects_unsupported(eng):
+    L = eng.lib()
+    p = eng.SvParams.driver(127)
+    p.subsampling = 1
+    cfg = eng.SvConfig(1242, 375, 0, 1, 1, 0)
+    h = ctypes.c_void_p()
+    assert L.sv_create(ctypes.byref(p), ctypes.byref(cfg), ctypes.byref(h)) == -4 and not h.value
+    assert b"subsampling" in L.sv_last_error(None)
+    p = eng.SvParams.driver(5)
+    assert L.sv_create(ctypes.byref(p), ctypes.byref(cfg), ctypes.byref(h)) == -1
+    assert L.sv_create(None, None, None) == -1
+
+
+def test_no_gpu_fails_loudly(eng):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(eng.StereoError):
+        eng.StereoEngine(320, 120, eng.SvParams.driver(63))
+
+
+@pytest.mark.parametrize("name", ["kitti0_d128", "kitti0_crop_d64", "cones_crop_robotics", "cones_crop_middlebury", "synth7_d64", "synth8_d32"])
+def test_host_stage_matches_oracle(eng, oracle, name):
+    e = util.digests()[name]
+    L, R = util.case_images(e)
+    oracle.run_stages(util.case_params(e, ElasParams), L, R)
+    s = eng.host_support_filter(util.case_params(e, eng.SvParams), oracle.stage("dcan_raw"), L.shape[1], L.shape[0])
+    assert np.array_equal(s.ravel(), oracle.stage("support"))
+    tl = eng.host_delaunay(np.stack([s[:, 0], s[:, 1]], 1))
+    tr = eng.host_delaunay(np.stack([s[:, 0] - s[:, 2], s[:, 1]], 1))
+    assert np.array_equal(tl.ravel(), oracle.stage("tri1")) and np.array_equal(tr.ravel(), oracle.stage("tri2"))
+
+
+def test_host_delaunay_random_sets(eng, oracle):
+    rng = np.random.default_rng(5)
+    for it in range(300):
+        n = int(rng.integers(3, 250))
+        if it % 3 == 0:
+            pts = rng.integers(0, 60, (n, 2)) * 5
+        elif it % 3 == 1:
+            pts = np.stack([rng.integers(-50, 300, n), rng.integers(0, 75, n) * 5], 1)
+        else:
+            pts = np.stack([rng.integers(0, 8, n) * 5, rng.integers(0, 8, n) * 5], 1)
+        if len(np.unique(pts, axis=0)) < 3:
+            continue
+        a, b = oracle.delaunay(pts.astype(np.float32)), eng.host_delaunay(pts)
+        assert a.shape == b.shape and np.array_equal(a, b), it
