@@ -40,6 +40,7 @@ def algorithmic_bytes_per_pair(N, Wc, Hc, Wimg, MW, ncell):
         "descriptor": 2 * N + 2 * desc,                       # gray L,R in; 16 B/px descriptors out (both images)
         "support_match": 2 * (2 * (Hc - 1)) * Wimg * 16 + 2 * Wc * Hc,  # descriptor rows v+-2 of every lattice row, both images; lattice out
         "grid_mark": 0, "grid_dilate": 2 * 2 * ncell * MW * 4,
+        "plane_fit": 0,
         "triangles_raster": 2 * 4 * N,                        # one tri_id write per covered pixel, both sides
         "dense_match": 2 * desc + 2 * 4 * N + 2 * 4 * N,      # both descriptor images, tri_id in, WTA out (both sides)
         "lr_check": 2 * 4 * N + 2 * 4 * N,
@@ -75,8 +76,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU per step")
-    ap.add_argument("--workers", type=int, default=0)
-    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--workers", type=int, default=0, help="host pool threads (0 = library default)")
+    ap.add_argument("--streams", type=int, default=0, help="driver threads / HIP streams (0 = library default)")
+    ap.add_argument("--chunk", type=int, default=0, help="pairs per launch (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=64, help="pairs timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
@@ -103,7 +105,7 @@ def main():
     d1 = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
     d2 = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
     params = eng.SvParams.driver(D - 1)
-    engine = eng.StereoEngine(W, H, params, device=local_rank, n_workers=args.workers, chunk=args.chunk)
+    engine = eng.StereoEngine(W, H, params, device=local_rank, n_workers=args.workers, chunk=args.chunk, n_streams=args.streams)
 
     def barrier():
         torch.cuda.synchronize()
@@ -133,7 +135,7 @@ def main():
     # batch-1 latency on rank 0 (ms/frame): one pair per call, one worker
     lat_ms = None
     if rank == 0:
-        e1 = eng.StereoEngine(W, H, params, device=local_rank, n_workers=1, chunk=1)
+        e1 = eng.StereoEngine(W, H, params, device=local_rank, n_workers=2, chunk=1, n_streams=1)
         l1, r1 = left[:1].contiguous(), right[:1].contiguous()
         o1, o2 = d1[:1].clone(), d2[:1].clone()
         for _ in range(5):

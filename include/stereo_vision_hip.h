@@ -85,9 +85,10 @@ typedef struct sv_config {
     int32_t width;      /* image width  (>= 32) */
     int32_t height;     /* image height (>= 32) */
     int32_t device;     /* HIP device ordinal */
-    int32_t n_workers;  /* host worker threads, each owning one HIP stream (0 = default) */
-    int32_t chunk;      /* pairs a worker keeps in flight per pipeline step (0 = default) */
+    int32_t n_workers;  /* host pool threads for the CPU stage between the two GPU phases (0 = default: min(16, cores)) */
+    int32_t chunk;      /* pairs per GPU launch / pipeline step of one stream (0 = default 16) */
     int32_t keep_debug; /* != 0: keep per-stage intermediates of the LAST processed pair for sv_debug_get */
+    int32_t n_streams;  /* driver threads, each owning one HIP stream and one slot of `chunk` pairs (0 = default 4) */
 } sv_config;
 
 int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out);

@@ -1,15 +1,16 @@
 // Batch engine + C ABI (group B of include/stereo_vision_hip.h).
 //
 // Execution model (MI355X-first, not the reference's one-pair-per-call globals):
-//   * one sv_handle = one GPU; W worker threads, each owning one HIP stream and one "slot" of device buffers
-//     for `chunk` pairs;
-//   * a batch is cut into chunks that workers pull from an atomic counter.  Per chunk a worker runs
+//   * one sv_handle = one GPU; S "driver" threads, each owning one HIP stream and one slot of device buffers for
+//     `chunk` pairs, plus a pool of W host worker threads shared by all drivers;
+//   * a batch is cut into chunks that drivers pull from an atomic counter.  Per chunk a driver runs
 //       phase 1 (GPU)  descriptors + support matching            -> D2H of the small support lattices
 //       host stage     in-place lattice filters + 2 Delaunay triangulations per pair (order-dependent /
-//                      pointer-chasing work that the reference also does on the CPU)
-//       phase 2 (GPU)  one H2D of the packed point/triangle lists, then planes+raster, grid, dense matching,
-//                      L/R check, speckle, gap interpolation, adaptive mean, median, output
-//     so that while one worker is in its host stage the other workers' kernels keep the GPU busy.
+//                      pointer-chasing work that the reference also does on the CPU), fanned out over the pool,
+//                      results packed into one pinned blob by atomic bump allocation
+//       phase 2 (GPU)  one H2D of the blob, then plane fit + raster, grid, dense matching, L/R check, speckle,
+//                      gap interpolation, adaptive mean, median, output
+//     so that while one driver waits for the pool the other drivers' (large) launches keep the GPU busy.
 //   * no allocation, no hipMalloc and no device-wide synchronisation inside the per-batch path.
 #include <math.h>
 #include <stdarg.h>
@@ -19,6 +20,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -41,7 +43,13 @@ struct TimedLaunch {
     hipEvent_t a, b;
 };
 
-struct Worker {
+struct HostScratch {  // per pool thread
+    Delaunay dl;
+    std::vector<int32_t> xy;
+    std::vector<int32_t> sup;
+};
+
+struct Worker {  // a "driver": one stream + one slot of device buffers
     sv_handle *h = nullptr;
     int id = 0;
     std::thread th;
@@ -54,13 +62,24 @@ struct Worker {
     bool blob_pending[2] = {false, false};
     int parity = 0;
     size_t blob_words = 0;
-    Delaunay dl;
-    std::vector<int32_t> xy;
+    // host-stage fan-out state of the chunk in flight
+    int32_t *cur_blob = nullptr;
+    int cur_i0 = 0;
+    std::atomic<size_t> blob_off{0};
+    std::atomic<int> pending{0};
+    std::mutex pmu;
+    std::condition_variable pcv;
+    std::string task_error;
     // timing
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> event_pool;
     size_t events_used = 0;
-    std::string error;
+};
+
+struct Task {
+    Worker *w;
+    int pair;  // index inside the chunk
+    int side;  // -1: filter stage (then triangulates side 0 and queues side 1); 1: triangulation of the right image
 };
 
 struct Job {
@@ -79,7 +98,14 @@ struct sv_handle {
     KParams kp;
     int nproc = 1;  // maps per pair that get post-processed
     int chunk = 1;
-    std::vector<Worker *> workers;
+    std::vector<Worker *> workers;  // drivers
+    // host pool
+    std::vector<std::thread> pool;
+    std::vector<HostScratch *> scratch;
+    std::mutex qmu;
+    std::condition_variable qcv;
+    std::deque<Task> queue;
+    bool pool_quit = false;
     // job control
     std::mutex mu;
     std::condition_variable cv_start, cv_done;
@@ -280,7 +306,7 @@ void process_chunk(Worker *w, int i0, int n) {
         dbg_put(h, "dcan_dims", dd, 2);
     }
 
-    // ---- host stage: filters + Delaunay, packed into one blob
+    // ---- host stage: filters + Delaunay fanned out over the pool, packed into one blob
     const int b = w->parity;
     w->parity ^= 1;
     if (w->blob_pending[b]) {
@@ -288,36 +314,30 @@ void process_chunk(Worker *w, int i0, int n) {
         w->blob_pending[b] = false;
     }
     int32_t *blob = w->h_blob[b];
-    size_t off = (size_t)w->dev.cap * META_WORDS;
-    for (int j = 0; j < n; j++) {
-        int32_t *meta = blob + (size_t)j * META_WORDS;
-        int32_t *sup = blob + off;
-        int ns = support_filter(h->p, w->h_dcan + (size_t)j * lat, d.W, d.H, sup, d.max_pts);
-        if (ns < 0) throw std::runtime_error("support point capacity exceeded");
-        meta[0] = ns;
-        meta[1] = (int32_t)off;
-        meta[2] = meta[4] = 0;
-        meta[3] = meta[5] = (int32_t)off;
-        meta[6] = meta[7] = 0;
-        if (job.status) job.status[i0 + j] = ns;
-        if (ns < 3) continue;  // elas.cpp:63-69
-        off += (size_t)ns * 3;
-        if ((int)w->xy.size() < 2 * ns) w->xy.resize(2 * ns);
-        for (int side = 0; side < 2; side++) {  // elas.cpp:449-461: left uses (u,v), right (u-d,v)
-            for (int q = 0; q < ns; q++) {
-                w->xy[2 * q] = side ? sup[3 * q] - sup[3 * q + 2] : sup[3 * q];
-                w->xy[2 * q + 1] = sup[3 * q + 1];
-            }
-            int nt = w->dl.triangulate(w->xy.data(), ns, blob + off, d.max_tri);
-            if (nt < 0) throw std::runtime_error("triangle capacity exceeded");
-            meta[2 + 2 * side] = nt;
-            meta[3 + 2 * side] = (int32_t)off;
-            off += (size_t)nt * 3;
-        }
-        if (dbg && j == n - 1) {
-            dbg_put(h, "support", sup, (size_t)ns * 3);
+    w->cur_blob = blob;
+    w->cur_i0 = i0;
+    w->blob_off.store((size_t)w->dev.cap * META_WORDS);
+    w->task_error.clear();
+    w->pending.store(n);
+    {
+        std::lock_guard<std::mutex> lk(h->qmu);
+        for (int j = 0; j < n; j++) h->queue.push_back(Task{w, j, -1});
+    }
+    h->qcv.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(w->pmu);
+        w->pcv.wait(lk, [&] { return w->pending.load() == 0; });
+    }
+    if (!w->task_error.empty()) throw std::runtime_error(w->task_error);
+    const size_t off = w->blob_off.load();
+    if (dbg) {
+        const int32_t *meta = blob + (size_t)(n - 1) * META_WORDS;
+        if (meta[0] >= 3) {
+            dbg_put(h, "support", blob + meta[1], (size_t)meta[0] * 3);
             dbg_put(h, "tri1", blob + meta[3], (size_t)meta[2] * 3);
             dbg_put(h, "tri2", blob + meta[5], (size_t)meta[4] * 3);
+        } else {
+            dbg_put(h, "support", w->h_dcan, 0);
         }
     }
 
@@ -352,6 +372,103 @@ void process_chunk(Worker *w, int i0, int n) {
     if (active) dbg_maps(h, w, "final", w->dev.disp, n - 1);
     launch_output(k, w->dev, n, job.d1 + (size_t)i0 * d.N, job.d2 ? job.d2 + (size_t)i0 * d.N : nullptr, st);
     HIP_TRY(hipGetLastError());
+}
+
+
+void pair_done(Worker *w) {
+    if (w->pending.fetch_sub(1) == 1) {
+        std::lock_guard<std::mutex> lk(w->pmu);
+        w->pcv.notify_all();
+    }
+}
+
+void note_error(Worker *w, const char *what) {
+    std::lock_guard<std::mutex> lk(w->pmu);
+    if (w->task_error.empty()) w->task_error = what;
+}
+
+// one Delaunay triangulation of a pair's support points; errors are recorded, never thrown (the caller's
+// completion accounting must run in any case)
+void triangulate_side(sv_handle *h, HostScratch *sc, Worker *w, int j, int side) {
+    const Dims &d = h->kp.d;
+    int32_t *blob = w->cur_blob;
+    int32_t *meta = blob + (size_t)j * META_WORDS;
+    const int ns = meta[0];
+    const int32_t *sup = blob + meta[1];
+    if ((int)sc->xy.size() < 2 * ns) sc->xy.resize(2 * ns);
+    for (int q = 0; q < ns; q++) {  // elas.cpp:449-461: left uses (u,v), right (u-d,v)
+        sc->xy[2 * q] = side ? sup[3 * q] - sup[3 * q + 2] : sup[3 * q];
+        sc->xy[2 * q + 1] = sup[3 * q + 1];
+    }
+    const int nt = sc->dl.triangulate(sc->xy.data(), ns, blob + meta[3 + 2 * side], 2 * ns);
+    if (nt < 0 || nt > d.max_tri) {
+        note_error(w, "triangle capacity exceeded");
+        meta[2 + 2 * side] = 0;
+        return;
+    }
+    meta[2 + 2 * side] = nt;
+}
+
+void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
+    Worker *w = t.w;
+    const Dims &d = h->kp.d;
+    const int lat = d.Wc * d.Hc;
+    int32_t *blob = w->cur_blob;
+    int32_t *meta = blob + (size_t)t.pair * META_WORDS;
+    if (t.side >= 0) {
+        triangulate_side(h, sc, w, t.pair, t.side);
+        if (__atomic_add_fetch(&meta[6], 1, __ATOMIC_ACQ_REL) == 2) pair_done(w);
+        return;
+    }
+    if ((int)sc->sup.size() < d.max_pts * 3) sc->sup.resize((size_t)d.max_pts * 3);
+    int ns = support_filter(h->p, w->h_dcan + (size_t)t.pair * lat, d.W, d.H, sc->sup.data(), d.max_pts);
+    if (ns < 0) {
+        note_error(w, "support point capacity exceeded");
+        ns = 0;
+    }
+    if (h->job.status) h->job.status[w->cur_i0 + t.pair] = ns;
+    meta[0] = ns;
+    meta[1] = meta[3] = meta[5] = 0;
+    meta[2] = meta[4] = 0;
+    meta[6] = meta[7] = 0;
+    if (ns < 3) {  // elas.cpp:63-69
+        pair_done(w);
+        return;
+    }
+    // 3*ns words of points + two triangle lists of at most 2*ns triangles each
+    const size_t need = (size_t)ns * 3 + 2 * ((size_t)2 * ns * 3);
+    const size_t off = w->blob_off.fetch_add(need);
+    if (off + need > w->blob_words) {
+        note_error(w, "host blob overflow");
+        meta[0] = 0;
+        pair_done(w);
+        return;
+    }
+    meta[1] = (int32_t)off;
+    meta[3] = (int32_t)(off + (size_t)ns * 3);
+    meta[5] = (int32_t)(off + (size_t)ns * 3 + (size_t)2 * ns * 3);
+    memcpy(blob + off, sc->sup.data(), sizeof(int32_t) * (size_t)ns * 3);
+    {
+        std::lock_guard<std::mutex> lk(h->qmu);
+        h->queue.push_front(Task{w, t.pair, 1});
+    }
+    h->qcv.notify_one();
+    triangulate_side(h, sc, w, t.pair, 0);
+    if (__atomic_add_fetch(&meta[6], 1, __ATOMIC_ACQ_REL) == 2) pair_done(w);
+}
+
+void pool_main(sv_handle *h, HostScratch *sc) {
+    for (;;) {
+        Task t;
+        {
+            std::unique_lock<std::mutex> lk(h->qmu);
+            h->qcv.wait(lk, [&] { return h->pool_quit || !h->queue.empty(); });
+            if (h->pool_quit && h->queue.empty()) return;
+            t = h->queue.front();
+            h->queue.pop_front();
+        }
+        run_task(h, sc, t);
+    }
 }
 
 void worker_main(Worker *w) {
@@ -402,9 +519,14 @@ void alloc_worker(sv_handle *h, Worker *w) {
     HIP_TRY(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
     dev_alloc(s.desc, cap * 2 * d.N * 16);
     dev_alloc(s.dcan, cap * d.Wc * d.Hc);
-    w->blob_words = cap * (META_WORDS + (size_t)d.max_pts * 3 + 2 * (size_t)d.max_tri * 3);
+    w->blob_words = cap * (META_WORDS + (size_t)d.max_pts * 3 + 2 * (size_t)d.max_tri * 3 + 64);
     dev_alloc(s.blob, w->blob_words);
     dev_alloc(s.trirec, cap * 2 * d.max_tri);
+    {
+        uint8_t *r = nullptr;
+        dev_alloc(r, cap * 2 * (size_t)d.max_tri * 36);
+        s.rrec = r;
+    }
     dev_alloc(s.planes, cap * 2 * d.max_tri * 6);
     dev_alloc(s.gmaskA, cap * 2 * d.ncell * d.MW);
     dev_alloc(s.gmaskB, cap * 2 * d.ncell * d.MW);
@@ -422,7 +544,7 @@ void alloc_worker(sv_handle *h, Worker *w) {
 
 void free_worker(Worker *w) {
     SlotDev &s = w->dev;
-    void *dptrs[] = {s.desc, s.dcan, s.blob, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize};
+    void *dptrs[] = {s.desc, s.dcan, s.blob, s.rrec, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize};
     for (void *p : dptrs)
         if (p) hipFree(p);
     if (w->h_dcan) hipHostFree(w->h_dcan);
@@ -535,8 +657,9 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     h->p = *params;
     h->cfg = *cfg;
     fill_kparams(h);
-    int nw = cfg->n_workers > 0 ? cfg->n_workers : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    h->chunk = cfg->chunk > 0 ? cfg->chunk : 4;
+    int npool = cfg->n_workers > 0 ? cfg->n_workers : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    int nw = cfg->n_streams > 0 ? cfg->n_streams : 4;
+    h->chunk = cfg->chunk > 0 ? cfg->chunk : 16;
     if (cfg->keep_debug) {
         nw = 1;
         h->chunk = 1;
@@ -559,6 +682,11 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         delete h;
         return SV_ERR_HIP;
     }
+    for (int i = 0; i < npool; i++) {
+        HostScratch *sc = new HostScratch();
+        h->scratch.push_back(sc);
+        h->pool.emplace_back(pool_main, h, sc);
+    }
     for (Worker *w : h->workers) w->th = std::thread(worker_main, w);
     *out = h;
     return SV_OK;
@@ -571,8 +699,18 @@ int sv_destroy(sv_handle *h) {
         h->quit = true;
         h->cv_start.notify_all();
     }
-    for (Worker *w : h->workers) {
+    for (Worker *w : h->workers)
         if (w->th.joinable()) w->th.join();
+    {
+        std::lock_guard<std::mutex> lk(h->qmu);
+        h->pool_quit = true;
+        h->qcv.notify_all();
+    }
+    for (std::thread &t : h->pool)
+        if (t.joinable()) t.join();
+    for (HostScratch *sc : h->scratch) delete sc;
+    (void)hipSetDevice(h->cfg.device);
+    for (Worker *w : h->workers) {
         free_worker(w);
         delete w;
     }

@@ -13,7 +13,7 @@ namespace sv {
 thread_local LaunchHook g_launch_hook = {nullptr, nullptr};
 
 const char *kernel_name(int id) {
-    static const char *names[K_COUNT] = {"descriptor", "support_match", "grid_mark", "grid_dilate", "triangles_raster", "dense_match", "lr_check",
+    static const char *names[K_COUNT] = {"descriptor", "support_match", "grid_mark", "grid_dilate", "plane_fit", "triangles_raster", "dense_match", "lr_check",
                                          "ccl_init", "ccl_merge", "ccl_count", "ccl_apply", "gap_rows", "gap_cols", "amean_h", "amean_v",
                                          "median_h", "median_v", "output"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void k_grid_dilate(KParams k, const uint32_t *
 }
 
 void launch_grid(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
-    hipMemsetAsync(s.gmaskA, 0, sizeof(uint32_t) * (size_t)n * 2 * k.d.ncell * k.d.MW, st);
+    (void)hipMemsetAsync(s.gmaskA, 0, sizeof(uint32_t) * (size_t)n * 2 * k.d.ncell * k.d.MW, st);
     SV_LAUNCH(K_GRID_MARK, k_grid_mark, dim3((k.d.max_pts + 255) / 256, 2, n), dim3(256), 0, st, k, s.blob, s.gmaskA);
     SV_LAUNCH(K_GRID_DILATE, k_grid_dilate, dim3((k.d.ncell * k.d.MW + 255) / 256, n * 2), dim3(256), 0, st, k, s.gmaskA, s.gmaskB);
 }
@@ -327,12 +327,17 @@ __device__ __forceinline__ bool solve3(double A[3][3], double B[3]) {
     return true;
 }
 
-__global__ __launch_bounds__(256) void k_triangles(KParams k, const int32_t *__restrict__ blob, float4 *__restrict__ trirec, float *__restrict__ planes,
-                                                   int32_t *__restrict__ tri_id) {
+// per-triangle record handed from k_planes to k_raster: column ranges and the three edge lines (elas.cpp:887-906)
+struct RasterRec {
+    int a_u, b_u, c_u;          // (int32_t)A_u, B_u, C_u
+    float ac_a, ac_b, ab_a, ab_b, bc_a, bc_b;
+};
+
+__global__ __launch_bounds__(256) void k_planes(KParams k, const int32_t *__restrict__ blob, float4 *__restrict__ trirec, float *__restrict__ planes,
+                                                RasterRec *__restrict__ rrec) {
     const Dims &d = k.d;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = blockIdx.z, side = blockIdx.y;
-    const int t = blockIdx.x * 4 + wave;
+    const int t = blockIdx.x * 256 + threadIdx.x;
     const int32_t *meta = blob + pair * META_WORDS;
     if (meta[0] < 3 || t >= meta[2 + 2 * side]) return;
     const size_t tbase = ((size_t)(pair * 2 + side) * d.max_tri + t);
@@ -365,11 +370,9 @@ __global__ __launch_bounds__(256) void k_triangles(KParams k, const int32_t *__r
     const float plane_a = side == 0 ? pl[0] : pl[3], plane_b = side == 0 ? pl[1] : pl[4], plane_c = side == 0 ? pl[2] : pl[5];
     const float plane_d = side == 0 ? pl[3] : pl[0];
     const bool valid = (double)fabsf(plane_a) < 0.7 && (double)fabsf(plane_d) < 0.7;  // elas.cpp:910
-    if (lane == 0) {
-        trirec[tbase] = make_float4(plane_a, plane_b, plane_c, valid ? 1.0f : 0.0f);
+    trirec[tbase] = make_float4(plane_a, plane_b, plane_c, valid ? 1.0f : 0.0f);
 #pragma unroll
-        for (int j = 0; j < 6; j++) planes[tbase * 6 + j] = pl[j];
-    }
+    for (int j = 0; j < 6; j++) planes[tbase * 6 + j] = pl[j];
     // corner sort wrt u, ascending (elas.cpp:859-884)
     float tu[3], tv[3];
 #pragma unroll
@@ -394,18 +397,40 @@ __global__ __launch_bounds__(256) void k_triangles(KParams k, const int32_t *__r
     if ((int)A_u != (int)B_u) AB_a = (A_v - B_v) / (A_u - B_u);
     if ((int)A_u != (int)C_u) AC_a = (A_v - C_v) / (A_u - C_u);
     if ((int)B_u != (int)C_u) BC_a = (B_v - C_v) / (B_u - C_u);
-    const float AB_b = A_v - AB_a * A_u, AC_b = A_v - AC_a * A_u, BC_b = B_v - BC_a * B_u;
+    RasterRec r;
+    r.a_u = (int)A_u;
+    r.b_u = (int)B_u;
+    r.c_u = (int)C_u;
+    r.ac_a = AC_a;
+    r.ac_b = A_v - AC_a * A_u;
+    r.ab_a = AB_a;
+    r.ab_b = A_v - AB_a * A_u;
+    r.bc_a = BC_a;
+    r.bc_b = B_v - BC_a * B_u;
+    rrec[tbase] = r;
+}
+
+// Scan conversion (elas.cpp:912-940): 16 lanes per triangle (lattice triangles are only a few columns wide), each lane
+// walks one column; atomicMax(triangle index) reproduces "the last triangle in list order that covers a pixel decides it".
+__global__ __launch_bounds__(256) void k_raster(KParams k, const int32_t *__restrict__ blob, const RasterRec *__restrict__ rrec, int32_t *__restrict__ tri_id) {
+    const Dims &d = k.d;
+    const int pair = blockIdx.z, side = blockIdx.y;
+    const int sub = threadIdx.x & 15;
+    const int t = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int32_t *meta = blob + pair * META_WORDS;
+    if (meta[0] < 3 || t >= meta[2 + 2 * side]) return;
+    const RasterRec r = rrec[(size_t)(pair * 2 + side) * d.max_tri + t];
     int32_t *ids = tri_id + (size_t)(pair * 2 + side) * d.N;
-    if ((int)A_u != (int)B_u) {  // :913-925
-        for (int u = max((int)A_u, 0) + lane; u < min((int)B_u, d.W); u += 64) {
-            const int v_1 = (int)(AC_a * (float)u + AC_b), v_2 = (int)(AB_a * (float)u + AB_b);
+    if (r.a_u != r.b_u) {  // :913-925
+        for (int u = max(r.a_u, 0) + sub; u < min(r.b_u, d.W); u += 16) {
+            const int v_1 = (int)(r.ac_a * (float)u + r.ac_b), v_2 = (int)(r.ab_a * (float)u + r.ab_b);
             const int lo = max(min(v_1, v_2), 0), hi = min(max(v_1, v_2), d.H);
             for (int v = lo; v < hi; v++) atomicMax(&ids[(size_t)v * d.W + u], t);
         }
     }
-    if ((int)B_u != (int)C_u) {  // :928-940
-        for (int u = max((int)B_u, 0) + lane; u < min((int)C_u, d.W); u += 64) {
-            const int v_1 = (int)(AC_a * (float)u + AC_b), v_2 = (int)(BC_a * (float)u + BC_b);
+    if (r.b_u != r.c_u) {  // :928-940
+        for (int u = max(r.b_u, 0) + sub; u < min(r.c_u, d.W); u += 16) {
+            const int v_1 = (int)(r.ac_a * (float)u + r.ac_b), v_2 = (int)(r.bc_a * (float)u + r.bc_b);
             const int lo = max(min(v_1, v_2), 0), hi = min(max(v_1, v_2), d.H);
             for (int v = lo; v < hi; v++) atomicMax(&ids[(size_t)v * d.W + u], t);
         }
@@ -413,8 +438,9 @@ __global__ __launch_bounds__(256) void k_triangles(KParams k, const int32_t *__r
 }
 
 void launch_triangles(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
-    hipMemsetAsync(s.tri_id, 0xFF, sizeof(int32_t) * (size_t)n * 2 * k.d.N, st);
-    SV_LAUNCH(K_TRIANGLES, k_triangles, dim3((k.d.max_tri + 3) / 4, 2, n), dim3(256), 0, st, k, s.blob, s.trirec, s.planes, s.tri_id);
+    (void)hipMemsetAsync(s.tri_id, 0xFF, sizeof(int32_t) * (size_t)n * 2 * k.d.N, st);
+    SV_LAUNCH(K_PLANES, k_planes, dim3((k.d.max_tri + 255) / 256, 2, n), dim3(256), 0, st, k, s.blob, s.trirec, s.planes, (RasterRec *)s.rrec);
+    SV_LAUNCH(K_TRIANGLES, k_raster, dim3((k.d.max_tri + 15) / 16, 2, n), dim3(256), 0, st, k, s.blob, (const RasterRec *)s.rrec, s.tri_id);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -711,71 +737,83 @@ void launch_gap_rows(const KParams &k, const SlotDev &s, int n, int nproc, hipSt
     SV_LAUNCH(K_GAP_ROWS, k_gap_rows, dim3(k.d.H, n * nproc), dim3(64), 0, st, k, nproc, s.blob, s.disp);
 }
 
-__global__ __launch_bounds__(64) void k_gap_cols(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp) {
+// Columns: a workgroup owns 64 columns; its 4 wavefronts split the rows.  Pass 1 builds the per-column validity
+// bit masks in LDS (coalesced row reads), pass 2 resolves every invalid pixel on its own from the masks.
+__global__ __launch_bounds__(256) void k_gap_cols(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp) {
     const Dims &d = k.d;
     const int m = blockIdx.y;
     if (blob[(m / nproc) * META_WORDS] < 3) return;
     float *D = disp + map_offset(d, m, nproc);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u = blockIdx.x * 64 + lane;
     extern __shared__ unsigned long long cmask[];  // [nw][64]
     const int nw = (d.H + 63) / 64;
     const bool live = u < d.W;
-    for (int w = 0; w < nw; w++) {
+    for (int w = wave; w < nw; w += 4) {
         unsigned long long word = 0;
         const int vend = min(64, d.H - w * 64);
+        const float *col = D + (size_t)(w * 64) * d.W + u;
+#pragma unroll 8
         for (int b = 0; b < vend; b++) {
-            const float val = live ? D[(size_t)(w * 64 + b) * d.W + u] : -1.0f;
+            const float val = live ? col[(size_t)b * d.W] : -1.0f;
             word |= (unsigned long long)(val >= 0) << b;
         }
         cmask[w * 64 + lane] = word;
     }
+    __syncthreads();
     if (!live) return;
     const int gw = k.gap_width;
-    int v = 0, pv = -1;
-    while (v < d.H) {
-        const unsigned long long word = cmask[(v >> 6) * 64 + lane];
-        if ((word >> (v & 63)) & 1ull) {
-            pv = v;
-            v++;
-            continue;
-        }
-        // rows v.. are invalid: find the next valid row
-        int nv = -1;
-        {
-            int w = v >> 6;
-            unsigned long long rest = (word >> (v & 63)) << (v & 63);
-            for (;;) {
-                if (rest) {
-                    nv = w * 64 + __ffsll((long long)rest) - 1;
-                    break;
+    for (int w = wave; w < nw; w += 4) {
+        const unsigned long long word = cmask[w * 64 + lane];
+        const int vend = min(64, d.H - w * 64);
+        unsigned long long inval = ~word & (vend == 64 ? ~0ull : ((1ull << vend) - 1ull));
+        while (inval) {
+            const int b = __ffsll((long long)inval) - 1;
+            inval &= inval - 1;
+            const int v = w * 64 + b;
+            // previous valid row
+            int pv = -1;
+            {
+                unsigned long long below = word & ((1ull << b) - 1ull);
+                int ww = w;
+                for (;;) {
+                    if (below) {
+                        pv = ww * 64 + 63 - __clzll((long long)below);
+                        break;
+                    }
+                    if (--ww < 0) break;
+                    below = cmask[ww * 64 + lane];
                 }
-                if (++w >= nw) break;
-                rest = cmask[w * 64 + lane];
+            }
+            int nv = -1;
+            {
+                unsigned long long above = b == 63 ? 0ull : (word >> (b + 1)) << (b + 1);
+                int ww = w;
+                for (;;) {
+                    if (above) {
+                        nv = ww * 64 + __ffsll((long long)above) - 1;
+                        break;
+                    }
+                    if (++ww >= nw) break;
+                    above = cmask[ww * 64 + lane];
+                }
+            }
+            if (pv >= 0 && nv >= 0) {
+                if (nv - pv - 1 <= gw) D[(size_t)v * d.W + u] = gap_value(D[(size_t)pv * d.W + u], D[(size_t)nv * d.W + u]);  // :1232-1251
+            } else if (k.add_corners) {
+                if (pv < 0 && nv >= 0) {
+                    if (v >= nv - gw) D[(size_t)v * d.W + u] = D[(size_t)nv * d.W + u];  // :1268-1278
+                } else if (nv < 0 && pv >= 0) {
+                    if (v <= pv + gw) D[(size_t)v * d.W + u] = D[(size_t)pv * d.W + u];  // :1281-1291
+                }
             }
         }
-        if (pv >= 0 && nv >= 0) {
-            if (nv - pv - 1 <= gw) {  // :1232-1251
-                const float val = gap_value(D[(size_t)pv * d.W + u], D[(size_t)nv * d.W + u]);
-                for (int vv = v; vv < nv; vv++) D[(size_t)vv * d.W + u] = val;
-            }
-        } else if (k.add_corners) {
-            if (pv < 0 && nv >= 0) {  // :1268-1278
-                const float val = D[(size_t)nv * d.W + u];
-                for (int vv = max(nv - gw, 0); vv < nv; vv++) D[(size_t)vv * d.W + u] = val;
-            } else if (nv < 0 && pv >= 0) {  // :1281-1291
-                const float val = D[(size_t)pv * d.W + u];
-                for (int vv = pv + 1; vv <= min(pv + gw, d.H - 1); vv++) D[(size_t)vv * d.W + u] = val;
-            }
-        }
-        if (nv < 0) break;
-        v = nv;
     }
 }
 
 void launch_gap_cols(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st) {
     const size_t shmem = (size_t)((k.d.H + 63) / 64) * 64 * sizeof(unsigned long long);
-    SV_LAUNCH(K_GAP_COLS, k_gap_cols, dim3((k.d.W + 63) / 64, n * nproc), dim3(64), shmem, st, k, nproc, s.blob, s.disp);
+    SV_LAUNCH(K_GAP_COLS, k_gap_cols, dim3((k.d.W + 63) / 64, n * nproc), dim3(256), shmem, st, k, nproc, s.blob, s.disp);
 }
 
 // ------------------------------------------------------------------------------------------------------------
