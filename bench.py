@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="pairs per launch (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=64, help="pairs timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--gather", action="store_true", help="after the timed region, also gather all left maps on rank 0 (RCCL) and report the time")
     args = ap.parse_args()
 
     import torch
@@ -97,9 +98,11 @@ def main():
 
     eng = importlib.import_module(PKG + ".engine")
     synth = importlib.import_module(PKG + ".synth")
+    par = importlib.import_module(PKG + ".parallel")
     B = args.batch
-    # distinct pairs per rank: seeds 1000 + rank*B + i
-    batch = synth.make_batch(1000 + rank * B, B, H, W, D)
+    # weak scaling: every rank owns B distinct pairs (seeds 1000 + rank*B + i); no data-path collective
+    seeds = par.pair_seeds(rank, B)
+    batch = synth.make_batch(seeds[0], B, H, W, D)
     left = torch.from_numpy(np.ascontiguousarray(batch[:, 0])).cuda()
     right = torch.from_numpy(np.ascontiguousarray(batch[:, 1])).cuda()
     d1 = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
@@ -125,10 +128,15 @@ def main():
     elapsed = time.perf_counter() - t0
     ktimes = engine.kernel_times() if not args.no_kernel_timing else {}
     engine.timing(False)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = par.max_over_ranks(elapsed, device="cuda")
+    gather_ms = None
+    if args.gather and world > 1:  # the optional "trivial gather" of finished maps on rank 0 over RCCL/xGMI, outside the timed region
+        barrier()
+        g0 = time.perf_counter()
+        allmaps = par.gather_maps(d1, dst=0)
+        barrier()
+        gather_ms = round(1e3 * (time.perf_counter() - g0), 3)
+        del allmaps
     valid_frac = float((d1 >= 0).float().mean().item())
     checksum = float(d1.double().sum().item())
 
@@ -164,7 +172,7 @@ def main():
             "config": {"workload": "kitti_1242x375_D128_batch%d_per_gpu_streamed" % B, "width": W, "height": H, "disp_max": D - 1,
                        "preset": "driver(MIDDLEBURY+only_left+adaptive_mean+median)", "pairs_per_gpu_per_step": B,
                        "parallelism": "batch-sharded x%d, no data-path collective" % world},
-            "latency_ms_batch1": lat_ms,
+            "latency_ms_batch1": lat_ms, "gather_ms": gather_ms,
             "valid_fraction": round(valid_frac, 4), "checksum_rank0": checksum,
         }
         if ktimes:

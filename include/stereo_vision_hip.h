@@ -150,6 +150,11 @@ Uchar4 *getColor(void); /* reference: stereo_vision.cpp:625-627 */
 
 /* Last disparity image of the legacy path as the reference's `dmap` (u8 = saturate(round(4*d)), stereo_vision.cpp:316). */
 const unsigned char *sv_legacy_last_dmap(int *width, int *height);
+/* The 4x4 disparity-to-depth matrix Q the legacy path uses (row major), NULL before the first frame. */
+const double *sv_legacy_Q(void);
+/* Test hook: Q (and P1,P2) of the stereoRectify restatement for a calibration file; K1,K2 are divided by `scale` first
+ * (stereo_vision.cpp:364-376).  variant 1 = OpenCV 4.x rule set (the product), 0 = pre-3.4.2 rule set. */
+int sv_debug_stereo_rectify(const char *yaml, int image_w, int image_h, double scale, int variant, double *Q16, double *P1P2_24);
 
 #ifdef __cplusplus
 }

@@ -1,14 +1,192 @@
-// Group (A) of include/stereo_vision_hip.h: the reference's exported symbols.  (Filled in by legacy.cpp proper.)
+// Group (A) of include/stereo_vision_hip.h: the reference's three exported symbols, so that the reference's
+// ctypes binding (stereo_vision/sv.py:164-192) can load this library in place of stereo_vision_serial*.so.
+//
+//   generatePointCloud   reference: src/serial_includes/main/stereo_vision.cpp:565-623
+//     first call  -> externalInit (:498-562): freeze width/height/scale/calibration, stereoRectify -> Q, allocate `points`
+//     every call  -> wrap BGRA buffers, resize (identity: out size == input size, :587-591), cvtColor BGRA2GRAY (:338-339),
+//                    generateDisparityMap (:296-318: Elas MIDDLEBURY + postprocess_only_left + adaptive mean, then
+//                    convertTo(CV_8UC1, 4.0)), publishPointCloud (:222-259: (X,Y,Z) = Q*[x y d 1] / w)
+//   clean / getColor     :105-114 / :625-627
+//
+// Everything per frame runs on the GPU: gray conversion, the ELAS engine, the x4 u8 conversion and the reprojection
+// (legacy_kernels.hip); the host only moves the caller's buffers in and the point array out.
+//
+// Documented deviations from the reference: clean() does not exit(0); `points` is filled on every call
+// (the reference only fills it when graphics==true and otherwise returns uninitialised memory); YOLO object tracking,
+// the GLUT viewer and imshow windows are not part of this library (objectTracking/graphics/display are accepted and
+// ignored); subsampling==true is refused.
+#include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime.h>
 
 #include "../../include/stereo_vision_hip.h"
+#include "calib.h"
+
+namespace sv {
+void launch_bgra_to_gray(const unsigned char *bgra_l, const unsigned char *bgra_r, unsigned char *gray_l, unsigned char *gray_r, int n, hipStream_t st);
+void launch_dmap_and_cloud(const float *disp, unsigned char *dmap, double *points, const double *Q16, int W, int H, hipStream_t st);
+}  // namespace sv
+
+namespace {
+
+struct Legacy {
+    bool ready = false;
+    bool failed = false;
+    int W = 0, H = 0;
+    sv_handle *engine = nullptr;
+    sv::Rectification rect;
+    double *d_Q = nullptr;
+    unsigned char *d_bgra_l = nullptr, *d_bgra_r = nullptr, *d_gray_l = nullptr, *d_gray_r = nullptr, *d_dmap = nullptr;
+    float *d_disp = nullptr, *d_disp2 = nullptr;
+    double *d_points = nullptr;
+    Double3 *points = nullptr;          // host, library-owned (stereo_vision.cpp:89-93)
+    std::vector<Uchar4> colors;         // last left image
+    std::vector<unsigned char> dmap;    // last u8 disparity image
+    hipStream_t stream = nullptr;
+};
+
+Legacy g;
+std::mutex g_mu;
+
+#define L_TRY(expr)                                                                              \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            fprintf(stderr, "stereo_vision_hip: %s failed: %s\n", #expr, hipGetErrorString(e_)); \
+            return false;                                                                        \
+        }                                                                                        \
+    } while (0)
+
+bool legacy_init(int width, int height, float scale, const char *yaml, bool subsampling) {
+    if (subsampling) {
+        fprintf(stderr, "stereo_vision_hip: subsampling=true is not supported\n");
+        return false;
+    }
+    g.W = width;
+    g.H = height;
+    sv::Calibration c;
+    std::string err;
+    printf("Using CAMERA_CALIBRATION_YAML : %s\n", yaml ? yaml : "(null)");
+    if (!sv::load_calibration_yaml(yaml, c, err)) {
+        fprintf(stderr, "stereo_vision_hip: %s\n", err.c_str());
+        return false;
+    }
+    for (int i = 0; i < 6; i++) {  // K1, K2 first two rows /= scale_factor (stereo_vision.cpp:364-376)
+        c.K1[i] /= scale;
+        c.K2[i] /= scale;
+    }
+    sv::stereo_rectify(c, width, height, width, height, 0.0, g.rect);  // :439, calib_img_size == out_img_size (:524-525)
+
+    sv_params p;
+    sv_params_init(&p, SV_DRIVER);  // stereo_vision.cpp:307-311 (disp_max stays 255)
+    sv_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.width = width;
+    cfg.height = height;
+    cfg.device = 0;
+    cfg.n_workers = 2;
+    cfg.n_streams = 1;
+    cfg.chunk = 1;
+    if (sv_create(&p, &cfg, &g.engine) != SV_OK) {
+        fprintf(stderr, "stereo_vision_hip: %s\n", sv_last_error(nullptr));
+        return false;
+    }
+    const size_t N = (size_t)width * height;
+    L_TRY(hipSetDevice(0));
+    L_TRY(hipStreamCreate(&g.stream));
+    L_TRY(hipMalloc((void **)&g.d_bgra_l, N * 4));
+    L_TRY(hipMalloc((void **)&g.d_bgra_r, N * 4));
+    L_TRY(hipMalloc((void **)&g.d_gray_l, N));
+    L_TRY(hipMalloc((void **)&g.d_gray_r, N));
+    L_TRY(hipMalloc((void **)&g.d_dmap, N));
+    L_TRY(hipMalloc((void **)&g.d_disp, N * sizeof(float)));
+    L_TRY(hipMalloc((void **)&g.d_disp2, N * sizeof(float)));
+    L_TRY(hipMalloc((void **)&g.d_points, N * 3 * sizeof(double)));
+    L_TRY(hipMalloc((void **)&g.d_Q, 16 * sizeof(double)));
+    L_TRY(hipMemcpy(g.d_Q, g.rect.Q, 16 * sizeof(double), hipMemcpyHostToDevice));
+    g.points = (Double3 *)calloc(N, sizeof(Double3));
+    g.colors.assign(N, Uchar4{0, 0, 0, 0});
+    g.dmap.assign(N, 0);
+    printf("Init done\n");
+    return g.points != nullptr;
+}
+
+bool legacy_frame(const unsigned char *left, const unsigned char *right) {
+    const size_t N = (size_t)g.W * g.H;
+    L_TRY(hipMemcpyAsync(g.d_bgra_l, left, N * 4, hipMemcpyHostToDevice, g.stream));
+    L_TRY(hipMemcpyAsync(g.d_bgra_r, right, N * 4, hipMemcpyHostToDevice, g.stream));
+    sv::launch_bgra_to_gray(g.d_bgra_l, g.d_bgra_r, g.d_gray_l, g.d_gray_r, (int)N, g.stream);
+    // leftdpf / rightdpf start as zeros every frame (stereo_vision.cpp:304-305)
+    L_TRY(hipMemsetAsync(g.d_disp, 0, N * sizeof(float), g.stream));
+    L_TRY(hipMemsetAsync(g.d_disp2, 0, N * sizeof(float), g.stream));
+    L_TRY(hipStreamSynchronize(g.stream));
+    if (sv_process_batch_device(g.engine, g.d_gray_l, g.d_gray_r, 1, g.W, g.d_disp, g.d_disp2, nullptr) != SV_OK) {
+        fprintf(stderr, "stereo_vision_hip: %s\n", sv_last_error(g.engine));
+        return false;
+    }
+    sv::launch_dmap_and_cloud(g.d_disp, g.d_dmap, g.d_points, g.d_Q, g.W, g.H, g.stream);
+    L_TRY(hipMemcpyAsync(g.points, g.d_points, N * sizeof(Double3), hipMemcpyDeviceToHost, g.stream));
+    L_TRY(hipMemcpyAsync(g.dmap.data(), g.d_dmap, N, hipMemcpyDeviceToHost, g.stream));
+    L_TRY(hipStreamSynchronize(g.stream));
+    memcpy(g.colors.data(), left, N * 4);
+    return true;
+}
+
+}  // namespace
 
 extern "C" {
-Double3 *generatePointCloud(unsigned char *, unsigned char *, char *, int, int, bool, bool, bool, bool, int, int, const char *, const char *, const char *, bool, bool) {
-    fprintf(stderr, "generatePointCloud: not wired yet\n");
-    return nullptr;
+
+Double3 *generatePointCloud(unsigned char *left, unsigned char *right, char *CAMERA_CALIBRATION_YAML, int width, int height, bool kittiCalibration,
+                            bool objectTracking, bool graphics, bool display, int scale, int pc_extrapolation, const char *YOLO_CFG,
+                            const char *YOLO_WEIGHTS, const char *YOLO_CLASSES, bool removeSky, bool subsampling) {
+    (void)kittiCalibration;
+    (void)graphics;
+    (void)display;
+    (void)pc_extrapolation;  // the reference ignores the argument in favour of its global default 1 (stereo_vision.cpp:582)
+    (void)YOLO_CFG;
+    (void)YOLO_WEIGHTS;
+    (void)YOLO_CLASSES;
+    (void)removeSky;  // dmapOLD.copyTo(dmapOLD, sky_mask) copies an image onto itself (stereo_vision.cpp:604-607): no effect
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!left || !right) return nullptr;
+    if (!g.ready && !g.failed) {  // function-static init of the reference (stereo_vision.cpp:582): first call freezes the state
+        if (objectTracking) printf("\n** Object tracking requested: not provided by this library (detector weights are not part of the hot path)\n");
+        else printf("\n** Object tracking disabled\n");
+        g.ready = legacy_init(width, height, (float)scale, CAMERA_CALIBRATION_YAML, subsampling);
+        g.failed = !g.ready;
+    }
+    if (!g.ready) return nullptr;
+    if (!legacy_frame(left, right)) return nullptr;
+    return g.points;
 }
-void clean(void) {}
-Uchar4 *getColor(void) { return nullptr; }
-const unsigned char *sv_legacy_last_dmap(int *, int *) { return nullptr; }
+
+void clean(void) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g.engine) sv_destroy(g.engine);
+    void *dptrs[] = {g.d_bgra_l, g.d_bgra_r, g.d_gray_l, g.d_gray_r, g.d_dmap, g.d_disp, g.d_disp2, g.d_points, g.d_Q};
+    for (void *p : dptrs)
+        if (p) (void)hipFree(p);
+    if (g.stream) (void)hipStreamDestroy(g.stream);
+    free(g.points);
+    g = Legacy();
+    printf("\n\nProgram exitted successfully!\n\n");  // stereo_vision.cpp:111 (the reference then calls exit(0); we return)
 }
+
+Uchar4 *getColor(void) { return g.colors.empty() ? nullptr : g.colors.data(); }
+
+const unsigned char *sv_legacy_last_dmap(int *width, int *height) {
+    if (width) *width = g.W;
+    if (height) *height = g.H;
+    return g.dmap.empty() ? nullptr : g.dmap.data();
+}
+
+const double *sv_legacy_Q(void) { return g.ready ? g.rect.Q : nullptr; }
+
+} /* extern "C" */

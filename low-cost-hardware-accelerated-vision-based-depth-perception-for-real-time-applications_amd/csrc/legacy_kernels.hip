@@ -1,0 +1,44 @@
+// Front-/back-end maps of the legacy entry point, on the GPU:
+//   BGRA -> gray        cv::cvtColor(COLOR_BGRA2GRAY) for 8-bit images, OpenCV 4.x fixed point (15-bit weights
+//                       B 3735, G 19235, R 9798, rounding 1<<14)              call site: stereo_vision.cpp:338-339
+//   f32 -> u8 x4        leftdpf.convertTo(dmap, CV_8UC1, 4.0) = saturate(round-half-even(4*d))       :316
+//   reprojection        pos = Q*[i j d 1]^T, (X,Y,Z) = pos.xyz / pos.w in double                     :233-256
+// OpenCV is an un-vendored dependency of the reference: these restate its documented arithmetic (parity unpinned).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sv {
+
+__global__ __launch_bounds__(256) void k_bgra_to_gray(const uchar4 *__restrict__ l, const uchar4 *__restrict__ r, uint8_t *__restrict__ gl, uint8_t *__restrict__ gr, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uchar4 a = l[i], b = r[i];  // x = B, y = G, z = R, w = A
+    gl[i] = (uint8_t)((a.x * 3735 + a.y * 19235 + a.z * 9798 + 16384) >> 15);
+    gr[i] = (uint8_t)((b.x * 3735 + b.y * 19235 + b.z * 9798 + 16384) >> 15);
+}
+
+void launch_bgra_to_gray(const unsigned char *bgra_l, const unsigned char *bgra_r, unsigned char *gray_l, unsigned char *gray_r, int n, hipStream_t st) {
+    hipLaunchKernelGGL(k_bgra_to_gray, dim3((n + 255) / 256), dim3(256), 0, st, (const uchar4 *)bgra_l, (const uchar4 *)bgra_r, gray_l, gray_r, n);
+}
+
+__global__ __launch_bounds__(256) void k_dmap_cloud(const float *__restrict__ disp, uint8_t *__restrict__ dmap, double *__restrict__ pts, const double *__restrict__ Q, int W, int H) {
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i >= W) return;
+    const size_t p = (size_t)j * W + i;
+    int v = __float2int_rn(disp[p] * 4.0f);  // cvRound: round half to even
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    dmap[p] = (uint8_t)v;
+    const double x = (double)i, y = (double)j, d = (double)v;
+    double pos[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) pos[r] = ((Q[4 * r] * x + Q[4 * r + 1] * y) + Q[4 * r + 2] * d) + Q[4 * r + 3];
+    pts[3 * p] = pos[0] / pos[3];
+    pts[3 * p + 1] = pos[1] / pos[3];
+    pts[3 * p + 2] = pos[2] / pos[3];
+}
+
+void launch_dmap_and_cloud(const float *disp, unsigned char *dmap, double *points, const double *Q16, int W, int H, hipStream_t st) {
+    hipLaunchKernelGGL(k_dmap_cloud, dim3((W + 255) / 256, H), dim3(256), 0, st, disp, dmap, points, Q16, W, H);
+}
+
+}  // namespace sv

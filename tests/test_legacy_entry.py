@@ -1,0 +1,81 @@
+"""The reference's Python entry point / exported symbols on top of the HIP library: mirrors the
+reference's own smoke test (tests/test_demo.py) but with assertions."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import util
+from pyoracle import ElasParams
+
+
+def _q(eng, w, h, scale=1.0, variant=1):
+    L = ctypes.CDLL(eng.LIB_PATH)
+    L.sv_debug_stereo_rectify.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    Q = np.zeros(16)
+    P = np.zeros(24)
+    yml = os.path.join(os.path.dirname(eng.LIB_PATH), "stereo_vision", "data", "kitti_2011_09_26.yml").encode()
+    assert L.sv_debug_stereo_rectify(yml, w, h, scale, variant, Q.ctypes.data, P.ctypes.data) == 0
+    return Q.reshape(4, 4), P[:12].reshape(3, 4), P[12:].reshape(3, 4)
+
+
+def test_stereo_rectify_structure():
+    """Properties every stereoRectify result has (no OpenCV here to compare numbers with: parity unpinned)."""
+    eng = util.pkg("engine")
+    util.pkg("build").build()
+    Q, P1, P2 = _q(eng, 1242, 375)
+    f, cx, cy = Q[2, 3], -Q[0, 3], -Q[1, 3]
+    assert Q[0, 0] == 1 and Q[1, 1] == 1 and Q[2, 2] == 0 and Q[3, 3] == 0  # CALIB_ZERO_DISPARITY: cx1 == cx2
+    assert abs(1.0 / Q[3, 2] - 0.5372) < 1e-3                               # 1/Tx = |T| of the rig (0.537 m baseline)
+    assert P1[0, 0] == f and P1[0, 2] == cx and P1[1, 2] == cy and P2[0, 2] == cx
+    assert abs(P2[0, 3] / f + 1.0 / Q[3, 2]) < 1e-9                          # P2[0][3] = Tx * f
+    assert 600 < f < 1400 and 0 < cx < 1242 and 0 < cy < 375
+    Qh, _, _ = _q(eng, 621, 187, scale=2.0)
+    assert abs(Qh[2, 3] / f - 0.5) < 0.01                                    # half-size images: half the focal length
+
+
+@pytest.mark.gpu
+def test_generate_point_cloud_like_reference_smoke_test():
+    eng = util.pkg("engine")
+    svmod = util.pkg("stereo_vision")
+    L, R = util.load_png("kitti0_left.png"), util.load_png("kitti0_right.png")
+    H, W = L.shape
+    s = svmod.stereo_vision(objectTracking=False, width=W, height=H)
+    try:
+        pts = s.generatePointCloud(np.repeat(L[:, :, None], 3, 2), np.repeat(R[:, :, None], 3, 2))
+        assert pts.shape == (W * H, 3) and pts.dtype == np.float64
+        pts = np.array(pts)
+        dmap = s.last_disparity_u8()
+        s.sv.sv_legacy_Q.restype = ctypes.POINTER(ctypes.c_double)
+        Q = np.ctypeslib.as_array(s.sv.sv_legacy_Q(), shape=(16,)).reshape(4, 4).copy()
+        pts2 = np.array(s.generatePointCloud(np.repeat(L[:, :, None], 3, 2), np.repeat(R[:, :, None], 3, 2)))
+    finally:
+        s.close()
+    assert np.array_equal(pts, pts2, equal_nan=True)
+    # gray(B=G=R=g) == g with the 15-bit weights (they sum to 32768), so the disparity equals the golden kitti0 result at disp_max 255
+    final = util.golden_npz("kitti0_d256")["final1"].reshape(H, W)
+    want = np.clip(np.rint(final * np.float32(4.0)), 0, 255).astype(np.uint8)
+    assert np.array_equal(dmap, want)
+    jj, ii = np.mgrid[0:H, 0:W]
+    V = np.stack([ii.ravel().astype(np.float64), jj.ravel().astype(np.float64), want.ravel().astype(np.float64), np.ones(W * H)], 0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        pos = ((Q[:, 0:1] * V[0] + Q[:, 1:2] * V[1]) + Q[:, 2:3] * V[2]) + Q[:, 3:4]
+        exp = (pos[:3] / pos[3]).T
+    assert np.array_equal(pts, exp, equal_nan=True)
+    assert np.isfinite(pts[want.ravel() > 0]).all()
+
+
+@pytest.mark.gpu
+def test_reference_smoke_input_zero_images():
+    """tests/test_demo.py of the reference: all-zero images must go through (there: (1242,375) 2-D arrays, which its
+    own cvtColor would reject; here proper (375,1242,3) images)."""
+    svmod = util.pkg("stereo_vision")
+    s = svmod.stereo_vision(objectTracking=False, width=1242, height=375)
+    try:
+        z = np.zeros((375, 1242, 3), np.uint8)
+        pts = np.array(s.generatePointCloud(z, z))
+        dmap = s.last_disparity_u8()
+    finally:
+        s.close()
+    assert pts.shape == (1242 * 375, 3) and not dmap.any()
