@@ -127,21 +127,30 @@ void launch_descriptor(const KParams &k, const uint8_t *left, const uint8_t *rig
 //     One wavefront per lattice point; lanes stride over the disparity range; energy = 4-corner SAD (64 bytes);
 //     per-wavefront reduction of (best energy, lowest best d) and the second order statistic.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int support_match(const KParams &k, const uint8_t *__restrict__ A, const uint8_t *__restrict__ B, int u, int v, bool right_image, int lane) {
+// Rows v-2 and v+2 of both descriptor images are staged in LDS for a run of SUP_CANDS consecutive lattice points:
+// the forward search reads the right image over [u-2-dmax, u+2], the backward check the left image over
+// [u-d-2, u-d+2+dmax]; neighbouring lattice points (5 px apart) share almost all of it.
+#define SUP_CANDS 16
+
+struct SupRows {            // one staged image: two rows (v-2, v+2), columns [c0, c0+n)
+    const uint4 *r0, *r1;
+    int c0;
+};
+
+__device__ __forceinline__ int support_match(const KParams &k, const uint8_t *__restrict__ Aimg, const SupRows &A, const SupRows &B, int u, int v, bool right_image,
+                                             int lane) {
     const int W = k.d.W, H = k.d.H;
     if (!(u >= 5 && u <= W - 6 && v >= 5 && v <= H - 6)) return -1;  // elas.cpp:279
-    const uint4 centre = ld16(A + ((size_t)v * W + u) * 16);
+    const uint4 centre = ld16(Aimg + ((size_t)v * W + u) * 16);
     if ((int)texture16(centre) < k.support_texture) return -1;  // :296-300
     const int dmax = right_image ? min(k.d.disp_max, W - u - 5) : min(k.d.disp_max, u - 5);  // :318-323 (disp_min = 0)
     if (dmax < 10) return -1;                                                                // :326
-    const size_t r0 = ((size_t)(v - 2) * W) * 16, r1 = ((size_t)(v + 2) * W) * 16;
-    const uint4 a0 = ld16(A + r0 + (size_t)(u - 2) * 16), a1 = ld16(A + r0 + (size_t)(u + 2) * 16);
-    const uint4 a2 = ld16(A + r1 + (size_t)(u - 2) * 16), a3 = ld16(A + r1 + (size_t)(u + 2) * 16);
+    const int ua = u - A.c0;
+    const uint4 a0 = A.r0[ua - 2], a1 = A.r0[ua + 2], a2 = A.r1[ua - 2], a3 = A.r1[ua + 2];
     uint32_t e1 = 0x7FFFu, d1 = 0xFFFFu, e2 = 0x7FFFu;
     for (int dd = lane; dd <= dmax; dd += 64) {
-        const int uw = right_image ? u + dd : u - dd;
-        const uint8_t *p0 = B + r0 + (size_t)uw * 16, *p1 = B + r1 + (size_t)uw * 16;
-        uint32_t e = sad16(a0, ld16(p0 - 32)) + sad16(a1, ld16(p0 + 32)) + sad16(a2, ld16(p1 - 32)) + sad16(a3, ld16(p1 + 32));  // :341-349
+        const int ub = (right_image ? u + dd : u - dd) - B.c0;
+        uint32_t e = sad16(a0, B.r0[ub - 2]) + sad16(a1, B.r0[ub + 2]) + sad16(a2, B.r1[ub - 2]) + sad16(a3, B.r1[ub + 2]);  // :341-349
         if (e < e1) {  // :352-360, ascending d within a lane
             e2 = e1;
             e1 = e;
@@ -161,30 +170,51 @@ __device__ __forceinline__ int support_match(const KParams &k, const uint8_t *__
 
 __global__ __launch_bounds__(256) void k_support(KParams k, const uint8_t *__restrict__ desc, int16_t *__restrict__ dcan) {
     const Dims &d = k.d;
+    extern __shared__ uint4 sup_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cand = blockIdx.x * 4 + wave;
-    if (cand >= d.Wc * d.Hc) return;
-    const int pair = blockIdx.y;
-    const int uc = cand % d.Wc, vc = cand / d.Wc;
+    const int pair = blockIdx.z, vc = blockIdx.y + 1;
+    const int uc0 = 1 + blockIdx.x * SUP_CANDS, uc1 = min(uc0 + SUP_CANDS, d.Wc);  // candidates [uc0, uc1)
+    const int v = vc * d.step;
     const uint8_t *d1 = desc + ((size_t)(pair * 2) * d.N) * 16, *d2 = d1 + (size_t)d.N * 16;
-    int res;
-    if (uc == 0 || vc == 0) {
-        res = 0;  // calloc'd border of the lattice (elas.cpp:387): counts as a valid d=0 neighbour in the filters
-    } else {
-        const int u = uc * d.step, v = vc * d.step;
-        res = -1;
-        int dd = support_match(k, d1, d2, u, v, false, lane);
-        if (dd >= 0) {
-            int d2v = support_match(k, d2, d1, u - dd, v, true, lane);
-            if (d2v >= 0 && abs(dd - d2v) <= k.lr_threshold) res = dd;  // :404-409
+    const int u_lo = uc0 * d.step, u_hi = (uc1 - 1) * d.step;
+    // staged column ranges, clipped to the image
+    const int r_c0 = max(u_lo - 2 - d.disp_max, 0), r_c1 = min(u_hi + 2, d.W - 1);
+    const int l_c0 = max(u_lo - 2 - d.disp_max, 0), l_c1 = min(u_hi + 2 + d.disp_max, d.W - 1);
+    const int nR = r_c1 - r_c0 + 1, nL = l_c1 - l_c0 + 1;
+    uint4 *sR0 = sup_lds, *sR1 = sR0 + nR, *sL0 = sR1 + nR, *sL1 = sL0 + nL;
+    if (v - 2 >= 0 && v + 2 < d.H) {
+        const uint4 *gR0 = reinterpret_cast<const uint4 *>(d2) + (size_t)(v - 2) * d.W + r_c0, *gR1 = reinterpret_cast<const uint4 *>(d2) + (size_t)(v + 2) * d.W + r_c0;
+        const uint4 *gL0 = reinterpret_cast<const uint4 *>(d1) + (size_t)(v - 2) * d.W + l_c0, *gL1 = reinterpret_cast<const uint4 *>(d1) + (size_t)(v + 2) * d.W + l_c0;
+        for (int i = threadIdx.x; i < nR; i += 256) {
+            sR0[i] = gR0[i];
+            sR1[i] = gR1[i];
+        }
+        for (int i = threadIdx.x; i < nL; i += 256) {
+            sL0[i] = gL0[i];
+            sL1[i] = gL1[i];
         }
     }
-    if (lane == 0) dcan[(size_t)pair * d.Wc * d.Hc + cand] = (int16_t)res;
+    __syncthreads();
+    const SupRows L{sL0, sL1, l_c0}, R{sR0, sR1, r_c0};
+    for (int uc = uc0 + wave; uc < uc1; uc += 4) {
+        const int u = uc * d.step;
+        int res = -1;
+        const int dd = support_match(k, d1, L, R, u, v, false, lane);
+        if (dd >= 0) {
+            const int d2v = support_match(k, d2, R, L, u - dd, v, true, lane);
+            if (d2v >= 0 && abs(dd - d2v) <= k.lr_threshold) res = dd;  // :404-409
+        }
+        if (lane == 0) dcan[(size_t)pair * d.Wc * d.Hc + (size_t)vc * d.Wc + uc] = (int16_t)res;
+    }
 }
 
 void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
-    dim3 grid((k.d.Wc * k.d.Hc + 3) / 4, n);
-    SV_LAUNCH(K_SUPPORT, k_support, grid, dim3(256), 0, st, k, s.desc, s.dcan);
+    // row 0 / column 0 of the calloc'd lattice stay 0 (elas.cpp:387): they count as valid d=0 neighbours in the filters
+    (void)hipMemsetAsync(s.dcan, 0, sizeof(int16_t) * (size_t)n * k.d.Wc * k.d.Hc, st);
+    const int span = (SUP_CANDS - 1) * k.d.step;
+    const size_t shmem = sizeof(uint4) * 2 * ((size_t)(span + k.d.disp_max + 5) + (size_t)(span + 2 * k.d.disp_max + 5));
+    dim3 grid((k.d.Wc - 1 + SUP_CANDS - 1) / SUP_CANDS, k.d.Hc - 1, n);
+    SV_LAUNCH(K_SUPPORT, k_support, grid, dim3(256), shmem, st, k, s.desc, s.dcan);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -412,27 +442,48 @@ __global__ __launch_bounds__(256) void k_planes(KParams k, const int32_t *__rest
 
 // Scan conversion (elas.cpp:912-940): 16 lanes per triangle (lattice triangles are only a few columns wide), each lane
 // walks one column; atomicMax(triangle index) reproduces "the last triangle in list order that covers a pixel decides it".
+__device__ __forceinline__ int group16_min(int v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 16));
+    return v;
+}
+__device__ __forceinline__ int group16_max(int v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 16));
+    return v;
+}
+
 __global__ __launch_bounds__(256) void k_raster(KParams k, const int32_t *__restrict__ blob, const RasterRec *__restrict__ rrec, int32_t *__restrict__ tri_id) {
     const Dims &d = k.d;
     const int pair = blockIdx.z, side = blockIdx.y;
     const int sub = threadIdx.x & 15;
     const int t = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int32_t *meta = blob + pair * META_WORDS;
-    if (meta[0] < 3 || t >= meta[2 + 2 * side]) return;
-    const RasterRec r = rrec[(size_t)(pair * 2 + side) * d.max_tri + t];
+    const bool live = meta[0] >= 3 && t < meta[2 + 2 * side];  // whole 16-lane groups are live or not
+    RasterRec r;
+    if (live) r = rrec[(size_t)(pair * 2 + side) * d.max_tri + t];
     int32_t *ids = tri_id + (size_t)(pair * 2 + side) * d.N;
-    if (r.a_u != r.b_u) {  // :913-925
-        for (int u = max(r.a_u, 0) + sub; u < min(r.b_u, d.W); u += 16) {
-            const int v_1 = (int)(r.ac_a * (float)u + r.ac_b), v_2 = (int)(r.ab_a * (float)u + r.ab_b);
-            const int lo = max(min(v_1, v_2), 0), hi = min(max(v_1, v_2), d.H);
-            for (int v = lo; v < hi; v++) atomicMax(&ids[(size_t)v * d.W + u], t);
-        }
-    }
-    if (r.b_u != r.c_u) {  // :928-940
-        for (int u = max(r.b_u, 0) + sub; u < min(r.c_u, d.W); u += 16) {
-            const int v_1 = (int)(r.ac_a * (float)u + r.ac_b), v_2 = (int)(r.bc_a * (float)u + r.bc_b);
-            const int lo = max(min(v_1, v_2), 0), hi = min(max(v_1, v_2), d.H);
-            for (int v = lo; v < hi; v++) atomicMax(&ids[(size_t)v * d.W + u], t);
+#pragma unroll
+    for (int part = 0; part < 2; part++) {  // :913-925 (A->B with lines AC, AB) and :928-940 (B->C with lines AC, BC)
+        const int ua = part == 0 ? r.a_u : r.b_u, ub = part == 0 ? r.b_u : r.c_u;
+        const float e_a = part == 0 ? r.ab_a : r.bc_a, e_b = part == 0 ? r.ab_b : r.bc_b;
+        const int u_begin = live && ua != ub ? max(ua, 0) : 0, u_end = live && ua != ub ? min(ub, d.W) : 0;
+        const int width = group16_max(u_end - u_begin);  // uniform in the group anyway; keeps the shuffles convergent
+        for (int base = 0; base < width; base += 16) {
+            const int u = u_begin + base + sub;
+            int lo = 0x7FFFFFFF, hi = -0x7FFFFFFF;
+            if (u < u_end) {
+                const int v_1 = (int)(r.ac_a * (float)u + r.ac_b), v_2 = (int)(e_a * (float)u + e_b);
+                lo = max(min(v_1, v_2), 0);
+                hi = min(max(v_1, v_2), d.H);
+                if (lo >= hi) {
+                    lo = 0x7FFFFFFF;
+                    hi = -0x7FFFFFFF;
+                }
+            }
+            const int glo = group16_min(lo), ghi = group16_max(hi);
+            for (int v = glo; v < ghi; v++)  // the 16 lanes of a triangle touch one row segment per step
+                if (v >= lo && v < hi) atomicMax(&ids[(size_t)v * d.W + u], t);
         }
     }
 }
@@ -452,17 +503,26 @@ void launch_triangles(const KParams &k, const SlotDev &s, int n, hipStream_t st)
 __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restrict__ desc, const int32_t *__restrict__ blob, const int32_t *__restrict__ tri_id,
                                                const float4 *__restrict__ trirec, const uint32_t *__restrict__ gB, float *__restrict__ wta) {
     const Dims &d = k.d;
+    extern __shared__ uint4 other_row[];  // the searched image's descriptor row over every column this workgroup can reach
     const int ps = blockIdx.z, pair = ps >> 1, side = ps & 1;
     if (blob[pair * META_WORDS] < 3) return;
-    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+    const int x0 = blockIdx.x * 256, u = x0 + threadIdx.x, v = blockIdx.y;
+    const uint8_t *d1 = desc + ((size_t)(pair * 2) * d.N) * 16, *d2 = d1 + (size_t)d.N * 16;
+    const size_t line = (size_t)d.W * max(min(v, d.H - 3), 2) * 16;  // elas.cpp:718
+    const uint8_t *A = (side ? d2 : d1) + line, *B = (side ? d1 : d2) + line;
+    // left pixel u looks at right columns u-d, right pixel u at left columns u+d, d in [0, disp_max]
+    const int c0 = side ? x0 : max(x0 - d.disp_max, 0);
+    const int c1 = side ? min(x0 + 255 + d.disp_max, d.W - 1) : min(x0 + 255, d.W - 1);
+    {
+        const uint4 *g = reinterpret_cast<const uint4 *>(B) + c0;
+        for (int i = threadIdx.x; i <= c1 - c0; i += 256) other_row[i] = g[i];
+    }
+    __syncthreads();
     if (u >= d.W) return;
     const size_t pix = (size_t)v * d.W + u;
     const int t = tri_id[(size_t)ps * d.N + pix];
     float out = -10.0f;  // elas.cpp:823-824
     if (t >= 0 && u >= 2 && u < d.W - 2) {
-        const uint8_t *d1 = desc + ((size_t)(pair * 2) * d.N) * 16, *d2 = d1 + (size_t)d.N * 16;
-        const size_t line = (size_t)d.W * max(min(v, d.H - 3), 2) * 16;  // :718
-        const uint8_t *A = (side ? d2 : d1) + line, *B = (side ? d1 : d2) + line;
         const uint4 own = ld16(A + (size_t)u * 16);
         if ((int)texture16(own) >= k.match_texture) {  // :732-736
             const float4 rec = trirec[(size_t)ps * d.max_tri + t];
@@ -472,6 +532,7 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
             const bool valid = rec.w != 0.0f;
             const int gx = (int)floorf((float)u / (float)d.grid_size), gy = (int)floorf((float)v / (float)d.grid_size);
             const uint32_t *cell = gB + ((size_t)ps * d.ncell + (size_t)gy * d.gw + gx) * d.MW;
+            const uint4 *row = other_row - c0;
             int min_val = 10000, min_d = -1;
             for (int w = 0; w < d.MW; w++) {  // grid candidates outside the band (:759-767 / :778-786)
                 uint32_t m = cell[w];
@@ -487,7 +548,7 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
                     const int dc = 32 * w + b;
                     const int uw = side ? u + dc : u - dc;
                     if (uw < 2 || uw >= d.W - 2) continue;
-                    const int val = (int)sad16(own, ld16(B + (size_t)uw * 16));
+                    const int val = (int)sad16(own, row[uw]);
                     if (val < min_val) {
                         min_val = val;
                         min_d = dc;
@@ -497,7 +558,7 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
             for (int dc = d_plane_min; dc <= d_plane_max; dc++) {  // the band, with the plane prior (:768-774 / :787-793)
                 const int uw = side ? u + dc : u - dc;
                 if (uw < 2 || uw >= d.W - 2) continue;
-                const int val = (int)sad16(own, ld16(B + (size_t)uw * 16)) + (valid ? k.prior[abs(dc - d_plane)] : 0);
+                const int val = (int)sad16(own, row[uw]) + (valid ? k.prior[abs(dc - d_plane)] : 0);
                 if (val < min_val) {
                     min_val = val;
                     min_d = dc;
@@ -510,7 +571,8 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
 }
 
 void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
-    SV_LAUNCH(K_DENSE, k_dense, dim3((k.d.W + 255) / 256, k.d.H, n * 2), dim3(256), 0, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta);
+    const size_t shmem = sizeof(uint4) * (size_t)(256 + k.d.disp_max);
+    SV_LAUNCH(K_DENSE, k_dense, dim3((k.d.W + 255) / 256, k.d.H, n * 2), dim3(256), shmem, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -824,35 +886,19 @@ void launch_gap_cols(const KParams &k, const SlotDev &s, int n, int nproc, hipSt
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float absq(float x) { return __uint_as_float(__float_as_uint(x) & 0x4F000000u); }
 
-// x[i] = window value of pixel (first + i), i = 0..7; returns true and the filtered value when the reference would store it
-__device__ __forceinline__ bool amean8(const float x[8], float xc, int first, float &out) {
-    float wsum[4], fsum[4];
+// xs[j] = window value held in ring slot j (the pixel of the window whose index is congruent to j mod 8), xc = centre value.
+// Returns true and the filtered value when the reference would store it.  Everything is statically indexed: the
+// slot <-> pixel rotation is done on the load addresses, not on registers.
+__device__ __forceinline__ bool amean8(const float xs[8], float xc, float &out) {
+    float w[8], f[8];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        float t0 = 4.0f - absq(x[i] - xc), t1 = 4.0f - absq(x[i + 4] - xc);
-        float w0 = 0.0f > t0 ? 0.0f : t0, w1 = 0.0f > t1 ? 0.0f : t1;  // _mm_max_ps(xconst0, t)
-        float f0 = x[i] * w0, f1 = x[i + 4] * w1;
-        wsum[i] = w0 + w1;  // pixels i and i+4 share an SSE lane (slots s and s+4); the add is commutative
-        fsum[i] = f0 + f1;
+    for (int j = 0; j < 8; j++) {
+        const float t = 4.0f - absq(xs[j] - xc);
+        w[j] = 0.0f > t ? 0.0f : t;  // _mm_max_ps(xconst0, t)
+        f[j] = xs[j] * w[j];
     }
-    // lane of pixel i is (first + i) & 3: rotate so that index j is SSE lane j
-    const int r = first & 3;
-    float ws0, ws1, ws2, ws3, fs0, fs1, fs2, fs3;
-    if (r == 0) {
-        ws0 = wsum[0], ws1 = wsum[1], ws2 = wsum[2], ws3 = wsum[3];
-        fs0 = fsum[0], fs1 = fsum[1], fs2 = fsum[2], fs3 = fsum[3];
-    } else if (r == 1) {
-        ws0 = wsum[3], ws1 = wsum[0], ws2 = wsum[1], ws3 = wsum[2];
-        fs0 = fsum[3], fs1 = fsum[0], fs2 = fsum[1], fs3 = fsum[2];
-    } else if (r == 2) {
-        ws0 = wsum[2], ws1 = wsum[3], ws2 = wsum[0], ws3 = wsum[1];
-        fs0 = fsum[2], fs1 = fsum[3], fs2 = fsum[0], fs3 = fsum[1];
-    } else {
-        ws0 = wsum[1], ws1 = wsum[2], ws2 = wsum[3], ws3 = wsum[0];
-        fs0 = fsum[1], fs1 = fsum[2], fs2 = fsum[3], fs3 = fsum[0];
-    }
-    const float weight_sum = ws0 + ws1 + ws2 + ws3;
-    const float factor_sum = fs0 + fs1 + fs2 + fs3;
+    const float weight_sum = (w[0] + w[4]) + (w[1] + w[5]) + (w[2] + w[6]) + (w[3] + w[7]);  // elas.cpp:1427-1434
+    const float factor_sum = (f[0] + f[4]) + (f[1] + f[5]) + (f[2] + f[6]) + (f[3] + f[7]);
     if (weight_sum > 0) {
         const float dd = factor_sum / weight_sum;
         if (dd >= 0) {
@@ -874,14 +920,15 @@ __global__ __launch_bounds__(256) void k_amean_h(KParams k, int nproc, const int
     const float self = D[u];
     float out = self < 0 ? -10.0f : 0.0f;  // D_tmp: -10 where invalid (:1313-1318), canonical 0 elsewhere (:1308)
     if (v >= 3 && v < d.H - 3 && u >= 4 && u <= d.W - 4) {  // centre u of window u-4..u+3 (:1402-1441)
-        float x[8];
+        const int first = u - 4;
+        float xs[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const float t = D[u - 4 + i];
-            x[i] = t < 0 ? -10.0f : t;
+        for (int j = 0; j < 8; j++) {
+            const float t = D[first + ((j - first) & 7)];
+            xs[j] = t < 0 ? -10.0f : t;
         }
         float r;
-        if (amean8(x, x[4], u - 4, r)) out = r;
+        if (amean8(xs, self < 0 ? -10.0f : self, r)) out = r;
     }
     tmp[off + (size_t)v * d.W + u] = out;
 }
@@ -894,11 +941,12 @@ __global__ __launch_bounds__(256) void k_amean_v(KParams k, int nproc, const int
     const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
     if (u < 3 || u >= d.W - 3 || v < 4 || v > d.H - 4) return;  // :1445-1484
     const float *T = tmp + off;
-    float x[8];
+    const int first = v - 4;
+    float xs[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) x[i] = T[(size_t)(v - 4 + i) * d.W + u];
+    for (int j = 0; j < 8; j++) xs[j] = T[(size_t)(first + ((j - first) & 7)) * d.W + u];
     float r;
-    if (amean8(x, x[4], v - 4, r)) disp[off + (size_t)v * d.W + u] = r;
+    if (amean8(xs, T[(size_t)v * d.W + u], r)) disp[off + (size_t)v * d.W + u] = r;
 }
 
 void launch_amean(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st) {
