@@ -77,7 +77,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU per step")
     ap.add_argument("--workers", type=int, default=0, help="host pool threads (0 = library default)")
-    ap.add_argument("--streams", type=int, default=0, help="driver threads / HIP streams (0 = library default)")
+    ap.add_argument("--streams", type=int, default=0, help="phase-2 HIP streams (0 = library default)")
+    ap.add_argument("--slots", type=int, default=0, help="pipeline slots = chunks in flight (0 = library default)")
     ap.add_argument("--chunk", type=int, default=0, help="pairs per launch (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=64, help="pairs timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -108,7 +109,7 @@ def main():
     d1 = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
     d2 = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
     params = eng.SvParams.driver(D - 1)
-    engine = eng.StereoEngine(W, H, params, device=local_rank, n_workers=args.workers, chunk=args.chunk, n_streams=args.streams)
+    engine = eng.StereoEngine(W, H, params, device=local_rank, n_workers=args.workers, chunk=args.chunk, n_streams=args.streams, n_slots=args.slots)
 
     def barrier():
         torch.cuda.synchronize()
@@ -143,7 +144,7 @@ def main():
     # batch-1 latency on rank 0 (ms/frame): one pair per call, one worker
     lat_ms = None
     if rank == 0:
-        e1 = eng.StereoEngine(W, H, params, device=local_rank, n_workers=2, chunk=1, n_streams=1)
+        e1 = eng.StereoEngine(W, H, params, device=local_rank, n_workers=2, chunk=1, n_streams=1, n_slots=2)
         l1, r1 = left[:1].contiguous(), right[:1].contiguous()
         o1, o2 = d1[:1].clone(), d2[:1].clone()
         for _ in range(5):

@@ -1,17 +1,19 @@
 // Batch engine + C ABI (group B of include/stereo_vision_hip.h).
 //
-// Execution model (MI355X-first, not the reference's one-pair-per-call globals):
-//   * one sv_handle = one GPU; S "driver" threads, each owning one HIP stream and one slot of device buffers for
-//     `chunk` pairs, plus a pool of W host worker threads shared by all drivers;
-//   * a batch is cut into chunks that drivers pull from an atomic counter.  Per chunk a driver runs
-//       phase 1 (GPU)  descriptors + support matching            -> D2H of the small support lattices
-//       host stage     in-place lattice filters + 2 Delaunay triangulations per pair (order-dependent /
-//                      pointer-chasing work that the reference also does on the CPU), fanned out over the pool,
-//                      results packed into one pinned blob by atomic bump allocation
-//       phase 2 (GPU)  one H2D of the blob, then plane fit + raster, grid, dense matching, L/R check, speckle,
-//                      gap interpolation, adaptive mean, median, output
-//     so that while one driver waits for the pool the other drivers' (large) launches keep the GPU busy.
-//   * no allocation, no hipMalloc and no device-wide synchronisation inside the per-batch path.
+// Execution model (MI355X-first, not the reference's one-pair-per-call globals).  One sv_handle = one GPU.  A batch is cut
+// into chunks of `chunk` pairs that flow through a three-stage software pipeline over a ring of `n_slots` buffer slots:
+//
+//   stage 1  "issuer" thread, stream P1:   descriptors + support matching for chunk k, D2H of the small support lattices
+//   stage 2  host pool (W threads):         per pair the order-dependent in-place lattice filters and the two Delaunay
+//                                           triangulations (work the reference also does on the CPU), packed by atomic bump
+//                                           allocation into the slot's pinned blob; a "dispatcher" thread feeds the pool as
+//                                           soon as a chunk's lattices have landed
+//   stage 3  "finisher" thread, streams P2: one H2D of the blob, then grid, plane fit + raster, dense matching, L/R check,
+//                                           speckle, gap interpolation, adaptive mean, median, output
+//
+// Stage 1 runs ahead as far as the ring allows, so the pool always has work and phase-1 kernels of later chunks overlap
+// phase-2 kernels of earlier ones on the GPU.  Every launch covers a whole chunk (batch index in blockIdx.z / .y).
+// No allocation, hipMalloc or device-wide synchronisation on the per-batch path.
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -43,41 +45,36 @@ struct TimedLaunch {
     hipEvent_t a, b;
 };
 
+struct TimingCtx {  // per issuing thread
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+};
+
 struct HostScratch {  // per pool thread
     Delaunay dl;
     std::vector<int32_t> xy;
     std::vector<int32_t> sup;
 };
 
-struct Worker {  // a "driver": one stream + one slot of device buffers
-    sv_handle *h = nullptr;
+enum SlotState { SLOT_FREE = 0, SLOT_BUSY = 1, SLOT_DRAINING = 2 };  // DRAINING: phase 2 issued, ev_free recorded
+
+struct Slot {
     int id = 0;
-    std::thread th;
-    hipStream_t stream = nullptr;
     SlotDev dev{};
-    // pinned host staging
-    int16_t *h_dcan = nullptr;      // [cap][Hc*Wc]
-    int32_t *h_blob[2] = {nullptr, nullptr};
-    hipEvent_t blob_copied[2] = {nullptr, nullptr};
-    bool blob_pending[2] = {false, false};
-    int parity = 0;
+    int16_t *h_dcan = nullptr;  // pinned [cap][Hc*Wc]
+    int32_t *h_blob = nullptr;  // pinned
     size_t blob_words = 0;
-    // host-stage fan-out state of the chunk in flight
-    int32_t *cur_blob = nullptr;
-    int cur_i0 = 0;
+    hipEvent_t ev_p1 = nullptr, ev_free = nullptr;
+    int state = SLOT_FREE;
+    // chunk in flight
+    int i0 = 0, n = 0;
     std::atomic<size_t> blob_off{0};
     std::atomic<int> pending{0};
-    std::mutex pmu;
-    std::condition_variable pcv;
-    std::string task_error;
-    // timing
-    std::vector<TimedLaunch> timed;
-    std::vector<hipEvent_t> event_pool;
-    size_t events_used = 0;
 };
 
 struct Task {
-    Worker *w;
+    Slot *s;
     int pair;  // index inside the chunk
     int side;  // -1: filter stage (then triangulates side 0 and queues side 1); 1: triangulation of the right image
 };
@@ -87,7 +84,7 @@ struct Job {
     int batch = 0, stride = 0;
     float *d1 = nullptr, *d2 = nullptr;
     int32_t *status = nullptr;
-    std::atomic<int> next{0};
+    int nchunks = 0;
 };
 
 }  // namespace
@@ -98,7 +95,20 @@ struct sv_handle {
     KParams kp;
     int nproc = 1;  // maps per pair that get post-processed
     int chunk = 1;
-    std::vector<Worker *> workers;  // drivers
+    std::vector<Slot *> slots;
+    hipStream_t sP1 = nullptr;
+    std::vector<hipStream_t> sP2;
+    // control threads + queues
+    std::thread t_issue, t_dispatch, t_finish;
+    std::mutex mu;  // guards: generation, quit, job_done, slot states, q1, q2, error
+    std::condition_variable cv;
+    uint64_t generation = 0;
+    bool quit = false, job_done = true;
+    std::deque<Slot *> q1;  // phase 1 issued, waiting for the dispatcher
+    std::deque<Slot *> q2;  // host stage complete, waiting for phase 2
+    Job job;
+    std::string error;
+    bool failed = false;
     // host pool
     std::vector<std::thread> pool;
     std::vector<HostScratch *> scratch;
@@ -106,17 +116,9 @@ struct sv_handle {
     std::condition_variable qcv;
     std::deque<Task> queue;
     bool pool_quit = false;
-    // job control
-    std::mutex mu;
-    std::condition_variable cv_start, cv_done;
-    Job job;
-    uint64_t generation = 0;
-    int running = 0;
-    bool quit = false;
-    std::string error;
-    bool failed = false;
     // timing
     bool timing = false;
+    TimingCtx tc_issue, tc_finish;
     std::mutex tmu;
     double k_ms[K_COUNT] = {0};
     int64_t k_calls[K_COUNT] = {0};
@@ -207,38 +209,46 @@ void fill_kparams(sv_handle *h) {
 }
 
 void timing_hook(void *ctx, int id, bool before, hipStream_t st) {
-    Worker *w = (Worker *)ctx;
+    TimingCtx *t = (TimingCtx *)ctx;
     if (before) {
-        if (w->events_used + 2 > w->event_pool.size()) {
+        if (t->used + 2 > t->pool.size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-            w->event_pool.push_back(a);
-            w->event_pool.push_back(b);
+            t->pool.push_back(a);
+            t->pool.push_back(b);
         }
-        TimedLaunch t{id, w->event_pool[w->events_used], w->event_pool[w->events_used + 1]};
-        w->events_used += 2;
-        w->timed.push_back(t);
-        hipEventRecord(t.a, st);
-    } else if (!w->timed.empty()) {
-        hipEventRecord(w->timed.back().b, st);
+        TimedLaunch tl{id, t->pool[t->used], t->pool[t->used + 1]};
+        t->used += 2;
+        t->timed.push_back(tl);
+        (void)hipEventRecord(tl.a, st);
+    } else if (!t->timed.empty()) {
+        (void)hipEventRecord(t->timed.back().b, st);
     }
 }
 
-void collect_timing(Worker *w) {
-    sv_handle *h = w->h;
-    if (w->timed.empty()) return;
+void collect_timing(sv_handle *h, TimingCtx *t) {
+    if (t->timed.empty()) return;
     std::lock_guard<std::mutex> g(h->tmu);
-    for (const TimedLaunch &t : w->timed) {
+    for (const TimedLaunch &tl : t->timed) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
-            h->k_ms[t.id] += ms;
-            h->k_calls[t.id] += 1;
+        if (hipEventElapsedTime(&ms, tl.a, tl.b) == hipSuccess) {
+            h->k_ms[tl.id] += ms;
+            h->k_calls[tl.id] += 1;
         }
     }
-    w->timed.clear();
-    w->events_used = 0;
+    t->timed.clear();
+    t->used = 0;
 }
 
+void note_error(sv_handle *h, const char *what) {
+    std::lock_guard<std::mutex> lk(h->mu);
+    if (!h->failed) {
+        h->failed = true;
+        h->error = what;
+    }
+}
+
+// ---- debug snapshots (keep_debug: one slot, one pair per chunk) -----------------------------------------------------
 template <class T>
 void dbg_put(sv_handle *h, const char *name, const T *data, size_t count) {
     std::vector<uint8_t> &v = h->dbg[name];
@@ -246,29 +256,29 @@ void dbg_put(sv_handle *h, const char *name, const T *data, size_t count) {
     if (count) memcpy(v.data(), data, count * sizeof(T));
 }
 
-void dbg_from_device(sv_handle *h, Worker *w, const char *name, const void *dptr, size_t bytes) {
+void dbg_from_device(sv_handle *h, hipStream_t st, const char *name, const void *dptr, size_t bytes) {
     std::vector<uint8_t> &v = h->dbg[name];
     v.resize(bytes);
-    HIP_TRY(hipStreamSynchronize(w->stream));
-    HIP_TRY(hipMemcpy(v.data(), dptr, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (bytes) HIP_TRY(hipMemcpy(v.data(), dptr, bytes, hipMemcpyDeviceToHost));
 }
 
-void dbg_maps(sv_handle *h, Worker *w, const char *stage, const float *base, int j) {
+void dbg_maps(sv_handle *h, hipStream_t st, const char *stage, const float *base, int j) {
     const size_t N = h->kp.d.N;
     char name[64];
     for (int side = 0; side < 2; side++) {
         snprintf(name, sizeof(name), "%s%d", stage, side + 1);
-        dbg_from_device(h, w, name, base + ((size_t)j * 2 + side) * N, N * sizeof(float));
+        dbg_from_device(h, st, name, base + ((size_t)j * 2 + side) * N, N * sizeof(float));
     }
 }
 
 // compacted candidate lists in the reference's layout (elas.cpp:631-648) from the device bit masks
-void dbg_grid(sv_handle *h, Worker *w, int j) {
+void dbg_grid(sv_handle *h, hipStream_t st, Slot *s, int j) {
     const Dims &d = h->kp.d;
     std::vector<uint32_t> m((size_t)d.ncell * d.MW);
     for (int side = 0; side < 2; side++) {
-        HIP_TRY(hipStreamSynchronize(w->stream));
-        HIP_TRY(hipMemcpy(m.data(), w->dev.gmaskB + ((size_t)j * 2 + side) * d.ncell * d.MW, m.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(m.data(), s->dev.gmaskB + ((size_t)j * 2 + side) * d.ncell * d.MW, m.size() * 4, hipMemcpyDeviceToHost));
         std::vector<int32_t> g((size_t)d.ncell * (d.disp_max + 2), 0);
         for (int c = 0; c < d.ncell; c++) {
             int cnt = 0;
@@ -282,116 +292,84 @@ void dbg_grid(sv_handle *h, Worker *w, int j) {
     dbg_put(h, "grid_dims", gd, 3);
 }
 
-void process_chunk(Worker *w, int i0, int n) {
-    sv_handle *h = w->h;
+// ---- stage 1: issuer ---------------------------------------------------------------------------------------------------
+void issue_phase1(sv_handle *h, Slot *s) {
     const KParams &k = h->kp;
     const Dims &d = k.d;
     const Job &job = h->job;
-    const bool dbg = h->cfg.keep_debug != 0;
-    hipStream_t st = w->stream;
     const size_t in_pair = (size_t)d.H * job.stride;
     const int lat = d.Wc * d.Hc;
-
-    // ---- phase 1
-    launch_descriptor(k, job.left + (size_t)i0 * in_pair, job.right + (size_t)i0 * in_pair, in_pair, job.stride, w->dev, n, st);
-    launch_support(k, w->dev, n, st);
-    HIP_TRY(hipMemcpyAsync(w->h_dcan, w->dev.dcan, sizeof(int16_t) * (size_t)n * lat, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    if (dbg) {
-        const int j = n - 1;
-        dbg_from_device(h, w, "desc1", w->dev.desc + ((size_t)j * 2) * d.N * 16, (size_t)d.N * 16);
-        dbg_from_device(h, w, "desc2", w->dev.desc + ((size_t)j * 2 + 1) * d.N * 16, (size_t)d.N * 16);
-        dbg_put(h, "dcan_raw", w->h_dcan + (size_t)j * lat, lat);
+    launch_descriptor(k, job.left + (size_t)s->i0 * in_pair, job.right + (size_t)s->i0 * in_pair, in_pair, job.stride, s->dev, s->n, h->sP1);
+    launch_support(k, s->dev, s->n, h->sP1);
+    HIP_TRY(hipMemcpyAsync(s->h_dcan, s->dev.dcan, sizeof(int16_t) * (size_t)s->n * lat, hipMemcpyDeviceToHost, h->sP1));
+    HIP_TRY(hipEventRecord(s->ev_p1, h->sP1));
+    if (h->cfg.keep_debug) {
+        const int j = s->n - 1;
+        dbg_from_device(h, h->sP1, "desc1", s->dev.desc + ((size_t)j * 2) * d.N * 16, (size_t)d.N * 16);
+        dbg_from_device(h, h->sP1, "desc2", s->dev.desc + ((size_t)j * 2 + 1) * d.N * 16, (size_t)d.N * 16);
+        dbg_put(h, "dcan_raw", s->h_dcan + (size_t)j * lat, lat);
         int32_t dd[2] = {d.Wc, d.Hc};
         dbg_put(h, "dcan_dims", dd, 2);
     }
+}
 
-    // ---- host stage: filters + Delaunay fanned out over the pool, packed into one blob
-    const int b = w->parity;
-    w->parity ^= 1;
-    if (w->blob_pending[b]) {
-        HIP_TRY(hipEventSynchronize(w->blob_copied[b]));
-        w->blob_pending[b] = false;
-    }
-    int32_t *blob = w->h_blob[b];
-    w->cur_blob = blob;
-    w->cur_i0 = i0;
-    w->blob_off.store((size_t)w->dev.cap * META_WORDS);
-    w->task_error.clear();
-    w->pending.store(n);
-    {
-        std::lock_guard<std::mutex> lk(h->qmu);
-        for (int j = 0; j < n; j++) h->queue.push_back(Task{w, j, -1});
-    }
-    h->qcv.notify_all();
-    {
-        std::unique_lock<std::mutex> lk(w->pmu);
-        w->pcv.wait(lk, [&] { return w->pending.load() == 0; });
-    }
-    if (!w->task_error.empty()) throw std::runtime_error(w->task_error);
-    const size_t off = w->blob_off.load();
-    if (dbg) {
-        const int32_t *meta = blob + (size_t)(n - 1) * META_WORDS;
-        if (meta[0] >= 3) {
-            dbg_put(h, "support", blob + meta[1], (size_t)meta[0] * 3);
-            dbg_put(h, "tri1", blob + meta[3], (size_t)meta[2] * 3);
-            dbg_put(h, "tri2", blob + meta[5], (size_t)meta[4] * 3);
-        } else {
-            dbg_put(h, "support", w->h_dcan, 0);
+void issuer_main(sv_handle *h) {
+    (void)hipSetDevice(h->cfg.device);
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(h->mu);
+            h->cv.wait(lk, [&] { return h->quit || h->generation != seen; });
+            if (h->quit) return;
+            seen = h->generation;
+        }
+        g_launch_hook.fn = h->timing ? timing_hook : nullptr;
+        g_launch_hook.ctx = &h->tc_issue;
+        const int ns = (int)h->slots.size();
+        for (int c = 0; c < h->job.nchunks; c++) {
+            Slot *s = h->slots[c % ns];
+            bool drain = false;
+            {
+                std::unique_lock<std::mutex> lk(h->mu);
+                h->cv.wait(lk, [&] { return s->state != SLOT_BUSY; });
+                drain = s->state == SLOT_DRAINING;
+                s->state = SLOT_BUSY;
+            }
+            try {
+                if (drain) HIP_TRY(hipEventSynchronize(s->ev_free));
+                s->i0 = c * h->chunk;
+                s->n = std::min(h->chunk, h->job.batch - s->i0);
+                if (!h->failed) issue_phase1(h, s);
+            } catch (const std::exception &e) {
+                note_error(h, e.what());
+            }
+            {
+                std::lock_guard<std::mutex> lk(h->mu);
+                h->q1.push_back(s);
+            }
+            h->cv.notify_all();
         }
     }
+}
 
-    // ---- phase 2
-    HIP_TRY(hipMemcpyAsync(w->dev.blob, blob, off * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipEventRecord(w->blob_copied[b], st));
-    w->blob_pending[b] = true;
-    launch_grid(k, w->dev, n, st);
-    launch_triangles(k, w->dev, n, st);
-    launch_dense(k, w->dev, n, st);
-    launch_lr(k, w->dev, n, st);
-    const bool active = dbg && blob[(size_t)(n - 1) * META_WORDS] >= 3;
-    if (active) {
-        const int j = n - 1;
-        const int32_t *meta = blob + (size_t)j * META_WORDS;
-        dbg_grid(h, w, j);
-        dbg_from_device(h, w, "planes1", w->dev.planes + ((size_t)j * 2) * d.max_tri * 6, (size_t)meta[2] * 6 * sizeof(float));
-        dbg_from_device(h, w, "planes2", w->dev.planes + ((size_t)j * 2 + 1) * d.max_tri * 6, (size_t)meta[4] * 6 * sizeof(float));
-        dbg_from_device(h, w, "tri_id1", w->dev.tri_id + ((size_t)j * 2) * d.N, (size_t)d.N * 4);
-        dbg_from_device(h, w, "tri_id2", w->dev.tri_id + ((size_t)j * 2 + 1) * d.N, (size_t)d.N * 4);
-        dbg_maps(h, w, "wta", w->dev.wta, j);
-        dbg_maps(h, w, "lr", w->dev.disp, j);
+// ---- stage 2: dispatcher + host pool ---------------------------------------------------------------------------------
+void chunk_host_done(sv_handle *h, Slot *s) {
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->q2.push_back(s);
     }
-    launch_speckle(k, w->dev, n, h->nproc, st);
-    if (active) dbg_maps(h, w, "speckle", w->dev.disp, n - 1);
-    launch_gap_rows(k, w->dev, n, h->nproc, st);
-    launch_gap_cols(k, w->dev, n, h->nproc, st);
-    if (active) dbg_maps(h, w, "gap", w->dev.disp, n - 1);
-    if (h->p.filter_adaptive_mean) launch_amean(k, w->dev, n, h->nproc, st);
-    if (active) dbg_maps(h, w, "amean", w->dev.disp, n - 1);
-    if (h->p.filter_median) launch_median(k, w->dev, n, h->nproc, st);
-    if (active) dbg_maps(h, w, "final", w->dev.disp, n - 1);
-    launch_output(k, w->dev, n, job.d1 + (size_t)i0 * d.N, job.d2 ? job.d2 + (size_t)i0 * d.N : nullptr, st);
-    HIP_TRY(hipGetLastError());
+    h->cv.notify_all();
 }
 
-
-void pair_done(Worker *w) {
-    if (w->pending.fetch_sub(1) == 1) {
-        std::lock_guard<std::mutex> lk(w->pmu);
-        w->pcv.notify_all();
-    }
+void pair_done(sv_handle *h, Slot *s) {
+    if (s->pending.fetch_sub(1) == 1) chunk_host_done(h, s);
 }
 
-void note_error(Worker *w, const char *what) {
-    std::lock_guard<std::mutex> lk(w->pmu);
-    if (w->task_error.empty()) w->task_error = what;
-}
-
-// one Delaunay triangulation of a pair's support points; errors are recorded, never thrown (the caller's
-// completion accounting must run in any case)
-void triangulate_side(sv_handle *h, HostScratch *sc, Worker *w, int j, int side) {
+// one Delaunay triangulation of a pair's support points; errors are recorded, never thrown (the completion accounting of
+// the caller must run in any case)
+void triangulate_side(sv_handle *h, HostScratch *sc, Slot *s, int j, int side) {
     const Dims &d = h->kp.d;
-    int32_t *blob = w->cur_blob;
+    int32_t *blob = s->h_blob;
     int32_t *meta = blob + (size_t)j * META_WORDS;
     const int ns = meta[0];
     const int32_t *sup = blob + meta[1];
@@ -402,7 +380,7 @@ void triangulate_side(sv_handle *h, HostScratch *sc, Worker *w, int j, int side)
     }
     const int nt = sc->dl.triangulate(sc->xy.data(), ns, blob + meta[3 + 2 * side], 2 * ns);
     if (nt < 0 || nt > d.max_tri) {
-        note_error(w, "triangle capacity exceeded");
+        note_error(h, "triangle capacity exceeded");
         meta[2 + 2 * side] = 0;
         return;
     }
@@ -410,38 +388,38 @@ void triangulate_side(sv_handle *h, HostScratch *sc, Worker *w, int j, int side)
 }
 
 void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
-    Worker *w = t.w;
+    Slot *s = t.s;
     const Dims &d = h->kp.d;
     const int lat = d.Wc * d.Hc;
-    int32_t *blob = w->cur_blob;
+    int32_t *blob = s->h_blob;
     int32_t *meta = blob + (size_t)t.pair * META_WORDS;
     if (t.side >= 0) {
-        triangulate_side(h, sc, w, t.pair, t.side);
-        if (__atomic_add_fetch(&meta[6], 1, __ATOMIC_ACQ_REL) == 2) pair_done(w);
+        triangulate_side(h, sc, s, t.pair, t.side);
+        if (__atomic_add_fetch(&meta[6], 1, __ATOMIC_ACQ_REL) == 2) pair_done(h, s);
         return;
     }
     if ((int)sc->sup.size() < d.max_pts * 3) sc->sup.resize((size_t)d.max_pts * 3);
-    int ns = support_filter(h->p, w->h_dcan + (size_t)t.pair * lat, d.W, d.H, sc->sup.data(), d.max_pts);
+    int ns = support_filter(h->p, s->h_dcan + (size_t)t.pair * lat, d.W, d.H, sc->sup.data(), d.max_pts);
     if (ns < 0) {
-        note_error(w, "support point capacity exceeded");
+        note_error(h, "support point capacity exceeded");
         ns = 0;
     }
-    if (h->job.status) h->job.status[w->cur_i0 + t.pair] = ns;
+    if (h->job.status) h->job.status[s->i0 + t.pair] = ns;
     meta[0] = ns;
     meta[1] = meta[3] = meta[5] = 0;
     meta[2] = meta[4] = 0;
     meta[6] = meta[7] = 0;
     if (ns < 3) {  // elas.cpp:63-69
-        pair_done(w);
+        pair_done(h, s);
         return;
     }
     // 3*ns words of points + two triangle lists of at most 2*ns triangles each
     const size_t need = (size_t)ns * 3 + 2 * ((size_t)2 * ns * 3);
-    const size_t off = w->blob_off.fetch_add(need);
-    if (off + need > w->blob_words) {
-        note_error(w, "host blob overflow");
+    const size_t off = s->blob_off.fetch_add(need);
+    if (off + need > s->blob_words) {
+        note_error(h, "host blob overflow");
         meta[0] = 0;
-        pair_done(w);
+        pair_done(h, s);
         return;
     }
     meta[1] = (int32_t)off;
@@ -450,11 +428,11 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
     memcpy(blob + off, sc->sup.data(), sizeof(int32_t) * (size_t)ns * 3);
     {
         std::lock_guard<std::mutex> lk(h->qmu);
-        h->queue.push_front(Task{w, t.pair, 1});
+        h->queue.push_front(Task{s, t.pair, 1});
     }
     h->qcv.notify_one();
-    triangulate_side(h, sc, w, t.pair, 0);
-    if (__atomic_add_fetch(&meta[6], 1, __ATOMIC_ACQ_REL) == 2) pair_done(w);
+    triangulate_side(h, sc, s, t.pair, 0);
+    if (__atomic_add_fetch(&meta[6], 1, __ATOMIC_ACQ_REL) == 2) pair_done(h, s);
 }
 
 void pool_main(sv_handle *h, HostScratch *sc) {
@@ -471,38 +449,136 @@ void pool_main(sv_handle *h, HostScratch *sc) {
     }
 }
 
-void worker_main(Worker *w) {
-    sv_handle *h = w->h;
-    hipSetDevice(h->cfg.device);
+void dispatcher_main(sv_handle *h) {
+    (void)hipSetDevice(h->cfg.device);
+    for (;;) {
+        Slot *s = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(h->mu);
+            h->cv.wait(lk, [&] { return h->quit || !h->q1.empty(); });
+            if (h->quit) return;
+            s = h->q1.front();
+            h->q1.pop_front();
+        }
+        bool ok = !h->failed;
+        if (ok) {
+            if (hipEventSynchronize(s->ev_p1) != hipSuccess) {
+                note_error(h, "hipEventSynchronize(phase 1) failed");
+                ok = false;
+            }
+        }
+        if (!ok) {  // keep the pipeline moving: mark every pair as skipped
+            for (int j = 0; j < s->n; j++) {
+                int32_t *meta = s->h_blob + (size_t)j * META_WORDS;
+                for (int q = 0; q < META_WORDS; q++) meta[q] = 0;
+            }
+            s->blob_off.store((size_t)s->dev.cap * META_WORDS);
+            chunk_host_done(h, s);
+            continue;
+        }
+        s->blob_off.store((size_t)s->dev.cap * META_WORDS);
+        s->pending.store(s->n);
+        {
+            std::lock_guard<std::mutex> lk(h->qmu);
+            for (int j = 0; j < s->n; j++) h->queue.push_back(Task{s, j, -1});
+        }
+        h->qcv.notify_all();
+    }
+}
+
+// ---- stage 3: finisher -------------------------------------------------------------------------------------------------
+void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
+    const KParams &k = h->kp;
+    const Dims &d = k.d;
+    const Job &job = h->job;
+    const bool dbg = h->cfg.keep_debug != 0;
+    const int n = s->n;
+    int32_t *blob = s->h_blob;
+    const size_t off = s->blob_off.load();
+    if (dbg) {
+        const int32_t *meta = blob + (size_t)(n - 1) * META_WORDS;
+        dbg_put(h, "support", blob + meta[1], meta[0] >= 3 ? (size_t)meta[0] * 3 : 0);
+        dbg_put(h, "tri1", blob + meta[3], (size_t)meta[2] * 3);
+        dbg_put(h, "tri2", blob + meta[5], (size_t)meta[4] * 3);
+    }
+    HIP_TRY(hipMemcpyAsync(s->dev.blob, blob, off * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    launch_grid(k, s->dev, n, st);
+    launch_triangles(k, s->dev, n, st);
+    launch_dense(k, s->dev, n, st);
+    launch_lr(k, s->dev, n, st);
+    const bool active = dbg && blob[(size_t)(n - 1) * META_WORDS] >= 3;
+    if (active) {
+        const int j = n - 1;
+        const int32_t *meta = blob + (size_t)j * META_WORDS;
+        dbg_grid(h, st, s, j);
+        dbg_from_device(h, st, "planes1", s->dev.planes + ((size_t)j * 2) * d.max_tri * 6, (size_t)meta[2] * 6 * sizeof(float));
+        dbg_from_device(h, st, "planes2", s->dev.planes + ((size_t)j * 2 + 1) * d.max_tri * 6, (size_t)meta[4] * 6 * sizeof(float));
+        dbg_from_device(h, st, "tri_id1", s->dev.tri_id + ((size_t)j * 2) * d.N, (size_t)d.N * 4);
+        dbg_from_device(h, st, "tri_id2", s->dev.tri_id + ((size_t)j * 2 + 1) * d.N, (size_t)d.N * 4);
+        dbg_maps(h, st, "wta", s->dev.wta, j);
+        dbg_maps(h, st, "lr", s->dev.disp, j);
+    }
+    launch_speckle(k, s->dev, n, h->nproc, st);
+    if (active) dbg_maps(h, st, "speckle", s->dev.disp, n - 1);
+    launch_gap_rows(k, s->dev, n, h->nproc, st);
+    launch_gap_cols(k, s->dev, n, h->nproc, st);
+    if (active) dbg_maps(h, st, "gap", s->dev.disp, n - 1);
+    if (h->p.filter_adaptive_mean) launch_amean(k, s->dev, n, h->nproc, st);
+    if (active) dbg_maps(h, st, "amean", s->dev.disp, n - 1);
+    if (h->p.filter_median) launch_median(k, s->dev, n, h->nproc, st);
+    if (active) dbg_maps(h, st, "final", s->dev.disp, n - 1);
+    launch_output(k, s->dev, n, job.d1 + (size_t)s->i0 * d.N, job.d2 ? job.d2 + (size_t)s->i0 * d.N : nullptr, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev_free, st));
+}
+
+void finisher_main(sv_handle *h) {
+    (void)hipSetDevice(h->cfg.device);
     uint64_t seen = 0;
     for (;;) {
         {
             std::unique_lock<std::mutex> lk(h->mu);
-            h->cv_start.wait(lk, [&] { return h->quit || h->generation != seen; });
+            h->cv.wait(lk, [&] { return h->quit || h->generation != seen; });
             if (h->quit) return;
             seen = h->generation;
         }
         g_launch_hook.fn = h->timing ? timing_hook : nullptr;
-        g_launch_hook.ctx = w;
-        try {
-            for (;;) {
-                const int i0 = h->job.next.fetch_add(h->chunk);
-                if (i0 >= h->job.batch) break;
-                process_chunk(w, i0, std::min(h->chunk, h->job.batch - i0));
+        g_launch_hook.ctx = &h->tc_finish;
+        for (int c = 0; c < h->job.nchunks; c++) {
+            Slot *s = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(h->mu);
+                h->cv.wait(lk, [&] { return !h->q2.empty(); });
+                s = h->q2.front();
+                h->q2.pop_front();
             }
-            HIP_TRY(hipStreamSynchronize(w->stream));
-            if (h->timing) collect_timing(w);
-        } catch (const std::exception &e) {
-            std::lock_guard<std::mutex> lk(h->mu);
-            h->failed = true;
-            h->error = e.what();
-            h->job.next.store(h->job.batch);
-            hipStreamSynchronize(w->stream);
+            bool recorded = false;
+            try {
+                if (!h->failed) {
+                    issue_phase2(h, s, h->sP2[c % h->sP2.size()]);
+                    recorded = true;
+                }
+            } catch (const std::exception &e) {
+                note_error(h, e.what());
+            }
+            {
+                std::lock_guard<std::mutex> lk(h->mu);
+                s->state = recorded ? SLOT_DRAINING : SLOT_FREE;
+            }
+            h->cv.notify_all();
+        }
+        bool sync_ok = hipStreamSynchronize(h->sP1) == hipSuccess;
+        for (hipStream_t st : h->sP2) sync_ok = (hipStreamSynchronize(st) == hipSuccess) && sync_ok;
+        if (!sync_ok) note_error(h, "stream synchronisation failed");
+        if (h->timing) {
+            collect_timing(h, &h->tc_issue);
+            collect_timing(h, &h->tc_finish);
         }
         {
             std::lock_guard<std::mutex> lk(h->mu);
-            if (--h->running == 0) h->cv_done.notify_all();
+            h->job_done = true;
         }
+        h->cv.notify_all();
     }
 }
 
@@ -511,16 +587,15 @@ void dev_alloc(T *&p, size_t count) {
     HIP_TRY(hipMalloc((void **)&p, count * sizeof(T)));
 }
 
-void alloc_worker(sv_handle *h, Worker *w) {
+void alloc_slot(sv_handle *h, Slot *sl) {
     const Dims &d = h->kp.d;
     const size_t cap = (size_t)h->chunk;
-    SlotDev &s = w->dev;
+    SlotDev &s = sl->dev;
     s.cap = (int)cap;
-    HIP_TRY(hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking));
     dev_alloc(s.desc, cap * 2 * d.N * 16);
     dev_alloc(s.dcan, cap * d.Wc * d.Hc);
-    w->blob_words = cap * (META_WORDS + (size_t)d.max_pts * 3 + 2 * (size_t)d.max_tri * 3 + 64);
-    dev_alloc(s.blob, w->blob_words);
+    sl->blob_words = cap * (META_WORDS + (size_t)d.max_pts * 3 + 2 * (size_t)d.max_tri * 3 + 64);
+    dev_alloc(s.blob, sl->blob_words);
     dev_alloc(s.trirec, cap * 2 * d.max_tri);
     {
         uint8_t *r = nullptr;
@@ -535,25 +610,34 @@ void alloc_worker(sv_handle *h, Worker *w) {
     dev_alloc(s.disp, cap * 2 * d.N);
     dev_alloc(s.tmp, cap * 2 * d.N);
     dev_alloc(s.csize, cap * 2 * d.N);
-    HIP_TRY(hipHostMalloc((void **)&w->h_dcan, sizeof(int16_t) * cap * d.Wc * d.Hc, hipHostMallocDefault));
-    for (int b = 0; b < 2; b++) {
-        HIP_TRY(hipHostMalloc((void **)&w->h_blob[b], sizeof(int32_t) * w->blob_words, hipHostMallocDefault));
-        HIP_TRY(hipEventCreateWithFlags(&w->blob_copied[b], hipEventDisableTiming));
-    }
+    HIP_TRY(hipHostMalloc((void **)&sl->h_dcan, sizeof(int16_t) * cap * d.Wc * d.Hc, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&sl->h_blob, sizeof(int32_t) * sl->blob_words, hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&sl->ev_p1, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sl->ev_free, hipEventDisableTiming));
 }
 
-void free_worker(Worker *w) {
-    SlotDev &s = w->dev;
+void free_slot(Slot *sl) {
+    SlotDev &s = sl->dev;
     void *dptrs[] = {s.desc, s.dcan, s.blob, s.rrec, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize};
     for (void *p : dptrs)
-        if (p) hipFree(p);
-    if (w->h_dcan) hipHostFree(w->h_dcan);
-    for (int b = 0; b < 2; b++) {
-        if (w->h_blob[b]) hipHostFree(w->h_blob[b]);
-        if (w->blob_copied[b]) hipEventDestroy(w->blob_copied[b]);
+        if (p) (void)hipFree(p);
+    if (sl->h_dcan) (void)hipHostFree(sl->h_dcan);
+    if (sl->h_blob) (void)hipHostFree(sl->h_blob);
+    if (sl->ev_p1) (void)hipEventDestroy(sl->ev_p1);
+    if (sl->ev_free) (void)hipEventDestroy(sl->ev_free);
+}
+
+void free_handle_resources(sv_handle *h) {
+    (void)hipSetDevice(h->cfg.device);
+    for (Slot *sl : h->slots) {
+        free_slot(sl);
+        delete sl;
     }
-    for (hipEvent_t e : w->event_pool) hipEventDestroy(e);
-    if (w->stream) hipStreamDestroy(w->stream);
+    h->slots.clear();
+    for (TimingCtx *t : {&h->tc_issue, &h->tc_finish})
+        for (hipEvent_t e : t->pool) (void)hipEventDestroy(e);
+    if (h->sP1) (void)hipStreamDestroy(h->sP1);
+    for (hipStream_t st : h->sP2) (void)hipStreamDestroy(st);
 }
 
 int run_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status) {
@@ -564,7 +648,7 @@ int run_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, 
     }
     if (batch == 0) return SV_OK;
     std::unique_lock<std::mutex> lk(h->mu);
-    if (h->running != 0) {
+    if (!h->job_done) {
         h->error = "a batch is already in flight on this handle";
         return SV_ERR_STATE;
     }
@@ -575,12 +659,12 @@ int run_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, 
     h->job.d1 = d1;
     h->job.d2 = d2;
     h->job.status = status;
-    h->job.next.store(0);
+    h->job.nchunks = (batch + h->chunk - 1) / h->chunk;
     h->failed = false;
-    h->running = (int)h->workers.size();
+    h->job_done = false;
     h->generation++;
-    h->cv_start.notify_all();
-    h->cv_done.wait(lk, [&] { return h->running == 0; });
+    h->cv.notify_all();
+    h->cv.wait(lk, [&] { return h->job_done; });
     return h->failed ? SV_ERR_HIP : SV_OK;
 }
 
@@ -658,27 +742,31 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     h->cfg = *cfg;
     fill_kparams(h);
     int npool = cfg->n_workers > 0 ? cfg->n_workers : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    int nw = cfg->n_streams > 0 ? cfg->n_streams : 4;
+    int nslots = cfg->n_slots > 0 ? cfg->n_slots : 6;
+    int np2 = cfg->n_streams > 0 ? cfg->n_streams : 2;
     h->chunk = cfg->chunk > 0 ? cfg->chunk : 16;
     if (cfg->keep_debug) {
-        nw = 1;
+        nslots = 1;
+        np2 = 1;
         h->chunk = 1;
     }
     try {
         HIP_TRY(hipSetDevice(cfg->device));
-        for (int i = 0; i < nw; i++) {
-            Worker *w = new Worker();
-            w->h = h;
-            w->id = i;
-            h->workers.push_back(w);
-            alloc_worker(h, w);
+        HIP_TRY(hipStreamCreateWithFlags(&h->sP1, hipStreamNonBlocking));
+        for (int i = 0; i < np2; i++) {
+            hipStream_t st;
+            HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+            h->sP2.push_back(st);
+        }
+        for (int i = 0; i < nslots; i++) {
+            Slot *sl = new Slot();
+            sl->id = i;
+            h->slots.push_back(sl);
+            alloc_slot(h, sl);
         }
     } catch (const std::exception &e) {
         g_create_error = e.what();
-        for (Worker *w : h->workers) {
-            free_worker(w);
-            delete w;
-        }
+        free_handle_resources(h);
         delete h;
         return SV_ERR_HIP;
     }
@@ -687,7 +775,9 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         h->scratch.push_back(sc);
         h->pool.emplace_back(pool_main, h, sc);
     }
-    for (Worker *w : h->workers) w->th = std::thread(worker_main, w);
+    h->t_issue = std::thread(issuer_main, h);
+    h->t_dispatch = std::thread(dispatcher_main, h);
+    h->t_finish = std::thread(finisher_main, h);
     *out = h;
     return SV_OK;
 }
@@ -697,23 +787,19 @@ int sv_destroy(sv_handle *h) {
     {
         std::lock_guard<std::mutex> lk(h->mu);
         h->quit = true;
-        h->cv_start.notify_all();
     }
-    for (Worker *w : h->workers)
-        if (w->th.joinable()) w->th.join();
+    h->cv.notify_all();
+    for (std::thread *t : {&h->t_issue, &h->t_dispatch, &h->t_finish})
+        if (t->joinable()) t->join();
     {
         std::lock_guard<std::mutex> lk(h->qmu);
         h->pool_quit = true;
-        h->qcv.notify_all();
     }
+    h->qcv.notify_all();
     for (std::thread &t : h->pool)
         if (t.joinable()) t.join();
     for (HostScratch *sc : h->scratch) delete sc;
-    (void)hipSetDevice(h->cfg.device);
-    for (Worker *w : h->workers) {
-        free_worker(w);
-        delete w;
-    }
+    free_handle_resources(h);
     delete h;
     return SV_OK;
 }

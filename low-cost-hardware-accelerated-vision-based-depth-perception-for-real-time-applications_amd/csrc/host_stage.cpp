@@ -156,9 +156,9 @@ static inline int64_t incirc(const int32_t *xy, int a, int b, int c, int d) {
     return (adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) + (bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy) + (cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
 }
 
-uint32_t Delaunay::rnd(uint32_t choices) {  // triangle.cpp:3833-3836
+uint32_t Delaunay::rnd(uint32_t choices) {  // triangle.cpp:3833-3836; seed < 714025 so 32-bit arithmetic is exact
     seed_ = (seed_ * 1366u + 150889u) % 714025u;
-    return (uint32_t)(seed_ / (714025u / choices + 1));
+    return seed_ / (714025u / choices + 1);
 }
 
 Delaunay::H Delaunay::make() {  // triangle.cpp:2068-2101; slot 0 stands for "outer space"
@@ -168,23 +168,26 @@ Delaunay::H Delaunay::make() {  // triangle.cpp:2068-2101; slot 0 stands for "ou
     return (H)(n_slots_++) << 2;
 }
 
+// lexicographic (major, minor) order as one 64-bit key: major*2^32 + minor (|minor| < 2^31)
+static inline int64_t key_xy(int32_t major, int32_t minor) { return ((int64_t)major << 32) + (int64_t)minor; }
+
 // Randomised quicksort by (x, y) with the reference's pivot sequence (triangle.cpp:5183-5229): which of two coincident
 // points survives the duplicate scan depends on it.
-void Delaunay::sort_xy(int32_t *a, int n) {
+void Delaunay::sort_xy(Pt *a, int n) {
     if (n == 2) {
-        if (PX(a[0]) > PX(a[1]) || (PX(a[0]) == PX(a[1]) && PY(a[0]) > PY(a[1]))) std::swap(a[0], a[1]);
+        if (key_xy(a[0].x, a[0].y) > key_xy(a[1].x, a[1].y)) std::swap(a[0], a[1]);
         return;
     }
     const int pivot = (int)rnd((uint32_t)n);
-    const int64_t px = PX(a[pivot]), py = PY(a[pivot]);
+    const int64_t pk = key_xy(a[pivot].x, a[pivot].y);
     int left = -1, right = n;
     while (left < right) {
         do {
             left++;
-        } while (left <= right && (PX(a[left]) < px || (PX(a[left]) == px && PY(a[left]) < py)));
+        } while (left <= right && key_xy(a[left].x, a[left].y) < pk);
         do {
             right--;
-        } while (left <= right && (PX(a[right]) > px || (PX(a[right]) == px && PY(a[right]) > py)));
+        } while (left <= right && key_xy(a[right].x, a[right].y) > pk);
         if (left < right) std::swap(a[left], a[right]);
     }
     if (left > 1) sort_xy(a, left);
@@ -193,33 +196,42 @@ void Delaunay::sort_xy(int32_t *a, int n) {
 
 // Randomised partial partition around the median (triangle.cpp:5243-5294); the arrangement it leaves inside each half
 // decides the leaf order of the recursion, hence the diagonals chosen in co-circular quadruples.
-void Delaunay::median_split(int32_t *a, int n, int median, int axis) {
-    const int k1 = axis, k2 = 1 - axis;
-#define K1(v) ((int64_t)xy_[2 * (v) + k1])
-#define K2(v) ((int64_t)xy_[2 * (v) + k2])
+void Delaunay::median_split(Pt *a, int n, int median, int axis) {
+#define KEY(p) (axis == 0 ? key_xy((p).x, (p).y) : key_xy((p).y, (p).x))
     if (n == 2) {
-        if (K1(a[0]) > K1(a[1]) || (K1(a[0]) == K1(a[1]) && K2(a[0]) > K2(a[1]))) std::swap(a[0], a[1]);
+        if (KEY(a[0]) > KEY(a[1])) std::swap(a[0], a[1]);
         return;
     }
     const int pivot = (int)rnd((uint32_t)n);
-    const int64_t p1 = K1(a[pivot]), p2 = K2(a[pivot]);
+    const int64_t pk = KEY(a[pivot]);
     int left = -1, right = n;
-    while (left < right) {
-        do {
-            left++;
-        } while (left <= right && (K1(a[left]) < p1 || (K1(a[left]) == p1 && K2(a[left]) < p2)));
-        do {
-            right--;
-        } while (left <= right && (K1(a[right]) > p1 || (K1(a[right]) == p1 && K2(a[right]) > p2)));
-        if (left < right) std::swap(a[left], a[right]);
+    if (axis == 0) {
+        while (left < right) {
+            do {
+                left++;
+            } while (left <= right && key_xy(a[left].x, a[left].y) < pk);
+            do {
+                right--;
+            } while (left <= right && key_xy(a[right].x, a[right].y) > pk);
+            if (left < right) std::swap(a[left], a[right]);
+        }
+    } else {
+        while (left < right) {
+            do {
+                left++;
+            } while (left <= right && key_xy(a[left].y, a[left].x) < pk);
+            do {
+                right--;
+            } while (left <= right && key_xy(a[right].y, a[right].x) > pk);
+            if (left < right) std::swap(a[left], a[right]);
+        }
     }
-#undef K1
-#undef K2
+#undef KEY
     if (left > median) median_split(a, left, median, axis);
     if (right < median - 1) median_split(a + right + 1, n - right - 1, median - right - 1, axis);
 }
 
-void Delaunay::alternate(int32_t *a, int n, int axis) {  // triangle.cpp:5307-5325
+void Delaunay::alternate(Pt *a, int n, int axis) {  // triangle.cpp:5307-5325
     const int divider = n >> 1;
     if (n <= 3) axis = 0;
     median_split(a, n, divider, axis);
@@ -402,7 +414,8 @@ void Delaunay::merge(H &farleft, H &innerleft, H &innerright, H &farright, int a
 }
 
 // triangle.cpp:5670-5815
-void Delaunay::build(int32_t *a, int n, int axis, H &farleft, H &farright) {
+void Delaunay::build(const Pt *p, int n, int axis, H &farleft, H &farright) {
+    const int a[3] = {p[0].id, p[1].id, n > 2 ? p[2].id : -1};
     if (n == 2) {
         H l = make(), r = make();
         Tri *T = tris_.data();
@@ -479,8 +492,8 @@ void Delaunay::build(int32_t *a, int n, int axis, H &farleft, H &farright) {
     } else {
         const int divider = n >> 1;
         H innerleft, innerright;
-        build(a, divider, 1 - axis, farleft, innerleft);
-        build(a + divider, n - divider, 1 - axis, innerright, farright);
+        build(p, divider, 1 - axis, farleft, innerleft);
+        build(p + divider, n - divider, 1 - axis, innerright, farright);
         merge(farleft, innerleft, innerright, farright, axis);
     }
 }
@@ -494,12 +507,12 @@ int Delaunay::triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap) {
     if ((int)tris_.size() < 3 * n + 8) tris_.resize(3 * n + 8);
     n_slots_ = 0;
     make();
-    int32_t *a = order_.data();
-    for (int i = 0; i < n; i++) a[i] = i;
+    Pt *a = order_.data();
+    for (int i = 0; i < n; i++) a[i] = Pt{xy[2 * i], xy[2 * i + 1], i};
     sort_xy(a, n);
     int m = 0;
     for (int j = 1; j < n; j++) {  // triangle.cpp:5890-5903: the first of a group of coincident points is kept
-        if (xy[2 * a[m]] == xy[2 * a[j]] && xy[2 * a[m] + 1] == xy[2 * a[j] + 1]) continue;
+        if (a[m].x == a[j].x && a[m].y == a[j].y) continue;
         a[++m] = a[j];
     }
     m++;

@@ -37,17 +37,21 @@ class Delaunay {
     };
     typedef int32_t H;  // oriented-triangle handle: (slot << 2) | orientation
 
+    struct Pt {  // sort element: coordinates travel with the vertex id, so comparisons never chase an index
+        int32_t x, y, id;
+    };
+
     const int32_t *xy_ = nullptr;
     std::vector<Tri> tris_;
-    std::vector<int32_t> order_;
+    std::vector<Pt> order_;
     int n_slots_ = 0;
-    uint64_t seed_ = 1;
+    uint32_t seed_ = 1;
 
     H make();
-    void sort_xy(int32_t *a, int n);
-    void median_split(int32_t *a, int n, int median, int axis);
-    void alternate(int32_t *a, int n, int axis);
-    void build(int32_t *a, int n, int axis, H &farleft, H &farright);
+    void sort_xy(Pt *a, int n);
+    void median_split(Pt *a, int n, int median, int axis);
+    void alternate(Pt *a, int n, int axis);
+    void build(const Pt *a, int n, int axis, H &farleft, H &farright);
     void merge(H &farleft, H &innerleft, H &innerright, H &farright, int axis);
     uint32_t rnd(uint32_t choices);
 };

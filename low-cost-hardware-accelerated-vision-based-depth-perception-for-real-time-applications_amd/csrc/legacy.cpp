@@ -93,6 +93,7 @@ bool legacy_init(int width, int height, float scale, const char *yaml, bool subs
     cfg.device = 0;
     cfg.n_workers = 2;
     cfg.n_streams = 1;
+    cfg.n_slots = 2;
     cfg.chunk = 1;
     if (sv_create(&p, &cfg, &g.engine) != SV_OK) {
         fprintf(stderr, "stereo_vision_hip: %s\n", sv_last_error(nullptr));

@@ -46,7 +46,7 @@ class SvParams(ctypes.Structure):
 
 class SvConfig(ctypes.Structure):
     _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("device", ctypes.c_int32), ("n_workers", ctypes.c_int32),
-                ("chunk", ctypes.c_int32), ("keep_debug", ctypes.c_int32), ("n_streams", ctypes.c_int32)]
+                ("chunk", ctypes.c_int32), ("keep_debug", ctypes.c_int32), ("n_streams", ctypes.c_int32), ("n_slots", ctypes.c_int32)]
 
 
 _lib = None
@@ -109,11 +109,11 @@ class StereoEngine:
     d1, d2 = engine.process_device(left_u8_cuda, right_u8_cuda)     # torch tensors [B,H,W] -> float32 [B,H,W]
     """
 
-    def __init__(self, width, height, params=None, device=0, n_workers=0, chunk=0, keep_debug=False, n_streams=0):
+    def __init__(self, width, height, params=None, device=0, n_workers=0, chunk=0, keep_debug=False, n_streams=0, n_slots=0):
         L = lib()
         self.params = params if params is not None else SvParams.driver(127)
         self.width, self.height, self.device = int(width), int(height), int(device)
-        cfg = SvConfig(self.width, self.height, self.device, int(n_workers), int(chunk), int(bool(keep_debug)), int(n_streams))
+        cfg = SvConfig(self.width, self.height, self.device, int(n_workers), int(chunk), int(bool(keep_debug)), int(n_streams), int(n_slots))
         h = ctypes.c_void_p()
         rc = L.sv_create(ctypes.byref(self.params), ctypes.byref(cfg), ctypes.byref(h))
         if rc != 0:

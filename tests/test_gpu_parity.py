@@ -66,7 +66,7 @@ def test_batch_of_distinct_pairs_many_workers(eng, oracle):
     H, W, D, B = 120, 320, 64, 13
     batch = synth.make_batch(200, B, H, W, D)
     p = eng.SvParams.driver(D - 1)
-    e = eng.StereoEngine(W, H, p, n_workers=3, chunk=2, n_streams=3)
+    e = eng.StereoEngine(W, H, p, n_workers=3, chunk=2, n_streams=2, n_slots=3)
     try:
         left = torch.from_numpy(batch[:, 0].copy()).cuda()
         right = torch.from_numpy(batch[:, 1].copy()).cuda()
@@ -129,8 +129,8 @@ def test_determinism_full_size(eng):
     left = torch.from_numpy(batch[:, 0].copy()).cuda()
     right = torch.from_numpy(batch[:, 1].copy()).cuda()
     outs = []
-    for nw, ch, ns in ((1, 6, 1), (4, 1, 3)):
-        e = eng.StereoEngine(1242, 375, eng.SvParams.driver(127), n_workers=nw, chunk=ch, n_streams=ns)
+    for nw, ch, ns, nsl in ((1, 6, 1, 1), (4, 1, 2, 4)):
+        e = eng.StereoEngine(1242, 375, eng.SvParams.driver(127), n_workers=nw, chunk=ch, n_streams=ns, n_slots=nsl)
         try:
             d1, d2 = e.process_device(left, right)
             torch.cuda.synchronize()
