@@ -89,7 +89,7 @@ typedef struct sv_config {
     int32_t chunk;      /* pairs per GPU launch = pairs per pipeline slot (0 = default 16) */
     int32_t keep_debug; /* != 0: keep per-stage intermediates of the LAST processed pair for sv_debug_get */
     int32_t n_streams;  /* HIP streams the second GPU phase alternates over (0 = default 2); phase 1 has its own stream */
-    int32_t n_slots;    /* buffer slots (chunks in flight) of the 3-stage pipeline (0 = default 6) */
+    int32_t n_slots;    /* buffer slots (chunks in flight) of the 3-stage pipeline (0 = default 10) */
 } sv_config;
 
 int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out);

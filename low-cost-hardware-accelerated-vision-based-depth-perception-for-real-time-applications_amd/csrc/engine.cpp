@@ -505,7 +505,9 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
     launch_grid(k, s->dev, n, st);
     launch_triangles(k, s->dev, n, st);
     launch_dense(k, s->dev, n, st);
-    launch_lr(k, s->dev, n, st);
+    float *u1 = job.d1 + (size_t)s->i0 * d.N, *u2 = job.d2 ? job.d2 + (size_t)s->i0 * d.N : nullptr;
+    const bool only_left = h->nproc == 1;
+    launch_lr(k, s->dev, n, st, only_left ? u2 : nullptr);  // with postprocess_only_left the checked right map is final
     const bool active = dbg && blob[(size_t)(n - 1) * META_WORDS] >= 3;
     if (active) {
         const int j = n - 1;
@@ -525,9 +527,12 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
     if (active) dbg_maps(h, st, "gap", s->dev.disp, n - 1);
     if (h->p.filter_adaptive_mean) launch_amean(k, s->dev, n, h->nproc, st);
     if (active) dbg_maps(h, st, "amean", s->dev.disp, n - 1);
-    if (h->p.filter_median) launch_median(k, s->dev, n, h->nproc, st);
+    if (h->p.filter_median) {  // the last stage writes the caller's maps itself
+        launch_median(k, s->dev, n, h->nproc, st, u1, only_left ? nullptr : u2);
+    } else {
+        launch_output(k, s->dev, n, u1, only_left ? nullptr : u2, st);
+    }
     if (active) dbg_maps(h, st, "final", s->dev.disp, n - 1);
-    launch_output(k, s->dev, n, job.d1 + (size_t)s->i0 * d.N, job.d2 ? job.d2 + (size_t)s->i0 * d.N : nullptr, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev_free, st));
 }
@@ -742,7 +747,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     h->cfg = *cfg;
     fill_kparams(h);
     int npool = cfg->n_workers > 0 ? cfg->n_workers : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    int nslots = cfg->n_slots > 0 ? cfg->n_slots : 6;
+    int nslots = cfg->n_slots > 0 ? cfg->n_slots : 10;
     int np2 = cfg->n_streams > 0 ? cfg->n_streams : 2;
     h->chunk = cfg->chunk > 0 ? cfg->chunk : 16;
     if (cfg->keep_debug) {

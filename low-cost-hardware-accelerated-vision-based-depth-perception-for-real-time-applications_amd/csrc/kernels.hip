@@ -66,47 +66,119 @@ __device__ __forceinline__ int sat_u8(int x) { return x < 0 ? 0 : (x > 255 ? 255
 //     then one 16-byte store per pixel (1 KiB per wavefront store instruction).  Pixels outside
 //     [3,W-3)x[3,H-3) get the canonical zero descriptor (the reference leaves them uninitialised).
 // ------------------------------------------------------------------------------------------------------------
+// LDS tiles are byte images with word-aligned rows; tile column c <-> image column x0 - 4 + c, so every 4-pixel group
+// of the output tile starts on a word.  All LDS traffic is 32-bit; bytes are picked with v_perm_b32 / v_bfe.
+#define DESC_TW 64   // output tile width
+#define DESC_TH 16   // output tile height
+#define DESC_GS 76   // gray tile row stride in bytes (19 words)  : rows y0-3 .. y0+TH+2
+#define DESC_DS 72   // du/dv tile row stride in bytes (18 words) : rows y0-2 .. y0+TH+1
+
+// byte i (0..7) of the 8-byte little-endian pair (lo, hi)
+__device__ __forceinline__ uint32_t byte_of(uint32_t lo, uint32_t hi, int i) { return i < 4 ? (lo >> (8 * i)) & 0xFFu : (hi >> (8 * (i - 4))) & 0xFFu; }
+
 __global__ __launch_bounds__(256) void k_descriptor(const uint8_t *__restrict__ left, const uint8_t *__restrict__ right, size_t in_pair_stride, int stride,
                                                     uint8_t *__restrict__ desc, Dims d) {
     const int img = blockIdx.z & 1, pair = blockIdx.z >> 1;
     const uint8_t *I = (img ? right : left) + (size_t)pair * in_pair_stride;
     uint8_t *out = desc + ((size_t)(pair * 2 + img) * d.N) * 16;
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 8;
-    __shared__ uint8_t g[14][72];
-    __shared__ uint8_t sdu[12][68];
-    __shared__ uint8_t sdv[12][68];
+    const int x0 = blockIdx.x * DESC_TW, y0 = blockIdx.y * DESC_TH;
+    __shared__ __attribute__((aligned(16))) uint8_t g[(DESC_TH + 6) * DESC_GS];
+    __shared__ __attribute__((aligned(16))) uint8_t sdu[(DESC_TH + 4) * DESC_DS];
+    __shared__ __attribute__((aligned(16))) uint8_t sdv[(DESC_TH + 4) * DESC_DS];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 14 * 70; i += 256) {
-        int r = i / 70, c = i - r * 70;
-        int y = y0 - 3 + r, x = x0 - 3 + c;
-        g[r][c] = (x >= 0 && x < d.W && y >= 0 && y < d.H) ? I[(size_t)y * stride + x] : (uint8_t)0;
-    }
-    __syncthreads();
-    for (int i = tid; i < 12 * 68; i += 256) {
-        int r = i / 68, c = i - r * 68;
-        // du/dv at (x0-2+c, y0-2+r); gray rows r..r+2 are y-1..y+1, gray cols c..c+2 are x-1..x+1
-        int a0 = g[r][c], a1 = g[r + 1][c], a2 = g[r + 2][c];
-        int b0 = g[r][c + 1], b2 = g[r + 2][c + 1];
-        int c0 = g[r][c + 2], c1 = g[r + 1][c + 2], c2 = g[r + 2][c + 2];
-        int Sl = a0 + 2 * a1 + a2, Sr = c0 + 2 * c1 + c2;  // vertical (1,2,1) at x-1, x+1
-        int Tl = a0 - a2, Tc = b0 - b2, Tr = c0 - c2;       // vertical (1,0,-1) at x-1, x, x+1
-        sdu[r][c] = (uint8_t)sat_u8(((Sl - Sr) >> 2) + 128);
-        sdv[r][c] = (uint8_t)sat_u8(((Tl + 2 * Tc + Tr) >> 2) + 128);
-    }
-    __syncthreads();
-    const int tx = tid & 63, ty = tid >> 6;
+    // phase A: gray tile, one word (4 pixels) per item; pixels outside the image read as 0 (they never reach a valid descriptor)
+    for (int i = tid; i < (DESC_TH + 6) * (DESC_GS / 4); i += 256) {
+        const int r = i / (DESC_GS / 4), cw = i - r * (DESC_GS / 4);
+        const int y = y0 - 3 + r, xb = x0 - 4 + 4 * cw;
+        uint32_t w = 0;
+        if (y >= 0 && y < d.H) {
+            const uint8_t *row = I + (size_t)y * stride;
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int rr = ty + 4 * k;
-        const int x = x0 + tx, y = y0 + rr;
-        if (x >= d.W || y >= d.H) continue;
+            for (int j = 0; j < 4; j++) {
+                const int x = xb + j;
+                if (x >= 0 && x < d.W) w |= (uint32_t)row[x] << (8 * j);
+            }
+        }
+        *reinterpret_cast<uint32_t *>(&g[r * DESC_GS + 4 * cw]) = w;
+    }
+    __syncthreads();
+    // phase B: du/dv, one word (4 pixels) per item.  du/dv row r <-> y = y0-2+r uses gray rows r, r+1, r+2 (y-1, y, y+1);
+    // columns c..c+3 use gray columns c-1..c+4.
+    for (int i = tid; i < (DESC_TH + 4) * (DESC_DS / 4); i += 256) {
+        const int r = i / (DESC_DS / 4), cw = i - r * (DESC_DS / 4);
+        const int c = 4 * cw;
+        uint32_t du_w = 0, dv_w = 0;
+        if (cw >= 0) {
+            // 12 gray bytes per row: words c-4, c, c+4 (clamped inside the tile; the clamped ones only feed unused columns)
+            const int wl = max(c - 4, 0), wr = min(c + 4, DESC_GS - 4);
+            uint32_t a[3][3];
+#pragma unroll
+            for (int rr = 0; rr < 3; rr++) {
+                const uint8_t *gr = &g[(r + rr) * DESC_GS];
+                a[rr][0] = *reinterpret_cast<const uint32_t *>(gr + wl);
+                a[rr][1] = *reinterpret_cast<const uint32_t *>(gr + c);
+                a[rr][2] = *reinterpret_cast<const uint32_t *>(gr + wr);
+            }
+            // column sums for gray columns c-1 .. c+4 (6 columns): S = (1,2,1) vertical, T = (1,0,-1) vertical
+            int S[6], T[6];
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                // gray column c-1+q: q=0 -> byte 3 of word 0; q=1..4 -> bytes 0..3 of word 1; q=5 -> byte 0 of word 2
+                int t0, t1, t2;
+                if (q == 0) {
+                    t0 = (a[0][0] >> 24) & 0xFF, t1 = (a[1][0] >> 24) & 0xFF, t2 = (a[2][0] >> 24) & 0xFF;
+                } else if (q == 5) {
+                    t0 = a[0][2] & 0xFF, t1 = a[1][2] & 0xFF, t2 = a[2][2] & 0xFF;
+                } else {
+                    t0 = (a[0][1] >> (8 * (q - 1))) & 0xFF, t1 = (a[1][1] >> (8 * (q - 1))) & 0xFF, t2 = (a[2][1] >> (8 * (q - 1))) & 0xFF;
+                }
+                S[q] = t0 + 2 * t1 + t2;
+                T[q] = t0 - t2;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {  // pixel column c+j: neighbours are S/T index j (x-1), j+1 (x), j+2 (x+1)
+                const int du = sat_u8(((S[j] - S[j + 2]) >> 2) + 128);
+                const int dv = sat_u8(((T[j] + 2 * T[j + 1] + T[j + 2]) >> 2) + 128);
+                du_w |= (uint32_t)du << (8 * j);
+                dv_w |= (uint32_t)dv << (8 * j);
+            }
+        }
+        *reinterpret_cast<uint32_t *>(&sdu[r * DESC_DS + c]) = du_w;
+        *reinterpret_cast<uint32_t *>(&sdv[r * DESC_DS + c]) = dv_w;
+    }
+    __syncthreads();
+    // phase C: each thread assembles the descriptors of 4 consecutive pixels of one row (descriptor.cpp:105-121)
+    const int qx = tid & 15, ry = tid >> 4;  // pixels x0+4qx .. +3, row y0+ry
+    const int y = y0 + ry;
+    if (y >= d.H) return;
+    const int c = 4 + 4 * qx;  // tile column of the quad's first pixel
+    // du rows y-2..y+2 are tile rows ry..ry+4 ; dv rows y-1..y+1 are tile rows ry+1..ry+3
+    const uint8_t *u0 = &sdu[(ry + 0) * DESC_DS + c], *u1 = &sdu[(ry + 1) * DESC_DS + c], *u2 = &sdu[(ry + 2) * DESC_DS + c];
+    const uint8_t *u3 = &sdu[(ry + 3) * DESC_DS + c], *u4 = &sdu[(ry + 4) * DESC_DS + c];
+    const uint8_t *w1 = &sdv[(ry + 1) * DESC_DS + c], *w2 = &sdv[(ry + 2) * DESC_DS + c], *w3 = &sdv[(ry + 3) * DESC_DS + c];
+#define LDW(p, off) (*reinterpret_cast<const uint32_t *>((p) + (off)))
+    const uint32_t r0 = LDW(u0, 0), r4 = LDW(u4, 0);
+    const uint32_t r1a = LDW(u1, -4), r1b = LDW(u1, 0), r1c = LDW(u1, 4);
+    const uint32_t r2a = LDW(u2, -4), r2b = LDW(u2, 0), r2c = LDW(u2, 4);
+    const uint32_t r3a = LDW(u3, -4), r3b = LDW(u3, 0), r3c = LDW(u3, 4);
+    const uint32_t v1 = LDW(w1, 0), v3 = LDW(w3, 0);
+    const uint32_t v2a = LDW(w2, -4), v2b = LDW(w2, 0), v2c = LDW(w2, 4);
+#undef LDW
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int x = x0 + 4 * qx + j;
+        if (x >= d.W) break;
         uint4 o = make_uint4(0, 0, 0, 0);
         if (x >= 3 && x < d.W - 3 && y >= 3 && y < d.H - 3) {
-            const int cx = tx + 2;  // column of x in the du/dv tile; row of y is rr+2
-            uint32_t b0 = sdu[rr][cx], b1 = sdu[rr + 1][cx - 2], b2 = sdu[rr + 1][cx], b3 = sdu[rr + 1][cx + 2];
-            uint32_t b4 = sdu[rr + 2][cx - 1], b5 = sdu[rr + 2][cx], b7 = sdu[rr + 2][cx + 1];
-            uint32_t b8 = sdu[rr + 3][cx - 2], b9 = sdu[rr + 3][cx], b10 = sdu[rr + 3][cx + 2], b11 = sdu[rr + 4][cx];
-            uint32_t b12 = sdv[rr + 1][cx], b13 = sdv[rr + 2][cx - 1], b14 = sdv[rr + 2][cx + 1], b15 = sdv[rr + 3][cx];
+            // byte k of the 12-byte window (a,b,c) starting at column c-4: column c+j+off is window byte 4+j+off
+#define WB(a, b, cc, off) ((4 + j + (off)) < 4 ? ((a) >> (8 * (4 + j + (off)))) & 0xFFu : (4 + j + (off)) < 8 ? ((b) >> (8 * (j + (off)))) & 0xFFu : ((cc) >> (8 * (j + (off) - 4))) & 0xFFu)
+            const uint32_t b0 = (r0 >> (8 * j)) & 0xFFu, b11 = (r4 >> (8 * j)) & 0xFFu;
+            const uint32_t b1 = WB(r1a, r1b, r1c, -2), b2 = WB(r1a, r1b, r1c, 0), b3 = WB(r1a, r1b, r1c, 2);
+            const uint32_t b4 = WB(r2a, r2b, r2c, -1), b5 = WB(r2a, r2b, r2c, 0), b7 = WB(r2a, r2b, r2c, 1);
+            const uint32_t b8 = WB(r3a, r3b, r3c, -2), b9 = WB(r3a, r3b, r3c, 0), b10 = WB(r3a, r3b, r3c, 2);
+            const uint32_t b12 = (v1 >> (8 * j)) & 0xFFu, b15 = (v3 >> (8 * j)) & 0xFFu;
+            const uint32_t b13 = WB(v2a, v2b, v2c, -1), b14 = WB(v2a, v2b, v2c, 1);
+#undef WB
             o.x = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
             o.y = b4 | (b5 << 8) | (b5 << 16) | (b7 << 24);
             o.z = b8 | (b9 << 8) | (b10 << 16) | (b11 << 24);
@@ -117,7 +189,7 @@ __global__ __launch_bounds__(256) void k_descriptor(const uint8_t *__restrict__ 
 }
 
 void launch_descriptor(const KParams &k, const uint8_t *left, const uint8_t *right, size_t in_pair_stride, int stride, const SlotDev &s, int n, hipStream_t st) {
-    dim3 grid((k.d.W + 63) / 64, (k.d.H + 7) / 8, n * 2);
+    dim3 grid((k.d.W + DESC_TW - 1) / DESC_TW, (k.d.H + DESC_TH - 1) / DESC_TH, n * 2);
     SV_LAUNCH(K_DESCRIPTOR, k_descriptor, grid, dim3(256), 0, st, left, right, in_pair_stride, stride, s.desc, k.d);
 }
 
@@ -137,12 +209,23 @@ struct SupRows {            // one staged image: two rows (v-2, v+2), columns [c
     int c0;
 };
 
+// butterfly over the 64 lanes that keeps, per lane pair, the smaller (energy<<16|d) key and the second smallest energy
+__device__ __forceinline__ void wave_top2(uint32_t &k1, uint32_t &e2) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const uint32_t ok = (uint32_t)__shfl_xor((int)k1, off, 64);
+        const uint32_t oe = (uint32_t)__shfl_xor((int)e2, off, 64);
+        const uint32_t hi = (ok > k1 ? ok : k1) >> 16;  // energy of the larger key: second-best candidate of the pair
+        k1 = ok < k1 ? ok : k1;
+        e2 = min(min(e2, oe), hi);
+    }
+}
+
 __device__ __forceinline__ int support_match(const KParams &k, const uint8_t *__restrict__ Aimg, const SupRows &A, const SupRows &B, int u, int v, bool right_image,
                                              int lane) {
     const int W = k.d.W, H = k.d.H;
     if (!(u >= 5 && u <= W - 6 && v >= 5 && v <= H - 6)) return -1;  // elas.cpp:279
-    const uint4 centre = ld16(Aimg + ((size_t)v * W + u) * 16);
-    if ((int)texture16(centre) < k.support_texture) return -1;  // :296-300
+    const uint4 centre = ld16(Aimg + ((size_t)v * W + u) * 16);  // consumed after the search so that its latency is hidden
     const int dmax = right_image ? min(k.d.disp_max, W - u - 5) : min(k.d.disp_max, u - 5);  // :318-323 (disp_min = 0)
     if (dmax < 10) return -1;                                                                // :326
     const int ua = u - A.c0;
@@ -159,11 +242,12 @@ __device__ __forceinline__ int support_match(const KParams &k, const uint8_t *__
             e2 = e;
         }
     }
-    const uint32_t key = (e1 << 16) | d1;      // min over keys = lowest energy, then lowest d (first-wins under strict <)
-    const uint32_t best = wave_min_u32(key);
-    const uint32_t contrib = (key == best) ? e2 : e1;  // second order statistic of the energy multiset
-    const uint32_t second = wave_min_u32(contrib);
-    const float E1 = (float)(best >> 16), E2 = (float)second;
+    // min over keys = lowest energy, then lowest d (first-wins under strict <); e2 ends as the second order statistic of the
+    // whole energy multiset
+    uint32_t best = (e1 << 16) | d1;
+    wave_top2(best, e2);
+    if ((int)texture16(centre) < k.support_texture) return -1;  // :296-300 (wave-uniform: every lane loaded the same descriptor)
+    const float E1 = (float)(best >> 16), E2 = (float)e2;
     if (E1 < k.support_threshold * E2) return (int)(best & 0xFFFFu);  // :364
     return -1;
 }
@@ -534,7 +618,33 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
             const uint32_t *cell = gB + ((size_t)ps * d.ncell + (size_t)gy * d.gw + gx) * d.MW;
             const uint4 *row = other_row - c0;
             int min_val = 10000, min_d = -1;
-            for (int w = 0; w < d.MW; w++) {  // grid candidates outside the band (:759-767 / :778-786)
+            uint32_t mw[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) mw[w] = w < d.MW ? cell[w] : 0u;  // all mask loads in flight at once
+#pragma unroll
+            for (int w = 0; w < 8; w++) {  // grid candidates outside the band (:759-767 / :778-786)
+                if (w >= d.MW) break;
+                uint32_t m = mw[w];
+                const int lo = d_plane_min - 32 * w, hi = d_plane_max - 32 * w;
+                if (lo <= 31 && hi >= 0 && lo <= hi) {
+                    const int l = max(lo, 0), h = min(hi, 31);
+                    const uint32_t upto_h = h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u);
+                    m &= ~(upto_h & ~((1u << l) - 1u));
+                }
+                while (m) {
+                    const int b = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    const int dc = 32 * w + b;
+                    const int uw = side ? u + dc : u - dc;
+                    if (uw < 2 || uw >= d.W - 2) continue;
+                    const int val = (int)sad16(own, row[uw]);
+                    if (val < min_val) {
+                        min_val = val;
+                        min_d = dc;
+                    }
+                }
+            }
+            for (int w = 8; w < d.MW; w++) {  // disp_max > 255: remaining words straight from memory
                 uint32_t m = cell[w];
                 const int lo = d_plane_min - 32 * w, hi = d_plane_max - 32 * w;
                 if (lo <= 31 && hi >= 0 && lo <= hi) {
@@ -578,7 +688,8 @@ void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------------------
 // K6  left/right consistency check      reference: elas.cpp:946-1011
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lr(KParams k, const int32_t *__restrict__ blob, const float *__restrict__ wta, float *__restrict__ disp) {
+__global__ __launch_bounds__(256) void k_lr(KParams k, const int32_t *__restrict__ blob, const float *__restrict__ wta, float *__restrict__ disp,
+                                            float *__restrict__ user_d2) {
     const Dims &d = k.d;
     const int pair = blockIdx.z;
     if (blob[pair * META_WORDS] < 3) return;
@@ -594,10 +705,11 @@ __global__ __launch_bounds__(256) void k_lr(KParams k, const int32_t *__restrict
     if (d2 >= 0 && uw2 >= 0 && uw2 < (float)d.W) o2 = (fabsf(W1[row + (int)uw2] - d2) > thr) ? -10.0f : d2;
     disp[(size_t)(pair * 2) * d.N + row + u] = o1;
     disp[(size_t)(pair * 2 + 1) * d.N + row + u] = o2;
+    if (user_d2) user_d2[(size_t)pair * d.N + row + u] = o2;  // postprocess_only_left: the checked right map is already final
 }
 
-void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
-    SV_LAUNCH(K_LR, k_lr, dim3((k.d.W + 255) / 256, k.d.H, n), dim3(256), 0, st, k, s.blob, s.wta, s.disp);
+void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st, float *user_d2) {
+    SV_LAUNCH(K_LR, k_lr, dim3((k.d.W + 255) / 256, k.d.H, n), dim3(256), 0, st, k, s.blob, s.wta, s.disp, user_d2);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -991,24 +1103,31 @@ __global__ __launch_bounds__(256) void k_median_h(KParams k, int nproc, const in
     tmp[off + (size_t)v * d.W + u] = out;
 }
 
-__global__ __launch_bounds__(256) void k_median_v(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ tmp, float *__restrict__ disp) {
+__global__ __launch_bounds__(256) void k_median_v(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ tmp, float *__restrict__ disp,
+                                                  float *__restrict__ user_d1, float *__restrict__ user_d2) {
     const Dims &d = k.d;
     const int m = blockIdx.z;
-    if (blob[(m / nproc) * META_WORDS] < 3) return;
+    const int pair = m / nproc, side = m - pair * nproc;
+    if (blob[pair * META_WORDS] < 3) return;
     const size_t off = map_offset(d, m, nproc);
     const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
-    if (u < 3 || u >= d.W - 3 || v < 3 || v >= d.H - 3) return;
-    const size_t p = off + (size_t)v * d.W + u;
-    if (!(disp[p] >= 0)) return;
-    const float *T = tmp + p;
-    const size_t W = d.W;
-    disp[p] = median7(T[-3 * (long)W], T[-2 * (long)W], T[-(long)W], T[0], T[W], T[2 * W], T[3 * W]);
+    if (u >= d.W) return;
+    const size_t q = (size_t)v * d.W + u, p = off + q;
+    float val = disp[p];
+    if (u >= 3 && u < d.W - 3 && v >= 3 && v < d.H - 3 && val >= 0) {
+        const float *T = tmp + p;
+        const long W = d.W;
+        val = median7(T[-3 * W], T[-2 * W], T[-W], T[0], T[W], T[2 * W], T[3 * W]);
+        disp[p] = val;
+    }
+    float *user = side == 0 ? user_d1 : user_d2;  // the last stage writes the caller's map directly
+    if (user) user[(size_t)pair * d.N + q] = val;
 }
 
-void launch_median(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st) {
+void launch_median(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st, float *user_d1, float *user_d2) {
     dim3 grid((k.d.W + 255) / 256, k.d.H, n * nproc);
     SV_LAUNCH(K_MEDIAN_H, k_median_h, grid, dim3(256), 0, st, k, nproc, s.blob, s.disp, s.tmp);
-    SV_LAUNCH(K_MEDIAN_V, k_median_v, grid, dim3(256), 0, st, k, nproc, s.blob, s.tmp, s.disp);
+    SV_LAUNCH(K_MEDIAN_V, k_median_v, grid, dim3(256), 0, st, k, nproc, s.blob, s.tmp, s.disp, user_d1, user_d2);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -61,12 +61,12 @@ void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st);
 void launch_grid(const KParams &k, const SlotDev &s, int n, hipStream_t st);
 void launch_triangles(const KParams &k, const SlotDev &s, int n, hipStream_t st);
 void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st);
-void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st);
+void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st, float *user_d2);
 void launch_speckle(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
 void launch_gap_rows(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
 void launch_gap_cols(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
 void launch_amean(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
-void launch_median(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
+void launch_median(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st, float *user_d1, float *user_d2);
 void launch_output(const KParams &k, const SlotDev &s, int n, float *d1, float *d2, hipStream_t st);
 
 // names of the kernels behind each wrapper, in launch order, for timing reports
