@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="pairs per launch (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=64, help="pairs timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--serial-kernels", action="store_true", help="extra pass with one slot / one stream (no kernel overlap) to get clean per-kernel times")
     ap.add_argument("--gather", action="store_true", help="after the timed region, also gather all left maps on rank 0 (RCCL) and report the time")
     args = ap.parse_args()
 
@@ -141,6 +142,17 @@ def main():
     valid_frac = float((d1 >= 0).float().mean().item())
     checksum = float(d1.double().sum().item())
 
+    serial_k = None
+    if args.serial_kernels and rank == 0:
+        es = eng.StereoEngine(W, H, params, device=local_rank, n_workers=args.workers, chunk=args.chunk or 16, n_streams=1, n_slots=1)
+        es.process_device(left, right, d1, d2)
+        es.timing(True)
+        es.process_device(left, right, d1, d2)
+        kt = es.kernel_times()
+        es.close()
+        serial_k = {k: round(1e3 * v[0] / B, 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0]) if v[1] > 0}
+        serial_k["_sum"] = round(sum(serial_k.values()), 3)
+
     # batch-1 latency on rank 0 (ms/frame): one pair per call, one worker
     lat_ms = None
     if rank == 0:
@@ -173,7 +185,7 @@ def main():
             "config": {"workload": "kitti_1242x375_D128_batch%d_per_gpu_streamed" % B, "width": W, "height": H, "disp_max": D - 1,
                        "preset": "driver(MIDDLEBURY+only_left+adaptive_mean+median)", "pairs_per_gpu_per_step": B,
                        "parallelism": "batch-sharded x%d, no data-path collective" % world},
-            "latency_ms_batch1": lat_ms, "gather_ms": gather_ms,
+            "latency_ms_batch1": lat_ms, "gather_ms": gather_ms, "serial_kernel_us_per_pair": serial_k,
             "valid_fraction": round(valid_frac, 4), "checksum_rank0": checksum,
         }
         if ktimes:

@@ -204,28 +204,43 @@ void launch_descriptor(const KParams &k, const uint8_t *left, const uint8_t *rig
 // [u-d-2, u-d+2+dmax]; neighbouring lattice points (5 px apart) share almost all of it.
 #define SUP_CANDS 16
 
-struct SupRows {            // one staged image: two rows (v-2, v+2), columns [c0, c0+n)
-    const uint4 *r0, *r1;
+struct SupRows {            // one staged image: rows v-2, v+2 (corner blocks) and v (texture test), columns [c0, c0+n)
+    const uint4 *r0, *r1, *rc;
     int c0;
 };
 
-// butterfly over the 64 lanes that keeps, per lane pair, the smaller (energy<<16|d) key and the second smallest energy
-__device__ __forceinline__ void wave_top2(uint32_t &k1, uint32_t &e2) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const uint32_t ok = (uint32_t)__shfl_xor((int)k1, off, 64);
-        const uint32_t oe = (uint32_t)__shfl_xor((int)e2, off, 64);
-        const uint32_t hi = (ok > k1 ? ok : k1) >> 16;  // energy of the larger key: second-best candidate of the pair
-        k1 = ok < k1 ? ok : k1;
-        e2 = min(min(e2, oe), hi);
-    }
+// Wavefront reduction with DPP row shifts (no LDS crossbar traffic): an inclusive scan over disjoint lane ranges
+// (row_shr 1,2,4,8, then row_bcast 15 / 31), total in lane 63.  The element is (k1, e2): k1 = smallest (energy<<16|d) key,
+// e2 = second smallest energy of the lanes merged so far; lanes without a source receive the identity.
+__device__ __forceinline__ void top2_merge(uint32_t &k1, uint32_t &e2, uint32_t ok, uint32_t oe) {
+    const uint32_t hi = (ok > k1 ? ok : k1) >> 16;  // energy of the larger key: runner-up of the merged pair
+    k1 = ok < k1 ? ok : k1;
+    e2 = min(min(e2, oe), hi);
 }
 
-__device__ __forceinline__ int support_match(const KParams &k, const uint8_t *__restrict__ Aimg, const SupRows &A, const SupRows &B, int u, int v, bool right_image,
-                                             int lane) {
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void top2_dpp_step(uint32_t &k1, uint32_t &e2) {
+    const uint32_t ok = (uint32_t)__builtin_amdgcn_update_dpp((int)0x7FFFFFFF, (int)k1, CTRL, ROW_MASK, 0xf, false);
+    const uint32_t oe = (uint32_t)__builtin_amdgcn_update_dpp((int)0x7FFF, (int)e2, CTRL, ROW_MASK, 0xf, false);
+    top2_merge(k1, e2, ok, oe);
+}
+
+__device__ __forceinline__ void wave_top2(uint32_t &k1, uint32_t &e2) {
+    top2_dpp_step<0x111, 0xf>(k1, e2);  // row_shr:1
+    top2_dpp_step<0x112, 0xf>(k1, e2);  // row_shr:2
+    top2_dpp_step<0x114, 0xf>(k1, e2);  // row_shr:4
+    top2_dpp_step<0x118, 0xf>(k1, e2);  // row_shr:8
+    top2_dpp_step<0x142, 0xa>(k1, e2);  // row_bcast:15 into rows 1 and 3
+    top2_dpp_step<0x143, 0xc>(k1, e2);  // row_bcast:31 into rows 2 and 3
+    k1 = (uint32_t)__builtin_amdgcn_readlane((int)k1, 63);
+    e2 = (uint32_t)__builtin_amdgcn_readlane((int)e2, 63);
+}
+
+__device__ __forceinline__ int support_match(const KParams &k, const SupRows &A, const SupRows &B, int u, int v, bool right_image, int lane) {
     const int W = k.d.W, H = k.d.H;
     if (!(u >= 5 && u <= W - 6 && v >= 5 && v <= H - 6)) return -1;  // elas.cpp:279
-    const uint4 centre = ld16(Aimg + ((size_t)v * W + u) * 16);  // consumed after the search so that its latency is hidden
+    const uint4 centre = A.rc[u - A.c0];
+    if ((int)texture16(centre) < k.support_texture) return -1;  // :296-300
     const int dmax = right_image ? min(k.d.disp_max, W - u - 5) : min(k.d.disp_max, u - 5);  // :318-323 (disp_min = 0)
     if (dmax < 10) return -1;                                                                // :326
     const int ua = u - A.c0;
@@ -246,7 +261,6 @@ __device__ __forceinline__ int support_match(const KParams &k, const uint8_t *__
     // whole energy multiset
     uint32_t best = (e1 << 16) | d1;
     wave_top2(best, e2);
-    if ((int)texture16(centre) < k.support_texture) return -1;  // :296-300 (wave-uniform: every lane loaded the same descriptor)
     const float E1 = (float)(best >> 16), E2 = (float)e2;
     if (E1 < k.support_threshold * E2) return (int)(best & 0xFFFFu);  // :364
     return -1;
@@ -265,27 +279,29 @@ __global__ __launch_bounds__(256) void k_support(KParams k, const uint8_t *__res
     const int r_c0 = max(u_lo - 2 - d.disp_max, 0), r_c1 = min(u_hi + 2, d.W - 1);
     const int l_c0 = max(u_lo - 2 - d.disp_max, 0), l_c1 = min(u_hi + 2 + d.disp_max, d.W - 1);
     const int nR = r_c1 - r_c0 + 1, nL = l_c1 - l_c0 + 1;
-    uint4 *sR0 = sup_lds, *sR1 = sR0 + nR, *sL0 = sR1 + nR, *sL1 = sL0 + nL;
+    uint4 *sR0 = sup_lds, *sR1 = sR0 + nR, *sRc = sR1 + nR, *sL0 = sRc + nR, *sL1 = sL0 + nL, *sLc = sL1 + nL;
     if (v - 2 >= 0 && v + 2 < d.H) {
-        const uint4 *gR0 = reinterpret_cast<const uint4 *>(d2) + (size_t)(v - 2) * d.W + r_c0, *gR1 = reinterpret_cast<const uint4 *>(d2) + (size_t)(v + 2) * d.W + r_c0;
-        const uint4 *gL0 = reinterpret_cast<const uint4 *>(d1) + (size_t)(v - 2) * d.W + l_c0, *gL1 = reinterpret_cast<const uint4 *>(d1) + (size_t)(v + 2) * d.W + l_c0;
+        const uint4 *gR = reinterpret_cast<const uint4 *>(d2) + (size_t)v * d.W + r_c0, *gL = reinterpret_cast<const uint4 *>(d1) + (size_t)v * d.W + l_c0;
+        const long up = -2L * d.W, dn = 2L * d.W;
         for (int i = threadIdx.x; i < nR; i += 256) {
-            sR0[i] = gR0[i];
-            sR1[i] = gR1[i];
+            sR0[i] = gR[up + i];
+            sR1[i] = gR[dn + i];
+            sRc[i] = gR[i];
         }
         for (int i = threadIdx.x; i < nL; i += 256) {
-            sL0[i] = gL0[i];
-            sL1[i] = gL1[i];
+            sL0[i] = gL[up + i];
+            sL1[i] = gL[dn + i];
+            sLc[i] = gL[i];
         }
     }
     __syncthreads();
-    const SupRows L{sL0, sL1, l_c0}, R{sR0, sR1, r_c0};
+    const SupRows L{sL0, sL1, sLc, l_c0}, R{sR0, sR1, sRc, r_c0};
     for (int uc = uc0 + wave; uc < uc1; uc += 4) {
         const int u = uc * d.step;
         int res = -1;
-        const int dd = support_match(k, d1, L, R, u, v, false, lane);
+        const int dd = support_match(k, L, R, u, v, false, lane);
         if (dd >= 0) {
-            const int d2v = support_match(k, d2, R, L, u - dd, v, true, lane);
+            const int d2v = support_match(k, R, L, u - dd, v, true, lane);
             if (d2v >= 0 && abs(dd - d2v) <= k.lr_threshold) res = dd;  // :404-409
         }
         if (lane == 0) dcan[(size_t)pair * d.Wc * d.Hc + (size_t)vc * d.Wc + uc] = (int16_t)res;
@@ -296,7 +312,7 @@ void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
     // row 0 / column 0 of the calloc'd lattice stay 0 (elas.cpp:387): they count as valid d=0 neighbours in the filters
     (void)hipMemsetAsync(s.dcan, 0, sizeof(int16_t) * (size_t)n * k.d.Wc * k.d.Hc, st);
     const int span = (SUP_CANDS - 1) * k.d.step;
-    const size_t shmem = sizeof(uint4) * 2 * ((size_t)(span + k.d.disp_max + 5) + (size_t)(span + 2 * k.d.disp_max + 5));
+    const size_t shmem = sizeof(uint4) * 3 * ((size_t)(span + k.d.disp_max + 5) + (size_t)(span + 2 * k.d.disp_max + 5));
     dim3 grid((k.d.Wc - 1 + SUP_CANDS - 1) / SUP_CANDS, k.d.Hc - 1, n);
     SV_LAUNCH(K_SUPPORT, k_support, grid, dim3(256), shmem, st, k, s.desc, s.dcan);
 }
@@ -594,6 +610,23 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
     const uint8_t *d1 = desc + ((size_t)(pair * 2) * d.N) * 16, *d2 = d1 + (size_t)d.N * 16;
     const size_t line = (size_t)d.W * max(min(v, d.H - 3), 2) * 16;  // elas.cpp:718
     const uint8_t *A = (side ? d2 : d1) + line, *B = (side ? d1 : d2) + line;
+    // per-pixel global loads first (triangle id, own descriptor, the cell's candidate mask): they overlap the LDS staging
+    const bool inimg = u < d.W;
+    const size_t pix = (size_t)v * d.W + min(u, d.W - 1);
+    const int t = inimg ? tri_id[(size_t)ps * d.N + pix] : -1;
+    const bool work = t >= 0 && u >= 2 && u < d.W - 2;
+    uint4 own = make_uint4(0, 0, 0, 0);
+    uint32_t mw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float4 rec = make_float4(0, 0, 0, 0);
+    const uint32_t *cell = gB;
+    if (work) {
+        own = ld16(A + (size_t)u * 16);
+        rec = trirec[(size_t)ps * d.max_tri + t];
+        const int gx = (int)floorf((float)u / (float)d.grid_size), gy = (int)floorf((float)v / (float)d.grid_size);
+        cell = gB + ((size_t)ps * d.ncell + (size_t)gy * d.gw + gx) * d.MW;
+#pragma unroll
+        for (int w = 0; w < 8; w++) mw[w] = w < d.MW ? cell[w] : 0u;
+    }
     // left pixel u looks at right columns u-d, right pixel u at left columns u+d, d in [0, disp_max]
     const int c0 = side ? x0 : max(x0 - d.disp_max, 0);
     const int c1 = side ? min(x0 + 255 + d.disp_max, d.W - 1) : min(x0 + 255, d.W - 1);
@@ -602,42 +635,43 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
         for (int i = threadIdx.x; i <= c1 - c0; i += 256) other_row[i] = g[i];
     }
     __syncthreads();
-    if (u >= d.W) return;
-    const size_t pix = (size_t)v * d.W + u;
-    const int t = tri_id[(size_t)ps * d.N + pix];
+    if (!inimg) return;
     float out = -10.0f;  // elas.cpp:823-824
-    if (t >= 0 && u >= 2 && u < d.W - 2) {
-        const uint4 own = ld16(A + (size_t)u * 16);
+    if (work) {
         if ((int)texture16(own) >= k.match_texture) {  // :732-736
-            const float4 rec = trirec[(size_t)ps * d.max_tri + t];
             const int d_plane = (int)(rec.x * (float)u + rec.y * (float)v + rec.z);  // :739, ((a*u)+(b*v))+c without contraction
             const int d_plane_min = max(d_plane - k.plane_radius, 0);
             const int d_plane_max = min(d_plane + k.plane_radius, d.D - 1);
             const bool valid = rec.w != 0.0f;
-            const int gx = (int)floorf((float)u / (float)d.grid_size), gy = (int)floorf((float)v / (float)d.grid_size);
-            const uint32_t *cell = gB + ((size_t)ps * d.ncell + (size_t)gy * d.gw + gx) * d.MW;
-            const uint4 *row = other_row - c0;
+            // disparities whose warped column stays inside [2, W-3] (:763, :770 / :782, :789), as a range instead of a per-candidate test
+            const int a_lo = side ? 0 : max(u - (d.W - 3), 0), a_hi = side ? min(d.W - 3 - u, d.D - 1) : min(u - 2, d.D - 1);
+            const uint4 *pu = other_row + (u - c0);  // candidate d lives at pu[-d] (left pixel) or pu[+d] (right pixel)
+            const int sgn = side ? 1 : -1;
             int min_val = 10000, min_d = -1;
-            uint32_t mw[8];
+            const int b_lo = max(d_plane_min, a_lo), b_hi = min(d_plane_max, a_hi);
 #pragma unroll
-            for (int w = 0; w < 8; w++) mw[w] = w < d.MW ? cell[w] : 0u;  // all mask loads in flight at once
-#pragma unroll
-            for (int w = 0; w < 8; w++) {  // grid candidates outside the band (:759-767 / :778-786)
+            for (int w = 0; w < 8; w++) {  // grid candidates outside the band (:759-767 / :778-786), ascending d
                 if (w >= d.MW) break;
                 uint32_t m = mw[w];
-                const int lo = d_plane_min - 32 * w, hi = d_plane_max - 32 * w;
-                if (lo <= 31 && hi >= 0 && lo <= hi) {
-                    const int l = max(lo, 0), h = min(hi, 31);
-                    const uint32_t upto_h = h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u);
-                    m &= ~(upto_h & ~((1u << l) - 1u));
+                {   // keep [a_lo, a_hi], drop [d_plane_min, d_plane_max]
+                    const int lo = a_lo - 32 * w, hi = a_hi - 32 * w;
+                    uint32_t keep = 0;
+                    if (lo <= 31 && hi >= 0 && lo <= hi) {
+                        const int l = max(lo, 0), h = min(hi, 31);
+                        keep = (h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u)) & ~((1u << l) - 1u);
+                    }
+                    m &= keep;
+                    const int lo2 = d_plane_min - 32 * w, hi2 = d_plane_max - 32 * w;
+                    if (lo2 <= 31 && hi2 >= 0 && lo2 <= hi2) {
+                        const int l = max(lo2, 0), h = min(hi2, 31);
+                        m &= ~((h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u)) & ~((1u << l) - 1u));
+                    }
                 }
                 while (m) {
                     const int b = __ffs((int)m) - 1;
                     m &= m - 1;
                     const int dc = 32 * w + b;
-                    const int uw = side ? u + dc : u - dc;
-                    if (uw < 2 || uw >= d.W - 2) continue;
-                    const int val = (int)sad16(own, row[uw]);
+                    const int val = (int)sad16(own, pu[sgn * dc]);
                     if (val < min_val) {
                         min_val = val;
                         min_d = dc;
@@ -646,29 +680,18 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
             }
             for (int w = 8; w < d.MW; w++) {  // disp_max > 255: remaining words straight from memory
                 uint32_t m = cell[w];
-                const int lo = d_plane_min - 32 * w, hi = d_plane_max - 32 * w;
-                if (lo <= 31 && hi >= 0 && lo <= hi) {
-                    const int l = max(lo, 0), h = min(hi, 31);
-                    const uint32_t upto_h = h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u);
-                    m &= ~(upto_h & ~((1u << l) - 1u));
-                }
-                while (m) {
-                    const int b = __ffs((int)m) - 1;
-                    m &= m - 1;
+                for (int b = 0; b < 32; b++) {
                     const int dc = 32 * w + b;
-                    const int uw = side ? u + dc : u - dc;
-                    if (uw < 2 || uw >= d.W - 2) continue;
-                    const int val = (int)sad16(own, row[uw]);
+                    if (!((m >> b) & 1u) || dc < a_lo || dc > a_hi || (dc >= d_plane_min && dc <= d_plane_max)) continue;
+                    const int val = (int)sad16(own, pu[sgn * dc]);
                     if (val < min_val) {
                         min_val = val;
                         min_d = dc;
                     }
                 }
             }
-            for (int dc = d_plane_min; dc <= d_plane_max; dc++) {  // the band, with the plane prior (:768-774 / :787-793)
-                const int uw = side ? u + dc : u - dc;
-                if (uw < 2 || uw >= d.W - 2) continue;
-                const int val = (int)sad16(own, row[uw]) + (valid ? k.prior[abs(dc - d_plane)] : 0);
+            for (int dc = b_lo; dc <= b_hi; dc++) {  // the band, with the plane prior (:768-774 / :787-793)
+                const int val = (int)sad16(own, pu[sgn * dc]) + (valid ? k.prior[abs(dc - d_plane)] : 0);
                 if (val < min_val) {
                     min_val = val;
                     min_d = dc;
@@ -724,15 +747,17 @@ __device__ __forceinline__ size_t map_offset(const Dims &d, int m, int nproc) { 
     return (size_t)(pair * 2 + side) * d.N;
 }
 
+// csize[p]: run length (> 0) at the first pixel of every horizontal run of linked valid pixels, 0 elsewhere.
+// cnt[p]  : component size accumulator, meaningful at root pixels (roots are always run starts).
 __global__ __launch_bounds__(64) void k_ccl_init(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ disp, int32_t *__restrict__ label,
-                                                 int32_t *__restrict__ csize) {
+                                                 int32_t *__restrict__ csize, int32_t *__restrict__ cnt) {
     const Dims &d = k.d;
     const int m = blockIdx.y;
     if (blob[(m / nproc) * META_WORDS] < 3) return;
     const size_t off = map_offset(d, m, nproc);
     const int v = blockIdx.x, lane = threadIdx.x;
     const float *D = disp + off + (size_t)v * d.W;
-    int32_t *L = label + off + (size_t)v * d.W, *S = csize + off + (size_t)v * d.W;
+    int32_t *L = label + off + (size_t)v * d.W, *S = csize + off + (size_t)v * d.W, *C = cnt + off + (size_t)v * d.W;
     int carry_start = -1;
     float carry_val = -10.0f;
     for (int u0 = 0; u0 < d.W; u0 += 64) {
@@ -744,13 +769,26 @@ __global__ __launch_bounds__(64) void k_ccl_init(KParams k, int nproc, const int
         const bool link = valid && left >= 0 && fabsf(val - left) <= k.speckle_sim;
         const unsigned long long brk = __ballot(!link);  // bit set: this pixel starts a run (or is invalid)
         const unsigned long long upto = brk & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-        int start = upto ? (u0 + 63 - __clzll((long long)upto)) : carry_start;
+        const int start = upto ? (u0 + 63 - __clzll((long long)upto)) : carry_start;
+        // the run ends here if the next pixel does not link to this one (next chunk's first pixel: decided there)
+        const bool next_breaks = lane == 63 ? false : ((brk >> (lane + 1)) & 1ull) != 0;
         if (u < d.W) {
             L[u] = valid ? (int)(v * d.W + start) : -1;
-            S[u] = 0;
+            if (!(valid && start == u)) S[u] = 0;       // run starts get their length from the run's last pixel
+            C[u] = 0;
+            if (valid && (next_breaks || u == d.W - 1)) S[start] = u - start + 1;
         }
+        // a run that reaches lane 63 continues into the next chunk unless that chunk's lane 0 breaks it
+        const int prev_start = carry_start;
+        (void)prev_start;
         carry_start = __shfl(valid ? start : -1, 63, 64);
         carry_val = __shfl(val, 63, 64);
+        if (u0 + 64 < d.W) {
+            // peek: does the first pixel of the next chunk link to our lane 63?  If not, close the run now.
+            const float nxt = D[u0 + 64];
+            const bool cont = carry_start >= 0 && nxt >= 0 && fabsf(nxt - carry_val) <= k.speckle_sim;
+            if (lane == 63 && valid && !cont) S[start] = u - start + 1;
+        }
     }
 }
 
@@ -797,53 +835,46 @@ __global__ __launch_bounds__(256) void k_ccl_merge(KParams k, int nproc, const i
     ccl_union(label + off, v * d.W + u, (v - 1) * d.W + u);
 }
 
-__global__ __launch_bounds__(256) void k_ccl_count(KParams k, int nproc, const int32_t *__restrict__ blob, int32_t *__restrict__ label, int32_t *__restrict__ csize) {
-    const Dims &d = k.d;
-    const int m = blockIdx.y;
-    if (blob[(m / nproc) * META_WORDS] < 3) return;
-    const size_t off = map_offset(d, m, nproc);
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    int32_t *L = label + off, *S = csize + off;
-    int root = -1;
-    if (p < d.N && L[p] >= 0) {
-        root = ccl_find(L, p);
-        L[p] = root;
-    }
-    // wavefront-level aggregation of equal roots, and no more adds once a component is known to be large enough
-    const int lane = threadIdx.x & 63;
-    bool pending = root >= 0;
-    unsigned long long todo = __ballot(pending);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int r = __shfl(root, leader, 64);
-        const bool same = pending && root == r;
-        const unsigned long long grp = __ballot(same);
-        if (lane == leader) {
-            if (__hip_atomic_load(&S[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k.speckle_size) atomicAdd(&S[r], (int)__popcll(grp));
-        }
-        pending = pending && !same;
-        todo &= ~grp;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_ccl_apply(KParams k, int nproc, const int32_t *__restrict__ blob, const int32_t *__restrict__ label,
-                                                   const int32_t *__restrict__ csize, float *__restrict__ disp) {
+// One thread per pixel, only run starts act: chase the root once per run (path-compressing the start) and add the run's
+// length to the root's counter -- unless that counter has already reached speckle_size (sizes only need to be told apart
+// at that threshold; a stale read merely causes a harmless extra add).
+__global__ __launch_bounds__(256) void k_ccl_count(KParams k, int nproc, const int32_t *__restrict__ blob, int32_t *__restrict__ label, const int32_t *__restrict__ csize,
+                                                   int32_t *__restrict__ cnt) {
     const Dims &d = k.d;
     const int m = blockIdx.y;
     if (blob[(m / nproc) * META_WORDS] < 3) return;
     const size_t off = map_offset(d, m, nproc);
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= d.N) return;
-    const int r = label[off + p];
-    if (r >= 0 && csize[off + r] < k.speckle_size) disp[off + p] = -10.0f;  // elas.cpp:1109-1114
+    const int len = csize[off + p];
+    if (len <= 0) return;
+    int32_t *L = label + off;
+    const int root = ccl_find(L, p);
+    if (root != p) L[p] = root;
+    if (cnt[off + root] < k.speckle_size) atomicAdd(&cnt[off + root], len);
+}
+
+__global__ __launch_bounds__(256) void k_ccl_apply(KParams k, int nproc, const int32_t *__restrict__ blob, const int32_t *__restrict__ label,
+                                                   const int32_t *__restrict__ cnt, float *__restrict__ disp) {
+    const Dims &d = k.d;
+    const int m = blockIdx.y;
+    if (blob[(m / nproc) * META_WORDS] < 3) return;
+    const size_t off = map_offset(d, m, nproc);
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= d.N) return;
+    const int start = label[off + p];
+    if (start < 0) return;
+    const int root = label[off + start];  // run start -> root (run starts were compressed by k_ccl_count; a root points at itself)
+    if (cnt[off + root] < k.speckle_size) disp[off + p] = -10.0f;  // elas.cpp:1109-1114
 }
 
 void launch_speckle(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st) {
     const int maps = n * nproc;
-    SV_LAUNCH(K_CCL_INIT, k_ccl_init, dim3(k.d.H, maps), dim3(64), 0, st, k, nproc, s.blob, s.disp, s.tri_id, s.csize);
+    int32_t *cnt = reinterpret_cast<int32_t *>(s.tmp);  // the filters' scratch map is free during speckle removal
+    SV_LAUNCH(K_CCL_INIT, k_ccl_init, dim3(k.d.H, maps), dim3(64), 0, st, k, nproc, s.blob, s.disp, s.tri_id, s.csize, cnt);
     SV_LAUNCH(K_CCL_MERGE, k_ccl_merge, dim3((k.d.W + 255) / 256, k.d.H - 1, maps), dim3(256), 0, st, k, nproc, s.blob, s.disp, s.tri_id);
-    SV_LAUNCH(K_CCL_COUNT, k_ccl_count, dim3((k.d.N + 255) / 256, maps), dim3(256), 0, st, k, nproc, s.blob, s.tri_id, s.csize);
-    SV_LAUNCH(K_CCL_APPLY, k_ccl_apply, dim3((k.d.N + 255) / 256, maps), dim3(256), 0, st, k, nproc, s.blob, s.tri_id, s.csize, s.disp);
+    SV_LAUNCH(K_CCL_COUNT, k_ccl_count, dim3((k.d.N + 255) / 256, maps), dim3(256), 0, st, k, nproc, s.blob, s.tri_id, s.csize, cnt);
+    SV_LAUNCH(K_CCL_APPLY, k_ccl_apply, dim3((k.d.N + 255) / 256, maps), dim3(256), 0, st, k, nproc, s.blob, s.tri_id, cnt, s.disp);
 }
 
 // ------------------------------------------------------------------------------------------------------------

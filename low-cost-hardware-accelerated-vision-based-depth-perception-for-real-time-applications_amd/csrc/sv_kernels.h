@@ -52,7 +52,7 @@ struct SlotDev {
     float *wta;         // [cap][2][N]  integer WTA disparity (-1 / -10 invalid)
     float *disp;        // [cap][2][N]  L/R-checked maps, post-processed in place
     float *tmp;         // [cap][2][N]  scratch of the separable filters
-    int32_t *csize;     // [cap][2][N]  CCL component sizes (at root pixels)
+    int32_t *csize;     // [cap][2][N]  CCL run lengths (at run-start pixels); component sizes accumulate in `tmp`
 };
 
 // ---- launch wrappers (kernels.hip).  `n` = pairs in this launch; `nproc` = maps per pair to post-process (1 or 2).
