@@ -307,7 +307,13 @@ void issue_phase1(sv_handle *h, Slot *s) {
         const int j = s->n - 1;
         dbg_from_device(h, h->sP1, "desc1", s->dev.desc + ((size_t)j * 2) * d.N * 16, (size_t)d.N * 16);
         dbg_from_device(h, h->sP1, "desc2", s->dev.desc + ((size_t)j * 2 + 1) * d.N * 16, (size_t)d.N * 16);
-        dbg_put(h, "dcan_raw", s->h_dcan + (size_t)j * lat, lat);
+        {
+            std::vector<int16_t> rowmajor((size_t)lat);  // the oracle's layout is [Hc][Wc]; the device writes [Wc][Hc]
+            const int16_t *T = s->h_dcan + (size_t)j * lat;
+            for (int vc = 0; vc < d.Hc; vc++)
+                for (int uc = 0; uc < d.Wc; uc++) rowmajor[(size_t)vc * d.Wc + uc] = T[(size_t)uc * d.Hc + vc];
+            dbg_put(h, "dcan_raw", rowmajor.data(), lat);
+        }
         int32_t dd[2] = {d.Wc, d.Hc};
         dbg_put(h, "dcan_dims", dd, 2);
     }
@@ -399,7 +405,7 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
         return;
     }
     if ((int)sc->sup.size() < d.max_pts * 3) sc->sup.resize((size_t)d.max_pts * 3);
-    int ns = support_filter(h->p, s->h_dcan + (size_t)t.pair * lat, d.W, d.H, sc->sup.data(), d.max_pts);
+    int ns = support_filter_t(h->p, s->h_dcan + (size_t)t.pair * lat, d.W, d.H, sc->sup.data(), d.max_pts);
     if (ns < 0) {
         note_error(h, "support point capacity exceeded");
         ns = 0;

@@ -19,38 +19,42 @@ static void lattice_dims(const sv_params &p, int W, int H, int &Wc, int &Hc) {  
     Hc = (H + step - 1) / step;
 }
 
-// elas.cpp:152-176.  In place and order dependent: a point invalidated earlier in the (u outer, v inner) scan no longer
-// supports later points.  Counting stops as soon as incon_min_support is reached (the reference only tests `<`).
-static void drop_inconsistent(const sv_params &p, int16_t *D, int Wc, int Hc) {
+// All three filters scan the lattice u outer / v inner (elas.cpp:154-155, 196-197), so the lattice is kept TRANSPOSED
+// here, T[uc * Hc + vc]: the inner loop then walks contiguous memory (the GPU writes it in this layout).
+
+// elas.cpp:152-176.  In place and order dependent: a point invalidated earlier in the scan no longer supports later
+// points.  Counting stops as soon as incon_min_support is reached (the reference only tests `<`).
+static void drop_inconsistent(const sv_params &p, int16_t *T, int Wc, int Hc) {
     const int win = p.incon_window_size, thr = p.incon_threshold, need = p.incon_min_support;
     for (int uc = 0; uc < Wc; uc++) {
         const int u_lo = std::max(uc - win, 0), u_hi = std::min(uc + win, Wc - 1);
+        int16_t *col = T + (size_t)uc * Hc;
         for (int vc = 0; vc < Hc; vc++) {
-            const int d = D[vc * Wc + uc];
+            const int d = col[vc];
             if (d < 0) continue;
             const int v_lo = std::max(vc - win, 0), v_hi = std::min(vc + win, Hc - 1);
             int support = 0;
-            for (int v2 = v_lo; v2 <= v_hi && support < need; v2++) {
-                const int16_t *row = D + v2 * Wc;
-                for (int u2 = u_lo; u2 <= u_hi; u2++) {
-                    const int d2 = row[u2];
+            for (int u2 = u_lo; u2 <= u_hi && support < need; u2++) {
+                const int16_t *c2 = T + (size_t)u2 * Hc;
+                for (int v2 = v_lo; v2 <= v_hi; v2++) {
+                    const int d2 = c2[v2];
                     support += (d2 >= 0) & (abs(d - d2) <= thr);
                 }
             }
-            if (support < need) D[vc * Wc + uc] = -1;
+            if (support < need) col[vc] = -1;
         }
     }
 }
 
 // elas.cpp:178-233 with redun_max_dist = 5, redun_threshold = 1 (:419-420); in place.
-static void drop_redundant(int16_t *D, int Wc, int Hc, int max_dist, int thr, bool vertical) {
-    const int stride = vertical ? Wc : 1;
+static void drop_redundant(int16_t *T, int Wc, int Hc, int max_dist, int thr, bool vertical) {
+    const int stride = vertical ? 1 : Hc;
     for (int uc = 0; uc < Wc; uc++)
         for (int vc = 0; vc < Hc; vc++) {
-            const int d = D[vc * Wc + uc];
+            int16_t *q = T + (size_t)uc * Hc + vc;
+            const int d = *q;
             if (d < 0) continue;
             const int pos = vertical ? vc : uc, len = vertical ? Hc : Wc;
-            const int16_t *q = D + vc * Wc + uc;
             bool both = true;
             for (int dir = -1; dir <= 1 && both; dir += 2) {
                 bool found = false;
@@ -65,21 +69,21 @@ static void drop_redundant(int16_t *D, int Wc, int Hc, int max_dist, int thr, bo
                 }
                 both = found;
             }
-            if (both) D[vc * Wc + uc] = -1;
+            if (both) *q = -1;
         }
 }
 
-int support_filter(const sv_params &p, int16_t *dcan, int W, int H, int32_t *out, int cap) {
+int support_filter_t(const sv_params &p, int16_t *T, int W, int H, int32_t *out, int cap) {
     int Wc, Hc;
     lattice_dims(p, W, H, Wc, Hc);
-    drop_inconsistent(p, dcan, Wc, Hc);
-    drop_redundant(dcan, Wc, Hc, 5, 1, true);
-    drop_redundant(dcan, Wc, Hc, 5, 1, false);
+    drop_inconsistent(p, T, Wc, Hc);
+    drop_redundant(T, Wc, Hc, 5, 1, true);
+    drop_redundant(T, Wc, Hc, 5, 1, false);
     const int step = p.candidate_stepsize;
     int n = 0;
     for (int uc = 1; uc < Wc; uc++)  // elas.cpp:424-428: u outer, v inner
         for (int vc = 1; vc < Hc; vc++) {
-            const int d = dcan[vc * Wc + uc];
+            const int d = T[(size_t)uc * Hc + vc];
             if (d < 0) continue;
             if (n < cap) {
                 out[3 * n] = uc * step;
@@ -119,6 +123,19 @@ int support_filter(const sv_params &p, int16_t *dcan, int W, int H, int32_t *out
     } else if (n > cap) {
         return -n;
     }
+    return n;
+}
+
+// row-major [Hc][Wc] front-end (the oracle's / reference's layout)
+int support_filter(const sv_params &p, int16_t *dcan, int W, int H, int32_t *out, int cap) {
+    int Wc, Hc;
+    lattice_dims(p, W, H, Wc, Hc);
+    std::vector<int16_t> T((size_t)Wc * Hc);
+    for (int vc = 0; vc < Hc; vc++)
+        for (int uc = 0; uc < Wc; uc++) T[(size_t)uc * Hc + vc] = dcan[(size_t)vc * Wc + uc];
+    const int n = support_filter_t(p, T.data(), W, H, out, cap);
+    for (int vc = 0; vc < Hc; vc++)
+        for (int uc = 0; uc < Wc; uc++) dcan[(size_t)vc * Wc + uc] = T[(size_t)uc * Hc + vc];
     return n;
 }
 

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void k_support(KParams k, const uint8_t *__res
             const int d2v = support_match(k, R, L, u - dd, v, true, lane);
             if (d2v >= 0 && abs(dd - d2v) <= k.lr_threshold) res = dd;  // :404-409
         }
-        if (lane == 0) dcan[(size_t)pair * d.Wc * d.Hc + (size_t)vc * d.Wc + uc] = (int16_t)res;
+        if (lane == 0) dcan[(size_t)pair * d.Wc * d.Hc + (size_t)uc * d.Hc + vc] = (int16_t)res;  // transposed: the host filters scan u outer / v inner
     }
 }
 

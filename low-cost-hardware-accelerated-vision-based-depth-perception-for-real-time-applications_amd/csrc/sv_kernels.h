@@ -38,7 +38,7 @@ constexpr int META_WORDS = 8;
 struct SlotDev {
     int cap;
     uint8_t *desc;      // [cap][2][N][16]   descriptors, image 0 = left, 1 = right
-    int16_t *dcan;      // [cap][Hc*Wc]      raw support lattice
+    int16_t *dcan;      // [cap][Wc][Hc]     raw support lattice, TRANSPOSED (u major) for the host filters
     int32_t *blob;      // host-stage results of the chunk, one H2D copy: [cap][8] meta words, then tightly packed data.
                         //   meta of pair p: [0] #support points  [1] offset of its (u,v,d) triples
                         //                   [2] #triangles left  [3] offset of their corner indices

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 CSV output (kernel stats + PMC counter collections) into one small per-kernel table.
+
+  python tools/summarize_rocprof.py --stats gpurun_out/kt --pmc gpurun_out/pmc_f gpurun_out/pmc_w --pairs-per-launch 16 -o profiles/x.csv
+"""
+import argparse
+import collections
+import csv
+import glob
+import os
+
+
+def short(name):
+    name = name.split("(")[0]
+    if name.startswith("void at::native"):
+        return "torch::" + name.split("::")[2].split("<")[0]
+    return name.replace("sv::", "")
+
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--stats", help="directory of a --kernel-trace --stats run")
+ap.add_argument("--pmc", nargs="*", default=[], help="directories of --pmc runs")
+ap.add_argument("--pairs-per-launch", type=float, default=16)
+ap.add_argument("-o", "--out", required=True)
+a = ap.parse_args()
+
+rows = collections.OrderedDict()
+if a.stats:
+    f = glob.glob(os.path.join(a.stats, "**", "*kernel_stats.csv"), recursive=True)[0]
+    for r in csv.DictReader(open(f)):
+        k = short(r["Name"])
+        rows[k] = {"kernel": k, "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2), "min_us": round(float(r["MinNs"]) / 1e3, 2),
+                   "max_us": round(float(r["MaxNs"]) / 1e3, 2), "pct": r["Percentage"], "us_per_pair": round(float(r["AverageNs"]) / 1e3 / a.pairs_per_launch, 3)}
+for d in a.pmc:
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    n = collections.defaultdict(collections.Counter)
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        n[k][r["Counter_Name"]] += 1
+    for k, cs in acc.items():
+        row = rows.setdefault(k, {"kernel": k})
+        for c, v in cs.items():
+            row[c + "_per_launch"] = round(v / n[k][c], 1)
+cols = []
+for r in rows.values():
+    for c in r:
+        if c not in cols:
+            cols.append(c)
+with open(a.out, "w", newline="") as f:
+    w = csv.DictWriter(f, fieldnames=cols)
+    w.writeheader()
+    for r in rows.values():
+        w.writerow(r)
+print("wrote", a.out, len(rows), "kernels")
