@@ -8,6 +8,8 @@
 // therefore no MFMA.  Batch dimension: blockIdx.z (or .y) walks the pairs of a launch.
 #include "sv_kernels.h"
 
+#include <algorithm>
+
 namespace sv {
 
 thread_local LaunchHook g_launch_hook = {nullptr, nullptr};
@@ -199,13 +201,14 @@ void launch_descriptor(const KParams &k, const uint8_t *left, const uint8_t *rig
 //     One wavefront per lattice point; lanes stride over the disparity range; energy = 4-corner SAD (64 bytes);
 //     per-wavefront reduction of (best energy, lowest best d) and the second order statistic.
 // ------------------------------------------------------------------------------------------------------------
-// Rows v-2 and v+2 of both descriptor images are staged in LDS for a run of SUP_CANDS consecutive lattice points:
-// the forward search reads the right image over [u-2-dmax, u+2], the backward check the left image over
-// [u-d-2, u-d+2+dmax]; neighbouring lattice points (5 px apart) share almost all of it.
-#define SUP_CANDS 16
+// Rows v-2 and v+2 of both descriptor images are staged in LDS for a run of consecutive lattice points of one lattice
+// row: the forward search reads the right image over [u-2-dmax, u+2], the backward check the left image over
+// [u-d-2, u-d+2+dmax]; neighbouring lattice points (5 px apart) share almost all of it, so the run is made as long as an
+// LDS budget allows (the whole row at KITTI size).
+#define SUP_THREADS 512
 
-struct SupRows {            // one staged image: rows v-2, v+2 (corner blocks) and v (texture test), columns [c0, c0+n)
-    const uint4 *r0, *r1, *rc;
+struct SupRows {            // one staged image: rows v-2 and v+2, columns [c0, c0+n)
+    const uint4 *r0, *r1;
     int c0;
 };
 
@@ -236,11 +239,11 @@ __device__ __forceinline__ void wave_top2(uint32_t &k1, uint32_t &e2) {
     e2 = (uint32_t)__builtin_amdgcn_readlane((int)e2, 63);
 }
 
-__device__ __forceinline__ int support_match(const KParams &k, const SupRows &A, const SupRows &B, int u, int v, bool right_image, int lane) {
+__device__ __forceinline__ int support_match(const KParams &k, const uint8_t *__restrict__ Aimg, const SupRows &A, const SupRows &B, int u, int v, bool right_image,
+                                             int lane) {
     const int W = k.d.W, H = k.d.H;
     if (!(u >= 5 && u <= W - 6 && v >= 5 && v <= H - 6)) return -1;  // elas.cpp:279
-    const uint4 centre = A.rc[u - A.c0];
-    if ((int)texture16(centre) < k.support_texture) return -1;  // :296-300
+    const uint4 centre = ld16(Aimg + ((size_t)v * W + u) * 16);  // used after the search: its latency hides behind it
     const int dmax = right_image ? min(k.d.disp_max, W - u - 5) : min(k.d.disp_max, u - 5);  // :318-323 (disp_min = 0)
     if (dmax < 10) return -1;                                                                // :326
     const int ua = u - A.c0;
@@ -261,17 +264,18 @@ __device__ __forceinline__ int support_match(const KParams &k, const SupRows &A,
     // whole energy multiset
     uint32_t best = (e1 << 16) | d1;
     wave_top2(best, e2);
+    if ((int)texture16(centre) < k.support_texture) return -1;  // :296-300 (wave-uniform: every lane holds the same descriptor)
     const float E1 = (float)(best >> 16), E2 = (float)e2;
     if (E1 < k.support_threshold * E2) return (int)(best & 0xFFFFu);  // :364
     return -1;
 }
 
-__global__ __launch_bounds__(256) void k_support(KParams k, const uint8_t *__restrict__ desc, int16_t *__restrict__ dcan) {
+__global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, int cands, const uint8_t *__restrict__ desc, int16_t *__restrict__ dcan) {
     const Dims &d = k.d;
     extern __shared__ uint4 sup_lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = blockIdx.z, vc = blockIdx.y + 1;
-    const int uc0 = 1 + blockIdx.x * SUP_CANDS, uc1 = min(uc0 + SUP_CANDS, d.Wc);  // candidates [uc0, uc1)
+    const int uc0 = 1 + blockIdx.x * cands, uc1 = min(uc0 + cands, d.Wc);  // candidates [uc0, uc1)
     const int v = vc * d.step;
     const uint8_t *d1 = desc + ((size_t)(pair * 2) * d.N) * 16, *d2 = d1 + (size_t)d.N * 16;
     const int u_lo = uc0 * d.step, u_hi = (uc1 - 1) * d.step;
@@ -279,29 +283,27 @@ __global__ __launch_bounds__(256) void k_support(KParams k, const uint8_t *__res
     const int r_c0 = max(u_lo - 2 - d.disp_max, 0), r_c1 = min(u_hi + 2, d.W - 1);
     const int l_c0 = max(u_lo - 2 - d.disp_max, 0), l_c1 = min(u_hi + 2 + d.disp_max, d.W - 1);
     const int nR = r_c1 - r_c0 + 1, nL = l_c1 - l_c0 + 1;
-    uint4 *sR0 = sup_lds, *sR1 = sR0 + nR, *sRc = sR1 + nR, *sL0 = sRc + nR, *sL1 = sL0 + nL, *sLc = sL1 + nL;
+    uint4 *sR0 = sup_lds, *sR1 = sR0 + nR, *sL0 = sR1 + nR, *sL1 = sL0 + nL;
     if (v - 2 >= 0 && v + 2 < d.H) {
         const uint4 *gR = reinterpret_cast<const uint4 *>(d2) + (size_t)v * d.W + r_c0, *gL = reinterpret_cast<const uint4 *>(d1) + (size_t)v * d.W + l_c0;
         const long up = -2L * d.W, dn = 2L * d.W;
-        for (int i = threadIdx.x; i < nR; i += 256) {
+        for (int i = threadIdx.x; i < nR; i += SUP_THREADS) {
             sR0[i] = gR[up + i];
             sR1[i] = gR[dn + i];
-            sRc[i] = gR[i];
         }
-        for (int i = threadIdx.x; i < nL; i += 256) {
+        for (int i = threadIdx.x; i < nL; i += SUP_THREADS) {
             sL0[i] = gL[up + i];
             sL1[i] = gL[dn + i];
-            sLc[i] = gL[i];
         }
     }
     __syncthreads();
-    const SupRows L{sL0, sL1, sLc, l_c0}, R{sR0, sR1, sRc, r_c0};
-    for (int uc = uc0 + wave; uc < uc1; uc += 4) {
+    const SupRows L{sL0, sL1, l_c0}, R{sR0, sR1, r_c0};
+    for (int uc = uc0 + wave; uc < uc1; uc += SUP_THREADS / 64) {
         const int u = uc * d.step;
         int res = -1;
-        const int dd = support_match(k, L, R, u, v, false, lane);
+        const int dd = support_match(k, d1, L, R, u, v, false, lane);
         if (dd >= 0) {
-            const int d2v = support_match(k, R, L, u - dd, v, true, lane);
+            const int d2v = support_match(k, d2, R, L, u - dd, v, true, lane);
             if (d2v >= 0 && abs(dd - d2v) <= k.lr_threshold) res = dd;  // :404-409
         }
         if (lane == 0) dcan[(size_t)pair * d.Wc * d.Hc + (size_t)uc * d.Hc + vc] = (int16_t)res;  // transposed: the host filters scan u outer / v inner
@@ -311,10 +313,15 @@ __global__ __launch_bounds__(256) void k_support(KParams k, const uint8_t *__res
 void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
     // row 0 / column 0 of the calloc'd lattice stay 0 (elas.cpp:387): they count as valid d=0 neighbours in the filters
     (void)hipMemsetAsync(s.dcan, 0, sizeof(int16_t) * (size_t)n * k.d.Wc * k.d.Hc, st);
-    const int span = (SUP_CANDS - 1) * k.d.step;
-    const size_t shmem = sizeof(uint4) * 3 * ((size_t)(span + k.d.disp_max + 5) + (size_t)(span + 2 * k.d.disp_max + 5));
-    dim3 grid((k.d.Wc - 1 + SUP_CANDS - 1) / SUP_CANDS, k.d.Hc - 1, n);
-    SV_LAUNCH(K_SUPPORT, k_support, grid, dim3(256), shmem, st, k, s.desc, s.dcan);
+    // longest run of lattice points whose two staged row pairs fit the LDS budget: 32 B * (2*span + 3*disp_max + 10) <= budget
+    const int budget = 40 * 1024;
+    int span = (budget / 32 - 3 * k.d.disp_max - 10) / 2;
+    int cands = span / k.d.step + 1;
+    cands = std::max(8, std::min(cands, k.d.Wc - 1));
+    span = (cands - 1) * k.d.step;
+    const size_t shmem = sizeof(uint4) * 2 * ((size_t)(span + k.d.disp_max + 5) + (size_t)(span + 2 * k.d.disp_max + 5));
+    dim3 grid((k.d.Wc - 1 + cands - 1) / cands, k.d.Hc - 1, n);
+    SV_LAUNCH(K_SUPPORT, k_support, grid, dim3(SUP_THREADS), shmem, st, k, cands, s.desc, s.dcan);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -600,112 +607,144 @@ void launch_triangles(const KParams &k, const SlotDev &s, int n, hipStream_t st)
 //     One lane per pixel; candidates = cell's grid mask outside the plane band (ascending), then the band
 //     (ascending, + prior); strict '<' keeps the first minimum, exactly like the sequential reference.
 // ------------------------------------------------------------------------------------------------------------
+// One workgroup = DENSE_TW columns of one row, BOTH sides: left pixel u needs right columns [u-disp_max, u], right pixel u
+// needs left columns [u, u+disp_max]; staging left[x0, x0+TW+disp_max) and right[x0-disp_max, x0+TW) once serves both
+// passes and also holds every pixel's own descriptor, so each descriptor row segment is fetched ~(TW+disp_max)/TW times
+// instead of ~2.5 times with one pass per launch.
+#define DENSE_TW 512
+
+__device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, int v, const uint4 own, const uint4 *pu, const float4 rec, const uint32_t *mw,
+                                             const uint32_t *cell) {
+    const Dims &d = k.d;
+    if ((int)texture16(own) < k.match_texture) return -10.0f;                   // elas.cpp:732-736 (the map keeps its -10)
+    const int d_plane = (int)(rec.x * (float)u + rec.y * (float)v + rec.z);      // :739, ((a*u)+(b*v))+c without contraction
+    const int d_plane_min = max(d_plane - k.plane_radius, 0);
+    const int d_plane_max = min(d_plane + k.plane_radius, d.D - 1);
+    const bool valid = rec.w != 0.0f;
+    // disparities whose warped column stays inside [2, W-3] (:763, :770 / :782, :789), as a range instead of a per-candidate test
+    const int a_lo = side ? 0 : max(u - (d.W - 3), 0), a_hi = side ? min(d.W - 3 - u, d.D - 1) : min(u - 2, d.D - 1);
+    const int sgn = side ? 1 : -1;  // candidate d lives at pu[-d] (left pixel) or pu[+d] (right pixel)
+    int min_val = 10000, min_d = -1;
+    const int b_lo = max(d_plane_min, a_lo), b_hi = min(d_plane_max, a_hi);
+#pragma unroll
+    for (int w = 0; w < 8; w++) {  // grid candidates outside the band (:759-767 / :778-786), ascending d
+        if (w >= d.MW) break;
+        uint32_t m = mw[w];
+        {  // keep [a_lo, a_hi], drop [d_plane_min, d_plane_max]
+            const int lo = a_lo - 32 * w, hi = a_hi - 32 * w;
+            uint32_t keep = 0;
+            if (lo <= 31 && hi >= 0 && lo <= hi) {
+                const int l = max(lo, 0), h = min(hi, 31);
+                keep = (h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u)) & ~((1u << l) - 1u);
+            }
+            m &= keep;
+            const int lo2 = d_plane_min - 32 * w, hi2 = d_plane_max - 32 * w;
+            if (lo2 <= 31 && hi2 >= 0 && lo2 <= hi2) {
+                const int l = max(lo2, 0), h = min(hi2, 31);
+                m &= ~((h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u)) & ~((1u << l) - 1u));
+            }
+        }
+        while (m) {
+            const int b = __ffs((int)m) - 1;
+            m &= m - 1;
+            const int dc = 32 * w + b;
+            const int val = (int)sad16(own, pu[sgn * dc]);
+            if (val < min_val) {
+                min_val = val;
+                min_d = dc;
+            }
+        }
+    }
+    for (int w = 8; w < d.MW; w++) {  // disp_max > 255: remaining words straight from memory
+        const uint32_t m = cell[w];
+        for (int b = 0; b < 32; b++) {
+            const int dc = 32 * w + b;
+            if (!((m >> b) & 1u) || dc < a_lo || dc > a_hi || (dc >= d_plane_min && dc <= d_plane_max)) continue;
+            const int val = (int)sad16(own, pu[sgn * dc]);
+            if (val < min_val) {
+                min_val = val;
+                min_d = dc;
+            }
+        }
+    }
+    // the band [d_plane - r, d_plane + r], ascending, with the plane prior (:768-774 / :787-793).  The offset o is uniform
+    // over the wavefront, so the prior is a scalar operand and the LDS reads do not depend on earlier iterations.
+    for (int o = -k.plane_radius; o <= k.plane_radius; o++) {
+        const int dc = d_plane + o;
+        if (dc < b_lo || dc > b_hi) continue;
+        const int val = (int)sad16(own, pu[sgn * dc]) + (valid ? k.prior[o < 0 ? -o : o] : 0);
+        if (val < min_val) {
+            min_val = val;
+            min_d = dc;
+        }
+    }
+    return min_d >= 0 ? (float)min_d : -1.0f;  // :797-800
+}
+
 __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restrict__ desc, const int32_t *__restrict__ blob, const int32_t *__restrict__ tri_id,
                                                const float4 *__restrict__ trirec, const uint32_t *__restrict__ gB, float *__restrict__ wta) {
     const Dims &d = k.d;
-    extern __shared__ uint4 other_row[];  // the searched image's descriptor row over every column this workgroup can reach
-    const int ps = blockIdx.z, pair = ps >> 1, side = ps & 1;
+    extern __shared__ uint4 dense_lds[];
+    const int pair = blockIdx.z;
     if (blob[pair * META_WORDS] < 3) return;
-    const int x0 = blockIdx.x * 256, u = x0 + threadIdx.x, v = blockIdx.y;
-    const uint8_t *d1 = desc + ((size_t)(pair * 2) * d.N) * 16, *d2 = d1 + (size_t)d.N * 16;
-    const size_t line = (size_t)d.W * max(min(v, d.H - 3), 2) * 16;  // elas.cpp:718
-    const uint8_t *A = (side ? d2 : d1) + line, *B = (side ? d1 : d2) + line;
-    // per-pixel global loads first (triangle id, own descriptor, the cell's candidate mask): they overlap the LDS staging
-    const bool inimg = u < d.W;
-    const size_t pix = (size_t)v * d.W + min(u, d.W - 1);
-    const int t = inimg ? tri_id[(size_t)ps * d.N + pix] : -1;
-    const bool work = t >= 0 && u >= 2 && u < d.W - 2;
-    uint4 own = make_uint4(0, 0, 0, 0);
-    uint32_t mw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float4 rec = make_float4(0, 0, 0, 0);
-    const uint32_t *cell = gB;
-    if (work) {
-        own = ld16(A + (size_t)u * 16);
-        rec = trirec[(size_t)ps * d.max_tri + t];
-        const int gx = (int)floorf((float)u / (float)d.grid_size), gy = (int)floorf((float)v / (float)d.grid_size);
-        cell = gB + ((size_t)ps * d.ncell + (size_t)gy * d.gw + gx) * d.MW;
+    const int x0 = blockIdx.x * DENSE_TW, v = blockIdx.y;
+    const int x1 = min(x0 + DENSE_TW, d.W);  // tile columns [x0, x1)
+    const size_t line = (size_t)d.W * max(min(v, d.H - 3), 2);  // elas.cpp:718: descriptor row, clamped
+    const uint4 *gL = reinterpret_cast<const uint4 *>(desc + ((size_t)(pair * 2) * d.N) * 16) + line;
+    const uint4 *gR = gL + (size_t)d.N;
+    // staged column ranges
+    const int l0 = x0, l1 = min(x1 - 1 + d.disp_max, d.W - 1);   // left image  [l0, l1]
+    const int r0 = max(x0 - d.disp_max, 0), r1 = x1 - 1;         // right image [r0, r1]
+    uint4 *sL = dense_lds, *sR = dense_lds + (DENSE_TW + d.disp_max);
+    for (int i = threadIdx.x; i <= l1 - l0; i += 256) sL[i] = gL[l0 + i];
+    for (int i = threadIdx.x; i <= r1 - r0; i += 256) sR[i] = gR[r0 + i];
+    // per-pixel global operands of this thread's pixels (two per side), requested before the barrier
+    int tt[2][DENSE_TW / 256];
 #pragma unroll
-        for (int w = 0; w < 8; w++) mw[w] = w < d.MW ? cell[w] : 0u;
-    }
-    // left pixel u looks at right columns u-d, right pixel u at left columns u+d, d in [0, disp_max]
-    const int c0 = side ? x0 : max(x0 - d.disp_max, 0);
-    const int c1 = side ? min(x0 + 255 + d.disp_max, d.W - 1) : min(x0 + 255, d.W - 1);
-    {
-        const uint4 *g = reinterpret_cast<const uint4 *>(B) + c0;
-        for (int i = threadIdx.x; i <= c1 - c0; i += 256) other_row[i] = g[i];
-    }
+    for (int side = 0; side < 2; side++)
+#pragma unroll
+        for (int j = 0; j < DENSE_TW / 256; j++) {
+            const int u = x0 + j * 256 + threadIdx.x;
+            tt[side][j] = u < x1 ? tri_id[(size_t)(pair * 2 + side) * d.N + (size_t)v * d.W + u] : -1;
+        }
     __syncthreads();
-    if (!inimg) return;
-    float out = -10.0f;  // elas.cpp:823-824
-    if (work) {
-        if ((int)texture16(own) >= k.match_texture) {  // :732-736
-            const int d_plane = (int)(rec.x * (float)u + rec.y * (float)v + rec.z);  // :739, ((a*u)+(b*v))+c without contraction
-            const int d_plane_min = max(d_plane - k.plane_radius, 0);
-            const int d_plane_max = min(d_plane + k.plane_radius, d.D - 1);
-            const bool valid = rec.w != 0.0f;
-            // disparities whose warped column stays inside [2, W-3] (:763, :770 / :782, :789), as a range instead of a per-candidate test
-            const int a_lo = side ? 0 : max(u - (d.W - 3), 0), a_hi = side ? min(d.W - 3 - u, d.D - 1) : min(u - 2, d.D - 1);
-            const uint4 *pu = other_row + (u - c0);  // candidate d lives at pu[-d] (left pixel) or pu[+d] (right pixel)
-            const int sgn = side ? 1 : -1;
-            int min_val = 10000, min_d = -1;
-            const int b_lo = max(d_plane_min, a_lo), b_hi = min(d_plane_max, a_hi);
 #pragma unroll
-            for (int w = 0; w < 8; w++) {  // grid candidates outside the band (:759-767 / :778-786), ascending d
-                if (w >= d.MW) break;
-                uint32_t m = mw[w];
-                {   // keep [a_lo, a_hi], drop [d_plane_min, d_plane_max]
-                    const int lo = a_lo - 32 * w, hi = a_hi - 32 * w;
-                    uint32_t keep = 0;
-                    if (lo <= 31 && hi >= 0 && lo <= hi) {
-                        const int l = max(lo, 0), h = min(hi, 31);
-                        keep = (h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u)) & ~((1u << l) - 1u);
+    for (int side = 0; side < 2; side++) {
+        const int ps = pair * 2 + side;
+#pragma unroll
+        for (int j = 0; j < DENSE_TW / 256; j++) {
+            const int u = x0 + j * 256 + threadIdx.x;
+            if (u >= x1) continue;
+            const int t = tt[side][j];
+            float out = -10.0f;  // elas.cpp:823-824
+            if (t >= 0 && u >= 2 && u < d.W - 2) {
+                const float4 rec = trirec[(size_t)ps * d.max_tri + t];
+                const int gx = (int)floorf((float)u / (float)d.grid_size), gy = (int)floorf((float)v / (float)d.grid_size);
+                const uint32_t *cell = gB + ((size_t)ps * d.ncell + (size_t)gy * d.gw + gx) * d.MW;
+                uint32_t mw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                if ((d.MW & 3) == 0) {  // 16-byte aligned cells: one or two wide loads
+                    const uint4 m0 = *reinterpret_cast<const uint4 *>(cell);
+                    mw[0] = m0.x, mw[1] = m0.y, mw[2] = m0.z, mw[3] = m0.w;
+                    if (d.MW >= 8) {
+                        const uint4 m1 = *reinterpret_cast<const uint4 *>(cell + 4);
+                        mw[4] = m1.x, mw[5] = m1.y, mw[6] = m1.z, mw[7] = m1.w;
                     }
-                    m &= keep;
-                    const int lo2 = d_plane_min - 32 * w, hi2 = d_plane_max - 32 * w;
-                    if (lo2 <= 31 && hi2 >= 0 && lo2 <= hi2) {
-                        const int l = max(lo2, 0), h = min(hi2, 31);
-                        m &= ~((h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u)) & ~((1u << l) - 1u));
-                    }
+                } else {
+#pragma unroll
+                    for (int w = 0; w < 8; w++) mw[w] = w < d.MW ? cell[w] : 0u;
                 }
-                while (m) {
-                    const int b = __ffs((int)m) - 1;
-                    m &= m - 1;
-                    const int dc = 32 * w + b;
-                    const int val = (int)sad16(own, pu[sgn * dc]);
-                    if (val < min_val) {
-                        min_val = val;
-                        min_d = dc;
-                    }
-                }
+                const uint4 own = side ? sR[u - r0] : sL[u - l0];
+                const uint4 *pu = side ? sL + (u - l0) : sR + (u - r0);  // the other image at the pixel's own column
+                out = dense_pixel(k, side, u, v, own, pu, rec, mw, cell);
             }
-            for (int w = 8; w < d.MW; w++) {  // disp_max > 255: remaining words straight from memory
-                uint32_t m = cell[w];
-                for (int b = 0; b < 32; b++) {
-                    const int dc = 32 * w + b;
-                    if (!((m >> b) & 1u) || dc < a_lo || dc > a_hi || (dc >= d_plane_min && dc <= d_plane_max)) continue;
-                    const int val = (int)sad16(own, pu[sgn * dc]);
-                    if (val < min_val) {
-                        min_val = val;
-                        min_d = dc;
-                    }
-                }
-            }
-            for (int dc = b_lo; dc <= b_hi; dc++) {  // the band, with the plane prior (:768-774 / :787-793)
-                const int val = (int)sad16(own, pu[sgn * dc]) + (valid ? k.prior[abs(dc - d_plane)] : 0);
-                if (val < min_val) {
-                    min_val = val;
-                    min_d = dc;
-                }
-            }
-            out = min_d >= 0 ? (float)min_d : -1.0f;  // :797-800
+            wta[(size_t)ps * d.N + (size_t)v * d.W + u] = out;
         }
     }
-    wta[(size_t)ps * d.N + pix] = out;
 }
 
 void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
-    const size_t shmem = sizeof(uint4) * (size_t)(256 + k.d.disp_max);
-    SV_LAUNCH(K_DENSE, k_dense, dim3((k.d.W + 255) / 256, k.d.H, n * 2), dim3(256), shmem, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta);
+    const size_t shmem = sizeof(uint4) * 2 * (size_t)(DENSE_TW + k.d.disp_max);
+    SV_LAUNCH(K_DENSE, k_dense, dim3((k.d.W + DENSE_TW - 1) / DENSE_TW, k.d.H, n), dim3(256), shmem, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta);
 }
 
 // ------------------------------------------------------------------------------------------------------------

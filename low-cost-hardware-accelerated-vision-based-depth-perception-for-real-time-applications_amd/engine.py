@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libstereo_vision_hip.so")
+LIB_PATH = os.environ.get("SV_LIB_PATH") or os.path.join(HERE, "libstereo_vision_hip.so")  # SV_LIB_PATH: kernel experiments only
 
 SV_ROBOTICS, SV_MIDDLEBURY, SV_DRIVER = 0, 1, 2
 
