@@ -41,7 +41,7 @@ def algorithmic_bytes_per_pair(N, Wc, Hc, Wimg, MW, ncell):
         "support_match": 2 * (2 * (Hc - 1)) * Wimg * 16 + 2 * Wc * Hc,  # descriptor rows v+-2 of every lattice row, both images; lattice out
         "grid_mark": 0, "grid_dilate": 2 * 2 * ncell * MW * 4,
         "plane_fit": 0,
-        "triangles_raster": 2 * 4 * N,                        # one tri_id write per covered pixel, both sides
+        "triangles_raster": 2 * 4 * N, "triangles_raster_fallback": 0,                        # one tri_id write per covered pixel, both sides
         "dense_match": 2 * desc + 2 * 4 * N + 2 * 4 * N,      # both descriptor images, tri_id in, WTA out (both sides)
         "lr_check": 2 * 4 * N + 2 * 4 * N,
         "ccl_init": 4 * N + 8 * N, "ccl_merge": 4 * N, "ccl_count": 4 * N + 4 * N, "ccl_apply": 8 * N + 4 * N,

@@ -15,7 +15,7 @@ namespace sv {
 thread_local LaunchHook g_launch_hook = {nullptr, nullptr};
 
 const char *kernel_name(int id) {
-    static const char *names[K_COUNT] = {"descriptor", "support_match", "grid_mark", "grid_dilate", "plane_fit", "triangles_raster", "dense_match", "lr_check",
+    static const char *names[K_COUNT] = {"descriptor", "support_match", "grid_mark", "grid_dilate", "plane_fit", "triangles_raster", "triangles_raster_fallback", "dense_match", "lr_check",
                                          "ccl_init", "ccl_merge", "ccl_count", "ccl_apply", "gap_rows", "gap_cols", "amean_h", "amean_v",
                                          "median_h", "median_v", "output"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
@@ -151,8 +151,7 @@ __global__ __launch_bounds__(256) void k_descriptor(const uint8_t *__restrict__ 
     __syncthreads();
     // phase C: each thread assembles the descriptors of 4 consecutive pixels of one row (descriptor.cpp:105-121)
     const int qx = tid & 15, ry = tid >> 4;  // pixels x0+4qx .. +3, row y0+ry
-    const int y = y0 + ry;
-    if (y >= d.H) return;
+    const int y = y0 + ry;  // rows beyond the image compute harmless values that are never stored
     const int c = 4 + 4 * qx;  // tile column of the quad's first pixel
     // du rows y-2..y+2 are tile rows ry..ry+4 ; dv rows y-1..y+1 are tile rows ry+1..ry+3
     const uint8_t *u0 = &sdu[(ry + 0) * DESC_DS + c], *u1 = &sdu[(ry + 1) * DESC_DS + c], *u2 = &sdu[(ry + 2) * DESC_DS + c];
@@ -166,10 +165,12 @@ __global__ __launch_bounds__(256) void k_descriptor(const uint8_t *__restrict__ 
     const uint32_t v1 = LDW(w1, 0), v3 = LDW(w3, 0);
     const uint32_t v2a = LDW(w2, -4), v2b = LDW(w2, 0), v2c = LDW(w2, 4);
 #undef LDW
+    // the four descriptors go to an LDS tile first so that the global stores below are fully coalesced (consecutive lanes ->
+    // consecutive 16-byte descriptors); written straight from here each store instruction would touch 64-byte-strided pieces
+    __shared__ uint4 otile[DESC_TH][DESC_TW];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int x = x0 + 4 * qx + j;
-        if (x >= d.W) break;
         uint4 o = make_uint4(0, 0, 0, 0);
         if (x >= 3 && x < d.W - 3 && y >= 3 && y < d.H - 3) {
             // byte k of the 12-byte window (a,b,c) starting at column c-4: column c+j+off is window byte 4+j+off
@@ -186,7 +187,13 @@ __global__ __launch_bounds__(256) void k_descriptor(const uint8_t *__restrict__ 
             o.z = b8 | (b9 << 8) | (b10 << 16) | (b11 << 24);
             o.w = b12 | (b13 << 8) | (b14 << 16) | (b15 << 24);
         }
-        *reinterpret_cast<uint4 *>(out + ((size_t)y * d.W + x) * 16) = o;
+        otile[ry][4 * qx + j] = o;
+    }
+    __syncthreads();
+    const int tw = min(DESC_TW, d.W - x0), th = min(DESC_TH, d.H - y0);
+    for (int i = tid; i < th * DESC_TW; i += 256) {
+        const int r = i / DESC_TW, cx = i - r * DESC_TW;
+        if (cx < tw) *reinterpret_cast<uint4 *>(out + ((size_t)(y0 + r) * d.W + x0 + cx) * 16) = otile[r][cx];
     }
 }
 
@@ -470,8 +477,15 @@ struct RasterRec {
     float ac_a, ac_b, ab_a, ab_b, bc_a, bc_b;
 };
 
+// Scan conversion goes through image tiles held in LDS: k_planes bins every triangle into the tiles its bounding box
+// touches, k_raster_tiles resolves "the last triangle in list order that covers a pixel decides it" with LDS atomicMax and
+// writes each tile with coalesced stores.  A tile list that overflows switches its (pair, side) to the global-atomic path.
+#define RT_W 64
+#define RT_H 32
+#define RT_CAP 512
+
 __global__ __launch_bounds__(256) void k_planes(KParams k, const int32_t *__restrict__ blob, float4 *__restrict__ trirec, float *__restrict__ planes,
-                                                RasterRec *__restrict__ rrec) {
+                                                RasterRec *__restrict__ rrec, int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_list, int32_t *__restrict__ tile_ovf) {
     const Dims &d = k.d;
     const int pair = blockIdx.z, side = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -545,6 +559,23 @@ __global__ __launch_bounds__(256) void k_planes(KParams k, const int32_t *__rest
     r.bc_a = BC_a;
     r.bc_b = B_v - BC_a * B_u;
     rrec[tbase] = r;
+    // bin into tiles: columns [max(A_u,0), min(C_u,W)), rows between the corners' v (+-1 for the float->int truncations)
+    const int ub = max(r.a_u, 0), ue = min(r.c_u, d.W);
+    const float vlo = fminf(fminf(A_v, B_v), C_v), vhi = fmaxf(fmaxf(A_v, B_v), C_v);
+    const int vb = max((int)vlo - 1, 0), ve = min((int)vhi + 2, d.H);  // rows [vb, ve)
+    if (ub < ue && vb < ve) {
+        const int ntx = (d.W + RT_W - 1) / RT_W, nty = (d.H + RT_H - 1) / RT_H;
+        const size_t tb = (size_t)(pair * 2 + side) * ntx * nty;
+        for (int ty = vb / RT_H; ty <= (ve - 1) / RT_H; ty++)
+            for (int tx = ub / RT_W; tx <= (ue - 1) / RT_W; tx++) {
+                const size_t tile = tb + (size_t)ty * ntx + tx;
+                const int slot = atomicAdd(&tile_cnt[tile], 1);
+                if (slot < RT_CAP)
+                    tile_list[tile * RT_CAP + slot] = t;
+                else
+                    tile_ovf[pair * 2 + side] = 1;
+            }
+    }
 }
 
 // Scan conversion (elas.cpp:912-940): 16 lanes per triangle (lattice triangles are only a few columns wide), each lane
@@ -560,22 +591,80 @@ __device__ __forceinline__ int group16_max(int v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_raster(KParams k, const int32_t *__restrict__ blob, const RasterRec *__restrict__ rrec, int32_t *__restrict__ tri_id) {
+// elas.cpp:912-940 for the part of every binned triangle that falls into this workgroup's tile
+__global__ __launch_bounds__(256) void k_raster_tiles(KParams k, const int32_t *__restrict__ blob, const RasterRec *__restrict__ rrec, const int32_t *__restrict__ tile_cnt,
+                                                      const int32_t *__restrict__ tile_list, const int32_t *__restrict__ tile_ovf, int32_t *__restrict__ tri_id) {
     const Dims &d = k.d;
     const int pair = blockIdx.z, side = blockIdx.y;
+    if (blob[pair * META_WORDS] < 3) return;
+    const int ntx = (d.W + RT_W - 1) / RT_W;
+    const int tx0 = (blockIdx.x % ntx) * RT_W, ty0 = (blockIdx.x / ntx) * RT_H;
+    __shared__ int32_t tile[RT_H][RT_W];
+    for (int i = threadIdx.x; i < RT_H * RT_W; i += 256) (&tile[0][0])[i] = -1;
+    __syncthreads();
+    const bool ovf = tile_ovf[pair * 2 + side] != 0;  // overflow somewhere in this map: k_raster (global atomics) does the work
+    const size_t gt = (size_t)(pair * 2 + side) * gridDim.x + blockIdx.x;
+    const int cnt = ovf ? 0 : tile_cnt[gt];
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int x_end = min(tx0 + RT_W, d.W), y_end = min(ty0 + RT_H, d.H);
+    for (int i = grp; i < cnt; i += 16) {  // whole 16-lane groups walk the list together
+        const int t = tile_list[gt * RT_CAP + i];
+        const RasterRec r = rrec[(size_t)(pair * 2 + side) * d.max_tri + t];
+#pragma unroll
+        for (int part = 0; part < 2; part++) {  // :913-925 (A->B, lines AC and AB) and :928-940 (B->C, lines AC and BC)
+            const int ua = part == 0 ? r.a_u : r.b_u, ub = part == 0 ? r.b_u : r.c_u;
+            if (ua == ub) continue;
+            const float e_a = part == 0 ? r.ab_a : r.bc_a, e_b = part == 0 ? r.ab_b : r.bc_b;
+            const int u_begin = max(max(ua, 0), tx0), u_end = min(min(ub, d.W), x_end);
+            for (int base = u_begin; base < u_end; base += 16) {
+                const int u = base + sub;
+                int lo = 0x7FFFFFFF, hi = -0x7FFFFFFF;
+                if (u < u_end) {
+                    const int v_1 = (int)(r.ac_a * (float)u + r.ac_b), v_2 = (int)(e_a * (float)u + e_b);
+                    lo = max(max(min(v_1, v_2), 0), ty0);
+                    hi = min(min(max(v_1, v_2), d.H), y_end);
+                    if (lo >= hi) {
+                        lo = 0x7FFFFFFF;
+                        hi = -0x7FFFFFFF;
+                    }
+                }
+                const int glo = group16_min(lo), ghi = group16_max(hi);
+                for (int v = glo; v < ghi; v++)
+                    if (v >= lo && v < hi) atomicMax(&tile[v - ty0][u - tx0], t);
+            }
+        }
+    }
+    __syncthreads();
+    int32_t *ids = tri_id + (size_t)(pair * 2 + side) * d.N;
+    for (int i = threadIdx.x; i < RT_H * RT_W; i += 256) {
+        const int r = i / RT_W, c = i - r * RT_W;
+        if (ty0 + r < d.H && tx0 + c < d.W) ids[(size_t)(ty0 + r) * d.W + tx0 + c] = tile[r][c];
+    }
+}
+
+// Fallback for maps whose tile lists overflowed: 16 lanes per triangle straight on global memory (k_raster_tiles has
+// already filled such maps with -1).
+__global__ __launch_bounds__(256) void k_raster(KParams k, const int32_t *__restrict__ blob, const RasterRec *__restrict__ rrec, const int32_t *__restrict__ tile_ovf,
+                                                int32_t *__restrict__ tri_id) {
+    const Dims &d = k.d;
+    const int pair = blockIdx.z, side = blockIdx.y;
+    if (tile_ovf[pair * 2 + side] == 0) return;
     const int sub = threadIdx.x & 15;
-    const int t = blockIdx.x * 16 + (threadIdx.x >> 4);
     const int32_t *meta = blob + pair * META_WORDS;
-    const bool live = meta[0] >= 3 && t < meta[2 + 2 * side];  // whole 16-lane groups are live or not
+    if (meta[0] < 3) return;
+    int32_t *ids = tri_id + (size_t)(pair * 2 + side) * d.N;
+    const int ntri = meta[2 + 2 * side];
+    for (int t0 = blockIdx.x * 16; t0 < ntri; t0 += gridDim.x * 16) {
+    const int t = t0 + (threadIdx.x >> 4);
+    const bool live = t < ntri;  // whole 16-lane groups are live or not
     RasterRec r;
     if (live) r = rrec[(size_t)(pair * 2 + side) * d.max_tri + t];
-    int32_t *ids = tri_id + (size_t)(pair * 2 + side) * d.N;
 #pragma unroll
-    for (int part = 0; part < 2; part++) {  // :913-925 (A->B with lines AC, AB) and :928-940 (B->C with lines AC, BC)
+    for (int part = 0; part < 2; part++) {
         const int ua = part == 0 ? r.a_u : r.b_u, ub = part == 0 ? r.b_u : r.c_u;
         const float e_a = part == 0 ? r.ab_a : r.bc_a, e_b = part == 0 ? r.ab_b : r.bc_b;
         const int u_begin = live && ua != ub ? max(ua, 0) : 0, u_end = live && ua != ub ? min(ub, d.W) : 0;
-        const int width = group16_max(u_end - u_begin);  // uniform in the group anyway; keeps the shuffles convergent
+        const int width = group16_max(u_end - u_begin);
         for (int base = 0; base < width; base += 16) {
             const int u = u_begin + base + sub;
             int lo = 0x7FFFFFFF, hi = -0x7FFFFFFF;
@@ -589,16 +678,20 @@ __global__ __launch_bounds__(256) void k_raster(KParams k, const int32_t *__rest
                 }
             }
             const int glo = group16_min(lo), ghi = group16_max(hi);
-            for (int v = glo; v < ghi; v++)  // the 16 lanes of a triangle touch one row segment per step
+            for (int v = glo; v < ghi; v++)
                 if (v >= lo && v < hi) atomicMax(&ids[(size_t)v * d.W + u], t);
         }
+    }
     }
 }
 
 void launch_triangles(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
-    (void)hipMemsetAsync(s.tri_id, 0xFF, sizeof(int32_t) * (size_t)n * 2 * k.d.N, st);
-    SV_LAUNCH(K_PLANES, k_planes, dim3((k.d.max_tri + 255) / 256, 2, n), dim3(256), 0, st, k, s.blob, s.trirec, s.planes, (RasterRec *)s.rrec);
-    SV_LAUNCH(K_TRIANGLES, k_raster, dim3((k.d.max_tri + 15) / 16, 2, n), dim3(256), 0, st, k, s.blob, (const RasterRec *)s.rrec, s.tri_id);
+    const int ntile = ((k.d.W + RT_W - 1) / RT_W) * ((k.d.H + RT_H - 1) / RT_H);
+    (void)hipMemsetAsync(s.tile_cnt, 0, sizeof(int32_t) * ((size_t)n * 2 * ntile + (size_t)s.cap * 2), st);  // counters + overflow flags (contiguous)
+    int32_t *ovf = s.tile_cnt + (size_t)s.cap * 2 * ntile;
+    SV_LAUNCH(K_PLANES, k_planes, dim3((k.d.max_tri + 255) / 256, 2, n), dim3(256), 0, st, k, s.blob, s.trirec, s.planes, (RasterRec *)s.rrec, s.tile_cnt, s.tile_list, ovf);
+    SV_LAUNCH(K_TRIANGLES, k_raster_tiles, dim3(ntile, 2, n), dim3(256), 0, st, k, s.blob, (const RasterRec *)s.rrec, s.tile_cnt, s.tile_list, ovf, s.tri_id);
+    SV_LAUNCH(K_TRIANGLES_FALLBACK, k_raster, dim3(64, 2, n), dim3(256), 0, st, k, s.blob, (const RasterRec *)s.rrec, ovf, s.tri_id);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -44,7 +44,9 @@ struct SlotDev {
                         //                   [2] #triangles left  [3] offset of their corner indices
                         //                   [4] #triangles right [5] offset           (offsets in int32 units from blob)
     float4 *trirec;     // [cap][2][max_tri]  (a, b, c, valid) of the side's own plane
-    void *rrec;         // [cap][2][max_tri]  raster records (k_planes -> k_raster), 36 B each
+    void *rrec;         // [cap][2][max_tri]  raster records (k_planes -> raster kernels), 36 B each
+    int32_t *tile_cnt;  // [cap][2][ntile] triangles binned per 64x32 raster tile, followed by [cap][2] overflow flags
+    int32_t *tile_list; // [cap][2][ntile][512] their indices
     float *planes;      // [cap][2][max_tri][6] t1a t1b t1c t2a t2b t2c (kept for parity tests)
     uint32_t *gmaskA;   // [cap][2][ncell][MW] support marks
     uint32_t *gmaskB;   // [cap][2][ncell][MW] after the 3x3 flat dilation
@@ -71,7 +73,7 @@ void launch_output(const KParams &k, const SlotDev &s, int n, float *d1, float *
 
 // names of the kernels behind each wrapper, in launch order, for timing reports
 enum KernelId {
-    K_DESCRIPTOR = 0, K_SUPPORT, K_GRID_MARK, K_GRID_DILATE, K_PLANES, K_TRIANGLES, K_DENSE, K_LR,
+    K_DESCRIPTOR = 0, K_SUPPORT, K_GRID_MARK, K_GRID_DILATE, K_PLANES, K_TRIANGLES, K_TRIANGLES_FALLBACK, K_DENSE, K_LR,
     K_CCL_INIT, K_CCL_MERGE, K_CCL_COUNT, K_CCL_APPLY, K_GAP_ROWS, K_GAP_COLS, K_AMEAN_H, K_AMEAN_V,
     K_MEDIAN_H, K_MEDIAN_V, K_OUTPUT, K_COUNT
 };
