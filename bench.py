@@ -45,7 +45,7 @@ def algorithmic_bytes_per_pair(N, Wc, Hc, Wimg, MW, ncell):
         "dense_match": 2 * desc + 2 * 4 * N + 2 * 4 * N,      # both descriptor images, tri_id in, WTA out (both sides)
         "lr_check": 2 * 4 * N + 2 * 4 * N,
         "ccl_init": 4 * N + 8 * N, "ccl_merge": 4 * N, "ccl_count": 4 * N + 4 * N, "ccl_apply": 8 * N + 4 * N,
-        "gap_rows": 8 * N, "gap_cols": 8 * N, "amean_h": 8 * N, "amean_v": 8 * N, "median_h": 8 * N, "median_v": 8 * N,
+        "gap_rows": 8 * N, "gap_cols": 8 * N, "adaptive_mean": 8 * N, "median": 8 * N + 4 * N,
         "output": 2 * 8 * N,
     }
 

@@ -272,6 +272,17 @@ void dbg_maps(sv_handle *h, hipStream_t st, const char *stage, const float *base
     }
 }
 
+// maps after an out-of-place stage: processed sides live in `cur`; with postprocess_only_left the right map stays in `disp`
+void dbg_maps_nproc(sv_handle *h, hipStream_t st, const char *stage, const float *cur, const float *disp, int j) {
+    const size_t N = h->kp.d.N;
+    char name[64];
+    for (int side = 0; side < 2; side++) {
+        snprintf(name, sizeof(name), "%s%d", stage, side + 1);
+        const float *base = (side < h->nproc) ? cur : disp;
+        dbg_from_device(h, st, name, base + ((size_t)j * 2 + side) * N, N * sizeof(float));
+    }
+}
+
 // compacted candidate lists in the reference's layout (elas.cpp:631-648) from the device bit masks
 void dbg_grid(sv_handle *h, hipStream_t st, Slot *s, int j) {
     const Dims &d = h->kp.d;
@@ -531,14 +542,20 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
     launch_gap_rows(k, s->dev, n, h->nproc, st);
     launch_gap_cols(k, s->dev, n, h->nproc, st);
     if (active) dbg_maps(h, st, "gap", s->dev.disp, n - 1);
-    if (h->p.filter_adaptive_mean) launch_amean(k, s->dev, n, h->nproc, st);
-    if (active) dbg_maps(h, st, "amean", s->dev.disp, n - 1);
-    if (h->p.filter_median) {  // the last stage writes the caller's maps itself
-        launch_median(k, s->dev, n, h->nproc, st, u1, only_left ? nullptr : u2);
-    } else {
-        launch_output(k, s->dev, n, u1, only_left ? nullptr : u2, st);
+    // the two separable filters are fused, out-of-place kernels: the maps ping-pong between `disp` and `tmp`
+    float *cur = s->dev.disp, *alt = s->dev.tmp;
+    if (h->p.filter_adaptive_mean) {
+        launch_amean(k, s->dev, n, h->nproc, st, cur, alt);
+        std::swap(cur, alt);
     }
-    if (active) dbg_maps(h, st, "final", s->dev.disp, n - 1);
+    if (active) dbg_maps_nproc(h, st, "amean", cur, s->dev.disp, n - 1);
+    if (h->p.filter_median) {  // the last stage writes the caller's maps itself
+        launch_median(k, s->dev, n, h->nproc, st, cur, alt, u1, only_left ? nullptr : u2);
+        std::swap(cur, alt);
+    } else {
+        launch_output(k, s->dev, n, cur, u1, only_left ? nullptr : u2, st);
+    }
+    if (active) dbg_maps_nproc(h, st, "final", cur, s->dev.disp, n - 1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev_free, st));
 }

@@ -16,8 +16,7 @@ thread_local LaunchHook g_launch_hook = {nullptr, nullptr};
 
 const char *kernel_name(int id) {
     static const char *names[K_COUNT] = {"descriptor", "support_match", "grid_mark", "grid_dilate", "plane_fit", "triangles_raster", "triangles_raster_fallback", "dense_match", "lr_check",
-                                         "ccl_init", "ccl_merge", "ccl_count", "ccl_apply", "gap_rows", "gap_cols", "amean_h", "amean_v",
-                                         "median_h", "median_v", "output"};
+                                         "ccl_init", "ccl_merge", "ccl_count", "ccl_apply", "gap_rows", "gap_cols", "adaptive_mean", "median", "output"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 
@@ -1184,50 +1183,68 @@ __device__ __forceinline__ bool amean8(const float xs[8], float xc, float &out) 
     return false;
 }
 
-__global__ __launch_bounds__(256) void k_amean_h(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ disp, float *__restrict__ tmp) {
+// Both passes in one kernel: a 64x32 output tile needs the horizontal result on rows y-4..y+3, which needs the input on
+// columns x-4..x+3; both live in LDS, so every input value is fetched from memory ~1.4 times instead of 16.  Out of place
+// (src -> dst): the vertical pass of another workgroup must never see this one's output.
+#define PF_TW 64
+#define PF_TH 32
+
+__global__ __launch_bounds__(256) void k_amean(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ src, float *__restrict__ dst) {
     const Dims &d = k.d;
     const int m = blockIdx.z;
     if (blob[(m / nproc) * META_WORDS] < 3) return;
     const size_t off = map_offset(d, m, nproc);
-    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
-    if (u >= d.W) return;
-    const float *D = disp + off + (size_t)v * d.W;
-    const float self = D[u];
-    float out = self < 0 ? -10.0f : 0.0f;  // D_tmp: -10 where invalid (:1313-1318), canonical 0 elsewhere (:1308)
-    if (v >= 3 && v < d.H - 3 && u >= 4 && u <= d.W - 4) {  // centre u of window u-4..u+3 (:1402-1441)
-        const int first = u - 4;
-        float xs[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const float t = D[first + ((j - first) & 7)];
-            xs[j] = t < 0 ? -10.0f : t;
+    const float *S = src + off;
+    const int x0 = blockIdx.x * PF_TW, y0 = blockIdx.y * PF_TH;
+    __shared__ float sD[PF_TH + 7][PF_TW + 8];  // D_copy (:1307-1318): rows y0-4.., columns x0-4..; invalid -> -10
+    __shared__ float sT[PF_TH + 7][PF_TW];      // D_tmp after the horizontal pass: rows y0-4.., columns x0..
+    for (int i = threadIdx.x; i < (PF_TH + 7) * (PF_TW + 8); i += 256) {
+        const int r = i / (PF_TW + 8), c = i - r * (PF_TW + 8);
+        const int y = y0 - 4 + r, x = x0 - 4 + c;
+        float val = -10.0f;
+        if (y >= 0 && y < d.H && x >= 0 && x < d.W) {
+            val = S[(size_t)y * d.W + x];
+            if (val < 0) val = -10.0f;
         }
-        float r;
-        if (amean8(xs, self < 0 ? -10.0f : self, r)) out = r;
+        sD[r][c] = val;
     }
-    tmp[off + (size_t)v * d.W + u] = out;
-}
-
-__global__ __launch_bounds__(256) void k_amean_v(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ tmp, float *__restrict__ disp) {
-    const Dims &d = k.d;
-    const int m = blockIdx.z;
-    if (blob[(m / nproc) * META_WORDS] < 3) return;
-    const size_t off = map_offset(d, m, nproc);
-    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
-    if (u < 3 || u >= d.W - 3 || v < 4 || v > d.H - 4) return;  // :1445-1484
-    const float *T = tmp + off;
-    const int first = v - 4;
-    float xs[8];
+    __syncthreads();
+    for (int i = threadIdx.x; i < (PF_TH + 7) * PF_TW; i += 256) {  // horizontal pass (:1402-1441)
+        const int r = i / PF_TW, cx = i - r * PF_TW;
+        const int y = y0 - 4 + r, x = x0 + cx;
+        const float self = sD[r][cx + 4];
+        float out = self < 0 ? -10.0f : 0.0f;  // D_tmp: -10 where invalid (:1313-1318), canonical 0 elsewhere (:1308)
+        if (y >= 3 && y < d.H - 3 && x >= 4 && x <= d.W - 4) {
+            const int first = x - 4;  // window x-4..x+3 = tile columns cx..cx+7; ring slot of pixel p is p & 7
+            float xs[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) xs[j] = T[(size_t)(first + ((j - first) & 7)) * d.W + u];
-    float r;
-    if (amean8(xs, T[(size_t)v * d.W + u], r)) disp[off + (size_t)v * d.W + u] = r;
+            for (int j = 0; j < 8; j++) xs[j] = sD[r][cx + ((j - first) & 7)];
+            float res;
+            if (amean8(xs, self, res)) out = res;
+        }
+        sT[r][cx] = out;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PF_TH * PF_TW; i += 256) {  // vertical pass (:1445-1484)
+        const int ry = i / PF_TW, cx = i - ry * PF_TW;
+        const int y = y0 + ry, x = x0 + cx;
+        if (y >= d.H || x >= d.W) continue;
+        float val = S[(size_t)y * d.W + x];  // untouched unless the filter produces a value
+        if (x >= 3 && x < d.W - 3 && y >= 4 && y <= d.H - 4) {
+            const int first = y - 4;  // window rows y-4..y+3 = tile rows ry..ry+7
+            float xs[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) xs[j] = sT[ry + ((j - first) & 7)][cx];
+            float res;
+            if (amean8(xs, sT[ry + 4][cx], res)) val = res;
+        }
+        dst[off + (size_t)y * d.W + x] = val;
+    }
 }
 
-void launch_amean(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st) {
-    dim3 grid((k.d.W + 255) / 256, k.d.H, n * nproc);
-    SV_LAUNCH(K_AMEAN_H, k_amean_h, grid, dim3(256), 0, st, k, nproc, s.blob, s.disp, s.tmp);
-    SV_LAUNCH(K_AMEAN_V, k_amean_v, grid, dim3(256), 0, st, k, nproc, s.blob, s.tmp, s.disp);
+void launch_amean(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st, const float *src, float *dst) {
+    dim3 grid((k.d.W + PF_TW - 1) / PF_TW, (k.d.H + PF_TH - 1) / PF_TH, n * nproc);
+    SV_LAUNCH(K_AMEAN, k_amean, grid, dim3(256), 0, st, k, nproc, s.blob, src, dst);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1250,53 +1267,58 @@ __device__ __forceinline__ float median7(float v0, float v1, float v2, float v3,
     return v3;
 }
 
-__global__ __launch_bounds__(256) void k_median_h(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ disp, float *__restrict__ tmp) {
-    const Dims &d = k.d;
-    const int m = blockIdx.z;
-    if (blob[(m / nproc) * META_WORDS] < 3) return;
-    const size_t off = map_offset(d, m, nproc);
-    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
-    if (u >= d.W) return;
-    const float *D = disp + off + (size_t)v * d.W;
-    float out = 0.0f;  // calloc'd D_temp (:1506)
-    if (u >= 3 && u < d.W - 3 && v >= 3 && v < d.H - 3) {
-        const float c = D[u];
-        out = c >= 0 ? median7(D[u - 3], D[u - 2], D[u - 1], c, D[u + 1], D[u + 2], D[u + 3]) : c;
-    }
-    tmp[off + (size_t)v * d.W + u] = out;
-}
-
-__global__ __launch_bounds__(256) void k_median_v(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ tmp, float *__restrict__ disp,
-                                                  float *__restrict__ user_d1, float *__restrict__ user_d2) {
+// Horizontal then vertical 7-tap median through LDS tiles, out of place (src -> dst, and straight into the caller's map).
+__global__ __launch_bounds__(256) void k_median(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ src, float *__restrict__ dst,
+                                                float *__restrict__ user_d1, float *__restrict__ user_d2) {
     const Dims &d = k.d;
     const int m = blockIdx.z;
     const int pair = m / nproc, side = m - pair * nproc;
     if (blob[pair * META_WORDS] < 3) return;
     const size_t off = map_offset(d, m, nproc);
-    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
-    if (u >= d.W) return;
-    const size_t q = (size_t)v * d.W + u, p = off + q;
-    float val = disp[p];
-    if (u >= 3 && u < d.W - 3 && v >= 3 && v < d.H - 3 && val >= 0) {
-        const float *T = tmp + p;
-        const long W = d.W;
-        val = median7(T[-3 * W], T[-2 * W], T[-W], T[0], T[W], T[2 * W], T[3 * W]);
-        disp[p] = val;
+    const float *S = src + off;
+    const int x0 = blockIdx.x * PF_TW, y0 = blockIdx.y * PF_TH;
+    __shared__ float sD[PF_TH + 6][PF_TW + 8];  // rows y0-3.., columns x0-3.. (70 used)
+    __shared__ float sT[PF_TH + 6][PF_TW];      // D_temp after the horizontal pass (:1515-1534): rows y0-3.., columns x0..
+    for (int i = threadIdx.x; i < (PF_TH + 6) * (PF_TW + 6); i += 256) {
+        const int r = i / (PF_TW + 6), c = i - r * (PF_TW + 6);
+        const int y = y0 - 3 + r, x = x0 - 3 + c;
+        sD[r][c] = (y >= 0 && y < d.H && x >= 0 && x < d.W) ? S[(size_t)y * d.W + x] : 0.0f;
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (PF_TH + 6) * PF_TW; i += 256) {
+        const int r = i / PF_TW, cx = i - r * PF_TW;
+        const int y = y0 - 3 + r, x = x0 + cx;
+        float out = 0.0f;  // calloc'd D_temp (:1506)
+        if (x >= 3 && x < d.W - 3 && y >= 3 && y < d.H - 3) {
+            const float c = sD[r][cx + 3];
+            out = c >= 0 ? median7(sD[r][cx], sD[r][cx + 1], sD[r][cx + 2], c, sD[r][cx + 4], sD[r][cx + 5], sD[r][cx + 6]) : c;
+        }
+        sT[r][cx] = out;
+    }
+    __syncthreads();
     float *user = side == 0 ? user_d1 : user_d2;  // the last stage writes the caller's map directly
-    if (user) user[(size_t)pair * d.N + q] = val;
+    for (int i = threadIdx.x; i < PF_TH * PF_TW; i += 256) {  // vertical pass (:1537-1556)
+        const int ry = i / PF_TW, cx = i - ry * PF_TW;
+        const int y = y0 + ry, x = x0 + cx;
+        if (y >= d.H || x >= d.W) continue;
+        float val = sD[ry + 3][cx + 3];
+        if (x >= 3 && x < d.W - 3 && y >= 3 && y < d.H - 3 && val >= 0)
+            val = median7(sT[ry][cx], sT[ry + 1][cx], sT[ry + 2][cx], sT[ry + 3][cx], sT[ry + 4][cx], sT[ry + 5][cx], sT[ry + 6][cx]);
+        const size_t q = (size_t)y * d.W + x;
+        dst[off + q] = val;
+        if (user) user[(size_t)pair * d.N + q] = val;
+    }
 }
 
-void launch_median(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st, float *user_d1, float *user_d2) {
-    dim3 grid((k.d.W + 255) / 256, k.d.H, n * nproc);
-    SV_LAUNCH(K_MEDIAN_H, k_median_h, grid, dim3(256), 0, st, k, nproc, s.blob, s.disp, s.tmp);
-    SV_LAUNCH(K_MEDIAN_V, k_median_v, grid, dim3(256), 0, st, k, nproc, s.blob, s.tmp, s.disp, user_d1, user_d2);
+void launch_median(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st, const float *src, float *dst, float *user_d1, float *user_d2) {
+    dim3 grid((k.d.W + PF_TW - 1) / PF_TW, (k.d.H + PF_TH - 1) / PF_TH, n * nproc);
+    SV_LAUNCH(K_MEDIAN, k_median, grid, dim3(256), 0, st, k, nproc, s.blob, src, dst, user_d1, user_d2);
 }
 
 // ------------------------------------------------------------------------------------------------------------
 // final copy into the caller's maps (pairs with < 3 support points are left untouched, as elas.cpp:63-69 does)
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_output(KParams k, const int32_t *__restrict__ blob, const float *__restrict__ disp, float *__restrict__ d1, float *__restrict__ d2) {
+__global__ __launch_bounds__(256) void k_output(KParams k, const int32_t *__restrict__ blob, const float *__restrict__ disp, float *__restrict__ d1, float *__restrict__ d2) {  // disp: current maps
     const Dims &d = k.d;
     const int pair = blockIdx.y;
     if (blob[pair * META_WORDS] < 3) return;
@@ -1314,8 +1336,8 @@ __global__ __launch_bounds__(256) void k_output(KParams k, const int32_t *__rest
     }
 }
 
-void launch_output(const KParams &k, const SlotDev &s, int n, float *d1, float *d2, hipStream_t st) {
-    SV_LAUNCH(K_OUTPUT, k_output, dim3((k.d.N / 4 + 256) / 256, n), dim3(256), 0, st, k, s.blob, s.disp, d1, d2);
+void launch_output(const KParams &k, const SlotDev &s, int n, const float *src, float *d1, float *d2, hipStream_t st) {
+    SV_LAUNCH(K_OUTPUT, k_output, dim3((k.d.N / 4 + 256) / 256, n), dim3(256), 0, st, k, s.blob, src, d1, d2);
 }
 
 }  // namespace sv

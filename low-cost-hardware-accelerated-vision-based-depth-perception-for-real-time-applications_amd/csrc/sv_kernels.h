@@ -52,8 +52,8 @@ struct SlotDev {
     uint32_t *gmaskB;   // [cap][2][ncell][MW] after the 3x3 flat dilation
     int32_t *tri_id;    // [cap][2][N]  last triangle covering a pixel, -1 = none; reused as CCL labels
     float *wta;         // [cap][2][N]  integer WTA disparity (-1 / -10 invalid)
-    float *disp;        // [cap][2][N]  L/R-checked maps, post-processed in place
-    float *tmp;         // [cap][2][N]  scratch of the separable filters
+    float *disp;        // [cap][2][N]  L/R-checked maps; speckle and gap stages work in place
+    float *tmp;         // [cap][2][N]  second map buffer: the fused filters ping-pong disp <-> tmp (CCL counters before that)
     int32_t *csize;     // [cap][2][N]  CCL run lengths (at run-start pixels); component sizes accumulate in `tmp`
 };
 
@@ -67,15 +67,14 @@ void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st, float 
 void launch_speckle(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
 void launch_gap_rows(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
 void launch_gap_cols(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
-void launch_amean(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
-void launch_median(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st, float *user_d1, float *user_d2);
-void launch_output(const KParams &k, const SlotDev &s, int n, float *d1, float *d2, hipStream_t st);
+void launch_amean(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st, const float *src, float *dst);
+void launch_median(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st, const float *src, float *dst, float *user_d1, float *user_d2);
+void launch_output(const KParams &k, const SlotDev &s, int n, const float *src, float *d1, float *d2, hipStream_t st);
 
 // names of the kernels behind each wrapper, in launch order, for timing reports
 enum KernelId {
     K_DESCRIPTOR = 0, K_SUPPORT, K_GRID_MARK, K_GRID_DILATE, K_PLANES, K_TRIANGLES, K_TRIANGLES_FALLBACK, K_DENSE, K_LR,
-    K_CCL_INIT, K_CCL_MERGE, K_CCL_COUNT, K_CCL_APPLY, K_GAP_ROWS, K_GAP_COLS, K_AMEAN_H, K_AMEAN_V,
-    K_MEDIAN_H, K_MEDIAN_V, K_OUTPUT, K_COUNT
+    K_CCL_INIT, K_CCL_MERGE, K_CCL_COUNT, K_CCL_APPLY, K_GAP_ROWS, K_GAP_COLS, K_AMEAN, K_MEDIAN, K_OUTPUT, K_COUNT
 };
 const char *kernel_name(int id);
 
