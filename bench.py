@@ -150,7 +150,7 @@ def main():
         es.process_device(left, right, d1, d2)
         kt = es.kernel_times()
         es.close()
-        serial_k = {k: round(1e3 * v[0] / B, 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0]) if v[1] > 0}
+        serial_k = {k: round(1e3 * v[0] / B, 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0]) if v[1] > 0 and not k.startswith("host:")}
         serial_k["_sum"] = round(sum(serial_k.values()), 3)
 
     # batch-1 latency on rank 0 (ms/frame): one pair per call, one worker
@@ -194,6 +194,9 @@ def main():
             Wc, Hc = (W + step - 1) // step, (H + step - 1) // step
             gw, gh = -(-W // params.grid_size), -(-H // params.grid_size)
             alg = algorithmic_bytes_per_pair(N, Wc, Hc, W, (D + 31) // 32, gw * gh)
+            host = {k: v for k, v in ktimes.items() if k.startswith("host:")}
+            ktimes = {k: v for k, v in ktimes.items() if not k.startswith("host:")}
+            out["host_stage_cpu_ms_per_pair"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in host.items()}
             tot = {k: v[0] for k, v in ktimes.items() if v[1] > 0}
             dom = max(tot, key=tot.get)
             ms, calls = ktimes[dom]

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -55,6 +56,7 @@ struct HostScratch {  // per pool thread
     Delaunay dl;
     std::vector<int32_t> xy;
     std::vector<int32_t> sup;
+    std::vector<int16_t> lattice;
 };
 
 enum SlotState { SLOT_FREE = 0, SLOT_BUSY = 1, SLOT_DRAINING = 2 };  // DRAINING: phase 2 issued, ev_free recorded
@@ -122,6 +124,7 @@ struct sv_handle {
     std::mutex tmu;
     double k_ms[K_COUNT] = {0};
     int64_t k_calls[K_COUNT] = {0};
+    std::atomic<int64_t> host_filter_ns{0}, host_delaunay_ns{0}, host_tasks{0};
     // debug
     std::map<std::string, std::vector<uint8_t>> dbg;
 };
@@ -395,7 +398,9 @@ void triangulate_side(sv_handle *h, HostScratch *sc, Slot *s, int j, int side) {
         sc->xy[2 * q] = side ? sup[3 * q] - sup[3 * q + 2] : sup[3 * q];
         sc->xy[2 * q + 1] = sup[3 * q + 1];
     }
+    const auto t0 = std::chrono::steady_clock::now();
     const int nt = sc->dl.triangulate(sc->xy.data(), ns, blob + meta[3 + 2 * side], 2 * ns);
+    if (h->timing) h->host_delaunay_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     if (nt < 0 || nt > d.max_tri) {
         note_error(h, "triangle capacity exceeded");
         meta[2 + 2 * side] = 0;
@@ -416,7 +421,15 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
         return;
     }
     if ((int)sc->sup.size() < d.max_pts * 3) sc->sup.resize((size_t)d.max_pts * 3);
-    int ns = support_filter_t(h->p, s->h_dcan + (size_t)t.pair * lat, d.W, d.H, sc->sup.data(), d.max_pts);
+    const auto tf0 = std::chrono::steady_clock::now();
+    // work on a private copy: the filters rewrite the lattice in place and the pinned buffer is DMA-visible memory
+    if ((int)sc->lattice.size() < lat + LATTICE_PAD) sc->lattice.assign((size_t)lat + LATTICE_PAD, 0);
+    memcpy(sc->lattice.data(), s->h_dcan + (size_t)t.pair * lat, sizeof(int16_t) * (size_t)lat);
+    int ns = support_filter_t(h->p, sc->lattice.data(), d.W, d.H, sc->sup.data(), d.max_pts);
+    if (h->timing) {
+        h->host_filter_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tf0).count();
+        h->host_tasks += 1;
+    }
     if (ns < 0) {
         note_error(h, "support point capacity exceeded");
         ns = 0;
@@ -643,7 +656,7 @@ void alloc_slot(sv_handle *h, Slot *sl) {
     dev_alloc(s.disp, cap * 2 * d.N);
     dev_alloc(s.tmp, cap * 2 * d.N);
     dev_alloc(s.csize, cap * 2 * d.N);
-    HIP_TRY(hipHostMalloc((void **)&sl->h_dcan, sizeof(int16_t) * cap * d.Wc * d.Hc, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&sl->h_dcan, sizeof(int16_t) * (cap * d.Wc * d.Hc + LATTICE_PAD), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&sl->h_blob, sizeof(int32_t) * sl->blob_words, hipHostMallocDefault));
     HIP_TRY(hipEventCreateWithFlags(&sl->ev_p1, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&sl->ev_free, hipEventDisableTiming));
@@ -915,7 +928,15 @@ int sv_kernel_times(sv_handle *h, const char **names, double *total_ms, int64_t 
         if (total_ms) total_ms[i] = h->k_ms[i];
         if (calls) calls[i] = h->k_calls[i];
     }
-    return K_COUNT;
+    // two pseudo entries: CPU time of the host stage (summed over pool threads), calls = pairs
+    static const char *host_names[2] = {"host:lattice_filter", "host:delaunay_x2"};
+    const int64_t ns[2] = {h->host_filter_ns.load(), h->host_delaunay_ns.load()};
+    for (int j = 0; j < 2 && K_COUNT + j < cap; j++) {
+        if (names) names[K_COUNT + j] = host_names[j];
+        if (total_ms) total_ms[K_COUNT + j] = 1e-6 * (double)ns[j];
+        if (calls) calls[K_COUNT + j] = h->host_tasks.load();
+    }
+    return K_COUNT + 2;
 }
 
 void sv_kernel_times_reset(sv_handle *h) {
@@ -925,6 +946,9 @@ void sv_kernel_times_reset(sv_handle *h) {
         h->k_ms[i] = 0;
         h->k_calls[i] = 0;
     }
+    h->host_filter_ns = 0;
+    h->host_delaunay_ns = 0;
+    h->host_tasks = 0;
 }
 
 void sv_kernel_timing_enable(sv_handle *h, int on) {

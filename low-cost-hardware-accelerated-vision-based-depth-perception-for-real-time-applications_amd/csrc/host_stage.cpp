@@ -7,6 +7,10 @@
 
 #include <algorithm>
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
 namespace sv {
 
 // ------------------------------------------------------------------------------------------------------------
@@ -24,7 +28,7 @@ static void lattice_dims(const sv_params &p, int W, int H, int &Wc, int &Hc) {  
 
 // elas.cpp:152-176.  In place and order dependent: a point invalidated earlier in the scan no longer supports later
 // points.  Counting stops as soon as incon_min_support is reached (the reference only tests `<`).
-static void drop_inconsistent(const sv_params &p, int16_t *T, int Wc, int Hc) {
+static void drop_inconsistent_scalar(const sv_params &p, int16_t *T, int Wc, int Hc) {
     const int win = p.incon_window_size, thr = p.incon_threshold, need = p.incon_min_support;
     for (int uc = 0; uc < Wc; uc++) {
         const int u_lo = std::max(uc - win, 0), u_hi = std::min(uc + win, Wc - 1);
@@ -46,7 +50,49 @@ static void drop_inconsistent(const sv_params &p, int16_t *T, int Wc, int Hc) {
     }
 }
 
-// elas.cpp:178-233 with redun_max_dist = 5, redun_threshold = 1 (:419-420); in place.
+#if defined(__x86_64__)
+// Same scan with one 16-lane int16 compare per window column (the window's <= 11 rows are contiguous in the transposed
+// lattice).  Reads up to 15 elements past a column's window: the caller's buffer is padded accordingly (LATTICE_PAD).
+__attribute__((target("avx2"))) static void drop_inconsistent_avx2(const sv_params &p, int16_t *T, int Wc, int Hc) {
+    const int win = p.incon_window_size, need = p.incon_min_support;
+    const __m256i vthr = _mm256_set1_epi16((short)p.incon_threshold), vneg1 = _mm256_set1_epi16(-1);
+    for (int uc = 0; uc < Wc; uc++) {
+        const int u_lo = std::max(uc - win, 0), u_hi = std::min(uc + win, Wc - 1);
+        int16_t *col = T + (size_t)uc * Hc;
+        for (int vc = 0; vc < Hc; vc++) {
+            const int d = col[vc];
+            if (d < 0) continue;
+            const int v_lo = std::max(vc - win, 0), v_hi = std::min(vc + win, Hc - 1);
+            const uint32_t lanes = (1u << (2 * (v_hi - v_lo + 1))) - 1u;  // movemask gives 2 bits per int16 lane
+            const __m256i vd = _mm256_set1_epi16((short)d);
+            int support = 0;
+            for (int u2 = u_lo; u2 <= u_hi && support < need; u2++) {
+                const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(T + (size_t)u2 * Hc + v_lo));
+                const __m256i diff = _mm256_abs_epi16(_mm256_sub_epi16(x, vd));
+                const __m256i ok = _mm256_andnot_si256(_mm256_cmpgt_epi16(diff, vthr), _mm256_cmpgt_epi16(x, vneg1));
+                support += __builtin_popcount((uint32_t)_mm256_movemask_epi8(ok) & lanes) >> 1;
+            }
+            if (support < need) col[vc] = -1;
+        }
+    }
+}
+#endif
+
+static void drop_inconsistent(const sv_params &p, int16_t *T, int Wc, int Hc) {
+#if defined(__x86_64__)
+    // disparities are < 1024 and the window has at most 11 rows: the int16 arithmetic cannot overflow
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    if (have_avx2 && p.incon_window_size <= 7 && p.incon_threshold >= 0 && p.incon_threshold < 16384) {
+        drop_inconsistent_avx2(p, T, Wc, Hc);
+        return;
+    }
+#endif
+    drop_inconsistent_scalar(p, T, Wc, Hc);
+}
+
+// elas.cpp:178-233 with redun_max_dist = 5, redun_threshold = 1 (:419-420); in place.  A point is dropped when, in BOTH
+// directions along the axis, some valid point with |dd| <= thr lies within max_dist steps ("first found" == "any found").
+// Branch-free per direction: the data-dependent early exits of the reference mispredict on almost every point.
 static void drop_redundant(int16_t *T, int Wc, int Hc, int max_dist, int thr, bool vertical) {
     const int stride = vertical ? 1 : Hc;
     for (int uc = 0; uc < Wc; uc++)
@@ -55,21 +101,17 @@ static void drop_redundant(int16_t *T, int Wc, int Hc, int max_dist, int thr, bo
             const int d = *q;
             if (d < 0) continue;
             const int pos = vertical ? vc : uc, len = vertical ? Hc : Wc;
-            bool both = true;
-            for (int dir = -1; dir <= 1 && both; dir += 2) {
-                bool found = false;
-                for (int j = 1; j <= max_dist; j++) {
-                    const int pp = pos + dir * j;
-                    if (pp < 0 || pp >= len) break;
-                    const int d2 = q[dir * j * stride];
-                    if (d2 >= 0 && abs(d - d2) <= thr) {
-                        found = true;
-                        break;
-                    }
-                }
-                both = found;
+            const int n_lo = std::min(max_dist, pos), n_hi = std::min(max_dist, len - 1 - pos);  // steps available before the border
+            int found_lo = 0, found_hi = 0;
+            for (int j = 1; j <= n_lo; j++) {
+                const int d2 = q[-j * stride];
+                found_lo |= (d2 >= 0) & (abs(d - d2) <= thr);
             }
-            if (both) *q = -1;
+            for (int j = 1; j <= n_hi; j++) {
+                const int d2 = q[j * stride];
+                found_hi |= (d2 >= 0) & (abs(d - d2) <= thr);
+            }
+            if (found_lo & found_hi) *q = -1;
         }
 }
 
@@ -130,7 +172,7 @@ int support_filter_t(const sv_params &p, int16_t *T, int W, int H, int32_t *out,
 int support_filter(const sv_params &p, int16_t *dcan, int W, int H, int32_t *out, int cap) {
     int Wc, Hc;
     lattice_dims(p, W, H, Wc, Hc);
-    std::vector<int16_t> T((size_t)Wc * Hc);
+    std::vector<int16_t> T((size_t)Wc * Hc + LATTICE_PAD, 0);
     for (int vc = 0; vc < Hc; vc++)
         for (int uc = 0; uc < Wc; uc++) T[(size_t)uc * Hc + vc] = dcan[(size_t)vc * Wc + uc];
     const int n = support_filter_t(p, T.data(), W, H, out, cap);

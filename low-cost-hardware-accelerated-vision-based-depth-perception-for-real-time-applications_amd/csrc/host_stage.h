@@ -18,6 +18,8 @@ namespace sv {
 // `dcan` is [Hc][Wc] (row/col 0 hold 0 = "valid d=0", elas.cpp:387) and is modified in place.
 // Writes (u,v,d) triples to `out` (capacity cap points); returns the point count (or -needed if cap is too small).
 int support_filter(const sv_params &p, int16_t *dcan, int W, int H, int32_t *out, int cap);
+// The transposed-lattice entry point may read (never write) up to LATTICE_PAD int16 elements past the end of T.
+constexpr int LATTICE_PAD = 16;
 // Same on the transposed lattice T[uc * Hc + vc] (the layout the GPU writes and the filters scan contiguously).
 int support_filter_t(const sv_params &p, int16_t *T, int W, int H, int32_t *out, int cap);
 
