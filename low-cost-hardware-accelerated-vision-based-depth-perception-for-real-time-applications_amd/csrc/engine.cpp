@@ -17,6 +17,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -208,6 +209,8 @@ void fill_kparams(sv_handle *h) {
     k.speckle_size = p.speckle_size;
     k.gap_width = p.ipol_gap_width;
     k.add_corners = p.add_corners;
+    k.rt_cap = 512;
+    if (const char *e = getenv("SV_DEBUG_RT_CAP")) k.rt_cap = std::max(0, std::min(512, atoi(e)));  // tests: force the raster fallback
     h->nproc = p.postprocess_only_left ? 1 : 2;
 }
 

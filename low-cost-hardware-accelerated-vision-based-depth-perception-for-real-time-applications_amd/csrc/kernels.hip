@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void k_planes(KParams k, const int32_t *__rest
             for (int tx = ub / RT_W; tx <= (ue - 1) / RT_W; tx++) {
                 const size_t tile = tb + (size_t)ty * ntx + tx;
                 const int slot = atomicAdd(&tile_cnt[tile], 1);
-                if (slot < RT_CAP)
+                if (slot < k.rt_cap)
                     tile_list[tile * RT_CAP + slot] = t;
                 else
                     tile_ovf[pair * 2 + side] = 1;

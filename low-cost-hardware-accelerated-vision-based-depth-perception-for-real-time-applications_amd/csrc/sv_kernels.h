@@ -30,6 +30,7 @@ struct KParams {
     int speckle_size;
     int gap_width;
     int add_corners;
+    int rt_cap;              // triangles a raster tile list may hold before its map falls back to global atomics (<= 512)
 };
 
 // Device buffers of one worker slot, each holding `cap` pairs back to back.

@@ -142,3 +142,50 @@ def test_determinism_full_size(eng):
     assert ((d1 == -10) | ((d1 >= 0) & (d1 <= 127))).all()
     assert ((d2 == -10) | ((d2 >= 0) & (d2 <= 127) & (d2 == np.round(d2)))).all()
     assert (d1 >= 0).mean() > 0.9
+
+
+def test_raster_fallback_path(eng, oracle, monkeypatch):
+    """Tile lists that overflow switch a map to the global-atomic rasteriser: force that with a tiny cap and check the maps."""
+    monkeypatch.setenv("SV_DEBUG_RT_CAP", "3")
+    entry = DIG["kitti0_crop_d64"]
+    L, R, d1, d2, nsup, st = _run_debug(eng, entry)
+    assert util.sha(st["wta1"]) == entry["stages"]["wta1"] and util.sha(st["wta2"]) == entry["stages"]["wta2"]
+    assert util.sha(d1) == entry["stages"]["final1"] and util.sha(d2) == entry["stages"]["final2"]
+
+
+def test_full_4k_pair(eng, oracle):
+    """BASELINE config 5 shape: one full 3840x2160 synthetic pair at D=192 against the oracle (bit-exact)."""
+    synth = util.pkg("synth")
+    L, R = synth.make_pair(5001, 2160, 3840, 192, scale=3)
+    p = eng.SvParams.driver(191)
+    e = eng.StereoEngine(3840, 2160, p, chunk=1, n_slots=1, n_streams=1, n_workers=2)
+    try:
+        d1, d2, status = e.process_host(L, R)
+    finally:
+        e.close()
+    o1, o2, _ = oracle.process(ElasParams.driver(191), L, R)
+    assert status[0] >= 3
+    assert np.array_equal(d1[0].view(np.uint8), o1.view(np.uint8))
+    assert np.array_equal(d2[0].view(np.uint8), o2.view(np.uint8))
+
+
+def test_robotics_preset_batch(eng, oracle):
+    """ROBOTICS preset (texture gate, gap width 3, no median, no corner points) on a small batch."""
+    import torch
+    synth = util.pkg("synth")
+    H, W, D, B = 96, 256, 48, 5
+    batch = synth.make_batch(300, B, H, W, D)
+    p = eng.SvParams.preset("robotics")
+    p.disp_max = D - 1
+    e = eng.StereoEngine(W, H, p, chunk=2, n_slots=2)
+    try:
+        d1, d2 = e.process_device(torch.from_numpy(batch[:, 0].copy()).cuda(), torch.from_numpy(batch[:, 1].copy()).cuda())
+        torch.cuda.synchronize()
+        d1, d2 = d1.cpu().numpy(), d2.cpu().numpy()
+    finally:
+        e.close()
+    po = ElasParams.preset("robotics")
+    po.disp_max = D - 1
+    for i in range(B):
+        o1, o2, _ = oracle.process(po, batch[i, 0], batch[i, 1])
+        assert np.array_equal(d1[i].view(np.uint8), o1.view(np.uint8)) and np.array_equal(d2[i].view(np.uint8), o2.view(np.uint8)), i
