@@ -60,12 +60,16 @@ struct HostScratch {  // per pool thread
     std::vector<int16_t> lattice;
 };
 
+constexpr int FSUP_COPY_PTS = 4096;  // support points per pair fetched with the bulk D2H (more are fetched on demand)
+
 enum SlotState { SLOT_FREE = 0, SLOT_BUSY = 1, SLOT_DRAINING = 2 };  // DRAINING: phase 2 issued, ev_free recorded
 
 struct Slot {
     int id = 0;
     SlotDev dev{};
     int16_t *h_dcan = nullptr;  // pinned [cap][Hc*Wc]
+    int32_t *h_fsup = nullptr;  // pinned [cap][FSUP_COPY_PTS][3]: head of the GPU-filtered support lists
+    int32_t *h_fnsup = nullptr; // pinned [cap]
     int32_t *h_blob = nullptr;  // pinned
     size_t blob_words = 0;
     hipEvent_t ev_p1 = nullptr, ev_free = nullptr;
@@ -98,6 +102,7 @@ struct sv_handle {
     KParams kp;
     int nproc = 1;  // maps per pair that get post-processed
     int chunk = 1;
+    bool gpu_filter = false;  // lattice filters on the GPU (k_support_filter) instead of the host pool
     std::vector<Slot *> slots;
     hipStream_t sP1 = nullptr;
     std::vector<hipStream_t> sP2;
@@ -212,6 +217,11 @@ void fill_kparams(sv_handle *h) {
     k.rt_cap = 512;
     if (const char *e = getenv("SV_DEBUG_RT_CAP")) k.rt_cap = std::max(0, std::min(512, atoi(e)));  // tests: force the raster fallback
     h->nproc = p.postprocess_only_left ? 1 : 2;
+    // the on-GPU lattice filter keeps the whole lattice (+ state) of a pair in the LDS of one workgroup and resolves a
+    // point's earlier neighbours with one 64-lane ballot: needs incon_window_size <= 5 and a lattice that fits
+    const char *force_host = getenv("SV_HOST_FILTER");
+    h->gpu_filter = !(force_host && atoi(force_host) != 0) && p.incon_window_size >= 0 && p.incon_window_size <= 5 &&
+                    (size_t)d.Wc * d.Hc < 65536 && support_filter_lds_bytes(k) <= 140 * 1024;
 }
 
 void timing_hook(void *ctx, int id, bool before, hipStream_t st) {
@@ -318,7 +328,15 @@ void issue_phase1(sv_handle *h, Slot *s) {
     const int lat = d.Wc * d.Hc;
     launch_descriptor(k, job.left + (size_t)s->i0 * in_pair, job.right + (size_t)s->i0 * in_pair, in_pair, job.stride, s->dev, s->n, h->sP1);
     launch_support(k, s->dev, s->n, h->sP1);
-    HIP_TRY(hipMemcpyAsync(s->h_dcan, s->dev.dcan, sizeof(int16_t) * (size_t)s->n * lat, hipMemcpyDeviceToHost, h->sP1));
+    if (h->gpu_filter) {
+        launch_support_filter(k, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s->dev, s->n, h->sP1);
+        HIP_TRY(hipMemcpyAsync(s->h_fnsup, s->dev.fnsup, sizeof(int32_t) * (size_t)s->n, hipMemcpyDeviceToHost, h->sP1));
+        const size_t w = sizeof(int32_t) * 3 * (size_t)std::min(FSUP_COPY_PTS, d.max_pts);
+        HIP_TRY(hipMemcpy2DAsync(s->h_fsup, sizeof(int32_t) * 3 * FSUP_COPY_PTS, s->dev.fsup, sizeof(int32_t) * 3 * (size_t)d.max_pts, w, (size_t)s->n,
+                                 hipMemcpyDeviceToHost, h->sP1));
+    }
+    if (!h->gpu_filter || h->cfg.keep_debug)
+        HIP_TRY(hipMemcpyAsync(s->h_dcan, s->dev.dcan, sizeof(int16_t) * (size_t)s->n * lat, hipMemcpyDeviceToHost, h->sP1));
     HIP_TRY(hipEventRecord(s->ev_p1, h->sP1));
     if (h->cfg.keep_debug) {
         const int j = s->n - 1;
@@ -424,19 +442,32 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
         return;
     }
     if ((int)sc->sup.size() < d.max_pts * 3) sc->sup.resize((size_t)d.max_pts * 3);
-    const auto tf0 = std::chrono::steady_clock::now();
-    // work on a private copy: the filters rewrite the lattice in place and the pinned buffer is DMA-visible memory
-    if ((int)sc->lattice.size() < lat + LATTICE_PAD) sc->lattice.assign((size_t)lat + LATTICE_PAD, 0);
-    memcpy(sc->lattice.data(), s->h_dcan + (size_t)t.pair * lat, sizeof(int16_t) * (size_t)lat);
-    int ns = support_filter_t(h->p, sc->lattice.data(), d.W, d.H, sc->sup.data(), d.max_pts);
-    if (h->timing) {
-        h->host_filter_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tf0).count();
-        h->host_tasks += 1;
+    int ns;
+    if (h->gpu_filter) {  // the lattice filters already ran on the GPU (k_support_filter): just pick up the list
+        ns = s->h_fnsup[t.pair];
+        if (ns < 0 || ns > d.max_pts) {
+            note_error(h, "corrupt support count from the GPU filter");
+            ns = 0;
+        }
+        if (ns <= FSUP_COPY_PTS) {
+            memcpy(sc->sup.data(), s->h_fsup + (size_t)t.pair * FSUP_COPY_PTS * 3, sizeof(int32_t) * 3 * (size_t)ns);
+        } else if (hipMemcpy(sc->sup.data(), s->dev.fsup + (size_t)t.pair * d.max_pts * 3, sizeof(int32_t) * 3 * (size_t)ns, hipMemcpyDeviceToHost) != hipSuccess) {
+            note_error(h, "hipMemcpy of a long support list failed");
+            ns = 0;
+        }
+    } else {
+        const auto tf0 = std::chrono::steady_clock::now();
+        // work on a private copy: the filters rewrite the lattice in place and the pinned buffer is DMA-visible memory
+        if ((int)sc->lattice.size() < lat + LATTICE_PAD) sc->lattice.assign((size_t)lat + LATTICE_PAD, 0);
+        memcpy(sc->lattice.data(), s->h_dcan + (size_t)t.pair * lat, sizeof(int16_t) * (size_t)lat);
+        ns = support_filter_t(h->p, sc->lattice.data(), d.W, d.H, sc->sup.data(), d.max_pts);
+        if (h->timing) h->host_filter_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tf0).count();
+        if (ns < 0) {
+            note_error(h, "support point capacity exceeded");
+            ns = 0;
+        }
     }
-    if (ns < 0) {
-        note_error(h, "support point capacity exceeded");
-        ns = 0;
-    }
+    if (h->timing) h->host_tasks += 1;
     if (h->job.status) h->job.status[s->i0 + t.pair] = ns;
     meta[0] = ns;
     meta[1] = meta[3] = meta[5] = 0;
@@ -640,6 +671,10 @@ void alloc_slot(sv_handle *h, Slot *sl) {
     dev_alloc(s.dcan, cap * d.Wc * d.Hc);
     sl->blob_words = cap * (META_WORDS + (size_t)d.max_pts * 3 + 2 * (size_t)d.max_tri * 3 + 64);
     dev_alloc(s.blob, sl->blob_words);
+    dev_alloc(s.fsup, cap * (size_t)d.max_pts * 3);
+    dev_alloc(s.fnsup, cap);
+    HIP_TRY(hipHostMalloc((void **)&sl->h_fsup, sizeof(int32_t) * cap * FSUP_COPY_PTS * 3, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void **)&sl->h_fnsup, sizeof(int32_t) * cap, hipHostMallocDefault));
     dev_alloc(s.trirec, cap * 2 * d.max_tri);
     {
         uint8_t *r = nullptr;
@@ -667,11 +702,13 @@ void alloc_slot(sv_handle *h, Slot *sl) {
 
 void free_slot(Slot *sl) {
     SlotDev &s = sl->dev;
-    void *dptrs[] = {s.desc, s.dcan, s.blob, s.rrec, s.tile_cnt, s.tile_list, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize};
+    void *dptrs[] = {s.desc, s.dcan, s.fsup, s.fnsup, s.blob, s.rrec, s.tile_cnt, s.tile_list, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize};
     for (void *p : dptrs)
         if (p) (void)hipFree(p);
     if (sl->h_dcan) (void)hipHostFree(sl->h_dcan);
     if (sl->h_blob) (void)hipHostFree(sl->h_blob);
+    if (sl->h_fsup) (void)hipHostFree(sl->h_fsup);
+    if (sl->h_fnsup) (void)hipHostFree(sl->h_fnsup);
     if (sl->ev_p1) (void)hipEventDestroy(sl->ev_p1);
     if (sl->ev_free) (void)hipEventDestroy(sl->ev_free);
 }

@@ -15,7 +15,7 @@ namespace sv {
 thread_local LaunchHook g_launch_hook = {nullptr, nullptr};
 
 const char *kernel_name(int id) {
-    static const char *names[K_COUNT] = {"descriptor", "support_match", "grid_mark", "grid_dilate", "plane_fit", "triangles_raster", "triangles_raster_fallback", "dense_match", "lr_check",
+    static const char *names[K_COUNT] = {"descriptor", "support_match", "support_filter", "grid_mark", "grid_dilate", "plane_fit", "triangles_raster", "triangles_raster_fallback", "dense_match", "lr_check",
                                          "ccl_init", "ccl_merge", "ccl_count", "ccl_apply", "gap_rows", "gap_cols", "adaptive_mean", "median", "output"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
@@ -328,6 +328,293 @@ void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
     const size_t shmem = sizeof(uint4) * 2 * ((size_t)(span + k.d.disp_max + 5) + (size_t)(span + 2 * k.d.disp_max + 5));
     dim3 grid((k.d.Wc - 1 + cands - 1) / cands, k.d.Hc - 1, n);
     SV_LAUNCH(K_SUPPORT, k_support, grid, dim3(SUP_THREADS), shmem, st, k, cands, s.desc, s.dcan);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// K2b support lattice -> support point list, on the GPU (one workgroup per pair, lattice in LDS)
+//     reference: elas.cpp:152-176 (removeInconsistentSupportPoints), :178-233 (removeRedundantSupportPoints x2, :419-420),
+//                :422-433 (collect, u outer / v inner), :235-264 (addCornerSupportPoints)
+//     The reference's filters are sequential in-place scans.  The inconsistency pass is made parallel by classification:
+//     when a lattice point is visited, the neighbours LATER in scan order are still unmodified, so
+//        c_late  = consistent neighbours later-or-equal in scan order (exact at visit time)
+//        c_all   = consistent neighbours in the original lattice (upper bound at visit time)
+//     c_late >= min_support -> certainly kept; c_all < min_support -> certainly dropped; only the rest ("uncertain") depend
+//     on the fate of earlier points and are resolved one after the other, in scan order, by one wavefront that counts the
+//     <= 60 earlier neighbours with a ballot.  The redundancy passes only couple points of one column / one row, so they
+//     run one lane per column / row.  Lattice layout: transposed, T[u*Hc + v] (scan order == index order).
+// ------------------------------------------------------------------------------------------------------------
+#define FST_NONE 0
+#define FST_KEEP 1
+#define FST_DROP 2
+#define FST_UNC 3
+
+#define FLT_THREADS 1024
+
+__device__ __forceinline__ int block_exclusive_scan(int val, int *s_scan, int *total) {  // FLT_THREADS threads
+    const int tid = threadIdx.x;
+    s_scan[tid] = val;
+    __syncthreads();
+#pragma unroll
+    for (int off = 1; off < FLT_THREADS; off <<= 1) {
+        const int add = tid >= off ? s_scan[tid - off] : 0;
+        __syncthreads();
+        s_scan[tid] += add;
+        __syncthreads();
+    }
+    *total = s_scan[FLT_THREADS - 1];
+    const int excl = s_scan[tid] - val;
+    __syncthreads();
+    return excl;
+}
+
+// order-preserving compaction of the lattice indices that satisfy `pred` (each thread owns a contiguous index range)
+template <class Pred>
+__device__ __forceinline__ int compact_indices(int lat, uint16_t *list, int *s_scan, Pred pred) {
+    const int tid = threadIdx.x;
+    const int per = (lat + FLT_THREADS - 1) / FLT_THREADS;
+    const int i_lo = min(tid * per, lat), i_hi = min(i_lo + per, lat);
+    int mine = 0;
+    for (int i = i_lo; i < i_hi; i++) mine += pred(i) ? 1 : 0;
+    int total;
+    int pos = block_exclusive_scan(mine, s_scan, &total);
+    for (int i = i_lo; i < i_hi; i++)
+        if (pred(i)) list[pos++] = (uint16_t)i;
+    __syncthreads();
+    return total;
+}
+
+// one step of a redundancy walk: `w[0..10]` = values at positions p-5..p+5 of the line (out-of-line slots hold -1)
+__device__ __forceinline__ bool redundant_here(const int w[11]) {
+    const int dd = w[5];
+    if (dd < 0) return false;
+    int lo = 0, hi = 0;
+#pragma unroll
+    for (int j = 1; j <= 5; j++) {
+        lo |= (w[5 - j] >= 0) & (abs(dd - w[5 - j]) <= 1);
+        hi |= (w[5 + j] >= 0) & (abs(dd - w[5 + j]) <= 1);
+    }
+    return (lo & hi) != 0;
+}
+
+__global__ __launch_bounds__(FLT_THREADS) void k_support_filter(KParams k, int win, int thr, int need, const int16_t *__restrict__ dcan, int32_t *__restrict__ fsup,
+                                                                int32_t *__restrict__ fnsup) {
+    const Dims &d = k.d;
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int Wc = d.Wc, Hc = d.Hc, lat = Wc * Hc;
+    extern __shared__ unsigned char flt_lds[];
+    int16_t *T = reinterpret_cast<int16_t *>(flt_lds);
+    uint16_t *list = reinterpret_cast<uint16_t *>(T + lat + (lat & 1));
+    uint8_t *st = reinterpret_cast<uint8_t *>(list + lat + (lat & 1));
+    __shared__ int s_scan[FLT_THREADS];
+    const int16_t *G = dcan + (size_t)pair * lat;
+    for (int i = tid; i < lat; i += FLT_THREADS) {
+        T[i] = G[i];
+        st[i] = FST_NONE;
+    }
+    __syncthreads();
+
+    // ---- inconsistency pass, classification (elas.cpp:152-176) over the compacted valid points; the 11x11 window
+    // (win <= 5) is fully unrolled, so the LDS reads of one point are independent and all in flight together
+    const int n_valid = compact_indices(lat, list, s_scan, [&](int i) { return T[i] >= 0; });
+    for (int q = tid; q < n_valid; q += FLT_THREADS) {
+        const int idx = list[q];
+        const int dd = T[idx];
+        const int u = idx / Hc, v = idx - u * Hc;
+        int c_late = 0, c_early = 0;
+#pragma unroll
+        for (int du = -5; du <= 5; du++) {
+            const int u2 = u + du;
+            const bool col_ok = du >= -win && du <= win && u2 >= 0 && u2 < Wc;
+            const int16_t *col = T + (col_ok ? u2 : u) * Hc;
+#pragma unroll
+            for (int dv = -5; dv <= 5; dv++) {
+                const int v2 = v + dv;
+                const bool ok = col_ok && dv >= -win && dv <= win && v2 >= 0 && v2 < Hc;
+                const int d2 = col[ok ? v2 : v];
+                const int hit = ok & (d2 >= 0) & (abs(dd - d2) <= thr);
+                if (du > 0 || (du == 0 && dv >= 0))
+                    c_late += hit;
+                else
+                    c_early += hit;
+            }
+        }
+        st[idx] = (uint8_t)(c_late >= need ? FST_KEEP : (c_late + c_early < need) ? FST_DROP : (FST_UNC | (c_late << 2)));
+    }
+    __syncthreads();
+    // refinement rounds over the compacted uncertain points, still fully parallel: earlier neighbours that are certainly
+    // kept count for sure, earlier neighbours that are certainly dropped never count.  (A round only reads states of
+    // EARLIER points and only turns UNC into KEEP/DROP; both decisions stay valid whatever the remaining UNC points
+    // become, so concurrent updates are benign.)
+    int n_unc = compact_indices(lat, list, s_scan, [&](int i) { return (st[i] & 3) == FST_UNC; });
+    for (int round = 0; round < 3 && n_unc > 0; round++) {
+        for (int q = tid; q < n_unc; q += FLT_THREADS) {
+            const int idx = list[q];
+            const int s0 = st[idx];
+            if ((s0 & 3) != FST_UNC) continue;
+            const int dd = T[idx], c_late = s0 >> 2;
+            const int u = idx / Hc, v = idx - u * Hc;
+            int sure = 0, maybe = 0;
+#pragma unroll
+            for (int du = -5; du <= 0; du++) {
+                const int u2 = u + du;
+                const bool col_ok = du >= -win && u2 >= 0;
+#pragma unroll
+                for (int dv = -5; dv <= 5; dv++) {
+                    if (du == 0 && dv >= 0) continue;
+                    const int v2 = v + dv;
+                    const bool ok = col_ok && dv >= -win && dv <= win && v2 >= 0 && v2 < Hc;
+                    const int j = (ok ? u2 : u) * Hc + (ok ? v2 : v);
+                    const int d2 = T[j], s2 = st[j] & 3;
+                    const int cons = ok & (d2 >= 0) & (abs(dd - d2) <= thr);
+                    sure += cons & (s2 == FST_KEEP);
+                    maybe += cons & (s2 == FST_UNC);
+                }
+            }
+            if (c_late + sure >= need)
+                st[idx] = FST_KEEP;
+            else if (c_late + sure + maybe < need)
+                st[idx] = FST_DROP;
+        }
+        __syncthreads();
+    }
+    // what is still uncertain is resolved in scan order by one wavefront: lanes = the earlier neighbours
+    // (win*(2win+1) + win <= 60 for win <= 5)
+    if (n_unc > 0) n_unc = compact_indices(lat, list, s_scan, [&](int i) { return (st[i] & 3) == FST_UNC; });
+    if (tid < 64) {
+        const int rowlen = 2 * win + 1, n_early = win * rowlen + win;
+        for (int i = 0; i < n_unc; i++) {
+            const int idx = list[i];
+            const int u = idx / Hc, v = idx - u * Hc;
+            const int dd = T[idx], c_late = st[idx] >> 2;
+            bool ok = false;
+            if (lane < n_early) {
+                const int u2 = lane < win * rowlen ? u - win + lane / rowlen : u;
+                const int v2 = lane < win * rowlen ? v - win + lane % rowlen : v - win + (lane - win * rowlen);
+                if (u2 >= 0 && v2 >= 0 && v2 < Hc) {
+                    const int d2 = T[u2 * Hc + v2];
+                    ok = d2 >= 0 && abs(dd - d2) <= thr && (st[u2 * Hc + v2] & 3) == FST_KEEP;
+                }
+            }
+            const int c = (int)__popcll(__ballot(ok));
+            if (lane == 0) st[idx] = (uint8_t)((c_late + c >= need) ? FST_KEEP : FST_DROP);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < lat; i += FLT_THREADS)
+        if ((st[i] & 3) == FST_DROP) T[i] = -1;
+    __syncthreads();
+
+    // ---- redundancy passes (elas.cpp:178-233; max_dist 5, threshold 1).  Only points of one column (vertical pass) or
+    // one row (horizontal pass) interact, so one lane walks one line; it keeps the 11 values around the current position
+    // in registers (positions behind reflect its own earlier invalidations) and reads one new value per step.
+    for (int u = tid; u < Wc; u += FLT_THREADS) {
+        int16_t *col = T + u * Hc;
+        int w[11];
+#pragma unroll
+        for (int j = 0; j < 11; j++) w[j] = (j >= 5 && j - 5 < Hc) ? (int)col[j - 5] : -1;
+        for (int v = 0; v < Hc; v++) {
+            if (redundant_here(w)) {
+                col[v] = -1;
+                w[5] = -1;
+            }
+#pragma unroll
+            for (int j = 0; j < 10; j++) w[j] = w[j + 1];
+            w[10] = v + 6 < Hc ? (int)col[v + 6] : -1;
+        }
+    }
+    __syncthreads();
+    for (int v = tid; v < Hc; v += FLT_THREADS) {
+        int w[11];
+#pragma unroll
+        for (int j = 0; j < 11; j++) w[j] = (j >= 5 && j - 5 < Wc) ? (int)T[(j - 5) * Hc + v] : -1;
+        for (int u = 0; u < Wc; u++) {
+            if (redundant_here(w)) {
+                T[u * Hc + v] = -1;
+                w[5] = -1;
+            }
+#pragma unroll
+            for (int j = 0; j < 10; j++) w[j] = w[j + 1];
+            w[10] = u + 6 < Wc ? (int)T[(u + 6) * Hc + v] : -1;
+        }
+    }
+    __syncthreads();
+
+    // ---- collect in scan order (elas.cpp:424-428; lattice row / column 0 excluded)
+    int32_t *out = fsup + (size_t)pair * d.max_pts * 3;
+    const int n_main = compact_indices(lat, list, s_scan, [&](int i) { return T[i] >= 0 && i >= Hc && (i % Hc) != 0; });
+    for (int q = tid; q < n_main; q += FLT_THREADS) {
+        const int i = list[q];
+        const int u = i / Hc, v = i - u * Hc;
+        out[3 * q] = u * d.step;
+        out[3 * q + 1] = v * d.step;
+        out[3 * q + 2] = T[i];
+    }
+    int n_total = n_main;
+    if (k.add_corners) {  // elas.cpp:235-264: the four image corners take the disparity of the nearest point (first minimum)
+        __syncthreads();
+        const int bu[4] = {0, 0, d.W - 1, d.W - 1}, bv[4] = {0, d.H - 1, 0, d.H - 1};
+        int cd[4];
+        int *s_dist = s_scan;                          // reuse: FLT_THREADS ints
+        int *s_idx = reinterpret_cast<int *>(st);      // the state bytes are no longer needed (lat >= 4*FLT_THREADS is not assumed:
+                                                       // see the size check at launch)
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            int best = 10000000, bidx = 0x7FFFFFFF;
+            for (int q = tid; q < n_main; q += FLT_THREADS) {  // ascending q within a thread: strict < keeps the first minimum
+                const int i = list[q];
+                const int pu = (i / Hc) * d.step, pv = (i % Hc) * d.step;
+                const int du = bu[c] - pu, dv = bv[c] - pv;
+                const int dist = du * du + dv * dv;
+                if (dist < best) {
+                    best = dist;
+                    bidx = q;
+                }
+            }
+            s_dist[tid] = best;
+            s_idx[tid] = bidx;
+            __syncthreads();
+            for (int off = FLT_THREADS / 2; off >= 1; off >>= 1) {
+                if (tid < off) {
+                    const int od = s_dist[tid + off], oi = s_idx[tid + off];
+                    if (od < s_dist[tid] || (od == s_dist[tid] && oi < s_idx[tid])) {
+                        s_dist[tid] = od;
+                        s_idx[tid] = oi;
+                    }
+                }
+                __syncthreads();
+            }
+            cd[c] = s_dist[0] < 10000000 ? (int)T[list[s_idx[0]]] : 0;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            int q = n_main;
+            for (int c = 0; c < 4; c++) {
+                out[3 * q] = bu[c];
+                out[3 * q + 1] = bv[c];
+                out[3 * q + 2] = cd[c];
+                q++;
+            }
+            for (int c = 2; c < 4; c++) {  // the two right-image corners (:258-259)
+                out[3 * q] = bu[c] + cd[c];
+                out[3 * q + 1] = bv[c];
+                out[3 * q + 2] = cd[c];
+                q++;
+            }
+        }
+        n_total = n_main + 6;
+    }
+    if (tid == 0) fnsup[pair] = n_total;
+}
+
+size_t support_filter_lds_bytes(const KParams &k) {
+    const size_t lat = (size_t)k.d.Wc * k.d.Hc;
+    return (lat + (lat & 1)) * 2 * 2 + std::max(lat, (size_t)4 * FLT_THREADS) + 16;  // lattice, index list, state bytes (reused by the corner search)
+}
+
+void launch_support_filter(const KParams &k, int win, int thr, int need, const SlotDev &s, int n, hipStream_t st) {
+    SV_LAUNCH(K_SUPPORT_FILTER, k_support_filter, dim3(n), dim3(FLT_THREADS), support_filter_lds_bytes(k), st, k, win, thr, need, s.dcan, s.fsup, s.fnsup);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -40,6 +40,8 @@ struct SlotDev {
     int cap;
     uint8_t *desc;      // [cap][2][N][16]   descriptors, image 0 = left, 1 = right
     int16_t *dcan;      // [cap][Wc][Hc]     raw support lattice, TRANSPOSED (u major) for the host filters
+    int32_t *fsup;      // [cap][max_pts][3] support points from the on-GPU lattice filter (when it is used)
+    int32_t *fnsup;     // [cap]
     int32_t *blob;      // host-stage results of the chunk, one H2D copy: [cap][8] meta words, then tightly packed data.
                         //   meta of pair p: [0] #support points  [1] offset of its (u,v,d) triples
                         //                   [2] #triangles left  [3] offset of their corner indices
@@ -61,6 +63,8 @@ struct SlotDev {
 // ---- launch wrappers (kernels.hip).  `n` = pairs in this launch; `nproc` = maps per pair to post-process (1 or 2).
 void launch_descriptor(const KParams &k, const uint8_t *left, const uint8_t *right, size_t in_pair_stride, int stride, const SlotDev &s, int n, hipStream_t st);
 void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st);
+size_t support_filter_lds_bytes(const KParams &k);
+void launch_support_filter(const KParams &k, int win, int thr, int need, const SlotDev &s, int n, hipStream_t st);
 void launch_grid(const KParams &k, const SlotDev &s, int n, hipStream_t st);
 void launch_triangles(const KParams &k, const SlotDev &s, int n, hipStream_t st);
 void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st);
@@ -74,7 +78,7 @@ void launch_output(const KParams &k, const SlotDev &s, int n, const float *src, 
 
 // names of the kernels behind each wrapper, in launch order, for timing reports
 enum KernelId {
-    K_DESCRIPTOR = 0, K_SUPPORT, K_GRID_MARK, K_GRID_DILATE, K_PLANES, K_TRIANGLES, K_TRIANGLES_FALLBACK, K_DENSE, K_LR,
+    K_DESCRIPTOR = 0, K_SUPPORT, K_SUPPORT_FILTER, K_GRID_MARK, K_GRID_DILATE, K_PLANES, K_TRIANGLES, K_TRIANGLES_FALLBACK, K_DENSE, K_LR,
     K_CCL_INIT, K_CCL_MERGE, K_CCL_COUNT, K_CCL_APPLY, K_GAP_ROWS, K_GAP_COLS, K_AMEAN, K_MEDIAN, K_OUTPUT, K_COUNT
 };
 const char *kernel_name(int id);
