@@ -72,7 +72,7 @@ struct Slot {
     int32_t *h_fnsup = nullptr; // pinned [cap]
     int32_t *h_blob = nullptr;  // pinned
     size_t blob_words = 0;
-    hipEvent_t ev_p1 = nullptr, ev_free = nullptr;
+    hipEvent_t ev_p1 = nullptr, ev_free = nullptr, ev_sup = nullptr;
     int state = SLOT_FREE;
     // chunk in flight
     int i0 = 0, n = 0;
@@ -104,7 +104,7 @@ struct sv_handle {
     int chunk = 1;
     bool gpu_filter = false;  // lattice filters on the GPU (k_support_filter) instead of the host pool
     std::vector<Slot *> slots;
-    hipStream_t sP1 = nullptr;
+    hipStream_t sP1 = nullptr, sPF = nullptr;  // phase 1; lattice filter + its D2H
     std::vector<hipStream_t> sP2;
     // control threads + queues
     std::thread t_issue, t_dispatch, t_finish;
@@ -222,6 +222,8 @@ void fill_kparams(sv_handle *h) {
     const char *force_host = getenv("SV_HOST_FILTER");
     h->gpu_filter = !(force_host && atoi(force_host) != 0) && p.incon_window_size >= 0 && p.incon_window_size <= 5 &&
                     (size_t)d.Wc * d.Hc < 65536 && support_filter_lds_bytes(k) <= 140 * 1024;
+    // (sv_create additionally keeps the filters on the host for chunk < 4: the GPU version is a ~0.4 ms latency chain,
+    //  worth it only when many pairs share it)
 }
 
 void timing_hook(void *ctx, int id, bool before, hipStream_t st) {
@@ -328,18 +330,24 @@ void issue_phase1(sv_handle *h, Slot *s) {
     const int lat = d.Wc * d.Hc;
     launch_descriptor(k, job.left + (size_t)s->i0 * in_pair, job.right + (size_t)s->i0 * in_pair, in_pair, job.stride, s->dev, s->n, h->sP1);
     launch_support(k, s->dev, s->n, h->sP1);
+    hipStream_t tail = h->sP1;
     if (h->gpu_filter) {
-        launch_support_filter(k, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s->dev, s->n, h->sP1);
-        HIP_TRY(hipMemcpyAsync(s->h_fnsup, s->dev.fnsup, sizeof(int32_t) * (size_t)s->n, hipMemcpyDeviceToHost, h->sP1));
+        // the filter is one long-running workgroup per pair: on its own stream it does not hold up the next chunk's phase 1
+        HIP_TRY(hipEventRecord(s->ev_sup, h->sP1));
+        HIP_TRY(hipStreamWaitEvent(h->sPF, s->ev_sup, 0));
+        tail = h->sPF;
+        launch_support_filter(k, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s->dev, s->n, tail);
+        HIP_TRY(hipMemcpyAsync(s->h_fnsup, s->dev.fnsup, sizeof(int32_t) * (size_t)s->n, hipMemcpyDeviceToHost, tail));
         const size_t w = sizeof(int32_t) * 3 * (size_t)std::min(FSUP_COPY_PTS, d.max_pts);
         HIP_TRY(hipMemcpy2DAsync(s->h_fsup, sizeof(int32_t) * 3 * FSUP_COPY_PTS, s->dev.fsup, sizeof(int32_t) * 3 * (size_t)d.max_pts, w, (size_t)s->n,
-                                 hipMemcpyDeviceToHost, h->sP1));
+                                 hipMemcpyDeviceToHost, tail));
     }
     if (!h->gpu_filter || h->cfg.keep_debug)
-        HIP_TRY(hipMemcpyAsync(s->h_dcan, s->dev.dcan, sizeof(int16_t) * (size_t)s->n * lat, hipMemcpyDeviceToHost, h->sP1));
-    HIP_TRY(hipEventRecord(s->ev_p1, h->sP1));
+        HIP_TRY(hipMemcpyAsync(s->h_dcan, s->dev.dcan, sizeof(int16_t) * (size_t)s->n * lat, hipMemcpyDeviceToHost, tail));
+    HIP_TRY(hipEventRecord(s->ev_p1, tail));
     if (h->cfg.keep_debug) {
         const int j = s->n - 1;
+        HIP_TRY(hipStreamSynchronize(tail));
         dbg_from_device(h, h->sP1, "desc1", s->dev.desc + ((size_t)j * 2) * d.N * 16, (size_t)d.N * 16);
         dbg_from_device(h, h->sP1, "desc2", s->dev.desc + ((size_t)j * 2 + 1) * d.N * 16, (size_t)d.N * 16);
         {
@@ -643,6 +651,7 @@ void finisher_main(sv_handle *h) {
             h->cv.notify_all();
         }
         bool sync_ok = hipStreamSynchronize(h->sP1) == hipSuccess;
+        sync_ok = (hipStreamSynchronize(h->sPF) == hipSuccess) && sync_ok;
         for (hipStream_t st : h->sP2) sync_ok = (hipStreamSynchronize(st) == hipSuccess) && sync_ok;
         if (!sync_ok) note_error(h, "stream synchronisation failed");
         if (h->timing) {
@@ -698,6 +707,7 @@ void alloc_slot(sv_handle *h, Slot *sl) {
     HIP_TRY(hipHostMalloc((void **)&sl->h_blob, sizeof(int32_t) * sl->blob_words, hipHostMallocDefault));
     HIP_TRY(hipEventCreateWithFlags(&sl->ev_p1, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&sl->ev_free, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&sl->ev_sup, hipEventDisableTiming));
 }
 
 void free_slot(Slot *sl) {
@@ -711,6 +721,7 @@ void free_slot(Slot *sl) {
     if (sl->h_fnsup) (void)hipHostFree(sl->h_fnsup);
     if (sl->ev_p1) (void)hipEventDestroy(sl->ev_p1);
     if (sl->ev_free) (void)hipEventDestroy(sl->ev_free);
+    if (sl->ev_sup) (void)hipEventDestroy(sl->ev_sup);
 }
 
 void free_handle_resources(sv_handle *h) {
@@ -723,6 +734,7 @@ void free_handle_resources(sv_handle *h) {
     for (TimingCtx *t : {&h->tc_issue, &h->tc_finish})
         for (hipEvent_t e : t->pool) (void)hipEventDestroy(e);
     if (h->sP1) (void)hipStreamDestroy(h->sP1);
+    if (h->sPF) (void)hipStreamDestroy(h->sPF);
     for (hipStream_t st : h->sP2) (void)hipStreamDestroy(st);
 }
 
@@ -836,9 +848,11 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         np2 = 1;
         h->chunk = 1;
     }
+    if (h->chunk < 4 && !getenv("SV_GPU_FILTER")) h->gpu_filter = false;
     try {
         HIP_TRY(hipSetDevice(cfg->device));
         HIP_TRY(hipStreamCreateWithFlags(&h->sP1, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&h->sPF, hipStreamNonBlocking));
         for (int i = 0; i < np2; i++) {
             hipStream_t st;
             HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));

@@ -38,8 +38,12 @@ def _run_debug(eng, entry):
     return L, R, d1[0], d2[0], int(status[0]), stages
 
 
+@pytest.mark.parametrize("gpu_filter", [False, True])
 @pytest.mark.parametrize("name", sorted(DIG))
-def test_every_stage_matches_oracle_and_golden(eng, oracle, name):
+def test_every_stage_matches_oracle_and_golden(eng, oracle, name, gpu_filter, monkeypatch):
+    """gpu_filter: lattice filters on the GPU (k_support_filter, the throughput configuration) or on the host pool."""
+    if gpu_filter:
+        monkeypatch.setenv("SV_GPU_FILTER", "1")
     entry = DIG[name]
     L, R, d1, d2, nsup, st = _run_debug(eng, entry)
     assert nsup == entry["n_support"]
