@@ -227,26 +227,28 @@ Delaunay::H Delaunay::make() {  // triangle.cpp:2068-2101; slot 0 stands for "ou
     return (H)(n_slots_++) << 2;
 }
 
-// lexicographic (major, minor) order as one 64-bit key: major*2^32 + minor (|minor| < 2^31)
-static inline int64_t key_xy(int32_t major, int32_t minor) { return ((int64_t)major << 32) + (int64_t)minor; }
+// sort keys: x and y are biased to unsigned 16-bit and packed as (x << 16 | y); the (y, x) order is the key rotated by 16
+constexpr int KEY_BIAS_X = 4096, KEY_BIAS_Y = 4096;
+static inline uint32_t key_pack(int32_t x, int32_t y) { return ((uint32_t)(x + KEY_BIAS_X) << 16) | (uint32_t)(y + KEY_BIAS_Y); }
+static inline uint32_t key_yx(uint32_t k) { return (k << 16) | (k >> 16); }
 
 // Randomised quicksort by (x, y) with the reference's pivot sequence (triangle.cpp:5183-5229): which of two coincident
 // points survives the duplicate scan depends on it.
 void Delaunay::sort_xy(Pt *a, int n) {
     if (n == 2) {
-        if (key_xy(a[0].x, a[0].y) > key_xy(a[1].x, a[1].y)) std::swap(a[0], a[1]);
+        if (a[0].key > a[1].key) std::swap(a[0], a[1]);
         return;
     }
     const int pivot = (int)rnd((uint32_t)n);
-    const int64_t pk = key_xy(a[pivot].x, a[pivot].y);
+    const uint32_t pk = a[pivot].key;
     int left = -1, right = n;
     while (left < right) {
         do {
             left++;
-        } while (left <= right && key_xy(a[left].x, a[left].y) < pk);
+        } while (left <= right && a[left].key < pk);
         do {
             right--;
-        } while (left <= right && key_xy(a[right].x, a[right].y) > pk);
+        } while (left <= right && a[right].key > pk);
         if (left < right) std::swap(a[left], a[right]);
     }
     if (left > 1) sort_xy(a, left);
@@ -256,36 +258,36 @@ void Delaunay::sort_xy(Pt *a, int n) {
 // Randomised partial partition around the median (triangle.cpp:5243-5294); the arrangement it leaves inside each half
 // decides the leaf order of the recursion, hence the diagonals chosen in co-circular quadruples.
 void Delaunay::median_split(Pt *a, int n, int median, int axis) {
-#define KEY(p) (axis == 0 ? key_xy((p).x, (p).y) : key_xy((p).y, (p).x))
     if (n == 2) {
-        if (KEY(a[0]) > KEY(a[1])) std::swap(a[0], a[1]);
+        const uint32_t k0 = axis == 0 ? a[0].key : key_yx(a[0].key), k1 = axis == 0 ? a[1].key : key_yx(a[1].key);
+        if (k0 > k1) std::swap(a[0], a[1]);
         return;
     }
     const int pivot = (int)rnd((uint32_t)n);
-    const int64_t pk = KEY(a[pivot]);
     int left = -1, right = n;
     if (axis == 0) {
+        const uint32_t pk = a[pivot].key;
         while (left < right) {
             do {
                 left++;
-            } while (left <= right && key_xy(a[left].x, a[left].y) < pk);
+            } while (left <= right && a[left].key < pk);
             do {
                 right--;
-            } while (left <= right && key_xy(a[right].x, a[right].y) > pk);
+            } while (left <= right && a[right].key > pk);
             if (left < right) std::swap(a[left], a[right]);
         }
     } else {
+        const uint32_t pk = key_yx(a[pivot].key);
         while (left < right) {
             do {
                 left++;
-            } while (left <= right && key_xy(a[left].y, a[left].x) < pk);
+            } while (left <= right && key_yx(a[left].key) < pk);
             do {
                 right--;
-            } while (left <= right && key_xy(a[right].y, a[right].x) > pk);
+            } while (left <= right && key_yx(a[right].key) > pk);
             if (left < right) std::swap(a[left], a[right]);
         }
     }
-#undef KEY
     if (left > median) median_split(a, left, median, axis);
     if (right < median - 1) median_split(a + right + 1, n - right - 1, median - right - 1, axis);
 }
@@ -567,11 +569,15 @@ int Delaunay::triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap) {
     n_slots_ = 0;
     make();
     Pt *a = order_.data();
-    for (int i = 0; i < n; i++) a[i] = Pt{xy[2 * i], xy[2 * i + 1], i};
+    for (int i = 0; i < n; i++) {
+        const int32_t x = xy[2 * i], y = xy[2 * i + 1];
+        if (x < -KEY_BIAS_X || x >= 65536 - KEY_BIAS_X || y < -KEY_BIAS_Y || y >= 65536 - KEY_BIAS_Y) return -2;  // outside the packed-key range
+        a[i] = Pt{key_pack(x, y), i};
+    }
     sort_xy(a, n);
     int m = 0;
     for (int j = 1; j < n; j++) {  // triangle.cpp:5890-5903: the first of a group of coincident points is kept
-        if (a[m].x == a[j].x && a[m].y == a[j].y) continue;
+        if (a[m].key == a[j].key) continue;
         a[++m] = a[j];
     }
     m++;

@@ -41,8 +41,9 @@ class Delaunay {
     };
     typedef int32_t H;  // oriented-triangle handle: (slot << 2) | orientation
 
-    struct Pt {  // sort element: coordinates travel with the vertex id, so comparisons never chase an index
-        int32_t x, y, id;
+    struct Pt {  // sort element: the coordinates travel with the vertex id as one biased (x << 16 | y) key, so a lexicographic
+        uint32_t key;  // (x, y) comparison is one unsigned compare and (y, x) order is the same key rotated by 16 bits
+        int32_t id;
     };
 
     const int32_t *xy_ = nullptr;
