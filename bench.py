@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="pairs per launch (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=64, help="pairs timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--sync-steps", action="store_true", help="wait for each step before submitting the next (default: streamed submission)")
     ap.add_argument("--serial-kernels", action="store_true", help="extra pass with one slot / one stream (no kernel overlap) to get clean per-kernel times")
     ap.add_argument("--gather", action="store_true", help="after the timed region, also gather all left maps on rank 0 (RCCL) and report the time")
     args = ap.parse_args()
@@ -125,8 +126,13 @@ def main():
         engine.timing(True)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        engine.process_device(left, right, d1, d2)
+    if args.sync_steps:
+        for _ in range(args.steps):
+            engine.process_device(left, right, d1, d2)
+    else:  # "streamed": the K batches are handed to the engine back to back, the next one fills the pipeline while the last drains
+        for _ in range(args.steps):
+            engine.submit_device(left, right, d1, d2)
+        engine.wait()
     barrier()
     elapsed = time.perf_counter() - t0
     ktimes = engine.kernel_times() if not args.no_kernel_timing else {}

@@ -106,7 +106,13 @@ const char *sv_last_error(const sv_handle *h); /* h may be NULL: error of the la
  * The call returns when all B pairs are complete (outputs visible to every stream of the device). */
 int sv_process_batch_device(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status);
 
-/* Same, host memory in and out (stages through pinned buffers; PCIe-inclusive). */
+/* Streaming form: sv_submit_batch_device enqueues a batch and returns at once; batches are processed in submission order and
+ * flow through the same pipeline back to back (the first chunks of batch k+1 overlap the last chunks of batch k).  sv_wait
+ * returns when every submitted batch is complete.  Buffers must stay valid until then.  sv_process_batch_device == submit + wait. */
+int sv_submit_batch_device(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status);
+int sv_wait(sv_handle *h);
+
+/* Same as sv_process_batch_device, host memory in and out (PCIe-inclusive). */
 int sv_process_batch_host(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status);
 
 /* Single pair with the exact argument meaning of Elas::process (elas.h:153-162): dims = {width, height, bytes per line}. */

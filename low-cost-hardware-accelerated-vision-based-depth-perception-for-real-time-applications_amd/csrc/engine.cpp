@@ -62,6 +62,15 @@ struct HostScratch {  // per pool thread
 
 constexpr int FSUP_COPY_PTS = 4096;  // support points per pair fetched with the bulk D2H (more are fetched on demand)
 
+struct Job {
+    const uint8_t *left = nullptr, *right = nullptr;
+    int batch = 0, stride = 0;
+    float *d1 = nullptr, *d2 = nullptr;
+    int32_t *status = nullptr;
+    int nchunks = 0;
+    int issued2 = 0;  // chunks whose second GPU phase has been enqueued (guarded by sv_handle::mu)
+};
+
 enum SlotState { SLOT_FREE = 0, SLOT_BUSY = 1, SLOT_DRAINING = 2 };  // DRAINING: phase 2 issued, ev_free recorded
 
 struct Slot {
@@ -75,6 +84,7 @@ struct Slot {
     hipEvent_t ev_p1 = nullptr, ev_free = nullptr, ev_sup = nullptr;
     int state = SLOT_FREE;
     // chunk in flight
+    Job *job = nullptr;
     int i0 = 0, n = 0;
     std::atomic<size_t> blob_off{0};
     std::atomic<int> pending{0};
@@ -86,13 +96,6 @@ struct Task {
     int side;  // -1: filter stage (then triangulates side 0 and queues side 1); 1: triangulation of the right image
 };
 
-struct Job {
-    const uint8_t *left = nullptr, *right = nullptr;
-    int batch = 0, stride = 0;
-    float *d1 = nullptr, *d2 = nullptr;
-    int32_t *status = nullptr;
-    int nchunks = 0;
-};
 
 }  // namespace
 
@@ -108,13 +111,15 @@ struct sv_handle {
     std::vector<hipStream_t> sP2;
     // control threads + queues
     std::thread t_issue, t_dispatch, t_finish;
-    std::mutex mu;  // guards: generation, quit, job_done, slot states, q1, q2, error
+    std::mutex mu;  // guards: job queue + counters, quit, slot states, q1, q2, error
     std::condition_variable cv;
-    uint64_t generation = 0;
-    bool quit = false, job_done = true;
+    std::deque<Job *> jobs;       // submitted, not yet picked up by the issuer
+    std::vector<Job *> live;      // submitted, not yet waited for
+    int jobs_submitted = 0, jobs_finished = 0;  // finished = all chunks' phase 2 enqueued
+    int ring_pos = 0;             // next slot of the ring (continues across batches)
+    bool quit = false;
     std::deque<Slot *> q1;  // phase 1 issued, waiting for the dispatcher
     std::deque<Slot *> q2;  // host stage complete, waiting for phase 2
-    Job job;
     std::string error;
     bool failed = false;
     // host pool
@@ -325,7 +330,7 @@ void dbg_grid(sv_handle *h, hipStream_t st, Slot *s, int j) {
 void issue_phase1(sv_handle *h, Slot *s) {
     const KParams &k = h->kp;
     const Dims &d = k.d;
-    const Job &job = h->job;
+    const Job &job = *s->job;
     const size_t in_pair = (size_t)d.H * job.stride;
     const int lat = d.Wc * d.Hc;
     launch_descriptor(k, job.left + (size_t)s->i0 * in_pair, job.right + (size_t)s->i0 * in_pair, in_pair, job.stride, s->dev, s->n, h->sP1);
@@ -364,19 +369,21 @@ void issue_phase1(sv_handle *h, Slot *s) {
 
 void issuer_main(sv_handle *h) {
     (void)hipSetDevice(h->cfg.device);
-    uint64_t seen = 0;
     for (;;) {
+        Job *job = nullptr;
         {
             std::unique_lock<std::mutex> lk(h->mu);
-            h->cv.wait(lk, [&] { return h->quit || h->generation != seen; });
+            h->cv.wait(lk, [&] { return h->quit || !h->jobs.empty(); });
             if (h->quit) return;
-            seen = h->generation;
+            job = h->jobs.front();
+            h->jobs.pop_front();
         }
         g_launch_hook.fn = h->timing ? timing_hook : nullptr;
         g_launch_hook.ctx = &h->tc_issue;
         const int ns = (int)h->slots.size();
-        for (int c = 0; c < h->job.nchunks; c++) {
-            Slot *s = h->slots[c % ns];
+        for (int c = 0; c < job->nchunks; c++) {
+            Slot *s = h->slots[h->ring_pos];
+            h->ring_pos = (h->ring_pos + 1) % ns;
             bool drain = false;
             {
                 std::unique_lock<std::mutex> lk(h->mu);
@@ -384,10 +391,11 @@ void issuer_main(sv_handle *h) {
                 drain = s->state == SLOT_DRAINING;
                 s->state = SLOT_BUSY;
             }
+            s->job = job;
+            s->i0 = c * h->chunk;
+            s->n = std::min(h->chunk, job->batch - s->i0);
             try {
                 if (drain) HIP_TRY(hipEventSynchronize(s->ev_free));
-                s->i0 = c * h->chunk;
-                s->n = std::min(h->chunk, h->job.batch - s->i0);
                 if (!h->failed) issue_phase1(h, s);
             } catch (const std::exception &e) {
                 note_error(h, e.what());
@@ -476,7 +484,7 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
         }
     }
     if (h->timing) h->host_tasks += 1;
-    if (h->job.status) h->job.status[s->i0 + t.pair] = ns;
+    if (s->job->status) s->job->status[s->i0 + t.pair] = ns;
     meta[0] = ns;
     meta[1] = meta[3] = meta[5] = 0;
     meta[2] = meta[4] = 0;
@@ -562,7 +570,7 @@ void dispatcher_main(sv_handle *h) {
 void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
     const KParams &k = h->kp;
     const Dims &d = k.d;
-    const Job &job = h->job;
+    const Job &job = *s->job;
     const bool dbg = h->cfg.keep_debug != 0;
     const int n = s->n;
     int32_t *blob = s->h_blob;
@@ -617,50 +625,31 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
 
 void finisher_main(sv_handle *h) {
     (void)hipSetDevice(h->cfg.device);
-    uint64_t seen = 0;
+    size_t rr = 0;
     for (;;) {
+        Slot *s = nullptr;
         {
             std::unique_lock<std::mutex> lk(h->mu);
-            h->cv.wait(lk, [&] { return h->quit || h->generation != seen; });
+            h->cv.wait(lk, [&] { return h->quit || !h->q2.empty(); });
             if (h->quit) return;
-            seen = h->generation;
+            s = h->q2.front();
+            h->q2.pop_front();
         }
         g_launch_hook.fn = h->timing ? timing_hook : nullptr;
         g_launch_hook.ctx = &h->tc_finish;
-        for (int c = 0; c < h->job.nchunks; c++) {
-            Slot *s = nullptr;
-            {
-                std::unique_lock<std::mutex> lk(h->mu);
-                h->cv.wait(lk, [&] { return !h->q2.empty(); });
-                s = h->q2.front();
-                h->q2.pop_front();
+        bool recorded = false;
+        try {
+            if (!h->failed) {
+                issue_phase2(h, s, h->sP2[rr++ % h->sP2.size()]);
+                recorded = true;
             }
-            bool recorded = false;
-            try {
-                if (!h->failed) {
-                    issue_phase2(h, s, h->sP2[c % h->sP2.size()]);
-                    recorded = true;
-                }
-            } catch (const std::exception &e) {
-                note_error(h, e.what());
-            }
-            {
-                std::lock_guard<std::mutex> lk(h->mu);
-                s->state = recorded ? SLOT_DRAINING : SLOT_FREE;
-            }
-            h->cv.notify_all();
-        }
-        bool sync_ok = hipStreamSynchronize(h->sP1) == hipSuccess;
-        sync_ok = (hipStreamSynchronize(h->sPF) == hipSuccess) && sync_ok;
-        for (hipStream_t st : h->sP2) sync_ok = (hipStreamSynchronize(st) == hipSuccess) && sync_ok;
-        if (!sync_ok) note_error(h, "stream synchronisation failed");
-        if (h->timing) {
-            collect_timing(h, &h->tc_issue);
-            collect_timing(h, &h->tc_finish);
+        } catch (const std::exception &e) {
+            note_error(h, e.what());
         }
         {
             std::lock_guard<std::mutex> lk(h->mu);
-            h->job_done = true;
+            s->state = recorded ? SLOT_DRAINING : SLOT_FREE;
+            if (++s->job->issued2 == s->job->nchunks) h->jobs_finished++;
         }
         h->cv.notify_all();
     }
@@ -738,32 +727,59 @@ void free_handle_resources(sv_handle *h) {
     for (hipStream_t st : h->sP2) (void)hipStreamDestroy(st);
 }
 
-int run_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status) {
+int submit_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status) {
     if (!h) return SV_ERR_ARG;
     if (!left || !right || !d1 || batch < 0 || stride < h->cfg.width) {
         h->error = "bad argument (null pointer, negative batch, or stride < width)";
         return SV_ERR_ARG;
     }
     if (batch == 0) return SV_OK;
-    std::unique_lock<std::mutex> lk(h->mu);
-    if (!h->job_done) {
-        h->error = "a batch is already in flight on this handle";
-        return SV_ERR_STATE;
+    Job *job = new Job();
+    job->left = left;
+    job->right = right;
+    job->batch = batch;
+    job->stride = stride;
+    job->d1 = d1;
+    job->d2 = d2;
+    job->status = status;
+    job->nchunks = (batch + h->chunk - 1) / h->chunk;
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        if (h->live.empty()) h->failed = false;
+        h->jobs.push_back(job);
+        h->live.push_back(job);
+        h->jobs_submitted++;
     }
-    h->job.left = left;
-    h->job.right = right;
-    h->job.batch = batch;
-    h->job.stride = stride;
-    h->job.d1 = d1;
-    h->job.d2 = d2;
-    h->job.status = status;
-    h->job.nchunks = (batch + h->chunk - 1) / h->chunk;
-    h->failed = false;
-    h->job_done = false;
-    h->generation++;
     h->cv.notify_all();
-    h->cv.wait(lk, [&] { return h->job_done; });
+    return SV_OK;
+}
+
+// Waits until every submitted batch is complete and its outputs are visible to every stream of the device.
+int wait_jobs(sv_handle *h) {
+    if (!h) return SV_ERR_ARG;
+    {
+        std::unique_lock<std::mutex> lk(h->mu);
+        h->cv.wait(lk, [&] { return h->jobs_finished == h->jobs_submitted; });
+    }
+    (void)hipSetDevice(h->cfg.device);
+    bool ok = hipStreamSynchronize(h->sP1) == hipSuccess;
+    ok = (hipStreamSynchronize(h->sPF) == hipSuccess) && ok;
+    for (hipStream_t st : h->sP2) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
+    if (!ok) note_error(h, "stream synchronisation failed");
+    if (h->timing) {
+        collect_timing(h, &h->tc_issue);
+        collect_timing(h, &h->tc_finish);
+    }
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (Job *j : h->live) delete j;
+    h->live.clear();
     return h->failed ? SV_ERR_HIP : SV_OK;
+}
+
+int run_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status) {
+    const int rc = submit_job(h, left, right, batch, stride, d1, d2, status);
+    if (rc != SV_OK) return rc;
+    return wait_jobs(h);
 }
 
 }  // namespace
@@ -884,6 +900,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
 
 int sv_destroy(sv_handle *h) {
     if (!h) return SV_ERR_ARG;
+    (void)wait_jobs(h);
     {
         std::lock_guard<std::mutex> lk(h->mu);
         h->quit = true;
@@ -909,6 +926,12 @@ const char *sv_last_error(const sv_handle *h) { return h ? h->error.c_str() : g_
 int sv_process_batch_device(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status) {
     return run_job(h, left, right, batch, stride, d1, d2, status);
 }
+
+int sv_submit_batch_device(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status) {
+    return submit_job(h, left, right, batch, stride, d1, d2, status);
+}
+
+int sv_wait(sv_handle *h) { return wait_jobs(h); }
 
 int sv_process_batch_host(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status) {
     if (!h) return SV_ERR_ARG;

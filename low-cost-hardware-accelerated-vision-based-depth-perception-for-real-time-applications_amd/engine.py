@@ -74,7 +74,9 @@ def lib():
     L.sv_destroy.restype = ctypes.c_int
     L.sv_last_error.argtypes = [ctypes.c_void_p]
     L.sv_last_error.restype = ctypes.c_char_p
-    for name in ("sv_process_batch_device", "sv_process_batch_host"):
+    L.sv_wait.argtypes = [ctypes.c_void_p]
+    L.sv_wait.restype = ctypes.c_int
+    for name in ("sv_process_batch_device", "sv_process_batch_host", "sv_submit_batch_device"):
         f = getattr(L, name)
         f.argtypes = [ctypes.c_void_p, u8p, u8p, ctypes.c_int, ctypes.c_int, f32p, f32p, i32p]
         f.restype = ctypes.c_int
@@ -151,6 +153,18 @@ class StereoEngine:
         self._check(lib().sv_process_batch_device(self._h, left.data_ptr(), right.data_ptr(), B, self.width, d1.data_ptr(),
                                                   d2.data_ptr() if d2 is not None else None, st))
         return d1, d2
+
+    def submit_device(self, left, right, d1, d2=None, status=None):
+        """Streaming form: enqueue a device-resident batch and return at once (call wait() before touching d1/d2).
+        Successive batches flow through the pipeline back to back."""
+        import torch
+        assert left.is_cuda and left.dtype == torch.uint8 and left.is_contiguous() and right.is_contiguous() and d1.is_contiguous()
+        st = status.ctypes.data_as(ctypes.c_void_p) if status is not None else None
+        self._check(lib().sv_submit_batch_device(self._h, left.data_ptr(), right.data_ptr(), left.shape[0], self.width, d1.data_ptr(),
+                                                 d2.data_ptr() if d2 is not None else None, st))
+
+    def wait(self):
+        self._check(lib().sv_wait(self._h))
 
     # ---- host path (numpy in / out, PCIe inclusive)
     def process_host(self, left, right, want_d2=True):

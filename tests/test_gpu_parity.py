@@ -193,3 +193,25 @@ def test_robotics_preset_batch(eng, oracle):
     for i in range(B):
         o1, o2, _ = oracle.process(po, batch[i, 0], batch[i, 1])
         assert np.array_equal(d1[i].view(np.uint8), o1.view(np.uint8)) and np.array_equal(d2[i].view(np.uint8), o2.view(np.uint8)), i
+
+
+def test_streamed_submission_equals_synchronous(eng):
+    """sv_submit_batch_device x3 + sv_wait gives the same bytes as three synchronous calls (distinct output buffers)."""
+    import torch
+    synth = util.pkg("synth")
+    H, W, D, B = 120, 320, 64, 10
+    batches = [synth.make_batch(400 + 50 * i, B, H, W, D) for i in range(3)]
+    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), chunk=4, n_slots=3, n_workers=4)
+    try:
+        ins = [(torch.from_numpy(b[:, 0].copy()).cuda(), torch.from_numpy(b[:, 1].copy()).cuda()) for b in batches]
+        ref = [e.process_device(l, r) for l, r in ins]
+        outs = [(torch.zeros_like(ref[0][0]), torch.zeros_like(ref[0][1])) for _ in ins]
+        torch.cuda.synchronize()
+        for (l, r), (o1, o2) in zip(ins, outs):
+            e.submit_device(l, r, o1, o2)
+        e.wait()
+        torch.cuda.synchronize()
+        for (a1, a2), (b1, b2) in zip(ref, outs):
+            assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    finally:
+        e.close()
