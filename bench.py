@@ -95,9 +95,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
+    # BENCH_BACKEND=gloo rehearses the multi-process path on a box with fewer GPUs than ranks (ranks then share devices and
+    # the control-plane collectives run on CPU tensors); the real runs use nccl (= RCCL) with one GPU per rank
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     eng = importlib.import_module(PKG + ".engine")
@@ -137,12 +146,12 @@ def main():
     elapsed = time.perf_counter() - t0
     ktimes = engine.kernel_times() if not args.no_kernel_timing else {}
     engine.timing(False)
-    elapsed = par.max_over_ranks(elapsed, device="cuda")
+    elapsed = par.max_over_ranks(elapsed, device=coll_dev)
     gather_ms = None
     if args.gather and world > 1:  # the optional "trivial gather" of finished maps on rank 0 over RCCL/xGMI, outside the timed region
         barrier()
         g0 = time.perf_counter()
-        allmaps = par.gather_maps(d1, dst=0)
+        allmaps = par.gather_maps(d1 if backend == "nccl" else d1.cpu(), dst=0)
         barrier()
         gather_ms = round(1e3 * (time.perf_counter() - g0), 3)
         del allmaps
