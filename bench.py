@@ -28,7 +28,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = "low-cost-hardware-accelerated-vision-based-depth-perception-for-real-time-applications_amd"
 sys.path.insert(0, ROOT)
 
-W, H, D = 1242, 375, 128
+W, H, D = 1242, 375, 128  # headline workload (BASELINE.json configs[1]/[2]); --workload switches to the other configs
+WORKLOADS = {  # name: (W, H, D, default pairs per GPU per step, chunk, slots, synth scale, first seed)
+    "kitti_d128": (1242, 375, 128, 256, 0, 0, 1, 1000),
+    "kitti_d256": (1242, 375, 256, 64, 0, 0, 1, 1000),     # configs[3]: LDS-pressure configuration
+    "4k_d192": (3840, 2160, 192, 32, 4, 4, 3, 5000),        # configs[4] shape (128 pairs per GPU there); 0.8 GB per pair in flight
+}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -63,11 +68,11 @@ def cpu_baseline(sample_pairs, synth):
     p = pyoracle.ElasParams.driver(D - 1)
     t = 0.0
     for i in range(sample_pairs):
-        L, R = synth.make_pair(1000 + i, H, W, D)
+        L, R = synth.make_pair(1000 + i, H, W, D, scale=3 if W > 2000 else 1)
         _, _, sec = lib.process(p, L, R, canonical=False, reps=1)
         t += sec
     return {"value": round(sample_pairs / t, 3), "unit": "pairs/s", "cores": 1, "kind": kind,
-            "sample": "%d synthetic KITTI-shaped pairs (seeds 1000..%d), 1242x375, D=128, Elas::process only, %.1f s" % (sample_pairs, 1000 + sample_pairs - 1, t),
+            "sample": "%d synthetic pairs (seeds 1000..%d), %dx%d, D=%d, Elas::process only, %.1f s" % (sample_pairs, 1000 + sample_pairs - 1, W, H, D, t),
             "ms_per_pair": round(1e3 * t / sample_pairs, 2), "host_cpus": os.cpu_count()}
 
 
@@ -76,7 +81,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (0 = the workload's default: 256 for the headline)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kitti_d128", help="kitti_d128 is BASELINE.json's metric configuration")
     ap.add_argument("--workers", type=int, default=0, help="host pool threads (0 = library default)")
     ap.add_argument("--streams", type=int, default=0, help="phase-2 HIP streams (0 = library default)")
     ap.add_argument("--slots", type=int, default=0, help="pipeline slots = chunks in flight (0 = library default)")
@@ -87,6 +93,11 @@ def main():
     ap.add_argument("--serial-kernels", action="store_true", help="extra pass with one slot / one stream (no kernel overlap) to get clean per-kernel times")
     ap.add_argument("--gather", action="store_true", help="after the timed region, also gather all left maps on rank 0 (RCCL) and report the time")
     args = ap.parse_args()
+    global W, H, D
+    W, H, D, wb, wchunk, wslots, wscale, wseed = WORKLOADS[args.workload]
+    args.batch = args.batch or wb
+    args.chunk = args.chunk or wchunk
+    args.slots = args.slots or wslots
 
     import torch
     import torch.distributed as dist
@@ -114,8 +125,8 @@ def main():
     par = importlib.import_module(PKG + ".parallel")
     B = args.batch
     # weak scaling: every rank owns B distinct pairs (seeds 1000 + rank*B + i); no data-path collective
-    seeds = par.pair_seeds(rank, B)
-    batch = synth.make_batch(seeds[0], B, H, W, D)
+    seeds = par.pair_seeds(rank, B, seed0=wseed)
+    batch = synth.make_batch(seeds[0], B, H, W, D, scale=wscale)
     left = torch.from_numpy(np.ascontiguousarray(batch[:, 0])).cuda()
     right = torch.from_numpy(np.ascontiguousarray(batch[:, 1])).cuda()
     d1 = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
@@ -198,7 +209,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "kitti_1242x375_D128_batch%d_per_gpu_streamed" % B, "width": W, "height": H, "disp_max": D - 1,
+            "config": {"workload": "%s_%dx%d_D%d_batch%d_per_gpu_streamed" % (args.workload.split("_")[0], W, H, D, B), "width": W, "height": H, "disp_max": D - 1,
                        "preset": "driver(MIDDLEBURY+only_left+adaptive_mean+median)", "pairs_per_gpu_per_step": B,
                        "parallelism": "batch-sharded x%d, no data-path collective" % world},
             "latency_ms_batch1": lat_ms, "gather_ms": gather_ms, "serial_kernel_us_per_pair": serial_k,
@@ -240,7 +251,7 @@ def main():
             out["kernel_ms_per_pair"] = {k: round(v / (B * args.steps), 5) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
             out["kernel_ms_per_pair"]["_sum"] = round(gpu_ms_total / (B * args.steps), 5)
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, synth)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample if W < 2000 else min(args.cpu_sample, 4), synth)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
