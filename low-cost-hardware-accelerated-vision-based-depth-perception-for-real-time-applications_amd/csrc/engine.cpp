@@ -226,6 +226,7 @@ void fill_kparams(sv_handle *h) {
     // point's earlier neighbours with one 64-lane ballot: needs incon_window_size <= 5 and a lattice that fits
     const char *force_host = getenv("SV_HOST_FILTER");
     h->gpu_filter = !(force_host && atoi(force_host) != 0) && p.incon_window_size >= 0 && p.incon_window_size <= 5 &&
+                    p.incon_min_support >= 0 && p.incon_min_support <= 60 && p.incon_threshold >= 0 &&  // c_late lives in 6 bits
                     (size_t)d.Wc * d.Hc < 65536 && support_filter_lds_bytes(k) <= 140 * 1024;
     // (sv_create additionally keeps the filters on the host for chunk < 4: the GPU version is a ~0.4 ms latency chain,
     //  worth it only when many pairs share it)
