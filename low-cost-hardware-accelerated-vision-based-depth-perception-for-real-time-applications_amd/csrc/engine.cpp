@@ -857,9 +857,26 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     h->cfg = *cfg;
     fill_kparams(h);
     int npool = cfg->n_workers > 0 ? cfg->n_workers : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    int nslots = cfg->n_slots > 0 ? cfg->n_slots : 10;
-    int np2 = cfg->n_streams > 0 ? cfg->n_streams : 2;
-    h->chunk = cfg->chunk > 0 ? cfg->chunk : 16;
+    // defaults: 32 pairs per launch, 12 slots, 4 phase-2 streams, scaled down so that the slots stay within a memory budget
+    // (about 80 bytes per pixel per pair in flight: 37 MB at KITTI size, 0.66 GB at 4K)
+    int np2 = cfg->n_streams > 0 ? cfg->n_streams : 4;
+    int nslots = cfg->n_slots > 0 ? cfg->n_slots : 12;
+    h->chunk = cfg->chunk > 0 ? cfg->chunk : 32;
+    if (cfg->chunk <= 0 || cfg->n_slots <= 0) {
+        size_t free_b = 0, total_b = 0;
+        (void)hipSetDevice(cfg->device);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
+        const double budget = std::min(24.0 * (1 << 30), 0.25 * (double)free_b);
+        const double per_pair = 80.0 * (double)h->kp.d.N + 4.0e6;
+        while ((double)h->chunk * nslots * per_pair > budget) {
+            if (cfg->chunk <= 0 && h->chunk > 1 && (h->chunk >= 2 * nslots || cfg->n_slots > 0 || nslots <= 3))
+                h->chunk = (h->chunk + 1) / 2;
+            else if (cfg->n_slots <= 0 && nslots > 3)
+                nslots--;
+            else
+                break;
+        }
+    }
     if (cfg->keep_debug) {
         nslots = 1;
         np2 = 1;
