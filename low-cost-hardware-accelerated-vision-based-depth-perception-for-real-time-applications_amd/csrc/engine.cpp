@@ -15,6 +15,7 @@
 // phase-2 kernels of earlier ones on the GPU.  Every launch covers a whole chunk (batch index in blockIdx.z / .y).
 // No allocation, hipMalloc or device-wide synchronisation on the per-batch path.
 #include <math.h>
+#include <sched.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -105,6 +106,7 @@ struct sv_handle {
     KParams kp;
     int nproc = 1;  // maps per pair that get post-processed
     int chunk = 1;
+    bool block_sync = false;  // host waits on events sleep (throughput mode) instead of spinning (latency mode)
     bool gpu_filter = false;  // lattice filters on the GPU (k_support_filter) instead of the host pool
     std::vector<Slot *> slots;
     hipStream_t sP1 = nullptr, sPF = nullptr;  // phase 1; lattice filter + its D2H
@@ -656,6 +658,40 @@ void finisher_main(sv_handle *h) {
     }
 }
 
+// Host cores this process may use: the cgroup CPU quota when there is one, else the affinity mask; shared evenly between
+// the ranks of one node (LOCAL_WORLD_SIZE, set by torch.distributed.run).  Without a visible quota the pool stays at 16.
+int default_pool_size() {
+    double cpus = 0.0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+        char q[64];
+        double period = 0.0;
+        if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0.0) cpus = atof(q) / period;
+        fclose(f);
+    }
+    if (cpus <= 0.0) {  // cgroup v1
+        double quota = -1.0, period = 0.0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(f, "%lf", &quota) != 1) quota = -1.0;
+            fclose(f);
+        }
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(f, "%lf", &period) != 1) period = 0.0;
+            fclose(f);
+        }
+        if (quota > 0.0 && period > 0.0) cpus = quota / period;
+    }
+    const bool have_quota = cpus > 0.0;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    int aff = (int)std::max(1u, std::thread::hardware_concurrency());
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) aff = std::max(1, CPU_COUNT(&set));
+    if (!have_quota || cpus > aff) cpus = aff;
+    int ranks = 1;
+    if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
+    const int share = std::max(1, (int)(cpus / ranks));
+    return std::max(1, std::min(have_quota ? 32 : 16, share));
+}
+
 template <class T>
 void dev_alloc(T *&p, size_t count) {
     HIP_TRY(hipMalloc((void **)&p, count * sizeof(T)));
@@ -695,8 +731,10 @@ void alloc_slot(sv_handle *h, Slot *sl) {
     dev_alloc(s.csize, cap * 2 * d.N);
     HIP_TRY(hipHostMalloc((void **)&sl->h_dcan, sizeof(int16_t) * (cap * d.Wc * d.Hc + LATTICE_PAD), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&sl->h_blob, sizeof(int32_t) * sl->blob_words, hipHostMallocDefault));
-    HIP_TRY(hipEventCreateWithFlags(&sl->ev_p1, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&sl->ev_free, hipEventDisableTiming));
+    // throughput mode: waiting threads sleep on the event instead of spinning, so the cores go to the Delaunay pool
+    const unsigned evf = hipEventDisableTiming | (h->block_sync ? hipEventBlockingSync : 0u);
+    HIP_TRY(hipEventCreateWithFlags(&sl->ev_p1, evf));
+    HIP_TRY(hipEventCreateWithFlags(&sl->ev_free, evf));
     HIP_TRY(hipEventCreateWithFlags(&sl->ev_sup, hipEventDisableTiming));
 }
 
@@ -856,7 +894,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     h->p = *params;
     h->cfg = *cfg;
     fill_kparams(h);
-    int npool = cfg->n_workers > 0 ? cfg->n_workers : (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    int npool = cfg->n_workers > 0 ? cfg->n_workers : default_pool_size();
     // defaults: 32 pairs per launch, 12 slots, 4 phase-2 streams, scaled down so that the slots stay within a memory budget
     // (about 80 bytes per pixel per pair in flight: 37 MB at KITTI size, 0.66 GB at 4K)
     int np2 = cfg->n_streams > 0 ? cfg->n_streams : 4;
@@ -883,6 +921,8 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         h->chunk = 1;
     }
     if (h->chunk < 4 && !getenv("SV_GPU_FILTER")) h->gpu_filter = false;
+    h->block_sync = h->chunk >= 4;
+    if (const char *e = getenv("SV_EVENT_SYNC")) h->block_sync = strcmp(e, "block") == 0;
     try {
         HIP_TRY(hipSetDevice(cfg->device));
         HIP_TRY(hipStreamCreateWithFlags(&h->sP1, hipStreamNonBlocking));

@@ -255,51 +255,75 @@ void Delaunay::sort_xy(Pt *a, int n) {
     if (right < n - 2) sort_xy(a + right + 1, n - right - 1);
 }
 
-// Randomised partial partition around the median (triangle.cpp:5243-5294); the arrangement it leaves inside each half
-// decides the leaf order of the recursion, hence the diagonals chosen in co-circular quadruples.
-void Delaunay::median_split(Pt *a, int n, int median, int axis) {
-    if (n == 2) {
-        const uint32_t k0 = axis == 0 ? a[0].key : key_yx(a[0].key), k1 = axis == 0 ? a[1].key : key_yx(a[1].key);
-        if (k0 > k1) std::swap(a[0], a[1]);
+// k-d ordering of the x-sorted vertex array.
+//
+// The reference re-orders the sorted array with randomised quickselects around medians of alternating axes
+// (alternateaxes / vertexmedian, triangle.cpp:5243-5325).  Its result does not depend on the pivots: after the duplicate
+// scan the (x, y) and (y, x) keys are both strict total orders, so every median cut is a unique set split, and the
+// recursion only stops at groups of <= 3 vertices which it leaves sorted by (x, y).  The same arrangement is produced
+// here without any selection: every node keeps its vertices in both orders (xs by (x, y), ys by (y, x)) and a cut is an
+// index split of one list plus a stable, branch-free partition of the other.  Elements are (y-rank << 32 | x-rank).
+void Delaunay::kd_order(uint64_t *xs, uint64_t *xalt, uint64_t *ys, uint64_t *yalt, int n, int axis, Pt *out) {
+    if (n <= 3) {  // leaves (and the forced axis 0 of triangle.cpp:5313-5316): (x, y) order
+        for (int i = 0; i < n; i++) out[i] = sorted_[(uint32_t)xs[i]];
         return;
     }
-    const int pivot = (int)rnd((uint32_t)n);
-    int left = -1, right = n;
+    const int divider = n >> 1;
+    int li = 0, ri = divider;
     if (axis == 0) {
-        const uint32_t pk = a[pivot].key;
-        while (left < right) {
-            do {
-                left++;
-            } while (left <= right && a[left].key < pk);
-            do {
-                right--;
-            } while (left <= right && a[right].key > pk);
-            if (left < right) std::swap(a[left], a[right]);
+        const uint32_t pivot = (uint32_t)xs[divider];
+        for (int i = 0; i < n; i++) {
+            const uint64_t e = ys[i];
+            const int l = (uint32_t)e < pivot;
+            yalt[l ? li : ri] = e;
+            li += l;
+            ri += 1 - l;
         }
+        kd_order(xs, xalt, yalt, ys, divider, 1, out);
+        kd_order(xs + divider, xalt + divider, yalt + divider, ys + divider, n - divider, 1, out + divider);
     } else {
-        const uint32_t pk = key_yx(a[pivot].key);
-        while (left < right) {
-            do {
-                left++;
-            } while (left <= right && key_yx(a[left].key) < pk);
-            do {
-                right--;
-            } while (left <= right && key_yx(a[right].key) > pk);
-            if (left < right) std::swap(a[left], a[right]);
+        const uint32_t pivot = (uint32_t)(ys[divider] >> 32);
+        for (int i = 0; i < n; i++) {
+            const uint64_t e = xs[i];
+            const int l = (uint32_t)(e >> 32) < pivot;
+            xalt[l ? li : ri] = e;
+            li += l;
+            ri += 1 - l;
         }
+        kd_order(xalt, xs, ys, yalt, divider, 0, out);
+        kd_order(xalt + divider, xs + divider, ys + divider, yalt + divider, n - divider, 0, out + divider);
     }
-    if (left > median) median_split(a, left, median, axis);
-    if (right < median - 1) median_split(a + right + 1, n - right - 1, median - right - 1, axis);
 }
 
-void Delaunay::alternate(Pt *a, int n, int axis) {  // triangle.cpp:5307-5325
-    const int divider = n >> 1;
-    if (n <= 3) axis = 0;
-    median_split(a, n, divider, axis);
-    if (n - divider >= 2) {
-        if (divider >= 2) alternate(a, divider, 1 - axis);
-        alternate(a + divider, n - divider, 1 - axis);
+// a[0..m) is sorted by (x, y) without duplicates; rearranges it into the order the reference's alternating cuts leave
+void Delaunay::alternate_cuts(Pt *a, int m) {
+    if (m <= 3) return;  // triangle.cpp:5904-5913 leaves such an array as sorted
+    if ((int)sorted_.size() < m) sorted_.resize(m);
+    if ((int)kd_.size() < 4 * m) kd_.resize((size_t)4 * m);
+    memcpy(sorted_.data(), a, sizeof(Pt) * (size_t)m);
+    uint64_t *xs = kd_.data(), *xalt = xs + m, *ys = xalt + m, *yalt = ys + m;
+    // (y, x) order = stable sort of the (x, y)-sorted array by y alone: two counting passes over the 16-bit biased y
+    uint32_t cnt0[257] = {0}, cnt1[257] = {0};
+    for (int i = 0; i < m; i++) {
+        const uint32_t y = a[i].key & 0xFFFFu;
+        cnt0[(y & 0xFF) + 1]++;
+        cnt1[(y >> 8) + 1]++;
     }
+    for (int i = 0; i < 256; i++) {
+        cnt0[i + 1] += cnt0[i];
+        cnt1[i + 1] += cnt1[i];
+    }
+    for (int i = 0; i < m; i++) xalt[cnt0[a[i].key & 0xFF]++] = ((uint64_t)(a[i].key & 0xFFFFu) << 32) | (uint32_t)i;
+    for (int i = 0; i < m; i++) {
+        const uint64_t e = xalt[i];
+        yalt[cnt1[(e >> 40) & 0xFF]++] = e;
+    }
+    for (int i = 0; i < m; i++) {  // y-rank of every vertex
+        const uint32_t p = (uint32_t)yalt[i];
+        xs[p] = ((uint64_t)i << 32) | p;
+        ys[i] = ((uint64_t)i << 32) | p;
+    }
+    kd_order(xs, xalt, ys, yalt, m, 0, a);
 }
 
 // triangle.cpp:5362-5651
@@ -582,11 +606,7 @@ int Delaunay::triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap) {
     }
     m++;
     if (m < 2) return 0;
-    const int divider = m >> 1;
-    if (m - divider >= 2) {  // :5904-5913
-        if (divider >= 2) alternate(a, divider, 1);
-        alternate(a + divider, m - divider, 1);
-    }
+    alternate_cuts(a, m);
     H hl, hr;
     build(a, m, 0, hl, hr);
     // Output in slot order (= pool order, triangle.cpp:7449-7500) skipping bounding triangles (what removeghosts,

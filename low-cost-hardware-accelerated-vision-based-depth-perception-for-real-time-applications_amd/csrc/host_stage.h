@@ -48,14 +48,15 @@ class Delaunay {
 
     const int32_t *xy_ = nullptr;
     std::vector<Tri> tris_;
-    std::vector<Pt> order_;
+    std::vector<Pt> order_, sorted_;
+    std::vector<uint64_t> kd_;
     int n_slots_ = 0;
     uint32_t seed_ = 1;
 
     H make();
     void sort_xy(Pt *a, int n);
-    void median_split(Pt *a, int n, int median, int axis);
-    void alternate(Pt *a, int n, int axis);
+    void kd_order(uint64_t *xs, uint64_t *xalt, uint64_t *ys, uint64_t *yalt, int n, int axis, Pt *out);
+    void alternate_cuts(Pt *a, int m);
     void build(const Pt *a, int n, int axis, H &farleft, H &farright);
     void merge(H &farleft, H &innerleft, H &innerright, H &farright, int axis);
     uint32_t rnd(uint32_t choices);
