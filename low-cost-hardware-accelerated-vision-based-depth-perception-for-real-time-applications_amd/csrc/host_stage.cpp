@@ -186,14 +186,16 @@ int support_filter(const sv_params &p, int16_t *dcan, int W, int H, int32_t *out
 // ------------------------------------------------------------------------------------------------------------
 
 namespace {
-constexpr int NEXT3[3] = {1, 2, 0}, PREV3[3] = {2, 0, 1};
-inline int32_t hnext(int32_t h) { return (h & ~3) | NEXT3[h & 3]; }
-inline int32_t hprev(int32_t h) { return (h & ~3) | PREV3[h & 3]; }
+// orientation arithmetic without table loads: next = {1, 2, 0}[o], prev = {2, 0, 1}[o]
+inline int next3(int o) { return (9 >> (2 * o)) & 3; }
+inline int prev3(int o) { return (18 >> (2 * o)) & 3; }
+inline int32_t hnext(int32_t h) { return (h & ~3) | next3(h & 3); }
+inline int32_t hprev(int32_t h) { return (h & ~3) | prev3(h & 3); }
 }  // namespace
 
 #define SYM(h) (T[(h) >> 2].nbr[(h)&3])
-#define ORG(h) (T[(h) >> 2].vtx[NEXT3[(h)&3]])
-#define DEST(h) (T[(h) >> 2].vtx[PREV3[(h)&3]])
+#define ORG(h) (T[(h) >> 2].vtx[next3((h)&3)])
+#define DEST(h) (T[(h) >> 2].vtx[prev3((h)&3)])
 #define APEX(h) (T[(h) >> 2].vtx[(h)&3])
 #define BOND(a, b)                       \
     do {                                 \
@@ -275,7 +277,7 @@ void Delaunay::kd_order(uint64_t *xs, uint64_t *xalt, uint64_t *ys, uint64_t *ya
         for (int i = 0; i < n; i++) {
             const uint64_t e = ys[i];
             const int l = (uint32_t)e < pivot;
-            yalt[l ? li : ri] = e;
+            yalt[ri + ((li - ri) & -l)] = e;
             li += l;
             ri += 1 - l;
         }
@@ -286,7 +288,7 @@ void Delaunay::kd_order(uint64_t *xs, uint64_t *xalt, uint64_t *ys, uint64_t *ya
         for (int i = 0; i < n; i++) {
             const uint64_t e = xs[i];
             const int l = (uint32_t)(e >> 32) < pivot;
-            xalt[l ? li : ri] = e;
+            xalt[ri + ((li - ri) & -l)] = e;
             li += l;
             ri += 1 - l;
         }
