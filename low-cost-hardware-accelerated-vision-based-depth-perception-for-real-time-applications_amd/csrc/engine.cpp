@@ -221,6 +221,13 @@ void fill_kparams(sv_handle *h) {
     k.speckle_size = p.speckle_size;
     k.gap_width = p.ipol_gap_width;
     k.add_corners = p.add_corners;
+    // run tables of the speckle stage: as many runs per 16-row band as fit next to the band's bit masks in 64 KB of LDS
+    k.ccl_cap = 2048;
+    if (const char *e = getenv("SV_DEBUG_CCL_CAP")) k.ccl_cap = std::max(1, atoi(e));  // tests: force the per-pixel slow path
+    {
+        const long room = (65536 - 256 - 16L * ((d.W + 63) / 64) * 28) / 16;
+        k.ccl_cap = (int)std::max(1L, std::min((long)k.ccl_cap, room));
+    }
     k.rt_cap = 512;
     if (const char *e = getenv("SV_DEBUG_RT_CAP")) k.rt_cap = std::max(0, std::min(512, atoi(e)));  // tests: force the raster fallback
     h->nproc = p.postprocess_only_left ? 1 : 2;
@@ -729,6 +736,13 @@ void alloc_slot(sv_handle *h, Slot *sl) {
     dev_alloc(s.disp, cap * 2 * d.N);
     dev_alloc(s.tmp, cap * 2 * d.N);
     dev_alloc(s.csize, cap * 2 * d.N);
+    {
+        uint8_t *w = nullptr;
+        const size_t bytes = ccl_ws_bytes(h->kp, (int)cap * 2);
+        dev_alloc(w, bytes);
+        HIP_TRY(hipMemset(w, 0, bytes));  // the overflow flags start cleared; k_ccl_finish clears the ones it consumes
+        s.ccl_ws = w;
+    }
     HIP_TRY(hipHostMalloc((void **)&sl->h_dcan, sizeof(int16_t) * (cap * d.Wc * d.Hc + LATTICE_PAD), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&sl->h_blob, sizeof(int32_t) * sl->blob_words, hipHostMallocDefault));
     // throughput mode: waiting threads sleep on the event instead of spinning, so the cores go to the Delaunay pool
@@ -740,7 +754,7 @@ void alloc_slot(sv_handle *h, Slot *sl) {
 
 void free_slot(Slot *sl) {
     SlotDev &s = sl->dev;
-    void *dptrs[] = {s.desc, s.dcan, s.fsup, s.fnsup, s.blob, s.rrec, s.tile_cnt, s.tile_list, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize};
+    void *dptrs[] = {s.desc, s.dcan, s.fsup, s.fnsup, s.blob, s.rrec, s.tile_cnt, s.tile_list, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize, s.ccl_ws};
     for (void *p : dptrs)
         if (p) (void)hipFree(p);
     if (sl->h_dcan) (void)hipHostFree(sl->h_dcan);

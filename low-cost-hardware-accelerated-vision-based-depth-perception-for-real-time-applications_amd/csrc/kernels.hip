@@ -16,7 +16,7 @@ thread_local LaunchHook g_launch_hook = {nullptr, nullptr};
 
 const char *kernel_name(int id) {
     static const char *names[K_COUNT] = {"descriptor", "support_match", "support_filter", "grid_mark", "grid_dilate", "plane_fit", "triangles_raster", "triangles_raster_fallback", "dense_match", "lr_check",
-                                         "ccl_init", "ccl_merge", "ccl_count", "ccl_apply", "gap_rows", "gap_cols", "adaptive_mean", "median", "output"};
+                                         "ccl_band", "ccl_finish", "gap_rows", "gap_cols", "adaptive_mean", "median", "output"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 
@@ -1157,59 +1157,73 @@ void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st, float 
 // K7  speckle removal = connected components of valid pixels under |dD| <= speckle_sim_threshold, 4-adjacency
 //     reference: elas.cpp:1013-1124 (BFS flood fill).  After the L/R stage every invalid pixel is exactly -10, so the
 //     reference's order-dependent BFS reduces to plain component labelling.
-//     Union-find on global memory: row runs give the initial labels, vertical links are merged with atomicMin,
-//     component sizes are counted (saturating at speckle_size) at the root pixel.
+//
+//     The nodes of the labelling are horizontal RUNS of linked pixels, not pixels:
+//       k_ccl_band    one workgroup per band of CCL_R rows.  Reads the band once, keeps three bit masks per row in LDS
+//                     (valid / run start / linked to the pixel above), numbers the runs by prefix pop-counts, unions
+//                     vertically adjacent runs in an LDS union-find (one thread per 64-pixel mask word, walking its set
+//                     bits), and writes one record per run (first pixel, length, band-local root, component size at
+//                     roots) plus the masks of its first and last row.
+//       k_ccl_finish  one workgroup per map.  Unions runs across band borders (global union-find over run records),
+//                     sums component sizes at the global roots and overwrites the runs of components smaller than
+//                     speckle_size with -10.  Only those pixels are written; no per-pixel label map exists.
+//     A band with more than ccl_cap runs flags its map; k_ccl_finish then labels that map with the slower per-pixel
+//     union-find on global memory (ccl_legacy_map), so any input is handled.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ size_t map_offset(const Dims &d, int m, int nproc) {  // m = pair*nproc + side
     const int pair = m / nproc, side = m - pair * nproc;
     return (size_t)(pair * 2 + side) * d.N;
 }
 
-// csize[p]: run length (> 0) at the first pixel of every horizontal run of linked valid pixels, 0 elsewhere.
-// cnt[p]  : component size accumulator, meaningful at root pixels (roots are always run starts).
-__global__ __launch_bounds__(64) void k_ccl_init(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ disp, int32_t *__restrict__ label,
-                                                 int32_t *__restrict__ csize, int32_t *__restrict__ cnt) {
-    const Dims &d = k.d;
-    const int m = blockIdx.y;
-    if (blob[(m / nproc) * META_WORDS] < 3) return;
-    const size_t off = map_offset(d, m, nproc);
-    const int v = blockIdx.x, lane = threadIdx.x;
-    const float *D = disp + off + (size_t)v * d.W;
-    int32_t *L = label + off + (size_t)v * d.W, *S = csize + off + (size_t)v * d.W, *C = cnt + off + (size_t)v * d.W;
-    int carry_start = -1;
-    float carry_val = -10.0f;
-    for (int u0 = 0; u0 < d.W; u0 += 64) {
-        const int u = u0 + lane;
-        const float val = u < d.W ? D[u] : -10.0f;
-        const bool valid = val >= 0;
-        float left = __shfl_up(val, 1, 64);
-        if (lane == 0) left = carry_val;
-        const bool link = valid && left >= 0 && fabsf(val - left) <= k.speckle_sim;
-        const unsigned long long brk = __ballot(!link);  // bit set: this pixel starts a run (or is invalid)
-        const unsigned long long upto = brk & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-        const int start = upto ? (u0 + 63 - __clzll((long long)upto)) : carry_start;
-        // the run ends here if the next pixel does not link to this one (next chunk's first pixel: decided there)
-        const bool next_breaks = lane == 63 ? false : ((brk >> (lane + 1)) & 1ull) != 0;
-        if (u < d.W) {
-            L[u] = valid ? (int)(v * d.W + start) : -1;
-            if (!(valid && start == u)) S[u] = 0;       // run starts get their length from the run's last pixel
-            C[u] = 0;
-            if (valid && (next_breaks || u == d.W - 1)) S[start] = u - start + 1;
-        }
-        // a run that reaches lane 63 continues into the next chunk unless that chunk's lane 0 breaks it
-        const int prev_start = carry_start;
-        (void)prev_start;
-        carry_start = __shfl(valid ? start : -1, 63, 64);
-        carry_val = __shfl(val, 63, 64);
-        if (u0 + 64 < d.W) {
-            // peek: does the first pixel of the next chunk link to our lane 63?  If not, close the run now.
-            const float nxt = D[u0 + 64];
-            const bool cont = carry_start >= 0 && nxt >= 0 && fabsf(nxt - carry_val) <= k.speckle_sim;
-            if (lane == 63 && valid && !cont) S[start] = u - start + 1;
-        }
-    }
+constexpr int CCL_R = 16;        // rows per band
+constexpr int CCL_THREADS = 512;
+
+struct CclWs {  // workspace views of one launch (ccl_views lays them out)
+    int4 *runs;          // [maps][nb][cap]  (first pixel, length, band-local root, component size if root)
+    int32_t *gparent;    // [maps][nb][cap]  union-find over run records, node = band*cap + run
+    int32_t *total;      // [maps][nb][cap]  component size, accumulated at global roots
+    int32_t *tcount;     // [maps][nb]       runs per band
+    int32_t *flag;       // [maps]           1 = some band overflowed; cleared by k_ccl_finish
+    uint64_t *bwords;    // [maps][nb][5][nch]  first row: start, valid, up-link masks; last row: start, valid masks
+    int32_t *bbase;      // [maps][nb][2][nch]  run number before each 64-pixel word of the first / last row
+    int cap, nb, nch;
+};
+
+static size_t ccl_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// carves the views out of the workspace; returns the bytes used
+static size_t ccl_views(const KParams &k, void *ws, int maps_cap, CclWs &w) {
+    w.cap = k.ccl_cap;
+    w.nb = (k.d.H + CCL_R - 1) / CCL_R;
+    w.nch = (k.d.W + 63) / 64;
+    uint8_t *base = static_cast<uint8_t *>(ws);
+    size_t o = 0;
+    const size_t nodes = (size_t)maps_cap * w.nb * w.cap;
+    w.runs = reinterpret_cast<int4 *>(base + o);
+    o += ccl_align(nodes * sizeof(int4));
+    w.gparent = reinterpret_cast<int32_t *>(base + o);
+    o += ccl_align(nodes * 4);
+    w.total = reinterpret_cast<int32_t *>(base + o);
+    o += ccl_align(nodes * 4);
+    w.tcount = reinterpret_cast<int32_t *>(base + o);
+    o += ccl_align((size_t)maps_cap * w.nb * 4);
+    w.flag = reinterpret_cast<int32_t *>(base + o);
+    o += ccl_align((size_t)maps_cap * 4);
+    w.bwords = reinterpret_cast<uint64_t *>(base + o);
+    o += ccl_align((size_t)maps_cap * w.nb * 5 * w.nch * 8);
+    w.bbase = reinterpret_cast<int32_t *>(base + o);
+    o += ccl_align((size_t)maps_cap * w.nb * 2 * w.nch * 4);
+    return o;
 }
 
+size_t ccl_ws_bytes(const KParams &k, int maps_cap) {
+    CclWs w;
+    return ccl_views(k, nullptr, maps_cap, w);
+}
+
+size_t ccl_lds_bytes(const KParams &k) { return (size_t)CCL_R * ((k.d.W + 63) / 64) * (3 * 8 + 4) + (size_t)k.ccl_cap * 4 * 4; }
+
+// union-find with the smaller index as root; works on LDS and on global memory
 __device__ __forceinline__ int ccl_find(const int32_t *L, int x) {
     int p = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (p != x) {
@@ -1235,64 +1249,304 @@ __device__ __forceinline__ void ccl_union(int32_t *L, int a, int b) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_ccl_merge(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ disp, int32_t *__restrict__ label) {
+__device__ __forceinline__ uint64_t bits_upto(int lane) { return lane == 63 ? ~0ull : ((2ull << lane) - 1ull); }
+__device__ __forceinline__ int ctz64(uint64_t x) { return __ffsll((long long)x) - 1; }
+
+// Vertical links of one mask word that join two runs not already joined by the link one pixel to the left:
+// L = up-link bits, H / Hu = "linked to the left neighbour" bits of this row / the row above, carry = up-link bit of the
+// last pixel of the previous word.
+__device__ __forceinline__ uint64_t ccl_new_links(uint64_t L, uint64_t H, uint64_t Hu, uint64_t carry) { return L & ~(H & Hu & ((L << 1) | carry)); }
+
+__global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ disp, CclWs ws) {
     const Dims &d = k.d;
-    const int m = blockIdx.z;
+    extern __shared__ uint64_t ccl_lds[];
+    const int m = blockIdx.y, band = blockIdx.x;
     if (blob[(m / nproc) * META_WORDS] < 3) return;
-    const size_t off = map_offset(d, m, nproc);
-    const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y + 1;
-    if (u >= d.W || v >= d.H) return;
-    const float *D = disp + off;
+    const int nch = ws.nch, cap = ws.cap;
+    const int v0 = band * CCL_R, rows = min(CCL_R, d.H - v0);
+    uint64_t *Sm = ccl_lds, *Vm = Sm + CCL_R * nch, *Lm = Vm + CCL_R * nch;  // [CCL_R][nch] run-start / valid / up-link masks
+    int32_t *base = reinterpret_cast<int32_t *>(Lm + CCL_R * nch);           // [CCL_R][nch] run starts of the row before the word
+    int32_t *parent = base + CCL_R * nch, *len = parent + cap, *size = len + cap, *start = size + cap;
+    __shared__ int32_t rowbase[CCL_R + 1];
+    const float *D = disp + map_offset(d, m, nproc);
     const float thr = k.speckle_sim;
-    const float c = D[(size_t)v * d.W + u], up = D[(size_t)(v - 1) * d.W + u];
-    if (!(c >= 0 && up >= 0 && fabsf(c - up) <= thr)) return;
-    if (u > 0) {  // the same vertical link already exists one pixel to the left inside both runs: nothing new to merge
-        const float cl = D[(size_t)v * d.W + u - 1], ul = D[(size_t)(v - 1) * d.W + u - 1];
-        if (cl >= 0 && ul >= 0 && fabsf(c - cl) <= thr && fabsf(up - ul) <= thr && fabsf(cl - ul) <= thr) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = CCL_THREADS / 64;
+    for (int i = tid; i < cap; i += CCL_THREADS) {
+        parent[i] = i;
+        len[i] = 0;
+        size[i] = 0;
     }
-    ccl_union(label + off, v * d.W + u, (v - 1) * d.W + u);
+    // masks: one wavefront per 64-pixel column strip; the strip's CCL_R+1 rows are requested at once, then reduced to masks
+    for (int c = wave; c < nch; c += nw) {
+        const int u = c * 64 + lane;
+        float val[CCL_R], lft[CCL_R];
+        float prev = (v0 > 0 && u < d.W) ? D[(size_t)(v0 - 1) * d.W + u] : -10.0f;
+#pragma unroll
+        for (int r = 0; r < CCL_R; r++) val[r] = (r < rows && u < d.W) ? D[(size_t)(v0 + r) * d.W + u] : -10.0f;
+#pragma unroll
+        for (int r = 0; r < CCL_R; r++) lft[r] = (lane == 0 && r < rows && u > 0) ? D[(size_t)(v0 + r) * d.W + u - 1] : -10.0f;
+#pragma unroll
+        for (int r = 0; r < CCL_R; r++) {
+            float left = __shfl_up(val[r], 1, 64);
+            if (lane == 0) left = lft[r];
+            const bool valid = val[r] >= 0;
+            const bool hl = valid && left >= 0 && fabsf(val[r] - left) <= thr;
+            const bool vl = valid && prev >= 0 && fabsf(val[r] - prev) <= thr;
+            const uint64_t V = __ballot(valid), S = __ballot(valid && !hl), L = __ballot(vl);
+            if (lane == 0 && r < rows) {
+                Vm[r * nch + c] = V;
+                Sm[r * nch + c] = S;
+                Lm[r * nch + c] = L;
+            }
+            prev = val[r];
+        }
+    }
+    __syncthreads();
+    // run numbering: exclusive prefix of the start counts along every row, then along the rows
+    for (int r = wave; r < rows; r += nw) {
+        int run = 0;
+        for (int c0 = 0; c0 < nch; c0 += 64) {
+            const int c = c0 + lane;
+            const int cnt = c < nch ? __popcll(Sm[r * nch + c]) : 0;
+            int incl = cnt;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o, 64);
+                if (lane >= o) incl += t;
+            }
+            if (c < nch) base[r * nch + c] = run + incl - cnt;
+            run += __shfl(incl, 63, 64);
+        }
+        if (lane == 0) rowbase[r + 1] = run;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        rowbase[0] = 0;
+        for (int r = 0; r < rows; r++) rowbase[r + 1] += rowbase[r];
+    }
+    __syncthreads();
+    const int T = rowbase[rows];
+    int32_t *tc = ws.tcount + (size_t)m * ws.nb + band;
+    if (T > cap) {  // too many runs for the LDS tables: the whole map goes the slow way
+        if (tid == 0) {
+            ws.flag[m] = 1;
+            *tc = 0;
+        }
+        return;
+    }
+    // run records (first pixel, length) and vertical unions: one THREAD per mask word, walking its set bits
+    for (int rc = tid; rc < rows * nch; rc += CCL_THREADS) {
+        const int r = rc / nch, c = rc - r * nch;
+        const uint64_t V = Vm[rc], S = Sm[rc], L = Lm[rc];
+        const int b0 = rowbase[r] + base[rc];  // number of the first run that starts in this word
+        const int pix0 = (v0 + r) * d.W + c * 64;
+        const uint64_t brk = S | ~V;           // a segment ends before the next start or invalid pixel
+        if ((V & 1ull) && !(S & 1ull)) {       // the run of the previous word continues into this one
+            const uint64_t bk = brk & ~1ull;
+            atomicAdd(&len[b0 - 1], bk ? ctz64(bk) : 64);
+        }
+        int j = b0;
+        for (uint64_t sb = S; sb; sb &= sb - 1, j++) {
+            const int pos = ctz64(sb);
+            const uint64_t bk = brk & ~bits_upto(pos);
+            atomicAdd(&len[j], (bk ? ctz64(bk) : 64) - pos);
+            start[j] = pix0 + pos;
+        }
+        if (r >= 1) {
+            const uint64_t Vu = Vm[rc - nch], Su = Sm[rc - nch];
+            const int bu = rowbase[r - 1] + base[rc - nch];
+            const uint64_t carry = c > 0 ? (Lm[rc - 1] >> 63) : 0ull;
+            for (uint64_t F = ccl_new_links(L, V & ~S, Vu & ~Su, carry); F; F &= F - 1) {
+                const uint64_t upto = bits_upto(ctz64(F));
+                ccl_union(parent, b0 + __popcll(S & upto) - 1, bu + __popcll(Su & upto) - 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < T; i += CCL_THREADS) {
+        const int root = ccl_find(parent, i);
+        parent[i] = root;
+        atomicAdd(&size[root], len[i]);
+    }
+    __syncthreads();
+    const size_t node0 = ((size_t)m * ws.nb + band) * cap;
+    for (int i = tid; i < T; i += CCL_THREADS) {
+        ws.runs[node0 + i] = make_int4(start[i], len[i], parent[i], size[i]);
+        ws.gparent[node0 + i] = band * cap + parent[i];
+        ws.total[node0 + i] = 0;
+    }
+    if (tid == 0) *tc = T;
+    uint64_t *bw = ws.bwords + ((size_t)m * ws.nb + band) * 5 * nch;
+    int32_t *bb = ws.bbase + ((size_t)m * ws.nb + band) * 2 * nch;
+    for (int c = tid; c < nch; c += CCL_THREADS) {
+        const int rl = (rows - 1) * nch + c;
+        bw[c] = Sm[c];
+        bw[nch + c] = Vm[c];
+        bw[2 * nch + c] = Lm[c];
+        bw[3 * nch + c] = Sm[rl];
+        bw[4 * nch + c] = Vm[rl];
+        bb[c] = base[c];
+        bb[nch + c] = rowbase[rows - 1] + base[rl];
+    }
 }
 
-// One thread per pixel, only run starts act: chase the root once per run (path-compressing the start) and add the run's
-// length to the root's counter -- unless that counter has already reached speckle_size (sizes only need to be told apart
-// at that threshold; a stale read merely causes a harmless extra add).
-__global__ __launch_bounds__(256) void k_ccl_count(KParams k, int nproc, const int32_t *__restrict__ blob, int32_t *__restrict__ label, const int32_t *__restrict__ csize,
-                                                   int32_t *__restrict__ cnt) {
+// ---- per-pixel union-find on global memory: the slow path for maps whose bands overflow the run tables ----
+// csize[p]: run length (> 0) at the first pixel of every horizontal run of linked valid pixels, 0 elsewhere.
+// cnt[p]  : component size accumulator, meaningful at root pixels (roots are always run starts).
+__device__ void ccl_legacy_init_row(const KParams &k, const float *D, int32_t *L, int32_t *S, int32_t *C, int v, int lane) {
     const Dims &d = k.d;
-    const int m = blockIdx.y;
-    if (blob[(m / nproc) * META_WORDS] < 3) return;
-    const size_t off = map_offset(d, m, nproc);
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= d.N) return;
-    const int len = csize[off + p];
-    if (len <= 0) return;
-    int32_t *L = label + off;
-    const int root = ccl_find(L, p);
-    if (root != p) L[p] = root;
-    if (cnt[off + root] < k.speckle_size) atomicAdd(&cnt[off + root], len);
+    int carry_start = -1;
+    float carry_val = -10.0f;
+    for (int u0 = 0; u0 < d.W; u0 += 64) {
+        const int u = u0 + lane;
+        const float val = u < d.W ? D[u] : -10.0f;
+        const bool valid = val >= 0;
+        float left = __shfl_up(val, 1, 64);
+        if (lane == 0) left = carry_val;
+        const bool link = valid && left >= 0 && fabsf(val - left) <= k.speckle_sim;
+        const unsigned long long brk = __ballot(!link);  // bit set: this pixel starts a run (or is invalid)
+        const unsigned long long upto = brk & bits_upto(lane);
+        const int start = upto ? (u0 + 63 - __clzll((long long)upto)) : carry_start;
+        // the run ends here if the next pixel does not link to this one (next chunk's first pixel: decided there)
+        const bool next_breaks = lane == 63 ? false : ((brk >> (lane + 1)) & 1ull) != 0;
+        if (u < d.W) {
+            L[u] = valid ? (int)(v * d.W + start) : -1;
+            if (!(valid && start == u)) S[u] = 0;       // run starts get their length from the run's last pixel
+            C[u] = 0;
+            if (valid && (next_breaks || u == d.W - 1)) S[start] = u - start + 1;
+        }
+        // a run that reaches lane 63 continues into the next chunk unless that chunk's lane 0 breaks it
+        carry_start = __shfl(valid ? start : -1, 63, 64);
+        carry_val = __shfl(val, 63, 64);
+        if (u0 + 64 < d.W) {
+            // peek: does the first pixel of the next chunk link to our lane 63?  If not, close the run now.
+            const float nxt = D[u0 + 64];
+            const bool cont = carry_start >= 0 && nxt >= 0 && fabsf(nxt - carry_val) <= k.speckle_sim;
+            if (lane == 63 && valid && !cont) S[start] = u - start + 1;
+        }
+    }
 }
 
-__global__ __launch_bounds__(256) void k_ccl_apply(KParams k, int nproc, const int32_t *__restrict__ blob, const int32_t *__restrict__ label,
-                                                   const int32_t *__restrict__ cnt, float *__restrict__ disp) {
+__device__ __forceinline__ void ccl_phase_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    __syncthreads();
+}
+
+__device__ void ccl_legacy_map(const KParams &k, float *D, int32_t *label, int32_t *csize, int32_t *cnt) {
     const Dims &d = k.d;
-    const int m = blockIdx.y;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const float thr = k.speckle_sim;
+    for (int v = tid >> 6; v < d.H; v += nt >> 6)
+        ccl_legacy_init_row(k, D + (size_t)v * d.W, label + (size_t)v * d.W, csize + (size_t)v * d.W, cnt + (size_t)v * d.W, v, tid & 63);
+    ccl_phase_sync();
+    for (int p = d.W + tid; p < d.N; p += nt) {  // vertical links
+        const int u = p % d.W;
+        const float c = D[p], up = D[p - d.W];
+        if (!(c >= 0 && up >= 0 && fabsf(c - up) <= thr)) continue;
+        if (u > 0) {  // the same vertical link already exists one pixel to the left inside both runs: nothing new to merge
+            const float cl = D[p - 1], ul = D[p - d.W - 1];
+            if (cl >= 0 && ul >= 0 && fabsf(c - cl) <= thr && fabsf(up - ul) <= thr && fabsf(cl - ul) <= thr) continue;
+        }
+        ccl_union(label, p, p - d.W);
+    }
+    ccl_phase_sync();
+    for (int p = tid; p < d.N; p += nt) {  // one root chase + add per run
+        const int len = csize[p];
+        if (len <= 0) continue;
+        const int root = ccl_find(label, p);
+        if (root != p) label[p] = root;
+        atomicAdd(&cnt[root], len);
+    }
+    ccl_phase_sync();
+    for (int p = tid; p < d.N; p += nt) {
+        const int start = __hip_atomic_load(&label[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (start < 0) continue;
+        const int root = __hip_atomic_load(&label[start], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // run starts were compressed above
+        if (__hip_atomic_load(&cnt[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k.speckle_size) D[p] = -10.0f;  // elas.cpp:1109-1114
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_ccl_finish(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp, CclWs ws, int staged,
+                                                     int32_t *__restrict__ label, int32_t *__restrict__ csize, int32_t *__restrict__ cnt) {
+    const Dims &d = k.d;
+    const int m = blockIdx.x;
     if (blob[(m / nproc) * META_WORDS] < 3) return;
     const size_t off = map_offset(d, m, nproc);
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= d.N) return;
-    const int start = label[off + p];
-    if (start < 0) return;
-    const int root = label[off + start];  // run start -> root (run starts were compressed by k_ccl_count; a root points at itself)
-    if (cnt[off + root] < k.speckle_size) disp[off + p] = -10.0f;  // elas.cpp:1109-1114
+    float *D = disp + off;
+    const int tid = threadIdx.x;
+    if (ws.flag[m]) {
+        ccl_legacy_map(k, D, label + off, csize + off, cnt + off);
+        __syncthreads();
+        if (tid == 0) ws.flag[m] = 0;
+        return;
+    }
+    const int nch = ws.nch, cap = ws.cap, nb = ws.nb;
+    int32_t *GP = ws.gparent + (size_t)m * nb * cap, *TOT = ws.total + (size_t)m * nb * cap;
+    const int4 *RUNS = ws.runs + (size_t)m * nb * cap;
+    const int32_t *TC = ws.tcount + (size_t)m * nb;
+    // border masks and run numbers of every band of the map: staged in LDS when they fit (staged != 0)
+    extern __shared__ uint64_t fin_lds[];
+    const uint64_t *BW = ws.bwords + (size_t)m * nb * 5 * nch;  // [nb][5][nch]
+    const int32_t *BB = ws.bbase + (size_t)m * nb * 2 * nch;    // [nb][2][nch]
+    if (staged) {
+        uint64_t *lw = fin_lds;
+        int32_t *lb = reinterpret_cast<int32_t *>(lw + (size_t)nb * 5 * nch);
+        for (int i = tid; i < nb * 5 * nch; i += 1024) lw[i] = BW[i];
+        for (int i = tid; i < nb * 2 * nch; i += 1024) lb[i] = BB[i];
+        BW = lw;
+        BB = lb;
+        __syncthreads();
+    }
+    // unions across band borders (first row of band b against the last row of band b-1): one thread per mask word
+    for (int idx = tid; idx < (nb - 1) * nch; idx += 1024) {
+        const int b = 1 + idx / nch, c = idx - (b - 1) * nch;
+        const uint64_t *bwb = BW + (size_t)b * 5 * nch, *bwp = bwb - 5 * nch;
+        const uint64_t L = bwb[2 * nch + c];
+        if (!L) continue;
+        const uint64_t S0 = bwb[c], V0 = bwb[nch + c], Sp = bwp[3 * nch + c], Vp = bwp[4 * nch + c];
+        const uint64_t carry = c > 0 ? (bwb[2 * nch + c - 1] >> 63) : 0ull;
+        const int32_t *bbb = BB + (size_t)b * 2 * nch, *bbp = bbb - 2 * nch;
+        const int n0 = b * cap + bbb[c], np = (b - 1) * cap + bbp[nch + c];
+        for (uint64_t F = ccl_new_links(L, V0 & ~S0, Vp & ~Sp, carry); F; F &= F - 1) {
+            const uint64_t upto = bits_upto(ctz64(F));
+            ccl_union(GP, n0 + __popcll(S0 & upto) - 1, np + __popcll(Sp & upto) - 1);
+        }
+    }
+    ccl_phase_sync();
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int b = wave; b < nb; b += 16) {  // component sizes at the global roots
+        const int T = TC[b];
+        for (int i = lane; i < T; i += 64) {
+            const int4 r = RUNS[b * cap + i];
+            if (r.z != i) continue;  // band-local roots carry their component's pixel count
+            atomicAdd(&TOT[ccl_find(GP, b * cap + i)], r.w);
+        }
+    }
+    ccl_phase_sync();
+    for (int b = wave; b < nb; b += 16) {  // runs of small components are wiped (elas.cpp:1109-1114)
+        const int T = TC[b];
+        for (int i = lane; i < T; i += 64) {
+            const int4 r = RUNS[b * cap + i];
+            const int g = ccl_find(GP, b * cap + r.z);
+            if (__hip_atomic_load(&TOT[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= k.speckle_size) continue;
+            for (int q = 0; q < r.y; q++) D[r.x + q] = -10.0f;
+        }
+    }
+}
+
+static size_t ccl_finish_lds_bytes(const KParams &k) {
+    const size_t nb = (k.d.H + CCL_R - 1) / CCL_R, nch = (k.d.W + 63) / 64;
+    return nb * nch * (5 * 8 + 2 * 4);
 }
 
 void launch_speckle(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st) {
     const int maps = n * nproc;
-    int32_t *cnt = reinterpret_cast<int32_t *>(s.tmp);  // the filters' scratch map is free during speckle removal
-    SV_LAUNCH(K_CCL_INIT, k_ccl_init, dim3(k.d.H, maps), dim3(64), 0, st, k, nproc, s.blob, s.disp, s.tri_id, s.csize, cnt);
-    SV_LAUNCH(K_CCL_MERGE, k_ccl_merge, dim3((k.d.W + 255) / 256, k.d.H - 1, maps), dim3(256), 0, st, k, nproc, s.blob, s.disp, s.tri_id);
-    SV_LAUNCH(K_CCL_COUNT, k_ccl_count, dim3((k.d.N + 255) / 256, maps), dim3(256), 0, st, k, nproc, s.blob, s.tri_id, s.csize, cnt);
-    SV_LAUNCH(K_CCL_APPLY, k_ccl_apply, dim3((k.d.N + 255) / 256, maps), dim3(256), 0, st, k, nproc, s.blob, s.tri_id, cnt, s.disp);
+    CclWs ws;
+    ccl_views(k, s.ccl_ws, s.cap * 2, ws);
+    SV_LAUNCH(K_CCL_BAND, k_ccl_band, dim3(ws.nb, maps), dim3(CCL_THREADS), ccl_lds_bytes(k), st, k, nproc, s.blob, s.disp, ws);
+    int32_t *cnt = reinterpret_cast<int32_t *>(s.tmp);  // slow path only: the filters' scratch map is free during speckle removal
+    const size_t fin = ccl_finish_lds_bytes(k);
+    const int staged = fin <= 60 * 1024;
+    SV_LAUNCH(K_CCL_FINISH, k_ccl_finish, dim3(maps), dim3(1024), staged ? fin : 0, st, k, nproc, s.blob, s.disp, ws, staged, s.tri_id, s.csize, cnt);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -30,6 +30,7 @@ struct KParams {
     int speckle_size;
     int gap_width;
     int add_corners;
+    int ccl_cap;             // runs a 16-row band may hold in the LDS tables of k_ccl_band before its map takes the slow path
     int rt_cap;              // triangles a raster tile list may hold before its map falls back to global atomics (<= 512)
 };
 
@@ -57,13 +58,16 @@ struct SlotDev {
     float *wta;         // [cap][2][N]  integer WTA disparity (-1 / -10 invalid)
     float *disp;        // [cap][2][N]  L/R-checked maps; speckle and gap stages work in place
     float *tmp;         // [cap][2][N]  second map buffer: the fused filters ping-pong disp <-> tmp (CCL counters before that)
-    int32_t *csize;     // [cap][2][N]  CCL run lengths (at run-start pixels); component sizes accumulate in `tmp`
+    int32_t *csize;     // [cap][2][N]  slow-path CCL only: run lengths (at run-start pixels); component sizes accumulate in `tmp`
+    void *ccl_ws;       // run records, union-find and border masks of the speckle stage (ccl_ws_bytes)
 };
 
 // ---- launch wrappers (kernels.hip).  `n` = pairs in this launch; `nproc` = maps per pair to post-process (1 or 2).
 void launch_descriptor(const KParams &k, const uint8_t *left, const uint8_t *right, size_t in_pair_stride, int stride, const SlotDev &s, int n, hipStream_t st);
 void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st);
 size_t support_filter_lds_bytes(const KParams &k);
+size_t ccl_ws_bytes(const KParams &k, int maps_cap);
+size_t ccl_lds_bytes(const KParams &k);
 void launch_support_filter(const KParams &k, int win, int thr, int need, const SlotDev &s, int n, hipStream_t st);
 void launch_grid(const KParams &k, const SlotDev &s, int n, hipStream_t st);
 void launch_triangles(const KParams &k, const SlotDev &s, int n, hipStream_t st);
@@ -79,7 +83,7 @@ void launch_output(const KParams &k, const SlotDev &s, int n, const float *src, 
 // names of the kernels behind each wrapper, in launch order, for timing reports
 enum KernelId {
     K_DESCRIPTOR = 0, K_SUPPORT, K_SUPPORT_FILTER, K_GRID_MARK, K_GRID_DILATE, K_PLANES, K_TRIANGLES, K_TRIANGLES_FALLBACK, K_DENSE, K_LR,
-    K_CCL_INIT, K_CCL_MERGE, K_CCL_COUNT, K_CCL_APPLY, K_GAP_ROWS, K_GAP_COLS, K_AMEAN, K_MEDIAN, K_OUTPUT, K_COUNT
+    K_CCL_BAND, K_CCL_FINISH, K_GAP_ROWS, K_GAP_COLS, K_AMEAN, K_MEDIAN, K_OUTPUT, K_COUNT
 };
 const char *kernel_name(int id);
 

@@ -157,6 +157,18 @@ def test_raster_fallback_path(eng, oracle, monkeypatch):
     assert util.sha(d1) == entry["stages"]["final1"] and util.sha(d2) == entry["stages"]["final2"]
 
 
+@pytest.mark.parametrize("cap", ["8", "300"])
+def test_speckle_slow_path(eng, oracle, monkeypatch, cap):
+    """Bands with more runs than the LDS run tables hold switch their map to the per-pixel union-find: force that with tiny
+    tables (8: every map; 300: only some bands overflow) and check the speckle stage and the final maps."""
+    monkeypatch.setenv("SV_DEBUG_CCL_CAP", cap)
+    for name in ("kitti0_crop_d64", "kitti0_d128"):
+        entry = DIG[name]
+        L, R, d1, d2, nsup, st = _run_debug(eng, entry)
+        assert util.sha(st["speckle1"]) == entry["stages"]["speckle1"]
+        assert util.sha(d1) == entry["stages"]["final1"]
+
+
 def test_full_4k_pair(eng, oracle):
     """BASELINE config 5 shape: one full 3840x2160 synthetic pair at D=192 against the oracle (bit-exact)."""
     synth = util.pkg("synth")
