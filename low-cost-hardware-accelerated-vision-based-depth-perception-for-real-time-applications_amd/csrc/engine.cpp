@@ -305,6 +305,22 @@ void dbg_maps(sv_handle *h, hipStream_t st, const char *stage, const float *base
     }
 }
 
+// 16-bit device maps, reported as f32 like every other stage
+void dbg_maps_i16(sv_handle *h, hipStream_t st, const char *stage, const int16_t *base, int j) {
+    const size_t N = h->kp.d.N;
+    char name[64];
+    std::vector<int16_t> raw(N);
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int side = 0; side < 2; side++) {
+        snprintf(name, sizeof(name), "%s%d", stage, side + 1);
+        HIP_TRY(hipMemcpy(raw.data(), base + ((size_t)j * 2 + side) * N, N * sizeof(int16_t), hipMemcpyDeviceToHost));
+        std::vector<uint8_t> &v = h->dbg[name];
+        v.resize(N * sizeof(float));
+        float *f = reinterpret_cast<float *>(v.data());
+        for (size_t i = 0; i < N; i++) f[i] = (float)raw[i];
+    }
+}
+
 // maps after an out-of-place stage: processed sides live in `cur`; with postprocess_only_left the right map stays in `disp`
 void dbg_maps_nproc(sv_handle *h, hipStream_t st, const char *stage, const float *cur, const float *disp, int j) {
     const size_t N = h->kp.d.N;
@@ -597,7 +613,8 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
     launch_dense(k, s->dev, n, st);
     float *u1 = job.d1 + (size_t)s->i0 * d.N, *u2 = job.d2 ? job.d2 + (size_t)s->i0 * d.N : nullptr;
     const bool only_left = h->nproc == 1;
-    launch_lr(k, s->dev, n, st, only_left ? u2 : nullptr);  // with postprocess_only_left the checked right map is final
+    // with postprocess_only_left the checked right map is final: it goes straight to the caller (or nowhere)
+    launch_lr(k, s->dev, n, st, only_left ? u2 : nullptr, !only_left || dbg);
     const bool active = dbg && blob[(size_t)(n - 1) * META_WORDS] >= 3;
     if (active) {
         const int j = n - 1;
@@ -607,7 +624,7 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
         dbg_from_device(h, st, "planes2", s->dev.planes + ((size_t)j * 2 + 1) * d.max_tri * 6, (size_t)meta[4] * 6 * sizeof(float));
         dbg_from_device(h, st, "tri_id1", s->dev.tri_id + ((size_t)j * 2) * d.N, (size_t)d.N * 4);
         dbg_from_device(h, st, "tri_id2", s->dev.tri_id + ((size_t)j * 2 + 1) * d.N, (size_t)d.N * 4);
-        dbg_maps(h, st, "wta", s->dev.wta, j);
+        dbg_maps_i16(h, st, "wta", s->dev.wta, j);
         dbg_maps(h, st, "lr", s->dev.disp, j);
     }
     launch_speckle(k, s->dev, n, h->nproc, st);

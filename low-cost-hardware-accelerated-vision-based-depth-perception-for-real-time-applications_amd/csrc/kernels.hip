@@ -1061,7 +1061,7 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
 }
 
 __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restrict__ desc, const int32_t *__restrict__ blob, const int32_t *__restrict__ tri_id,
-                                               const float4 *__restrict__ trirec, const uint32_t *__restrict__ gB, float *__restrict__ wta) {
+                                               const float4 *__restrict__ trirec, const uint32_t *__restrict__ gB, int16_t *__restrict__ wta) {
     const Dims &d = k.d;
     extern __shared__ uint4 dense_lds[];
     const int pair = blockIdx.z;
@@ -1116,7 +1116,7 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
                 const uint4 *pu = side ? sL + (u - l0) : sR + (u - r0);  // the other image at the pixel's own column
                 out = dense_pixel(k, side, u, v, own, pu, rec, mw, cell);
             }
-            wta[(size_t)ps * d.N + (size_t)v * d.W + u] = out;
+            wta[(size_t)ps * d.N + (size_t)v * d.W + u] = (int16_t)out;  // integer-valued: a disparity, -1 or -10
         }
     }
 }
@@ -1129,28 +1129,28 @@ void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------------------
 // K6  left/right consistency check      reference: elas.cpp:946-1011
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_lr(KParams k, const int32_t *__restrict__ blob, const float *__restrict__ wta, float *__restrict__ disp,
-                                            float *__restrict__ user_d2) {
+__global__ __launch_bounds__(256) void k_lr(KParams k, const int32_t *__restrict__ blob, const int16_t *__restrict__ wta, float *__restrict__ disp,
+                                            float *__restrict__ user_d2, int keep_right) {
     const Dims &d = k.d;
     const int pair = blockIdx.z;
     if (blob[pair * META_WORDS] < 3) return;
     const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
     if (u >= d.W) return;
-    const float *W1 = wta + (size_t)(pair * 2) * d.N, *W2 = W1 + d.N;
+    const int16_t *W1 = wta + (size_t)(pair * 2) * d.N, *W2 = W1 + d.N;
     const size_t row = (size_t)v * d.W;
-    const float d1 = W1[row + u], d2 = W2[row + u];
+    const float d1 = (float)W1[row + u], d2 = (float)W2[row + u];
     const float thr = (float)k.lr_threshold;
     float o1 = -10.0f, o2 = -10.0f;
     const float uw1 = (float)u - d1, uw2 = (float)u + d2;
-    if (d1 >= 0 && uw1 >= 0 && uw1 < (float)d.W) o1 = (fabsf(W2[row + (int)uw1] - d1) > thr) ? -10.0f : d1;
-    if (d2 >= 0 && uw2 >= 0 && uw2 < (float)d.W) o2 = (fabsf(W1[row + (int)uw2] - d2) > thr) ? -10.0f : d2;
+    if (d1 >= 0 && uw1 >= 0 && uw1 < (float)d.W) o1 = (fabsf((float)W2[row + (int)uw1] - d1) > thr) ? -10.0f : d1;
+    if (d2 >= 0 && uw2 >= 0 && uw2 < (float)d.W) o2 = (fabsf((float)W1[row + (int)uw2] - d2) > thr) ? -10.0f : d2;
     disp[(size_t)(pair * 2) * d.N + row + u] = o1;
-    disp[(size_t)(pair * 2 + 1) * d.N + row + u] = o2;
+    if (keep_right) disp[(size_t)(pair * 2 + 1) * d.N + row + u] = o2;  // later stages only read it when they process both sides
     if (user_d2) user_d2[(size_t)pair * d.N + row + u] = o2;  // postprocess_only_left: the checked right map is already final
 }
 
-void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st, float *user_d2) {
-    SV_LAUNCH(K_LR, k_lr, dim3((k.d.W + 255) / 256, k.d.H, n), dim3(256), 0, st, k, s.blob, s.wta, s.disp, user_d2);
+void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st, float *user_d2, bool keep_right) {
+    SV_LAUNCH(K_LR, k_lr, dim3((k.d.W + 255) / 256, k.d.H, n), dim3(256), 0, st, k, s.blob, s.wta, s.disp, user_d2, keep_right ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -55,7 +55,7 @@ struct SlotDev {
     uint32_t *gmaskA;   // [cap][2][ncell][MW] support marks
     uint32_t *gmaskB;   // [cap][2][ncell][MW] after the 3x3 flat dilation
     int32_t *tri_id;    // [cap][2][N]  last triangle covering a pixel, -1 = none; reused as CCL labels
-    float *wta;         // [cap][2][N]  integer WTA disparity (-1 / -10 invalid)
+    int16_t *wta;       // [cap][2][N]  WTA disparity (-1 / -10 invalid); 2 bytes per pixel: the values are integers < 32768
     float *disp;        // [cap][2][N]  L/R-checked maps; speckle and gap stages work in place
     float *tmp;         // [cap][2][N]  second map buffer: the fused filters ping-pong disp <-> tmp (CCL counters before that)
     int32_t *csize;     // [cap][2][N]  slow-path CCL only: run lengths (at run-start pixels); component sizes accumulate in `tmp`
@@ -72,7 +72,7 @@ void launch_support_filter(const KParams &k, int win, int thr, int need, const S
 void launch_grid(const KParams &k, const SlotDev &s, int n, hipStream_t st);
 void launch_triangles(const KParams &k, const SlotDev &s, int n, hipStream_t st);
 void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st);
-void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st, float *user_d2);
+void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st, float *user_d2, bool keep_right);
 void launch_speckle(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
 void launch_gap_rows(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
 void launch_gap_cols(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);
