@@ -49,11 +49,12 @@ void sobel_du_dv(const uint8_t *I, int W, int H, int stride, std::vector<uint8_t
 
 /* common_includes/elas/descriptor.cpp:96-124 (full-resolution branch).  Written for v in [3,H-3),
  * u in [3,W-3); the rest of the (uninitialised in the reference, :31) buffer is canonical zero. */
-void descriptor(const uint8_t *I, int W, int H, int stride, uint8_t *desc) {
+void descriptor(const uint8_t *I, int W, int H, int stride, uint8_t *desc, bool half_resolution = false) {
     std::vector<uint8_t> du, dv;
     sobel_du_dv(I, W, H, stride, du, dv);
     memset(desc, 0, (size_t)W * H * 16);
-    for (int v = 3; v < H - 3; v++) {
+    /* descriptor.cpp:48-93: with subsampling only every second line, starting at 4, is computed (same 16 taps) */
+    for (int v = half_resolution ? 4 : 3; v < H - 3; v += half_resolution ? 2 : 1) {
         const uint8_t *u0 = &du[(size_t)(v - 2) * W], *u1 = &du[(size_t)(v - 1) * W], *u2 = &du[(size_t)v * W];
         const uint8_t *u3 = &du[(size_t)(v + 1) * W], *u4 = &du[(size_t)(v + 2) * W];
         const uint8_t *w1 = &dv[(size_t)(v - 1) * W], *w2 = &dv[(size_t)v * W], *w3 = &dv[(size_t)(v + 1) * W];
@@ -130,8 +131,15 @@ int matching_disparity(const elas_params &P, int W, int H, int u, int v, const u
     return -1;
 }
 
-void candidate_dims(const elas_params &P, int W, int H, int &Wc, int &Hc) { /* elas.cpp:376-386 */
+inline int candidate_step(const elas_params &P) { /* elas.cpp:376-378: an even step at half resolution */
     int step = P.candidate_stepsize;
+    if (P.subsampling)
+        step += step % 2;
+    return step;
+}
+
+void candidate_dims(const elas_params &P, int W, int H, int &Wc, int &Hc) { /* elas.cpp:376-386 */
+    int step = candidate_step(P);
     Wc = 0;
     Hc = 0;
     for (int u = 0; u < W; u += step) Wc++;
@@ -142,7 +150,7 @@ void candidate_dims(const elas_params &P, int W, int H, int &Wc, int &Hc) { /* e
 void support_raw(const elas_params &P, const uint8_t *d1, const uint8_t *d2, int W, int H, int16_t *dcan) {
     int Wc, Hc;
     candidate_dims(P, W, H, Wc, Hc);
-    const int step = P.candidate_stepsize;
+    const int step = candidate_step(P);
     memset(dcan, 0, sizeof(int16_t) * (size_t)Wc * Hc);
     for (int uc = 1; uc < Wc; uc++)
         for (int vc = 1; vc < Hc; vc++) {
@@ -223,7 +231,7 @@ std::vector<Pt> support_filter(const elas_params &P, int16_t *dcan, int W, int H
     remove_redundant(dcan, Wc, Hc, 5, 1, true);
     remove_redundant(dcan, Wc, Hc, 5, 1, false);
     std::vector<Pt> s;
-    const int step = P.candidate_stepsize;
+    const int step = candidate_step(P);
     for (int uc = 1; uc < Wc; uc++)
         for (int vc = 1; vc < Hc; vc++)
             if (dcan[vc * Wc + uc] >= 0)
@@ -891,7 +899,9 @@ void find_match(DenseCtx &c, int u, int v, float plane_a, float plane_b, float p
             min_d = d_curr;
         }
     }
-    c.D[(size_t)v * W + u] = min_d >= 0 ? (float)min_d : -1.0f;
+    /* :707-711: at half resolution the result lands at (u/2, v/2) of a (W/2)-wide map */
+    const size_t d_addr = c.P.subsampling ? (size_t)(v / 2) * (W / 2) + u / 2 : (size_t)v * W + u;
+    c.D[d_addr] = min_d >= 0 ? (float)min_d : -1.0f;
 }
 
 /* elas.cpp:804-944 (computeDisparity). */
@@ -900,7 +910,9 @@ void dense(const elas_params &P, const int32_t *s, const int32_t *tri, const flo
     DenseCtx c{P, W, H, grid_, {0, 0, 0}, d1, d2, {}, 0, right_image, D};
     grid_dims_of(P, W, H, c.gd);
     const int disp_num = c.gd[0] - 1;
-    for (size_t i = 0; i < (size_t)W * H; i++) D[i] = -10;
+    const bool sub = P.subsampling != 0;
+    const size_t NM = sub ? (size_t)(W / 2) * (H / 2) : (size_t)W * H; /* :819-825 */
+    for (size_t i = 0; i < NM; i++) D[i] = -10;
     float two_sigma_squared = 2 * P.sigma * P.sigma;
     c.prior.resize(disp_num);
     for (int delta_d = 0; delta_d < disp_num; delta_d++) /* :830-831, float expf/logf as the reference resolves them */
@@ -940,13 +952,21 @@ void dense(const elas_params &P, const int32_t *s, const int32_t *tri, const flo
 
         if ((int32_t)A_u != (int32_t)B_u)
             for (int u = std::max((int32_t)A_u, 0); u < std::min((int32_t)B_u, W); u++) {
+                if (sub && u % 2 != 0) /* :915 */
+                    continue;
                 int v_1 = f2u2i(AC_a * (float)u + AC_b), v_2 = f2u2i(AB_a * (float)u + AB_b);
-                for (int v = std::min(v_1, v_2); v < std::max(v_1, v_2); v++) find_match(c, u, v, plane_a, plane_b, plane_c, valid);
+                for (int v = std::min(v_1, v_2); v < std::max(v_1, v_2); v++)
+                    if (!sub || v % 2 == 0) /* :919 */
+                        find_match(c, u, v, plane_a, plane_b, plane_c, valid);
             }
         if ((int32_t)B_u != (int32_t)C_u)
             for (int u = std::max((int32_t)B_u, 0); u < std::min((int32_t)C_u, W); u++) {
+                if (sub && u % 2 != 0) /* :930 */
+                    continue;
                 int v_1 = f2u2i(AC_a * (float)u + AC_b), v_2 = f2u2i(BC_a * (float)u + BC_b);
-                for (int v = std::min(v_1, v_2); v < std::max(v_1, v_2); v++) find_match(c, u, v, plane_a, plane_b, plane_c, valid);
+                for (int v = std::min(v_1, v_2); v < std::max(v_1, v_2); v++)
+                    if (!sub || v % 2 == 0) /* :934 */
+                        find_match(c, u, v, plane_a, plane_b, plane_c, valid);
             }
     }
 }
@@ -956,13 +976,20 @@ void dense(const elas_params &P, const int32_t *s, const int32_t *tri, const flo
  * ---------------------------------------------------------------------------------------------- */
 
 /* elas.cpp:946-1011 */
-void lr_check(const elas_params &P, float *D1, float *D2, int W, int H) {
+void lr_check(const elas_params &P, float *D1, float *D2, int W, int H) { /* W, H: map size (half the image at half resolution) */
     std::vector<float> C1(D1, D1 + (size_t)W * H), C2(D2, D2 + (size_t)W * H);
     for (int u = 0; u < W; u++)
         for (int v = 0; v < H; v++) {
             size_t addr = (size_t)v * W + u;
             float d1 = C1[addr], d2 = C2[addr];
-            float u_warp_1 = (float)u - d1, u_warp_2 = (float)u + d2;
+            float u_warp_1, u_warp_2;
+            if (P.subsampling) { /* :972-975: disparities stay in full-resolution pixels */
+                u_warp_1 = (float)u - d1 / 2;
+                u_warp_2 = (float)u + d2 / 2;
+            } else {
+                u_warp_1 = (float)u - d1;
+                u_warp_2 = (float)u + d2;
+            }
             if (d1 >= 0 && u_warp_1 >= 0 && u_warp_1 < W) {
                 if (fabs(C2[(size_t)v * W + (int32_t)u_warp_1] - d1) > P.lr_threshold)
                     D1[addr] = -10;
@@ -978,7 +1005,7 @@ void lr_check(const elas_params &P, float *D1, float *D2, int W, int H) {
 
 /* elas.cpp:1013-1124: breadth-first flood fill seeded at every unvisited pixel, u outer / v inner. */
 void speckle(const elas_params &P, float *D, int W, int H) {
-    const int min_size = P.speckle_size;
+    const int min_size = P.subsampling ? (int32_t)(sqrt((float)P.speckle_size) * 2) : P.speckle_size; /* :1017-1022 */
     std::vector<int32_t> done((size_t)W * H, 0), lu((size_t)W * H), lv((size_t)W * H);
     for (int u = 0; u < W; u++)
         for (int v = 0; v < H; v++) {
@@ -1011,7 +1038,7 @@ void speckle(const elas_params &P, float *D, int W, int H) {
 
 /* elas.cpp:1126-1294 */
 void gap(const elas_params &P, float *D, int W, int H) {
-    const int gw = P.ipol_gap_width;
+    const int gw = P.subsampling ? P.ipol_gap_width / 2 + 1 : P.ipol_gap_width; /* :1130-1135 */
     const float discon_threshold = 3.0;
     for (int v = 0; v < H; v++) {
         int count = 0;
@@ -1111,7 +1138,27 @@ inline bool amean_tap(const float val[8], float val_curr, float &d_out) {
 
 /* elas.cpp:1297-1494, full-resolution branch :1400-1485; D_tmp canonical zero where the reference leaves it
  * uninitialised (:1308). */
-void adaptive_mean(float *D, int W, int H) {
+/* one 4-tap step of the half-resolution branch (elas.cpp:1344-1362): plain left-to-right sums of the four slots */
+inline bool amean_tap4(const float val[8], float val_curr, float &d_out) {
+    float w[4], f[4];
+    for (int k = 0; k < 4; k++) {
+        float t = 4.0f - absq(val[k] - val_curr);
+        w[k] = 0.0f > t ? 0.0f : t;
+        f[k] = val[k] * w[k];
+    }
+    float weight_sum = w[0] + w[1] + w[2] + w[3];
+    float factor_sum = f[0] + f[1] + f[2] + f[3];
+    if (weight_sum > 0) {
+        float d = factor_sum / weight_sum;
+        if (d >= 0) {
+            d_out = d;
+            return true;
+        }
+    }
+    return false;
+}
+
+void adaptive_mean(float *D, int W, int H, bool sub = false) {
     std::vector<float> C(D, D + (size_t)W * H), T((size_t)W * H, 0.0f);
     for (size_t i = 0; i < (size_t)W * H; i++)
         if (D[i] < 0) {
@@ -1119,6 +1166,29 @@ void adaptive_mean(float *D, int W, int H) {
             T[i] = -10;
         }
     float val[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* the ring persists across rows and passes, as in the reference (:1324) */
+    if (sub) { /* elas.cpp:1332-1397: 4-pixel window u-3..u around the centre u-1 */
+        for (int v = 3; v < H - 3; v++) {
+            for (int u = 0; u < 3; u++) val[u] = C[(size_t)v * W + u];
+            for (int u = 3; u < W; u++) {
+                float val_curr = C[(size_t)v * W + (u - 1)];
+                val[u % 4] = C[(size_t)v * W + u];
+                float d;
+                if (amean_tap4(val, val_curr, d))
+                    T[(size_t)v * W + (u - 1)] = d;
+            }
+        }
+        for (int u = 3; u < W - 3; u++) {
+            for (int v = 0; v < 3; v++) val[v] = T[(size_t)v * W + u];
+            for (int v = 3; v < H; v++) {
+                float val_curr = T[(size_t)(v - 1) * W + u];
+                val[v % 4] = T[(size_t)v * W + u];
+                float d;
+                if (amean_tap4(val, val_curr, d))
+                    D[(size_t)(v - 1) * W + u] = d;
+            }
+        }
+        return;
+    }
     for (int v = 3; v < H - 3; v++) {
         for (int u = 0; u < 7; u++) val[u] = C[(size_t)v * W + u];
         for (int u = 7; u < W; u++) {
@@ -1186,10 +1256,13 @@ void put(const char *name, const T *data, size_t count) {
 }
 
 int run(const elas_params &P, const uint8_t *I1, const uint8_t *I2, int W, int H, int stride, float *D1, float *D2, bool keep) {
-    const size_t N = (size_t)W * H;
-    std::vector<uint8_t> desc1(N * 16), desc2(N * 16);
-    descriptor(I1, W, H, stride, desc1.data());
-    descriptor(I2, W, H, stride, desc2.data());
+    const size_t NI = (size_t)W * H;
+    const bool sub = P.subsampling != 0;
+    const int Wm = sub ? W / 2 : W, Hm = sub ? H / 2 : H; /* map size: elas.h:160-161 */
+    const size_t N = (size_t)Wm * Hm;
+    std::vector<uint8_t> desc1(NI * 16), desc2(NI * 16);
+    descriptor(I1, W, H, stride, desc1.data(), sub);
+    descriptor(I2, W, H, stride, desc2.data(), sub);
     int Wc, Hc;
     candidate_dims(P, W, H, Wc, Hc);
     std::vector<int16_t> dcan((size_t)Wc * Hc);
@@ -1232,38 +1305,38 @@ int run(const elas_params &P, const uint8_t *I1, const uint8_t *I2, int W, int H
         put("wta1", D1, N);
         put("wta2", D2, N);
     }
-    lr_check(P, D1, D2, W, H);
+    lr_check(P, D1, D2, Wm, Hm);
     if (keep) {
         put("lr1", D1, N);
         put("lr2", D2, N);
     }
-    speckle(P, D1, W, H);
+    speckle(P, D1, Wm, Hm);
     if (!P.postprocess_only_left)
-        speckle(P, D2, W, H);
+        speckle(P, D2, Wm, Hm);
     if (keep) {
         put("speckle1", D1, N);
         put("speckle2", D2, N);
     }
-    gap(P, D1, W, H);
+    gap(P, D1, Wm, Hm);
     if (!P.postprocess_only_left)
-        gap(P, D2, W, H);
+        gap(P, D2, Wm, Hm);
     if (keep) {
         put("gap1", D1, N);
         put("gap2", D2, N);
     }
     if (P.filter_adaptive_mean) {
-        adaptive_mean(D1, W, H);
+        adaptive_mean(D1, Wm, Hm, sub);
         if (!P.postprocess_only_left)
-            adaptive_mean(D2, W, H);
+            adaptive_mean(D2, Wm, Hm, sub);
     }
     if (keep) {
         put("amean1", D1, N);
         put("amean2", D2, N);
     }
     if (P.filter_median) {
-        median(D1, W, H);
+        median(D1, Wm, Hm);
         if (!P.postprocess_only_left)
-            median(D2, W, H);
+            median(D2, Wm, Hm);
     }
     if (keep) {
         put("final1", D1, N);
@@ -1278,8 +1351,6 @@ extern "C" {
 
 double orc_process(const elas_params *p, const uint8_t *I1, const uint8_t *I2, int W, int H, int stride, float *D1, float *D2, int canonical, int reps) {
     (void)canonical; /* always canonical: the restatement has no uninitialised reads */
-    if (p->subsampling)
-        return -1.0;
     if (reps < 1)
         reps = 1;
     auto t0 = std::chrono::steady_clock::now();
@@ -1290,8 +1361,6 @@ double orc_process(const elas_params *p, const uint8_t *I1, const uint8_t *I2, i
 
 int orc_run_stages(const elas_params *p, const uint8_t *I1, const uint8_t *I2, int W, int H, int stride) {
     g_store.clear();
-    if (p->subsampling)
-        return -2;
     std::vector<float> D1((size_t)W * H, 0.f), D2((size_t)W * H, 0.f); /* driver passes zeroed maps (stereo_vision.cpp:304-305) */
     return run(*p, I1, I2, W, H, stride, D1.data(), D2.data(), true);
 }
@@ -1350,6 +1419,7 @@ void orc_lr_check(const elas_params *p, float *D1, float *D2, int W, int H) { lr
 void orc_speckle(const elas_params *p, float *D, int W, int H) { speckle(*p, D, W, H); }
 void orc_gap(const elas_params *p, float *D, int W, int H) { gap(*p, D, W, H); }
 void orc_adaptive_mean(float *D, int W, int H) { adaptive_mean(D, W, H); }
+void orc_adaptive_mean_sub(float *D, int W, int H) { adaptive_mean(D, W, H, true); }
 void orc_median(float *D, int W, int H) { median(D, W, H); }
 
 } /* extern "C" */

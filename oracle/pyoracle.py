@@ -150,8 +150,9 @@ class _StageLib:
         H, W = left.shape
         l, lp = _u8(left)
         r, rp = _u8(right)
-        D1 = np.zeros((H, W), np.float32)
-        D2 = np.zeros((H, W), np.float32)
+        Hm, Wm = (H // 2, W // 2) if params.subsampling else (H, W)  # elas.h:160-161: half-size maps when subsampling
+        D1 = np.zeros((Hm, Wm), np.float32)
+        D2 = np.zeros((Hm, Wm), np.float32)
         t = self._proc(ctypes.byref(params), lp, rp, W, H, W, D1.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
                        D2.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), int(bool(canonical)), int(reps))
         return D1, D2, t

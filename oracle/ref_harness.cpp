@@ -133,8 +133,7 @@ double ref_process(const elas_params *p, const uint8_t *I1, const uint8_t *I2, i
  * every intermediate.  Returns the number of support points, or <0 on error. */
 int ref_run_stages(const elas_params *p, const uint8_t *I1_, const uint8_t *I2_, int W, int H, int stride) {
     g_store.clear();
-    if (p->subsampling)
-        return -2; /* half-resolution mode is outside the hot-path scope */
+    const bool sub = p->subsampling != 0;
     PerturbGuard guard(true);
     Elas elas(to_ref(p));
     elas.width = W;
@@ -155,15 +154,16 @@ int ref_run_stages(const elas_params *p, const uint8_t *I1_, const uint8_t *I2_,
     int n_support = 0;
     {
         /* elas.cpp:55-56 */
-        Descriptor desc1(elas.I1, W, H, bpl, false);
-        Descriptor desc2(elas.I2, W, H, bpl, false);
+        Descriptor desc1(elas.I1, W, H, bpl, sub);
+        Descriptor desc2(elas.I2, W, H, bpl, sub);
         put("desc1", desc1.I_desc, (size_t)16 * W * H);
         put("desc2", desc2.I_desc, (size_t)16 * W * H);
 
         /* Extra: the raw candidate lattice before the in-place filters, produced by the reference's own
          * computeMatchingDisparity in the loop order of elas.cpp:394-411. */
         {
-            const int step = p->candidate_stepsize;
+            int step = p->candidate_stepsize;
+            if (sub) step += step % 2; /* elas.cpp:377-378 */
             int Wc = 0, Hc = 0;
             for (int u = 0; u < W; u += step) Wc++;
             for (int v = 0; v < H; v += step) Hc++;
@@ -228,7 +228,8 @@ int ref_run_stages(const elas_params *p, const uint8_t *I1_, const uint8_t *I2_,
         put("grid_dims", grid_dims, 3);
 
         /* The driver hands in zero-initialised maps (stereo_vision.cpp:304-305). */
-        std::vector<float> D1((size_t)W * H, 0.f), D2((size_t)W * H, 0.f);
+        const size_t NM = sub ? (size_t)(W / 2) * (H / 2) : (size_t)W * H; /* elas.h:160-161: half-size maps when subsampling */
+        std::vector<float> D1(NM, 0.f), D2(NM, 0.f);
 
         /* elas.cpp:100-101 */
         elas.computeDisparity(p_support, tri_1, g1, grid_dims, desc1.I_desc, desc2.I_desc, 0, D1.data());

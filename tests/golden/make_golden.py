@@ -44,6 +44,11 @@ def params_for(case):
     return p
 
 
+def with_sub(p, case):
+    p.subsampling = 1 if case.get("subsampling") else 0  # half-resolution mode (elas.h:83-85)
+    return p
+
+
 def main():
     sys.path.insert(0, ROOT)
     import importlib
@@ -74,6 +79,12 @@ def main():
         dict(name="synth1000_d128", synth=dict(seed=1000, H=375, W=1242, D=128), preset="driver", disp_max=127, keep=[]),
         dict(name="synth7_d64", synth=dict(seed=7, H=120, W=320, D=64), preset="driver", disp_max=63, keep=["support", "tri1", "tri2", "wta1", "final1"]),
         dict(name="synth8_d32", synth=dict(seed=8, H=97, W=203, D=32), preset="driver", disp_max=31, keep=["support", "wta1", "final1"]),
+        # half-resolution mode (Elas::parameters::subsampling): maps are (W/2) x (H/2)
+        dict(name="kitti0_d128_sub", image="kitti0", preset="driver", disp_max=127, subsampling=1,
+             keep=["support", "tri1", "tri2", "wta1", "wta2", "lr1", "speckle1", "gap1", "amean1", "final1"]),
+        dict(name="kitti0_crop_d64_sub", image="kitti0_crop", preset="driver", disp_max=63, subsampling=1, keep=STAGES),
+        dict(name="cones_crop_robotics_sub", image="cones_crop", preset="robotics", disp_max=63, subsampling=1, keep=["support", "wta1", "final1", "final2"]),
+        dict(name="synth8_d32_sub", synth=dict(seed=8, H=97, W=203, D=32), preset="driver", disp_max=31, subsampling=1, keep=["support", "wta1", "final1"]),
         dict(name="synth5000_4kstrip_d192", synth=dict(seed=5000, H=512, W=3840, D=192, scale=3), preset="driver", disp_max=191, keep=[]),
     ]
     digests = {}
@@ -82,11 +93,13 @@ def main():
             L, R = synth.make_pair(**case["synth"])
         else:
             L, R = images[case["image"]]
-        p = params_for(case)
+        p = with_sub(params_for(case), case)
         n = ref.run_stages(p, L, R)
         st = {k: ref.stage(k) for k in STAGES}
         entry = {"n_support": int(n), "shape": [int(L.shape[0]), int(L.shape[1])], "preset": case["preset"], "disp_max": case["disp_max"],
                  "input_sha256": [sha(L), sha(R)], "stages": {k: sha(v) for k, v in st.items()}}
+        if case.get("subsampling"):
+            entry["subsampling"] = 1
         if "synth" in case:
             entry["synth"] = case["synth"]
         else:

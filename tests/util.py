@@ -51,10 +51,18 @@ def case_images(entry):
 def case_params(entry, cls):
     """cls: a ctypes params Structure class with .driver/.preset constructors."""
     if entry["preset"] == "driver":
-        return cls.driver(entry["disp_max"])
-    p = cls.preset(entry["preset"])
-    p.disp_max = entry["disp_max"]
+        p = cls.driver(entry["disp_max"])
+    else:
+        p = cls.preset(entry["preset"])
+        p.disp_max = entry["disp_max"]
+    p.subsampling = 1 if entry.get("subsampling") else 0
     return p
+
+
+def map_shape(entry):
+    """(rows, cols) of the disparity maps of a case: half the image size in half-resolution mode (elas.h:160-161)."""
+    h, w = entry["shape"]
+    return (h // 2, w // 2) if entry.get("subsampling") else (h, w)
 
 
 def golden_npz(name):
