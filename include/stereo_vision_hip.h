@@ -59,7 +59,7 @@ typedef struct sv_params {
     int32_t filter_median;         /* elas.h:80 */
     int32_t filter_adaptive_mean;  /* elas.h:81 */
     int32_t postprocess_only_left; /* elas.h:82 */
-    int32_t subsampling;           /* elas.h:83  must be 0 (half-resolution mode: SURVEY.md §8f rank 3) */
+    int32_t subsampling;           /* elas.h:83  (bool) half-resolution mode: disparity maps are (width/2) x (height/2) */
 } sv_params;
 
 enum sv_setting { SV_ROBOTICS = 0, SV_MIDDLEBURY = 1, SV_DRIVER = 2 };
@@ -74,7 +74,7 @@ typedef enum sv_status {
     SV_ERR_ARG = -1,         /* bad argument / unsupported parameter value */
     SV_ERR_HIP = -2,         /* a HIP runtime call failed */
     SV_ERR_NO_DEVICE = -3,   /* no usable GPU */
-    SV_ERR_UNSUPPORTED = -4, /* e.g. subsampling != 0 */
+    SV_ERR_UNSUPPORTED = -4, /* e.g. disp_min != 0 */
     SV_ERR_STATE = -5
 } sv_status;
 
@@ -98,7 +98,8 @@ const char *sv_last_error(const sv_handle *h); /* h may be NULL: error of the la
 
 /* B independent pairs, images and maps in DEVICE memory (HBM):
  *   left/right : uint8  [B][height][stride]   rectified gray rows (what Elas::process receives as I1/I2)
- *   d1 / d2    : float  [B][height][width]    disparity maps (what Elas::process writes to D1/D2);
+ *   d1 / d2    : float  [B][height][width]    disparity maps (what Elas::process writes to D1/D2); with params.subsampling
+ *                                             the maps are [B][height/2][width/2] (elas.h:160-161);
  *                                             d2 may be NULL.  Invalid pixels are -10 (elas.cpp:823-824, 987-991).
  *   status     : int32  [B] host array, may be NULL; per pair: number of support points, or <3 when the
  *                reference would have printed "ERROR: Need at least 3 support points!" (elas.cpp:63-69) — the

@@ -103,7 +103,8 @@ struct Task {
 struct sv_handle {
     sv_params p;
     sv_config cfg;
-    KParams kp;
+    KParams kp;      // image-space kernels (descriptor ... dense matching)
+    KParams kp_map;  // map-space kernels (L/R check ... median): W/H/N = map size
     int nproc = 1;  // maps per pair that get post-processed
     int chunk = 1;
     bool block_sync = false;  // host waits on events sleep (throughput mode) instead of spinning (latency mode)
@@ -156,10 +157,6 @@ namespace {
 
 int validate(const sv_params &p, const sv_config &c, std::string &err) {
     char b[256];
-    if (p.subsampling) {
-        err = "subsampling (half-resolution mode) is not supported";
-        return SV_ERR_UNSUPPORTED;
-    }
     if (p.disp_min != 0) {
         err = "disp_min must be 0";
         return SV_ERR_UNSUPPORTED;
@@ -197,6 +194,11 @@ void fill_kparams(sv_handle *h) {
     d.H = h->cfg.height;
     d.N = d.W * d.H;
     d.step = p.candidate_stepsize;
+    d.sub = p.subsampling ? 1 : 0;
+    if (d.sub) d.step += d.step % 2;  // elas.cpp:376-378: an even lattice step at half resolution
+    d.Wm = d.sub ? d.W / 2 : d.W;     // elas.h:160-161: half-size maps
+    d.Hm = d.sub ? d.H / 2 : d.H;
+    d.Nm = d.Wm * d.Hm;
     d.Wc = (d.W + d.step - 1) / d.step;
     d.Hc = (d.H + d.step - 1) / d.step;
     d.grid_size = p.grid_size;
@@ -230,6 +232,17 @@ void fill_kparams(sv_handle *h) {
     }
     k.rt_cap = 512;
     if (const char *e = getenv("SV_DEBUG_RT_CAP")) k.rt_cap = std::max(0, std::min(512, atoi(e)));  // tests: force the raster fallback
+    // the post-matching stages see the map as their image: W/H/N are the map size, and at half resolution the speckle and
+    // gap limits shrink (elas.cpp:1017-1022, 1130-1135)
+    KParams &km = h->kp_map;
+    km = k;
+    km.d.W = d.Wm;
+    km.d.H = d.Hm;
+    km.d.N = d.Nm;
+    if (d.sub) {
+        km.speckle_size = (int32_t)(sqrt((float)p.speckle_size) * 2);
+        km.gap_width = p.ipol_gap_width / 2 + 1;
+    }
     h->nproc = p.postprocess_only_left ? 1 : 2;
     // the on-GPU lattice filter keeps the whole lattice (+ state) of a pair in the LDS of one workgroup and resolves a
     // point's earlier neighbours with one 64-lane ballot: needs incon_window_size <= 5 and a lattice that fits
@@ -297,7 +310,7 @@ void dbg_from_device(sv_handle *h, hipStream_t st, const char *name, const void 
 }
 
 void dbg_maps(sv_handle *h, hipStream_t st, const char *stage, const float *base, int j) {
-    const size_t N = h->kp.d.N;
+    const size_t N = h->kp.d.Nm;
     char name[64];
     for (int side = 0; side < 2; side++) {
         snprintf(name, sizeof(name), "%s%d", stage, side + 1);
@@ -307,7 +320,7 @@ void dbg_maps(sv_handle *h, hipStream_t st, const char *stage, const float *base
 
 // 16-bit device maps, reported as f32 like every other stage
 void dbg_maps_i16(sv_handle *h, hipStream_t st, const char *stage, const int16_t *base, int j) {
-    const size_t N = h->kp.d.N;
+    const size_t N = h->kp.d.Nm;
     char name[64];
     std::vector<int16_t> raw(N);
     HIP_TRY(hipStreamSynchronize(st));
@@ -323,7 +336,7 @@ void dbg_maps_i16(sv_handle *h, hipStream_t st, const char *stage, const int16_t
 
 // maps after an out-of-place stage: processed sides live in `cur`; with postprocess_only_left the right map stays in `disp`
 void dbg_maps_nproc(sv_handle *h, hipStream_t st, const char *stage, const float *cur, const float *disp, int j) {
-    const size_t N = h->kp.d.N;
+    const size_t N = h->kp.d.Nm;
     char name[64];
     for (int side = 0; side < 2; side++) {
         snprintf(name, sizeof(name), "%s%d", stage, side + 1);
@@ -594,7 +607,7 @@ void dispatcher_main(sv_handle *h) {
 
 // ---- stage 3: finisher -------------------------------------------------------------------------------------------------
 void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
-    const KParams &k = h->kp;
+    const KParams &k = h->kp, &km = h->kp_map;  // image-space / map-space parameters
     const Dims &d = k.d;
     const Job &job = *s->job;
     const bool dbg = h->cfg.keep_debug != 0;
@@ -611,10 +624,10 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
     launch_grid(k, s->dev, n, st);
     launch_triangles(k, s->dev, n, st);
     launch_dense(k, s->dev, n, st);
-    float *u1 = job.d1 + (size_t)s->i0 * d.N, *u2 = job.d2 ? job.d2 + (size_t)s->i0 * d.N : nullptr;
+    float *u1 = job.d1 + (size_t)s->i0 * d.Nm, *u2 = job.d2 ? job.d2 + (size_t)s->i0 * d.Nm : nullptr;  // the caller's maps are [batch][Hm][Wm]
     const bool only_left = h->nproc == 1;
     // with postprocess_only_left the checked right map is final: it goes straight to the caller (or nowhere)
-    launch_lr(k, s->dev, n, st, only_left ? u2 : nullptr, !only_left || dbg);
+    launch_lr(km, s->dev, n, st, only_left ? u2 : nullptr, !only_left || dbg);
     const bool active = dbg && blob[(size_t)(n - 1) * META_WORDS] >= 3;
     if (active) {
         const int j = n - 1;
@@ -627,23 +640,23 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
         dbg_maps_i16(h, st, "wta", s->dev.wta, j);
         dbg_maps(h, st, "lr", s->dev.disp, j);
     }
-    launch_speckle(k, s->dev, n, h->nproc, st);
+    launch_speckle(km, s->dev, n, h->nproc, st);
     if (active) dbg_maps(h, st, "speckle", s->dev.disp, n - 1);
-    launch_gap_rows(k, s->dev, n, h->nproc, st);
-    launch_gap_cols(k, s->dev, n, h->nproc, st);
+    launch_gap_rows(km, s->dev, n, h->nproc, st);
+    launch_gap_cols(km, s->dev, n, h->nproc, st);
     if (active) dbg_maps(h, st, "gap", s->dev.disp, n - 1);
     // the two separable filters are fused, out-of-place kernels: the maps ping-pong between `disp` and `tmp`
     float *cur = s->dev.disp, *alt = s->dev.tmp;
     if (h->p.filter_adaptive_mean) {
-        launch_amean(k, s->dev, n, h->nproc, st, cur, alt);
+        launch_amean(km, s->dev, n, h->nproc, st, cur, alt);
         std::swap(cur, alt);
     }
     if (active) dbg_maps_nproc(h, st, "amean", cur, s->dev.disp, n - 1);
     if (h->p.filter_median) {  // the last stage writes the caller's maps itself
-        launch_median(k, s->dev, n, h->nproc, st, cur, alt, u1, only_left ? nullptr : u2);
+        launch_median(km, s->dev, n, h->nproc, st, cur, alt, u1, only_left ? nullptr : u2);
         std::swap(cur, alt);
     } else {
-        launch_output(k, s->dev, n, cur, u1, only_left ? nullptr : u2, st);
+        launch_output(km, s->dev, n, cur, u1, only_left ? nullptr : u2, st);
     }
     if (active) dbg_maps_nproc(h, st, "final", cur, s->dev.disp, n - 1);
     HIP_TRY(hipGetLastError());
@@ -1030,7 +1043,7 @@ int sv_process_batch_host(sv_handle *h, const uint8_t *left, const uint8_t *righ
     }
     if (batch == 0) return SV_OK;
     const Dims &d = h->kp.d;
-    const size_t in_bytes = (size_t)batch * d.H * stride, out_bytes = (size_t)batch * d.N * sizeof(float);
+    const size_t in_bytes = (size_t)batch * d.H * stride, out_bytes = (size_t)batch * d.Nm * sizeof(float);  // maps: [batch][Hm][Wm]
     uint8_t *dl = nullptr, *dr = nullptr;
     float *o1 = nullptr, *o2 = nullptr;
     int rc = SV_OK;

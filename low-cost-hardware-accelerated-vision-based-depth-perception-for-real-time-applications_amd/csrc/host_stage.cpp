@@ -17,8 +17,12 @@ namespace sv {
 // support lattice filters
 // ------------------------------------------------------------------------------------------------------------
 
+static int lattice_step(const sv_params &p) {  // elas.cpp:376-378: an even step at half resolution
+    return p.subsampling ? p.candidate_stepsize + p.candidate_stepsize % 2 : p.candidate_stepsize;
+}
+
 static void lattice_dims(const sv_params &p, int W, int H, int &Wc, int &Hc) {  // elas.cpp:376-386
-    const int step = p.candidate_stepsize;
+    const int step = lattice_step(p);
     Wc = (W + step - 1) / step;
     Hc = (H + step - 1) / step;
 }
@@ -121,7 +125,7 @@ int support_filter_t(const sv_params &p, int16_t *T, int W, int H, int32_t *out,
     drop_inconsistent(p, T, Wc, Hc);
     drop_redundant(T, Wc, Hc, 5, 1, true);
     drop_redundant(T, Wc, Hc, 5, 1, false);
-    const int step = p.candidate_stepsize;
+    const int step = lattice_step(p);
     int n = 0;
     for (int uc = 1; uc < Wc; uc++)  // elas.cpp:424-428: u outer, v inner
         for (int vc = 1; vc < Hc; vc++) {

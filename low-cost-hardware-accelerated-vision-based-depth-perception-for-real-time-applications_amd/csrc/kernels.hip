@@ -171,7 +171,8 @@ __global__ __launch_bounds__(256) void k_descriptor(const uint8_t *__restrict__ 
     for (int j = 0; j < 4; j++) {
         const int x = x0 + 4 * qx + j;
         uint4 o = make_uint4(0, 0, 0, 0);
-        if (x >= 3 && x < d.W - 3 && y >= 3 && y < d.H - 3) {
+        // descriptor.cpp:48-50: at half resolution only every second line, starting at 4, is computed
+        if (x >= 3 && x < d.W - 3 && y < d.H - 3 && (d.sub ? (y >= 4 && !(y & 1)) : y >= 3)) {
             // byte k of the 12-byte window (a,b,c) starting at column c-4: column c+j+off is window byte 4+j+off
 #define WB(a, b, cc, off) ((4 + j + (off)) < 4 ? ((a) >> (8 * (4 + j + (off)))) & 0xFFu : (4 + j + (off)) < 8 ? ((b) >> (8 * (j + (off)))) & 0xFFu : ((cc) >> (8 * (j + (off) - 4))) & 0xFFu)
             const uint32_t b0 = (r0 >> (8 * j)) & 0xFFu, b11 = (r4 >> (8 * j)) & 0xFFu;
@@ -1066,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
     extern __shared__ uint4 dense_lds[];
     const int pair = blockIdx.z;
     if (blob[pair * META_WORDS] < 3) return;
-    const int x0 = blockIdx.x * DENSE_TW, v = blockIdx.y;
+    const int x0 = blockIdx.x * DENSE_TW, v = d.sub ? 2 * blockIdx.y : blockIdx.y;  // half resolution: even rows only (elas.cpp:919)
     const int x1 = min(x0 + DENSE_TW, d.W);  // tile columns [x0, x1)
     const size_t line = (size_t)d.W * max(min(v, d.H - 3), 2);  // elas.cpp:718: descriptor row, clamped
     const uint4 *gL = reinterpret_cast<const uint4 *>(desc + ((size_t)(pair * 2) * d.N) * 16) + line;
@@ -1096,7 +1097,7 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
             if (u >= x1) continue;
             const int t = tt[side][j];
             float out = -10.0f;  // elas.cpp:823-824
-            if (t >= 0 && u >= 2 && u < d.W - 2) {
+            if (t >= 0 && u >= 2 && u < d.W - 2 && !(d.sub && (u & 1))) {
                 const float4 rec = trirec[(size_t)ps * d.max_tri + t];
                 const int gx = (int)floorf((float)u / (float)d.grid_size), gy = (int)floorf((float)v / (float)d.grid_size);
                 const uint32_t *cell = gB + ((size_t)ps * d.ncell + (size_t)gy * d.gw + gx) * d.MW;
@@ -1116,14 +1117,18 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
                 const uint4 *pu = side ? sL + (u - l0) : sR + (u - r0);  // the other image at the pixel's own column
                 out = dense_pixel(k, side, u, v, own, pu, rec, mw, cell);
             }
-            wta[(size_t)ps * d.N + (size_t)v * d.W + u] = (int16_t)out;  // integer-valued: a disparity, -1 or -10
+            // integer-valued: a disparity, -1 or -10.  Half resolution (elas.cpp:707-711): only even (u, v) are matched, result at (u/2, v/2)
+            if (!d.sub)
+                wta[(size_t)ps * d.N + (size_t)v * d.W + u] = (int16_t)out;
+            else if (!(u & 1) && (u >> 1) < d.Wm && (v >> 1) < d.Hm)
+                wta[(size_t)ps * d.Nm + (size_t)(v >> 1) * d.Wm + (u >> 1)] = (int16_t)out;
         }
     }
 }
 
 void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
     const size_t shmem = sizeof(uint4) * 2 * (size_t)(DENSE_TW + k.d.disp_max);
-    SV_LAUNCH(K_DENSE, k_dense, dim3((k.d.W + DENSE_TW - 1) / DENSE_TW, k.d.H, n), dim3(256), shmem, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta);
+    SV_LAUNCH(K_DENSE, k_dense, dim3((k.d.W + DENSE_TW - 1) / DENSE_TW, k.d.sub ? (k.d.H + 1) / 2 : k.d.H, n), dim3(256), shmem, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1141,7 +1146,8 @@ __global__ __launch_bounds__(256) void k_lr(KParams k, const int32_t *__restrict
     const float d1 = (float)W1[row + u], d2 = (float)W2[row + u];
     const float thr = (float)k.lr_threshold;
     float o1 = -10.0f, o2 = -10.0f;
-    const float uw1 = (float)u - d1, uw2 = (float)u + d2;
+    // half resolution (elas.cpp:972-975): the map is half size, the disparities are still full-resolution pixels
+    const float uw1 = d.sub ? (float)u - d1 / 2 : (float)u - d1, uw2 = d.sub ? (float)u + d2 / 2 : (float)u + d2;
     if (d1 >= 0 && uw1 >= 0 && uw1 < (float)d.W) o1 = (fabsf((float)W2[row + (int)uw1] - d1) > thr) ? -10.0f : d1;
     if (d2 >= 0 && uw2 >= 0 && uw2 < (float)d.W) o2 = (fabsf((float)W1[row + (int)uw2] - d2) > thr) ? -10.0f : d2;
     disp[(size_t)(pair * 2) * d.N + row + u] = o1;
@@ -1783,9 +1789,87 @@ __global__ __launch_bounds__(256) void k_amean(KParams k, int nproc, const int32
     }
 }
 
+// Half-resolution variant (elas.cpp:1332-1397): 4-pixel window p-2..p+1 around the centre p, ring slot = pixel index mod 4,
+// plain left-to-right sums of the four slots.
+__device__ __forceinline__ bool amean4(const float xs[4], float xc, float &out) {
+    float w[4], f[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const float t = 4.0f - absq(xs[j] - xc);
+        w[j] = 0.0f > t ? 0.0f : t;
+        f[j] = xs[j] * w[j];
+    }
+    const float weight_sum = w[0] + w[1] + w[2] + w[3];  // elas.cpp:1352-1353
+    const float factor_sum = f[0] + f[1] + f[2] + f[3];
+    if (weight_sum > 0) {
+        const float dd = factor_sum / weight_sum;
+        if (dd >= 0) {
+            out = dd;
+            return true;
+        }
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void k_amean_sub(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ src, float *__restrict__ dst) {
+    const Dims &d = k.d;  // map dimensions
+    const int m = blockIdx.z;
+    if (blob[(m / nproc) * META_WORDS] < 3) return;
+    const size_t off = map_offset(d, m, nproc);
+    const float *S = src + off;
+    const int x0 = blockIdx.x * PF_TW, y0 = blockIdx.y * PF_TH;
+    __shared__ float sD[PF_TH + 3][PF_TW + 4];  // D_copy: rows y0-2.., columns x0-2..; invalid -> -10
+    __shared__ float sT[PF_TH + 3][PF_TW];      // D_tmp after the horizontal pass: rows y0-2.., columns x0..
+    for (int i = threadIdx.x; i < (PF_TH + 3) * (PF_TW + 4); i += 256) {
+        const int r = i / (PF_TW + 4), c = i - r * (PF_TW + 4);
+        const int y = y0 - 2 + r, x = x0 - 2 + c;
+        float val = -10.0f;
+        if (y >= 0 && y < d.H && x >= 0 && x < d.W) {
+            val = S[(size_t)y * d.W + x];
+            if (val < 0) val = -10.0f;
+        }
+        sD[r][c] = val;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (PF_TH + 3) * PF_TW; i += 256) {  // horizontal pass (:1335-1364): centre x = u-1, u in [3, W)
+        const int r = i / PF_TW, cx = i - r * PF_TW;
+        const int y = y0 - 2 + r, x = x0 + cx;
+        const float self = sD[r][cx + 2];
+        float out = self < 0 ? -10.0f : 0.0f;  // D_tmp: -10 where invalid, canonical 0 elsewhere
+        if (y >= 3 && y < d.H - 3 && x >= 2 && x <= d.W - 2) {
+            const int first = x - 2;  // window x-2..x+1 = tile columns cx..cx+3; ring slot of pixel p is p & 3
+            float xs[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) xs[j] = sD[r][cx + ((j - first) & 3)];
+            float res;
+            if (amean4(xs, self, res)) out = res;
+        }
+        sT[r][cx] = out;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < PF_TH * PF_TW; i += 256) {  // vertical pass (:1367-1396): centre y = v-1, v in [3, H)
+        const int ry = i / PF_TW, cx = i - ry * PF_TW;
+        const int y = y0 + ry, x = x0 + cx;
+        if (y >= d.H || x >= d.W) continue;
+        float val = S[(size_t)y * d.W + x];  // untouched unless the filter produces a value
+        if (x >= 3 && x < d.W - 3 && y >= 2 && y <= d.H - 2) {
+            const int first = y - 2;  // window rows y-2..y+1 = tile rows ry..ry+3
+            float xs[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) xs[j] = sT[ry + ((j - first) & 3)][cx];
+            float res;
+            if (amean4(xs, sT[ry + 2][cx], res)) val = res;
+        }
+        dst[off + (size_t)y * d.W + x] = val;
+    }
+}
+
 void launch_amean(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st, const float *src, float *dst) {
     dim3 grid((k.d.W + PF_TW - 1) / PF_TW, (k.d.H + PF_TH - 1) / PF_TH, n * nproc);
-    SV_LAUNCH(K_AMEAN, k_amean, grid, dim3(256), 0, st, k, nproc, s.blob, src, dst);
+    if (k.d.sub)
+        SV_LAUNCH(K_AMEAN, k_amean_sub, grid, dim3(256), 0, st, k, nproc, s.blob, src, dst);
+    else
+        SV_LAUNCH(K_AMEAN, k_amean, grid, dim3(256), 0, st, k, nproc, s.blob, src, dst);
 }
 
 // ------------------------------------------------------------------------------------------------------------

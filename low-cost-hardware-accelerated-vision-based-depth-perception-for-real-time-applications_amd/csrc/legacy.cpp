@@ -14,7 +14,7 @@
 // Documented deviations from the reference: clean() does not exit(0); `points` is filled on every call
 // (the reference only fills it when graphics==true and otherwise returns uninitialised memory); YOLO object tracking,
 // the GLUT viewer and imshow windows are not part of this library (objectTracking/graphics/display are accepted and
-// ignored); subsampling==true is refused.
+// ignored).
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -65,10 +65,6 @@ std::mutex g_mu;
     } while (0)
 
 bool legacy_init(int width, int height, float scale, const char *yaml, bool subsampling) {
-    if (subsampling) {
-        fprintf(stderr, "stereo_vision_hip: subsampling=true is not supported\n");
-        return false;
-    }
     g.W = width;
     g.H = height;
     sv::Calibration c;
@@ -86,6 +82,10 @@ bool legacy_init(int width, int height, float scale, const char *yaml, bool subs
 
     sv_params p;
     sv_params_init(&p, SV_DRIVER);  // stereo_vision.cpp:307-311 (disp_max stays 255)
+    // param.subsampling = subsample (:309).  Elas then fills only the first (W/2)*(H/2) floats of the zeroed full-size
+    // leftdpf (:304, elas.h:160-161) and the driver converts / reprojects the whole W x H buffer as it stands; the engine
+    // writes the same floats into the same zeroed buffer, so the u8 map and the cloud come out as the reference's do.
+    p.subsampling = subsampling ? 1 : 0;
     sv_config cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.width = width;

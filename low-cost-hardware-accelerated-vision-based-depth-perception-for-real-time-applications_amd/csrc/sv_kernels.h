@@ -15,6 +15,9 @@ struct Dims {
     int ncell, MW;           // gw*gh cells, MW 32-bit mask words per cell (bit d set <=> disparity d is a candidate)
     int D, disp_max;         // D = disp_max + 1
     int max_pts, max_tri;    // capacities of the per-pair support / triangle arrays
+    int sub;                 // half-resolution mode (Elas::parameters::subsampling, elas.h:83-85)
+    int Wm, Hm, Nm;          // disparity MAP size: W/2 x H/2 when sub, else W x H.  The post-matching kernels get a KParams whose
+                             // W/H/N already ARE the map size (engine: kp_map); W/H/N of the matching kernels are the image size
 };
 
 // Everything a kernel needs besides buffers; passed by value.

@@ -115,6 +115,8 @@ class StereoEngine:
         L = lib()
         self.params = params if params is not None else SvParams.driver(127)
         self.width, self.height, self.device = int(width), int(height), int(device)
+        # disparity map size: half the image in half-resolution mode (Elas::parameters::subsampling, elas.h:83-85, 160-161)
+        self.map_height, self.map_width = (self.height // 2, self.width // 2) if self.params.subsampling else (self.height, self.width)
         cfg = SvConfig(self.width, self.height, self.device, int(n_workers), int(chunk), int(bool(keep_debug)), int(n_streams), int(n_slots))
         h = ctypes.c_void_p()
         rc = L.sv_create(ctypes.byref(self.params), ctypes.byref(cfg), ctypes.byref(h))
@@ -145,9 +147,9 @@ class StereoEngine:
         left, right = left.contiguous(), right.contiguous()
         B = left.shape[0]
         if d1 is None:
-            d1 = torch.zeros((B, self.height, self.width), dtype=torch.float32, device=left.device)
+            d1 = torch.zeros((B, self.map_height, self.map_width), dtype=torch.float32, device=left.device)
         if d2 is None and want_d2:
-            d2 = torch.zeros((B, self.height, self.width), dtype=torch.float32, device=left.device)
+            d2 = torch.zeros((B, self.map_height, self.map_width), dtype=torch.float32, device=left.device)
         torch.cuda.current_stream(left.device).synchronize()  # inputs/outputs are handed to the engine's own streams
         st = status.ctypes.data_as(ctypes.c_void_p) if status is not None else None
         self._check(lib().sv_process_batch_device(self._h, left.data_ptr(), right.data_ptr(), B, self.width, d1.data_ptr(),
@@ -174,8 +176,8 @@ class StereoEngine:
             left, right = left[None], right[None]
         B, H, W = left.shape
         assert (H, W) == (self.height, self.width) and right.shape == left.shape
-        d1 = np.zeros((B, H, W), np.float32)
-        d2 = np.zeros((B, H, W), np.float32) if want_d2 else None
+        d1 = np.zeros((B, self.map_height, self.map_width), np.float32)
+        d2 = np.zeros((B, self.map_height, self.map_width), np.float32) if want_d2 else None
         status = np.zeros(B, np.int32)
         self._check(lib().sv_process_batch_host(self._h, left.ctypes.data, right.ctypes.data, B, W, d1.ctypes.data,
                                                 d2.ctypes.data if d2 is not None else None, status.ctypes.data))
@@ -186,8 +188,8 @@ class StereoEngine:
         I1 = np.ascontiguousarray(I1, dtype=np.uint8)
         I2 = np.ascontiguousarray(I2, dtype=np.uint8)
         H, W = I1.shape
-        D1 = np.zeros((H, W), np.float32)
-        D2 = np.zeros((H, W), np.float32)
+        D1 = np.zeros((self.map_height, self.map_width), np.float32)
+        D2 = np.zeros((self.map_height, self.map_width), np.float32)
         dims = (ctypes.c_int32 * 3)(W, H, W)
         self._check(lib().sv_elas_process(self._h, I1.ctypes.data, I2.ctypes.data, D1.ctypes.data, D2.ctypes.data, dims))
         return D1, D2

@@ -79,3 +79,28 @@ def test_reference_smoke_input_zero_images():
     finally:
         s.close()
     assert pts.shape == (1242 * 375, 3) and not dmap.any()
+
+
+@pytest.mark.gpu
+def test_generate_point_cloud_subsampling(oracle):
+    """subsampling=True (sv.py constructor flag -> Elas::parameters::subsampling, stereo_vision.cpp:309): Elas fills the
+    first (W/2)*(H/2) floats of the driver's zeroed full-size leftdpf (:304, elas.h:160-161) and the driver converts the
+    whole buffer as it stands (:316) - reproduce exactly that buffer."""
+    svmod = util.pkg("stereo_vision")
+    L, R = util.load_png("kitti0_left.png"), util.load_png("kitti0_right.png")
+    H, W = L.shape
+    s = svmod.stereo_vision(objectTracking=False, width=W, height=H, subsampling=True)
+    try:
+        pts = np.array(s.generatePointCloud(np.repeat(L[:, :, None], 3, 2), np.repeat(R[:, :, None], 3, 2)))
+        dmap = s.last_disparity_u8()
+    finally:
+        s.close()
+    p = ElasParams.driver(255)
+    p.subsampling = 1
+    d1, _, _ = oracle.process(p, L, R)
+    assert d1.shape == (H // 2, W // 2)
+    buf = np.zeros(W * H, np.float32)
+    buf[:d1.size] = d1.ravel()
+    want = np.clip(np.rint(buf * np.float32(4.0)), 0, 255).astype(np.uint8).reshape(H, W)
+    assert np.array_equal(dmap, want)
+    assert pts.shape == (W * H, 3)
