@@ -160,6 +160,13 @@ Uchar4 *getColor(void); /* reference: stereo_vision.cpp:625-627 */
 const unsigned char *sv_legacy_last_dmap(int *width, int *height);
 /* The 4x4 disparity-to-depth matrix Q the legacy path uses (row major), NULL before the first frame. */
 const double *sv_legacy_Q(void);
+/* Mean 3-D position of the cloud inside each detector box (x, y, w, h in pixels), i.e. what publishPointCloud hands to its
+ * viewer for every tracked object (stereo_vision.cpp:261-278; the boxes come from a detector the caller runs - the
+ * reference's YOLO weights are not part of this library).  boxes: int32 [n][4]; out: double [n][3] = (X, Y, Z) sums over
+ * columns [clamp(x), clamp(x+w)) outer and rows [clamp(y), clamp(y+h)) inner of the last frame's points, divided by the
+ * box's pixel count - the reference's summation order, so the doubles are the reference's.  Returns 0, or -1 before the
+ * first frame / on bad arguments. */
+int sv_legacy_box_means(const int32_t *boxes, int n, double *out);
 /* Test hook: Q (and P1,P2) of the stereoRectify restatement for a calibration file; K1,K2 are divided by `scale` first
  * (stereo_vision.cpp:364-376).  variant 1 = OpenCV 4.x rule set (the product), 0 = pre-3.4.2 rule set. */
 int sv_debug_stereo_rectify(const char *yaml, int image_w, int image_h, double scale, int variant, double *Q16, double *P1P2_24);

@@ -190,4 +190,27 @@ const unsigned char *sv_legacy_last_dmap(int *width, int *height) {
 
 const double *sv_legacy_Q(void) { return g.ready ? g.rect.Q : nullptr; }
 
+int sv_legacy_box_means(const int32_t *boxes, int n, double *out) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.ready || !g.points || !boxes || !out || n < 0) return -1;
+    auto constrain = [](int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    for (int b = 0; b < n; b++) {  // stereo_vision.cpp:262-277
+        const int x = boxes[4 * b], y = boxes[4 * b + 1], w = boxes[4 * b + 2], hgt = boxes[4 * b + 3];
+        const int i_lb = constrain(x, 0, g.W - 1), i_ub = constrain(x + w, 0, g.W - 1);
+        const int j_lb = constrain(y, 0, g.H - 1), j_ub = constrain(y + hgt, 0, g.H - 1);
+        double X = 0, Y = 0, Z = 0;
+        for (int i = i_lb; i < i_ub; i++)
+            for (int j = j_lb; j < j_ub; ++j) {
+                X += g.points[(size_t)j * g.W + i].x;
+                Y += g.points[(size_t)j * g.W + i].y;
+                Z += g.points[(size_t)j * g.W + i].z;
+            }
+        const double cnt = (double)((i_ub - i_lb) * (j_ub - j_lb));  // int product converted at the division, as in the reference
+        out[3 * b] = X / cnt;
+        out[3 * b + 1] = Y / cnt;
+        out[3 * b + 2] = Z / cnt;
+    }
+    return 0;
+}
+
 } /* extern "C" */

@@ -77,6 +77,16 @@ class stereo_vision:
         p = self.sv.sv_legacy_last_dmap(ctypes.byref(w), ctypes.byref(h))
         return np.ctypeslib.as_array(p, shape=(h.value, w.value)).copy()
 
+    def object_positions(self, boxes):
+        """Mean (X, Y, Z) of the last frame's cloud inside each detector box [(x, y, w, h), ...] - what the reference's
+        publishPointCloud computes for its tracked objects (stereo_vision.cpp:261-278); boxes come from your own detector."""
+        b = np.ascontiguousarray(boxes, dtype=np.int32).reshape(-1, 4)
+        out = np.zeros((b.shape[0], 3), np.float64)
+        self.sv.sv_legacy_box_means.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        if self.sv.sv_legacy_box_means(b.ctypes.data, b.shape[0], out.ctypes.data) != 0:
+            raise RuntimeError("no frame has been processed yet")
+        return out
+
     def close(self):
         if not self._closed:
             self._closed = True

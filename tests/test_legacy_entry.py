@@ -49,6 +49,7 @@ def test_generate_point_cloud_like_reference_smoke_test():
         dmap = s.last_disparity_u8()
         s.sv.sv_legacy_Q.restype = ctypes.POINTER(ctypes.c_double)
         Q = np.ctypeslib.as_array(s.sv.sv_legacy_Q(), shape=(16,)).reshape(4, 4).copy()
+        means = s.object_positions([(600, 200, 24, 16), (-5, 360, 30, 40), (1230, 0, 50, 9)])
         pts2 = np.array(s.generatePointCloud(np.repeat(L[:, :, None], 3, 2), np.repeat(R[:, :, None], 3, 2)))
     finally:
         s.close()
@@ -64,6 +65,20 @@ def test_generate_point_cloud_like_reference_smoke_test():
         exp = (pos[:3] / pos[3]).T
     assert np.array_equal(pts, exp, equal_nan=True)
     assert np.isfinite(pts[want.ravel() > 0]).all()
+    # object positions (stereo_vision.cpp:261-278): sequential double sums, columns outer / rows inner, over clamped boxes
+    boxes = [(600, 200, 24, 16), (-5, 360, 30, 40), (1230, 0, 50, 9)]
+    P3 = pts.reshape(H, W, 3)
+    for (x, y, w, h), got in zip(boxes, means):
+        i0, i1 = min(max(x, 0), W - 1), min(max(x + w, 0), W - 1)
+        j0, j1 = min(max(y, 0), H - 1), min(max(y + h, 0), H - 1)
+        acc = [0.0, 0.0, 0.0]
+        with np.errstate(all="ignore"):
+            for i in range(i0, i1):
+                for j in range(j0, j1):
+                    for c in range(3):
+                        acc[c] = float(np.float64(acc[c]) + P3[j, i, c])
+            exp_m = np.array(acc) / np.float64((i1 - i0) * (j1 - j0))
+        assert np.array_equal(got, exp_m, equal_nan=True)
 
 
 @pytest.mark.gpu
