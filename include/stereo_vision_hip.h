@@ -86,10 +86,10 @@ typedef struct sv_config {
     int32_t height;     /* image height (>= 32) */
     int32_t device;     /* HIP device ordinal */
     int32_t n_workers;  /* host pool threads for the CPU stage between the two GPU phases (0 = default: min(16, cores)) */
-    int32_t chunk;      /* pairs per GPU launch = pairs per pipeline slot (0 = default 32, less for large images) */
+    int32_t chunk;      /* pairs per GPU launch = pairs per pipeline slot (0 = default 64, less for large images) */
     int32_t keep_debug; /* != 0: keep per-stage intermediates of the LAST processed pair for sv_debug_get */
     int32_t n_streams;  /* HIP streams the second GPU phase alternates over (0 = default 4); phase 1 has its own streams */
-    int32_t n_slots;    /* buffer slots (chunks in flight) of the 3-stage pipeline (0 = default 12, within a 24 GB budget) */
+    int32_t n_slots;    /* buffer slots (chunks in flight) of the 3-stage pipeline (0 = default 8, within a 24 GB budget) */
 } sv_config;
 
 int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out);

@@ -939,11 +939,11 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     h->cfg = *cfg;
     fill_kparams(h);
     int npool = cfg->n_workers > 0 ? cfg->n_workers : default_pool_size();
-    // defaults: 32 pairs per launch, 12 slots, 4 phase-2 streams, scaled down so that the slots stay within a memory budget
+    // defaults: 64 pairs per launch, 8 slots, 4 phase-2 streams, scaled down so that the slots stay within a memory budget
     // (about 80 bytes per pixel per pair in flight: 37 MB at KITTI size, 0.66 GB at 4K)
     int np2 = cfg->n_streams > 0 ? cfg->n_streams : 4;
-    int nslots = cfg->n_slots > 0 ? cfg->n_slots : 12;
-    h->chunk = cfg->chunk > 0 ? cfg->chunk : 32;
+    int nslots = cfg->n_slots > 0 ? cfg->n_slots : 8;
+    h->chunk = cfg->chunk > 0 ? cfg->chunk : 64;
     if (cfg->chunk <= 0 || cfg->n_slots <= 0) {
         size_t free_b = 0, total_b = 0;
         (void)hipSetDevice(cfg->device);
