@@ -56,7 +56,7 @@ def algorithmic_bytes_per_pair(N, Wc, Hc, Wimg, MW, ncell):
     }
 
 
-def cpu_baseline(sample_pairs, synth):
+def cpu_baseline(sample_pairs, synth, subsampling=False):
     """Reference serial path (or our port of it) on this host's cores, 1 thread, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
@@ -66,6 +66,7 @@ def cpu_baseline(sample_pairs, synth):
     else:
         lib, kind = pyoracle.Oracle(), "port"
     p = pyoracle.ElasParams.driver(D - 1)
+    p.subsampling = 1 if subsampling else 0
     t = 0.0
     for i in range(sample_pairs):
         L, R = synth.make_pair(1000 + i, H, W, D, scale=3 if W > 2000 else 1)
@@ -91,6 +92,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--sync-steps", action="store_true", help="wait for each step before submitting the next (default: streamed submission)")
     ap.add_argument("--serial-kernels", action="store_true", help="extra pass with one slot / one stream (no kernel overlap) to get clean per-kernel times")
+    ap.add_argument("--subsampling", action="store_true", help="Elas::parameters::subsampling (the reference's s1 benchmark rows): half-resolution maps")
     ap.add_argument("--gather", action="store_true", help="after the timed region, also gather all left maps on rank 0 (RCCL) and report the time")
     args = ap.parse_args()
     global W, H, D
@@ -129,9 +131,11 @@ def main():
     batch = synth.make_batch(seeds[0], B, H, W, D, scale=wscale)
     left = torch.from_numpy(np.ascontiguousarray(batch[:, 0])).cuda()
     right = torch.from_numpy(np.ascontiguousarray(batch[:, 1])).cuda()
-    d1 = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
-    d2 = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
     params = eng.SvParams.driver(D - 1)
+    params.subsampling = 1 if args.subsampling else 0  # the reference's "s1" rows (results_log.txt): half-resolution maps
+    Hm, Wm = (H // 2, W // 2) if args.subsampling else (H, W)
+    d1 = torch.empty((B, Hm, Wm), dtype=torch.float32, device="cuda")
+    d2 = torch.empty((B, Hm, Wm), dtype=torch.float32, device="cuda")
     engine = eng.StereoEngine(W, H, params, device=local_rank, n_workers=args.workers, chunk=args.chunk, n_streams=args.streams, n_slots=args.slots)
 
     def barrier():
@@ -210,7 +214,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s_%dx%d_D%d_batch%d_per_gpu_streamed" % (args.workload.split("_")[0], W, H, D, B), "width": W, "height": H, "disp_max": D - 1,
-                       "preset": "driver(MIDDLEBURY+only_left+adaptive_mean+median)", "pairs_per_gpu_per_step": B,
+                       "preset": "driver(MIDDLEBURY+only_left+adaptive_mean+median)" + ("+subsampling" if args.subsampling else ""), "pairs_per_gpu_per_step": B,
                        "parallelism": "batch-sharded x%d, no data-path collective" % world},
             "latency_ms_batch1": lat_ms, "gather_ms": gather_ms, "serial_kernel_us_per_pair": serial_k,
             "valid_fraction": round(valid_frac, 4), "checksum_rank0": checksum,
@@ -251,7 +255,7 @@ def main():
             out["kernel_ms_per_pair"] = {k: round(v / (B * args.steps), 5) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}
             out["kernel_ms_per_pair"]["_sum"] = round(gpu_ms_total / (B * args.steps), 5)
         if world == 1 and args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample if W < 2000 else min(args.cpu_sample, 4), synth)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample if W < 2000 else min(args.cpu_sample, 4), synth, args.subsampling)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

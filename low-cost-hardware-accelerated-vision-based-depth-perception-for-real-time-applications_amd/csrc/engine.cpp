@@ -223,11 +223,12 @@ void fill_kparams(sv_handle *h) {
     k.speckle_size = p.speckle_size;
     k.gap_width = p.ipol_gap_width;
     k.add_corners = p.add_corners;
-    // run tables of the speckle stage: as many runs per 16-row band as fit next to the band's bit masks in 64 KB of LDS
-    k.ccl_cap = 2048;
+    // run tables of the speckle stage (LDS of k_ccl_band, 16 B per run next to the band's bit masks): 2048 runs per 16-row band,
+    // more for wide images (a 4K band holds ~3x the pixels), within 144 KB of the CU's 160 KB
+    k.ccl_cap = std::max(2048, std::min(8192, ((d.W * 16 / 10 + 1023) / 1024) * 1024));
     if (const char *e = getenv("SV_DEBUG_CCL_CAP")) k.ccl_cap = std::max(1, atoi(e));  // tests: force the per-pixel slow path
     {
-        const long room = (65536 - 256 - 16L * ((d.W + 63) / 64) * 28) / 16;
+        const long room = (144L * 1024 - 256 - 16L * ((d.W + 63) / 64) * 28) / 16;
         k.ccl_cap = (int)std::max(1L, std::min((long)k.ccl_cap, room));
     }
     k.rt_cap = 512;
@@ -770,7 +771,7 @@ void alloc_slot(sv_handle *h, Slot *sl) {
         uint8_t *w = nullptr;
         const size_t bytes = ccl_ws_bytes(h->kp, (int)cap * 2);
         dev_alloc(w, bytes);
-        HIP_TRY(hipMemset(w, 0, bytes));  // the overflow flags start cleared; k_ccl_finish clears the ones it consumes
+        HIP_TRY(hipMemset(w, 0, bytes));  // the overflow flags start cleared; k_ccl_slow clears the ones it consumes
         s.ccl_ws = w;
     }
     HIP_TRY(hipHostMalloc((void **)&sl->h_dcan, sizeof(int16_t) * (cap * d.Wc * d.Hc + LATTICE_PAD), hipHostMallocDefault));

@@ -1170,11 +1170,12 @@ void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st, float 
 //                     vertically adjacent runs in an LDS union-find (one thread per 64-pixel mask word, walking its set
 //                     bits), and writes one record per run (first pixel, length, band-local root, component size at
 //                     roots) plus the masks of its first and last row.
-//       k_ccl_finish  one workgroup per map.  Unions runs across band borders (global union-find over run records),
-//                     sums component sizes at the global roots and overwrites the runs of components smaller than
-//                     speckle_size with -10.  Only those pixels are written; no per-pixel label map exists.
-//     A band with more than ccl_cap runs flags its map; k_ccl_finish then labels that map with the slower per-pixel
-//     union-find on global memory (ccl_legacy_map), so any input is handled.
+//       k_ccl_border / k_ccl_total / k_ccl_apply  ("ccl_finish" in the timing report): three small grid-wide passes over the
+//                     run records - unions across band borders (global union-find over run records), component sizes
+//                     summed at the global roots, runs of components smaller than speckle_size overwritten with -10.
+//                     Only those pixels are written; no per-pixel label map exists.
+//     A band with more than ccl_cap runs flags its map; k_ccl_slow then labels that map with the slower per-pixel
+//     union-find on global memory (ccl_legacy_map, one workgroup per flagged map), so any input is handled.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ size_t map_offset(const Dims &d, int m, int nproc) {  // m = pair*nproc + side
     const int pair = m / nproc, side = m - pair * nproc;
@@ -1189,7 +1190,7 @@ struct CclWs {  // workspace views of one launch (ccl_views lays them out)
     int32_t *gparent;    // [maps][nb][cap]  union-find over run records, node = band*cap + run
     int32_t *total;      // [maps][nb][cap]  component size, accumulated at global roots
     int32_t *tcount;     // [maps][nb]       runs per band
-    int32_t *flag;       // [maps]           1 = some band overflowed; cleared by k_ccl_finish
+    int32_t *flag;       // [maps]           1 = some band overflowed; cleared by k_ccl_slow
     uint64_t *bwords;    // [maps][nb][5][nch]  first row: start, valid, up-link masks; last row: start, valid masks
     int32_t *bbase;      // [maps][nb][2][nch]  run number before each 64-pixel word of the first / last row
     int cap, nb, nch;
@@ -1471,88 +1472,90 @@ __device__ void ccl_legacy_map(const KParams &k, float *D, int32_t *label, int32
     }
 }
 
-__global__ __launch_bounds__(1024) void k_ccl_finish(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp, CclWs ws, int staged,
-                                                     int32_t *__restrict__ label, int32_t *__restrict__ csize, int32_t *__restrict__ cnt) {
-    const Dims &d = k.d;
-    const int m = blockIdx.x;
-    if (blob[(m / nproc) * META_WORDS] < 3) return;
-    const size_t off = map_offset(d, m, nproc);
-    float *D = disp + off;
-    const int tid = threadIdx.x;
-    if (ws.flag[m]) {
-        ccl_legacy_map(k, D, label + off, csize + off, cnt + off);
-        __syncthreads();
-        if (tid == 0) ws.flag[m] = 0;
-        return;
-    }
+// ---- second half of the run-based labelling: three small grid-wide passes over the run records ----
+// (a) unions across band borders: first row of band b against the last row of band b-1, one thread per 64-pixel mask word
+__global__ __launch_bounds__(256) void k_ccl_border(KParams k, int nproc, const int32_t *__restrict__ blob, CclWs ws) {
+    const int m = blockIdx.y;
+    if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m]) return;
     const int nch = ws.nch, cap = ws.cap, nb = ws.nb;
-    int32_t *GP = ws.gparent + (size_t)m * nb * cap, *TOT = ws.total + (size_t)m * nb * cap;
-    const int4 *RUNS = ws.runs + (size_t)m * nb * cap;
-    const int32_t *TC = ws.tcount + (size_t)m * nb;
-    // border masks and run numbers of every band of the map: staged in LDS when they fit (staged != 0)
-    extern __shared__ uint64_t fin_lds[];
-    const uint64_t *BW = ws.bwords + (size_t)m * nb * 5 * nch;  // [nb][5][nch]
-    const int32_t *BB = ws.bbase + (size_t)m * nb * 2 * nch;    // [nb][2][nch]
-    if (staged) {
-        uint64_t *lw = fin_lds;
-        int32_t *lb = reinterpret_cast<int32_t *>(lw + (size_t)nb * 5 * nch);
-        for (int i = tid; i < nb * 5 * nch; i += 1024) lw[i] = BW[i];
-        for (int i = tid; i < nb * 2 * nch; i += 1024) lb[i] = BB[i];
-        BW = lw;
-        BB = lb;
-        __syncthreads();
-    }
-    // unions across band borders (first row of band b against the last row of band b-1): one thread per mask word
-    for (int idx = tid; idx < (nb - 1) * nch; idx += 1024) {
-        const int b = 1 + idx / nch, c = idx - (b - 1) * nch;
-        const uint64_t *bwb = BW + (size_t)b * 5 * nch, *bwp = bwb - 5 * nch;
-        const uint64_t L = bwb[2 * nch + c];
-        if (!L) continue;
-        const uint64_t S0 = bwb[c], V0 = bwb[nch + c], Sp = bwp[3 * nch + c], Vp = bwp[4 * nch + c];
-        const uint64_t carry = c > 0 ? (bwb[2 * nch + c - 1] >> 63) : 0ull;
-        const int32_t *bbb = BB + (size_t)b * 2 * nch, *bbp = bbb - 2 * nch;
-        const int n0 = b * cap + bbb[c], np = (b - 1) * cap + bbp[nch + c];
-        for (uint64_t F = ccl_new_links(L, V0 & ~S0, Vp & ~Sp, carry); F; F &= F - 1) {
-            const uint64_t upto = bits_upto(ctz64(F));
-            ccl_union(GP, n0 + __popcll(S0 & upto) - 1, np + __popcll(Sp & upto) - 1);
-        }
-    }
-    ccl_phase_sync();
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int b = wave; b < nb; b += 16) {  // component sizes at the global roots
-        const int T = TC[b];
-        for (int i = lane; i < T; i += 64) {
-            const int4 r = RUNS[b * cap + i];
-            if (r.z != i) continue;  // band-local roots carry their component's pixel count
-            atomicAdd(&TOT[ccl_find(GP, b * cap + i)], r.w);
-        }
-    }
-    ccl_phase_sync();
-    for (int b = wave; b < nb; b += 16) {  // runs of small components are wiped (elas.cpp:1109-1114)
-        const int T = TC[b];
-        for (int i = lane; i < T; i += 64) {
-            const int4 r = RUNS[b * cap + i];
-            const int g = ccl_find(GP, b * cap + r.z);
-            if (__hip_atomic_load(&TOT[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= k.speckle_size) continue;
-            for (int q = 0; q < r.y; q++) D[r.x + q] = -10.0f;
-        }
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (nb - 1) * nch) return;
+    const int b = 1 + idx / nch, c = idx - (b - 1) * nch;
+    const uint64_t *bwb = ws.bwords + ((size_t)m * nb + b) * 5 * nch, *bwp = bwb - 5 * nch;
+    const uint64_t L = bwb[2 * nch + c];
+    if (!L) return;
+    const uint64_t S0 = bwb[c], V0 = bwb[nch + c], Sp = bwp[3 * nch + c], Vp = bwp[4 * nch + c];
+    const uint64_t carry = c > 0 ? (bwb[2 * nch + c - 1] >> 63) : 0ull;
+    const int32_t *bbb = ws.bbase + ((size_t)m * nb + b) * 2 * nch, *bbp = bbb - 2 * nch;
+    const int n0 = b * cap + bbb[c], np = (b - 1) * cap + bbp[nch + c];
+    int32_t *GP = ws.gparent + (size_t)m * nb * cap;
+    for (uint64_t F = ccl_new_links(L, V0 & ~S0, Vp & ~Sp, carry); F; F &= F - 1) {
+        const uint64_t upto = bits_upto(ctz64(F));
+        ccl_union(GP, n0 + __popcll(S0 & upto) - 1, np + __popcll(Sp & upto) - 1);
     }
 }
 
-static size_t ccl_finish_lds_bytes(const KParams &k) {
-    const size_t nb = (k.d.H + CCL_R - 1) / CCL_R, nch = (k.d.W + 63) / 64;
-    return nb * nch * (5 * 8 + 2 * 4);
+// (b) component sizes at the global roots: every band-local root adds its component's pixel count
+__global__ __launch_bounds__(256) void k_ccl_total(KParams k, int nproc, const int32_t *__restrict__ blob, CclWs ws) {
+    const int m = blockIdx.y, b = blockIdx.x;
+    if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m]) return;
+    const int cap = ws.cap, nb = ws.nb;
+    const int T = ws.tcount[(size_t)m * nb + b];
+    const int32_t *GP = ws.gparent + (size_t)m * nb * cap;
+    int32_t *TOT = ws.total + (size_t)m * nb * cap;
+    const int4 *RUNS = ws.runs + ((size_t)m * nb + b) * cap;
+    for (int i = threadIdx.x; i < T; i += 256) {
+        const int4 r = RUNS[i];
+        if (r.z != i) continue;
+        atomicAdd(&TOT[ccl_find(GP, b * cap + i)], r.w);
+    }
+}
+
+// (c) runs of components smaller than speckle_size are wiped (elas.cpp:1109-1114); nothing else is written
+__global__ __launch_bounds__(256) void k_ccl_apply(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp, CclWs ws) {
+    const Dims &d = k.d;
+    const int m = blockIdx.y, b = blockIdx.x;
+    if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m]) return;
+    const int cap = ws.cap, nb = ws.nb;
+    const int T = ws.tcount[(size_t)m * nb + b];
+    const int32_t *GP = ws.gparent + (size_t)m * nb * cap, *TOT = ws.total + (size_t)m * nb * cap;
+    const int4 *RUNS = ws.runs + ((size_t)m * nb + b) * cap;
+    float *D = disp + map_offset(d, m, nproc);
+    for (int i = threadIdx.x; i < T; i += 256) {
+        const int4 r = RUNS[i];
+        if (r.y >= k.speckle_size) continue;  // a run that long is a large component by itself
+        if (TOT[ccl_find(GP, b * cap + r.z)] >= k.speckle_size) continue;
+        for (int q = 0; q < r.y; q++) D[r.x + q] = -10.0f;
+    }
+}
+
+// (d) maps whose bands overflowed the run tables: per-pixel union-find, one workgroup per flagged map (normally none)
+__global__ __launch_bounds__(1024) void k_ccl_slow(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp, CclWs ws,
+                                                   int32_t *__restrict__ label, int32_t *__restrict__ csize, int32_t *__restrict__ cnt) {
+    const int m = blockIdx.x;
+    if (blob[(m / nproc) * META_WORDS] < 3 || !ws.flag[m]) return;
+    const size_t off = map_offset(k.d, m, nproc);
+    ccl_legacy_map(k, disp + off, label + off, csize + off, cnt + off);
+    __syncthreads();
+    if (threadIdx.x == 0) ws.flag[m] = 0;
 }
 
 void launch_speckle(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st) {
     const int maps = n * nproc;
     CclWs ws;
     ccl_views(k, s.ccl_ws, s.cap * 2, ws);
-    SV_LAUNCH(K_CCL_BAND, k_ccl_band, dim3(ws.nb, maps), dim3(CCL_THREADS), ccl_lds_bytes(k), st, k, nproc, s.blob, s.disp, ws);
+    const size_t lds = ccl_lds_bytes(k);
+    if (lds > 64 * 1024) {  // wide images: larger run tables than the default dynamic-LDS limit allows
+        static size_t granted = 0;
+        if (lds > granted && hipFuncSetAttribute(reinterpret_cast<const void *>(k_ccl_band), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+            granted = lds;
+    }
+    SV_LAUNCH(K_CCL_BAND, k_ccl_band, dim3(ws.nb, maps), dim3(CCL_THREADS), lds, st, k, nproc, s.blob, s.disp, ws);
+    if (ws.nb > 1) SV_LAUNCH(K_CCL_FINISH, k_ccl_border, dim3(((ws.nb - 1) * ws.nch + 255) / 256, maps), dim3(256), 0, st, k, nproc, s.blob, ws);
+    SV_LAUNCH(K_CCL_FINISH, k_ccl_total, dim3(ws.nb, maps), dim3(256), 0, st, k, nproc, s.blob, ws);
+    SV_LAUNCH(K_CCL_FINISH, k_ccl_apply, dim3(ws.nb, maps), dim3(256), 0, st, k, nproc, s.blob, s.disp, ws);
     int32_t *cnt = reinterpret_cast<int32_t *>(s.tmp);  // slow path only: the filters' scratch map is free during speckle removal
-    const size_t fin = ccl_finish_lds_bytes(k);
-    const int staged = fin <= 60 * 1024;
-    SV_LAUNCH(K_CCL_FINISH, k_ccl_finish, dim3(maps), dim3(1024), staged ? fin : 0, st, k, nproc, s.blob, s.disp, ws, staged, s.tri_id, s.csize, cnt);
+    SV_LAUNCH(K_CCL_FINISH, k_ccl_slow, dim3(maps), dim3(1024), 0, st, k, nproc, s.blob, s.disp, ws, s.tri_id, s.csize, cnt);
 }
 
 // ------------------------------------------------------------------------------------------------------------
