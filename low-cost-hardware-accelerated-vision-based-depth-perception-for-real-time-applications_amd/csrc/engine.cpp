@@ -89,6 +89,9 @@ struct Slot {
     int i0 = 0, n = 0;
     std::atomic<size_t> blob_off{0};
     std::atomic<int> pending{0};
+    // latency mode (run_inline): the calling thread drives the chunk itself and spins on this flag instead of using the queues
+    bool inline_mode = false;
+    std::atomic<int> inline_done{0};
 };
 
 struct Task {
@@ -128,6 +131,8 @@ struct sv_handle {
     // host pool
     std::vector<std::thread> pool;
     std::vector<HostScratch *> scratch;
+    HostScratch *inline_scratch = nullptr;  // host-stage scratch of the calling thread (latency mode)
+    bool inline_ok = true;                  // SV_NO_INLINE=1 (tests) sends single pairs through the queued pipeline as well
     std::mutex qmu;
     std::condition_variable qcv;
     std::deque<Task> queue;
@@ -451,6 +456,10 @@ void issuer_main(sv_handle *h) {
 
 // ---- stage 2: dispatcher + host pool ---------------------------------------------------------------------------------
 void chunk_host_done(sv_handle *h, Slot *s) {
+    if (s->inline_mode) {
+        s->inline_done.store(1, std::memory_order_release);
+        return;
+    }
     {
         std::lock_guard<std::mutex> lk(h->mu);
         h->q2.push_back(s);
@@ -860,7 +869,63 @@ int wait_jobs(sv_handle *h) {
     return h->failed ? SV_ERR_HIP : SV_OK;
 }
 
+// Latency mode: one pair, chunk 1, nothing in flight.  The calling thread issues phase 1, spins on its event, runs the lattice
+// filter and the left triangulation itself (the right one goes to a pool thread meanwhile), issues phase 2 and waits for it:
+// no hand-over between the three control threads, which costs more than the kernels of a single pair.
+int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stride, float *d1, float *d2, int32_t *status) {
+    Job job;
+    job.left = left;
+    job.right = right;
+    job.batch = 1;
+    job.stride = stride;
+    job.d1 = d1;
+    job.d2 = d2;
+    job.status = status;
+    job.nchunks = 1;
+    Slot *s = h->slots[0];
+    h->failed = false;
+    s->job = &job;
+    s->i0 = 0;
+    s->n = 1;
+    s->inline_done.store(0);
+    s->inline_mode = true;
+    (void)hipSetDevice(h->cfg.device);
+    const LaunchHook saved = g_launch_hook;
+    try {
+        g_launch_hook.fn = h->timing ? timing_hook : nullptr;
+        g_launch_hook.ctx = &h->tc_issue;
+        issue_phase1(h, s);
+        HIP_TRY(hipEventSynchronize(s->ev_p1));
+        s->blob_off.store((size_t)s->dev.cap * META_WORDS);
+        s->pending.store(1);
+        run_task(h, h->inline_scratch, Task{s, 0, -1});
+        while (!s->inline_done.load(std::memory_order_acquire)) __builtin_ia32_pause();
+        g_launch_hook.ctx = &h->tc_finish;
+        issue_phase2(h, s, h->sP2[0]);
+        HIP_TRY(hipStreamSynchronize(h->sP2[0]));
+    } catch (const std::exception &e) {
+        note_error(h, e.what());
+        while (s->pending.load() > 0 && !s->inline_done.load()) __builtin_ia32_pause();  // a queued right-side task still refers to the slot
+    }
+    g_launch_hook = saved;
+    s->inline_mode = false;
+    s->job = nullptr;
+    if (h->timing) {
+        collect_timing(h, &h->tc_issue);
+        collect_timing(h, &h->tc_finish);
+    }
+    return h->failed ? SV_ERR_HIP : SV_OK;
+}
+
 int run_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status) {
+    if (h && batch == 1 && h->chunk == 1 && !h->cfg.keep_debug && !h->gpu_filter && left && right && d1 && stride >= h->cfg.width && h->inline_ok) {
+        bool idle;
+        {
+            std::lock_guard<std::mutex> lk(h->mu);
+            idle = h->live.empty() && h->jobs.empty();
+        }
+        if (idle) return run_inline(h, left, right, stride, d1, d2, status);
+    }
     const int rc = submit_job(h, left, right, batch, stride, d1, d2, status);
     if (rc != SV_OK) return rc;
     return wait_jobs(h);
@@ -994,6 +1059,8 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         h->scratch.push_back(sc);
         h->pool.emplace_back(pool_main, h, sc);
     }
+    h->inline_scratch = new HostScratch();
+    h->inline_ok = getenv("SV_NO_INLINE") == nullptr;
     h->t_issue = std::thread(issuer_main, h);
     h->t_dispatch = std::thread(dispatcher_main, h);
     h->t_finish = std::thread(finisher_main, h);
@@ -1019,6 +1086,7 @@ int sv_destroy(sv_handle *h) {
     for (std::thread &t : h->pool)
         if (t.joinable()) t.join();
     for (HostScratch *sc : h->scratch) delete sc;
+    delete h->inline_scratch;
     free_handle_resources(h);
     delete h;
     return SV_OK;

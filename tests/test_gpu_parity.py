@@ -157,6 +157,25 @@ def test_raster_fallback_path(eng, oracle, monkeypatch):
     assert util.sha(d1) == entry["stages"]["final1"] and util.sha(d2) == entry["stages"]["final2"]
 
 
+@pytest.mark.parametrize("inline", [True, False])
+def test_latency_mode_single_pairs(eng, monkeypatch, inline):
+    """chunk = 1, one pair per call: the calling thread drives the pair itself (run_inline); SV_NO_INLINE sends it through the
+    queued pipeline instead.  Both must give the golden maps, also for a pair without support points in between."""
+    if not inline:
+        monkeypatch.setenv("SV_NO_INLINE", "1")
+    entry = DIG["kitti0_d128"]
+    L, R = util.case_images(entry)
+    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=1, n_slots=2, n_streams=1, n_workers=2)
+    try:
+        for rep in range(3):
+            d1, d2, st = e.process_host(L, R)
+            assert st[0] == entry["n_support"] and util.sha(d1[0]) == entry["stages"]["final1"]
+            z1, z2, zs = e.process_host(np.zeros_like(L), np.zeros_like(R))
+            assert zs[0] >= 3 or not z1.any()  # MIDDLEBURY adds corner points: either a flat map or an untouched (zero) one
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("cap", ["8", "300"])
 def test_speckle_slow_path(eng, oracle, monkeypatch, cap):
     """Bands with more runs than the LDS run tables hold switch their map to the per-pixel union-find: force that with tiny
