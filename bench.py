@@ -48,8 +48,8 @@ def algorithmic_bytes_per_pair(N, Wc, Hc, Wimg, MW, ncell):
         "grid_mark": 0, "grid_dilate": 2 * 2 * ncell * MW * 4,
         "plane_fit": 0,
         "triangles_raster": 2 * 4 * N, "triangles_raster_fallback": 0,                        # one tri_id write per covered pixel, both sides
-        "dense_match": 2 * desc + 2 * 4 * N + 2 * 4 * N,      # both descriptor images, tri_id in, WTA out (both sides)
-        "lr_check": 2 * 4 * N + 2 * 4 * N,
+        "dense_match": 2 * desc + 2 * 4 * N + 2 * 2 * N,      # both descriptor images, tri_id in, int16 WTA out (both sides)
+        "lr_check": 2 * 2 * N + 2 * 4 * N,                    # int16 WTA maps in; checked left map + the caller's right map out
         "ccl_band": 4 * N, "ccl_finish": 0,
         "gap_rows": 8 * N, "gap_cols": 8 * N, "adaptive_mean": 8 * N, "median": 8 * N + 4 * N,
         "output": 2 * 8 * N,

@@ -9,6 +9,7 @@
 #include "sv_kernels.h"
 
 #include <algorithm>
+#include <atomic>
 
 namespace sv {
 
@@ -1546,9 +1547,12 @@ void launch_speckle(const KParams &k, const SlotDev &s, int n, int nproc, hipStr
     ccl_views(k, s.ccl_ws, s.cap * 2, ws);
     const size_t lds = ccl_lds_bytes(k);
     if (lds > 64 * 1024) {  // wide images: larger run tables than the default dynamic-LDS limit allows
-        static size_t granted = 0;
-        if (lds > granted && hipFuncSetAttribute(reinterpret_cast<const void *>(k_ccl_band), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
-            granted = lds;
+        static std::atomic<size_t> granted[64];  // per device: the attribute belongs to the function's code object on that device
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<size_t> &g = granted[dev & 63];
+        if (lds > g.load() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_ccl_band), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+            g.store(lds);
     }
     SV_LAUNCH(K_CCL_BAND, k_ccl_band, dim3(ws.nb, maps), dim3(CCL_THREADS), lds, st, k, nproc, s.blob, s.disp, ws);
     if (ws.nb > 1) SV_LAUNCH(K_CCL_FINISH, k_ccl_border, dim3(((ws.nb - 1) * ws.nch + 255) / 256, maps), dim3(256), 0, st, k, nproc, s.blob, ws);
