@@ -157,6 +157,21 @@ def test_raster_fallback_path(eng, oracle, monkeypatch):
     assert util.sha(d1) == entry["stages"]["final1"] and util.sha(d2) == entry["stages"]["final2"]
 
 
+def test_random_parameter_sets(eng, oracle):
+    """Elas::parameters far from the three presets (tools/fuzz_params.py): both maps, batch path and latency path, bit-exact."""
+    import sys
+
+    sys.path.insert(0, util.ROOT + "/tools")
+    import fuzz_params as fz
+
+    rng = np.random.default_rng(33)
+    shapes = [(150, 260), (97, 203), (200, 320), (128, 401)]
+    for i in range(16):
+        vals = fz.random_params(rng)
+        res = fz.run_case(eng, oracle, util.pkg("synth"), vals, 700 + i, shapes[i % 4])
+        assert all(r[0] and r[1] for r in res), (res, vals)
+
+
 @pytest.mark.parametrize("inline", [True, False])
 def test_latency_mode_single_pairs(eng, monkeypatch, inline):
     """chunk = 1, one pair per call: the calling thread drives the pair itself (run_inline); SV_NO_INLINE sends it through the

@@ -79,3 +79,26 @@ def test_delaunay_random_sets(ref, oracle):
         assert a.shape == b.shape and np.array_equal(a, b), (it, mode, n)
         done += 1
     assert done > 400
+
+
+def test_random_parameter_sets(ref, oracle):
+    """Parameter sets far from the presets (lattice step, window sizes, grid size, prior, thresholds, gap / speckle limits,
+    filter switches, half resolution): every stage of the restatement equals the reference's."""
+    import sys
+
+    sys.path.insert(0, util.ROOT + "/tools")
+    import fuzz_params as fz
+
+    rng = np.random.default_rng(21)
+    shapes = [(150, 260), (97, 203), (128, 401)]
+    for i in range(15):
+        vals = fz.random_params(rng)
+        H, W = shapes[i % 3]
+        L, R = util.pkg("synth").make_pair(500 + i, H, W, min(vals["disp_max"] + 1, 64))
+        p = fz.apply(ElasParams.preset("robotics"), vals)
+        n1 = ref.run_stages(p, L, R)
+        assert n1 == oracle.run_stages(p, L, R), vals
+        if n1 < 3:
+            continue
+        bad = [k for k in util.STAGES if not np.array_equal(ref.stage(k).view(np.uint8), oracle.stage(k).view(np.uint8))]
+        assert not bad, (bad, vals)
