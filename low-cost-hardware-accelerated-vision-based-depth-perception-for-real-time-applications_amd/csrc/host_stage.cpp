@@ -55,29 +55,41 @@ static void drop_inconsistent_scalar(const sv_params &p, int16_t *T, int Wc, int
 }
 
 #if defined(__x86_64__)
+// Valid entries (>= 0) of col[v0 .. v0+15] as a bit mask, 2 bits per int16 lane (movemask_epi8), rows >= Hc cleared.
+// An entry can only be invalidated when it is visited itself, so the mask stays right for the entries not yet visited.
+__attribute__((target("avx2"))) static inline uint32_t valid_lanes(const int16_t *col, int v0, int Hc) {
+    const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(col + v0));
+    uint32_t m = (uint32_t)_mm256_movemask_epi8(_mm256_cmpgt_epi16(x, _mm256_set1_epi16(-1)));
+    const int rows = Hc - v0;
+    if (rows < 16) m &= (1u << (2 * rows)) - 1u;
+    return m & 0x55555555u;  // one bit per lane
+}
+
 // Same scan with one 16-lane int16 compare per window column (the window's <= 11 rows are contiguous in the transposed
 // lattice).  Reads up to 15 elements past a column's window: the caller's buffer is padded accordingly (LATTICE_PAD).
+// Invalid entries are skipped 16 at a time through their validity mask instead of one mispredicted branch each.
 __attribute__((target("avx2"))) static void drop_inconsistent_avx2(const sv_params &p, int16_t *T, int Wc, int Hc) {
     const int win = p.incon_window_size, need = p.incon_min_support;
     const __m256i vthr = _mm256_set1_epi16((short)p.incon_threshold), vneg1 = _mm256_set1_epi16(-1);
     for (int uc = 0; uc < Wc; uc++) {
         const int u_lo = std::max(uc - win, 0), u_hi = std::min(uc + win, Wc - 1);
         int16_t *col = T + (size_t)uc * Hc;
-        for (int vc = 0; vc < Hc; vc++) {
-            const int d = col[vc];
-            if (d < 0) continue;
-            const int v_lo = std::max(vc - win, 0), v_hi = std::min(vc + win, Hc - 1);
-            const uint32_t lanes = (1u << (2 * (v_hi - v_lo + 1))) - 1u;  // movemask gives 2 bits per int16 lane
-            const __m256i vd = _mm256_set1_epi16((short)d);
-            int support = 0;
-            for (int u2 = u_lo; u2 <= u_hi && support < need; u2++) {
-                const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(T + (size_t)u2 * Hc + v_lo));
-                const __m256i diff = _mm256_abs_epi16(_mm256_sub_epi16(x, vd));
-                const __m256i ok = _mm256_andnot_si256(_mm256_cmpgt_epi16(diff, vthr), _mm256_cmpgt_epi16(x, vneg1));
-                support += __builtin_popcount((uint32_t)_mm256_movemask_epi8(ok) & lanes) >> 1;
+        for (int v0 = 0; v0 < Hc; v0 += 16)
+            for (uint32_t vm = valid_lanes(col, v0, Hc); vm; vm &= vm - 1) {
+                const int vc = v0 + (__builtin_ctz(vm) >> 1);
+                const int d = col[vc];
+                const int v_lo = std::max(vc - win, 0), v_hi = std::min(vc + win, Hc - 1);
+                const uint32_t lanes = (1u << (2 * (v_hi - v_lo + 1))) - 1u;  // movemask gives 2 bits per int16 lane
+                const __m256i vd = _mm256_set1_epi16((short)d);
+                int support = 0;
+                for (int u2 = u_lo; u2 <= u_hi && support < need; u2++) {
+                    const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(T + (size_t)u2 * Hc + v_lo));
+                    const __m256i diff = _mm256_abs_epi16(_mm256_sub_epi16(x, vd));
+                    const __m256i ok = _mm256_andnot_si256(_mm256_cmpgt_epi16(diff, vthr), _mm256_cmpgt_epi16(x, vneg1));
+                    support += __builtin_popcount((uint32_t)_mm256_movemask_epi8(ok) & lanes) >> 1;
+                }
+                if (support < need) col[vc] = -1;
             }
-            if (support < need) col[vc] = -1;
-        }
     }
 }
 #endif
@@ -97,7 +109,7 @@ static void drop_inconsistent(const sv_params &p, int16_t *T, int Wc, int Hc) {
 // elas.cpp:178-233 with redun_max_dist = 5, redun_threshold = 1 (:419-420); in place.  A point is dropped when, in BOTH
 // directions along the axis, some valid point with |dd| <= thr lies within max_dist steps ("first found" == "any found").
 // Branch-free per direction: the data-dependent early exits of the reference mispredict on almost every point.
-static void drop_redundant(int16_t *T, int Wc, int Hc, int max_dist, int thr, bool vertical) {
+static void drop_redundant_scalar(int16_t *T, int Wc, int Hc, int max_dist, int thr, bool vertical) {
     const int stride = vertical ? 1 : Hc;
     for (int uc = 0; uc < Wc; uc++)
         for (int vc = 0; vc < Hc; vc++) {
@@ -119,15 +131,91 @@ static void drop_redundant(int16_t *T, int Wc, int Hc, int max_dist, int thr, bo
         }
 }
 
-int support_filter_t(const sv_params &p, int16_t *T, int W, int H, int32_t *out, int cap) {
-    int Wc, Hc;
-    lattice_dims(p, W, H, Wc, Hc);
-    drop_inconsistent(p, T, Wc, Hc);
-    drop_redundant(T, Wc, Hc, 5, 1, true);
-    drop_redundant(T, Wc, Hc, 5, 1, false);
-    const int step = lattice_step(p);
+#if defined(__x86_64__)
+// Pass along v (the contiguous axis of the transposed lattice): the scan is sequential inside a column, so every point is
+// still visited in order, but its +-max_dist neighbourhood is one 16-lane window load: lanes 0..max_dist-1 are the points
+// below, lane max_dist the point itself, the next max_dist lanes the points above.  Points closer than max_dist to a column
+// end take the scalar path.  Requires max_dist <= 7.
+__attribute__((target("avx2"))) static void drop_redundant_v_avx2(int16_t *T, int Wc, int Hc, int max_dist, int thr) {
+    const __m256i vthr = _mm256_set1_epi16((short)thr), vneg1 = _mm256_set1_epi16(-1);
+    const uint32_t lo_bits = (1u << (2 * max_dist)) - 1u;                              // movemask: 2 bits per int16 lane
+    const uint32_t hi_bits = ((1u << (2 * max_dist)) - 1u) << (2 * (max_dist + 1));
+    for (int uc = 0; uc < Wc; uc++) {
+        int16_t *col = T + (size_t)uc * Hc;
+        for (int v0 = 0; v0 < Hc; v0 += 16)
+            for (uint32_t vm = valid_lanes(col, v0, Hc); vm; vm &= vm - 1) {
+                const int vc = v0 + (__builtin_ctz(vm) >> 1);
+                const int d = col[vc];
+                if (vc < max_dist || vc + max_dist >= Hc) {  // near a column end
+                    const int n_lo = std::min(max_dist, vc), n_hi = std::min(max_dist, Hc - 1 - vc);
+                    int found_lo = 0, found_hi = 0;
+                    for (int j = 1; j <= n_lo; j++) found_lo |= (col[vc - j] >= 0) & (abs(d - col[vc - j]) <= thr);
+                    for (int j = 1; j <= n_hi; j++) found_hi |= (col[vc + j] >= 0) & (abs(d - col[vc + j]) <= thr);
+                    if (found_lo & found_hi) col[vc] = -1;
+                    continue;
+                }
+                const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(col + vc - max_dist));
+                const __m256i diff = _mm256_abs_epi16(_mm256_sub_epi16(x, _mm256_set1_epi16((short)d)));
+                const __m256i ok = _mm256_andnot_si256(_mm256_cmpgt_epi16(diff, vthr), _mm256_cmpgt_epi16(x, vneg1));
+                const uint32_t m = (uint32_t)_mm256_movemask_epi8(ok);
+                if ((m & lo_bits) && (m & hi_bits)) col[vc] = -1;
+            }
+    }
+}
+
+// Pass along u: a point only looks at points of its own row v, so the 16 rows of a vector are independent of each other and
+// the column loop (u ascending) already is the reference's visiting order for each of them.
+__attribute__((target("avx2"))) static void drop_redundant_u_avx2(int16_t *T, int Wc, int Hc, int max_dist, int thr) {
+    const __m256i vthr = _mm256_set1_epi16((short)thr), vneg1 = _mm256_set1_epi16(-1);
+    alignas(32) int16_t lane_id[16];
+    for (int i = 0; i < 16; i++) lane_id[i] = (int16_t)i;
+    const __m256i vlane = _mm256_load_si256(reinterpret_cast<const __m256i *>(lane_id));
+    for (int uc = 0; uc < Wc; uc++) {
+        const int n_lo = std::min(max_dist, uc), n_hi = std::min(max_dist, Wc - 1 - uc);
+        int16_t *col = T + (size_t)uc * Hc;
+        for (int v0 = 0; v0 < Hc; v0 += 16) {
+            const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(col + v0));
+            const __m256i valid = _mm256_cmpgt_epi16(x, vneg1);
+            __m256i flo = _mm256_setzero_si256(), fhi = _mm256_setzero_si256();
+            for (int j = 1; j <= n_lo; j++) {
+                const __m256i y = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(col - (size_t)j * Hc + v0));
+                const __m256i near = _mm256_andnot_si256(_mm256_cmpgt_epi16(_mm256_abs_epi16(_mm256_sub_epi16(x, y)), vthr), _mm256_cmpgt_epi16(y, vneg1));
+                flo = _mm256_or_si256(flo, near);
+            }
+            for (int j = 1; j <= n_hi; j++) {
+                const __m256i y = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(col + (size_t)j * Hc + v0));
+                const __m256i near = _mm256_andnot_si256(_mm256_cmpgt_epi16(_mm256_abs_epi16(_mm256_sub_epi16(x, y)), vthr), _mm256_cmpgt_epi16(y, vneg1));
+                fhi = _mm256_or_si256(fhi, near);
+            }
+            // rows beyond the column's end belong to the next column: leave them alone
+            const __m256i inside = _mm256_cmpgt_epi16(_mm256_set1_epi16((short)std::min(Hc - v0, 16)), vlane);
+            const __m256i drop = _mm256_and_si256(_mm256_and_si256(valid, inside), _mm256_and_si256(flo, fhi));
+            _mm256_storeu_si256(reinterpret_cast<__m256i *>(col + v0), _mm256_blendv_epi8(x, vneg1, drop));
+        }
+    }
+}
+#endif
+
+static void drop_redundant(int16_t *T, int Wc, int Hc, int max_dist, int thr, bool vertical) {
+#if defined(__x86_64__)
+    // 16-lane loads may run up to 15 elements past the last column: the caller's buffer is padded (LATTICE_PAD)
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    if (have_avx2 && max_dist >= 1 && max_dist <= 7 && thr >= 0 && thr < 16384) {
+        if (vertical)
+            drop_redundant_v_avx2(T, Wc, Hc, max_dist, thr);
+        else
+            drop_redundant_u_avx2(T, Wc, Hc, max_dist, thr);
+        return;
+    }
+#endif
+    drop_redundant_scalar(T, Wc, Hc, max_dist, thr, vertical);
+}
+
+// elas.cpp:422-433: the surviving lattice points as (u, v, d) triples, u outer / v inner, row and column 0 excluded.
+// Returns the number of points found (only the first `cap` are stored).
+static int collect_points_scalar(const int16_t *T, int Wc, int Hc, int step, int32_t *out, int cap) {
     int n = 0;
-    for (int uc = 1; uc < Wc; uc++)  // elas.cpp:424-428: u outer, v inner
+    for (int uc = 1; uc < Wc; uc++)
         for (int vc = 1; vc < Hc; vc++) {
             const int d = T[(size_t)uc * Hc + vc];
             if (d < 0) continue;
@@ -138,19 +226,70 @@ int support_filter_t(const sv_params &p, int16_t *T, int W, int H, int32_t *out,
             }
             n++;
         }
+    return n;
+}
+
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) static int collect_points_avx2(const int16_t *T, int Wc, int Hc, int step, int32_t *out, int cap) {
+    int n = 0;
+    for (int uc = 1; uc < Wc; uc++) {
+        const int16_t *col = T + (size_t)uc * Hc;
+        for (int v0 = 0; v0 < Hc; v0 += 16) {
+            uint32_t vm = valid_lanes(col, v0, Hc);
+            if (v0 == 0) vm &= ~1u;  // row 0 is not part of the lattice proper (elas.cpp:394)
+            for (; vm; vm &= vm - 1) {
+                const int vc = v0 + (__builtin_ctz(vm) >> 1);
+                if (n < cap) {
+                    out[3 * n] = uc * step;
+                    out[3 * n + 1] = vc * step;
+                    out[3 * n + 2] = col[vc];
+                }
+                n++;
+            }
+        }
+    }
+    return n;
+}
+#endif
+
+static int collect_points(const int16_t *T, int Wc, int Hc, int step, int32_t *out, int cap) {
+#if defined(__x86_64__)
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    if (have_avx2) return collect_points_avx2(T, Wc, Hc, step, out, cap);
+#endif
+    return collect_points_scalar(T, Wc, Hc, step, out, cap);
+}
+
+int support_filter_t(const sv_params &p, int16_t *T, int W, int H, int32_t *out, int cap) {
+    int Wc, Hc;
+    lattice_dims(p, W, H, Wc, Hc);
+    drop_inconsistent(p, T, Wc, Hc);
+    drop_redundant(T, Wc, Hc, 5, 1, true);
+    drop_redundant(T, Wc, Hc, 5, 1, false);
+    const int step = lattice_step(p);
+    int n = 0;
+#ifdef SV_FILTER_PROFILE
+    const double tp0 = sv_prof_now();
+#endif
+    n = collect_points(T, Wc, Hc, step, out, cap);  // elas.cpp:424-428: u outer, v inner
+#ifdef SV_FILTER_PROFILE
+    const double tp1 = sv_prof_now();
+    sv_prof_collect += tp1 - tp0;
+    struct ProfEnd { double t0; ~ProfEnd() { sv_prof_corners += sv_prof_now() - t0; } } prof_end{tp1};
+#endif
     if (p.add_corners) {  // elas.cpp:235-264
         if (n + 6 > cap) return -(n + 6);
         const int bu[4] = {0, 0, W - 1, W - 1}, bv[4] = {0, H - 1, 0, H - 1};
         int bd[4] = {0, 0, 0, 0};
-        for (int i = 0; i < 4; i++) {
-            int best = 10000000;
-            for (int j = 0; j < n; j++) {
-                const int du = bu[i] - out[3 * j], dv = bv[i] - out[3 * j + 1];
+        int best[4] = {10000000, 10000000, 10000000, 10000000};
+        for (int j = 0; j < n; j++) {  // one pass for the four corners; strict '<' keeps the first of equally near points
+            const int pu = out[3 * j], pv = out[3 * j + 1], pd = out[3 * j + 2];
+            for (int i = 0; i < 4; i++) {
+                const int du = bu[i] - pu, dv = bv[i] - pv;
                 const int dist = du * du + dv * dv;
-                if (dist < best) {
-                    best = dist;
-                    bd[i] = out[3 * j + 2];
-                }
+                const bool nearer = dist < best[i];
+                best[i] = nearer ? dist : best[i];
+                bd[i] = nearer ? pd : bd[i];
             }
         }
         const int base = n;

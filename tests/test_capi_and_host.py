@@ -84,3 +84,36 @@ def test_host_delaunay_random_sets(eng, oracle):
             continue
         a, b = oracle.delaunay(pts.astype(np.float32)), eng.host_delaunay(pts)
         assert a.shape == b.shape and np.array_equal(a, b), it
+
+
+def test_host_filter_random_lattices(eng, oracle):
+    """The vectorised lattice filters (mask-driven scans, 16 rows per step) against the restatement's plain loops on random
+    lattices: sizes that are not multiples of 16, sparse and dense, every window size, with and without corner points."""
+    L = oracle.lib
+    L.orc_support_filter.argtypes = [ctypes.POINTER(ElasParams), ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    L.orc_support_filter.restype = ctypes.c_int
+    rng = np.random.default_rng(9)
+    for it in range(80):
+        W, H = int(rng.integers(40, 700)), int(rng.integers(40, 400))
+        po = ElasParams.preset("robotics" if it % 2 else "middlebury")
+        po.candidate_stepsize = int(rng.choice([3, 5, 6, 8]))
+        po.incon_window_size = int(rng.choice([0, 1, 3, 5, 7]))
+        po.incon_threshold = int(rng.integers(1, 8))
+        po.incon_min_support = int(rng.integers(1, 12))
+        po.add_corners = int(rng.integers(0, 2))
+        pe = eng.SvParams.preset("robotics")
+        for f, _ in eng.SvParams._fields_:
+            setattr(pe, f, getattr(po, f))
+        step = po.candidate_stepsize
+        Wc, Hc = (W + step - 1) // step, (H + step - 1) // step
+        noise = rng.integers(0, 60, (Hc, Wc))
+        ramp = np.add.outer(np.arange(Hc), np.arange(Wc)) // int(rng.integers(2, 9)) + int(rng.integers(0, 30))
+        d = np.where(rng.random((Hc, Wc)) < 0.5, noise, ramp)
+        d = np.where(rng.random((Hc, Wc)) < rng.uniform(0.05, 0.9), d, -1).astype(np.int16)
+        d[0, :] = 0
+        d[:, 0] = 0
+        want = np.zeros((Wc * Hc + 6, 3), np.int32)
+        a = d.copy()
+        n = L.orc_support_filter(ctypes.byref(po), a.ctypes.data, W, H, want.ctypes.data, want.shape[0])
+        got = eng.host_support_filter(pe, d.copy(), W, H)
+        assert n == got.shape[0] and np.array_equal(got, want[:n]), (it, W, H, step)
