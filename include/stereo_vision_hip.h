@@ -160,6 +160,18 @@ Uchar4 *getColor(void); /* reference: stereo_vision.cpp:625-627 */
 const unsigned char *sv_legacy_last_dmap(int *width, int *height);
 /* The 4x4 disparity-to-depth matrix Q the legacy path uses (row major), NULL before the first frame. */
 const double *sv_legacy_Q(void);
+/* Batched disparity -> point cloud on the device, for callers of the batch API: the driver's conversion dmap = saturate(
+ * round_half_even(4*d)) (stereo_vision.cpp:316) followed by publishPointCloud's reprojection pos = Q*[x y dmap 1]^T,
+ * (X,Y,Z) = pos.xyz/pos.w in double (:233-256) for every pixel, and optionally the CUDA variant's robot-frame transform
+ * XR*(X,Y,Z)+XT (parallel_includes/main/stereo_vision.cu:188-212).
+ *   disp       : float  [B][height][width]     device (e.g. d1 of sv_process_batch_device)
+ *   Q16        : double [16] HOST, row major   (e.g. sv_legacy_Q(), or your own stereoRectify result)
+ *   XR9 / XT3  : double [9] / [3] HOST, row major; both NULL = no transform (the serial driver)
+ *   dmap_out   : uint8  [B][height][width]     device, may be NULL
+ *   points_out : double [B][height][width][3]  device
+ * Runs on the device's default stream and returns when the points are complete. */
+int sv_reproject_batch_device(const float *disp, int batch, int width, int height, const double *Q16, const double *XR9, const double *XT3, unsigned char *dmap_out,
+                              double *points_out);
 /* Mean 3-D position of the cloud inside each detector box (x, y, w, h in pixels), i.e. what publishPointCloud hands to its
  * viewer for every tracked object (stereo_vision.cpp:261-278; the boxes come from a detector the caller runs - the
  * reference's YOLO weights are not part of this library).  boxes: int32 [n][4]; out: double [n][3] = (X, Y, Z) sums over

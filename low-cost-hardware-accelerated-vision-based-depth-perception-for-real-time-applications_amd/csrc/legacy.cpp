@@ -32,6 +32,8 @@
 namespace sv {
 void launch_bgra_to_gray(const unsigned char *bgra_l, const unsigned char *bgra_r, unsigned char *gray_l, unsigned char *gray_r, int n, hipStream_t st);
 void launch_dmap_and_cloud(const float *disp, unsigned char *dmap, double *points, const double *Q16, int W, int H, hipStream_t st);
+int launch_reproject_batch(const float *disp, int batch, int W, int H, const double *Q16, const double *XR9, const double *XT3, unsigned char *dmap, double *points,
+                           hipStream_t st);
 }  // namespace sv
 
 namespace {
@@ -189,6 +191,14 @@ const unsigned char *sv_legacy_last_dmap(int *width, int *height) {
 }
 
 const double *sv_legacy_Q(void) { return g.ready ? g.rect.Q : nullptr; }
+
+int sv_reproject_batch_device(const float *disp, int batch, int width, int height, const double *Q16, const double *XR9, const double *XT3, unsigned char *dmap_out,
+                              double *points_out) {
+    if (!disp || !Q16 || !points_out || batch < 0 || width < 1 || height < 1) return SV_ERR_ARG;
+    if (batch == 0) return SV_OK;
+    if (sv::launch_reproject_batch(disp, batch, width, height, Q16, XR9, XT3, dmap_out, points_out, nullptr) != 0) return SV_ERR_HIP;
+    return hipStreamSynchronize(nullptr) == hipSuccess ? SV_OK : SV_ERR_HIP;
+}
 
 int sv_legacy_box_means(const int32_t *boxes, int n, double *out) {
     std::lock_guard<std::mutex> lk(g_mu);

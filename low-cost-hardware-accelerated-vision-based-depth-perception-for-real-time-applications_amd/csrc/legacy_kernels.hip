@@ -41,4 +41,45 @@ void launch_dmap_and_cloud(const float *disp, unsigned char *dmap, double *point
     hipLaunchKernelGGL(k_dmap_cloud, dim3((W + 255) / 256, H), dim3(256), 0, st, disp, dmap, points, Q16, W, H);
 }
 
+// Batched form with the CUDA variant's optional robot-frame transform (parallel_includes/main/stereo_vision.cu:188-212:
+// point = XR * (X, Y, Z) + XT); Q / XR / XT travel as kernel arguments.
+struct ReprojectArgs {
+    double Q[16], XR[9], XT[3];
+    int has_xf;
+};
+
+__global__ __launch_bounds__(256) void k_reproject_batch(const float *__restrict__ disp, uint8_t *__restrict__ dmap, double *__restrict__ pts, ReprojectArgs a, int W, int H) {
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i >= W) return;
+    const size_t p = ((size_t)blockIdx.z * H + j) * W + i;
+    int v = __float2int_rn(disp[p] * 4.0f);  // convertTo(CV_8UC1, 4.0): round half to even, saturate
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    if (dmap) dmap[p] = (uint8_t)v;
+    const double x = (double)i, y = (double)j, d = (double)v;
+    double pos[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) pos[r] = ((a.Q[4 * r] * x + a.Q[4 * r + 1] * y) + a.Q[4 * r + 2] * d) + a.Q[4 * r + 3];
+    double X = pos[0] / pos[3], Y = pos[1] / pos[3], Z = pos[2] / pos[3];
+    if (a.has_xf) {
+        const double px = ((a.XR[0] * X + a.XR[1] * Y) + a.XR[2] * Z) + a.XT[0];
+        const double py = ((a.XR[3] * X + a.XR[4] * Y) + a.XR[5] * Z) + a.XT[1];
+        const double pz = ((a.XR[6] * X + a.XR[7] * Y) + a.XR[8] * Z) + a.XT[2];
+        X = px, Y = py, Z = pz;
+    }
+    pts[3 * p] = X;
+    pts[3 * p + 1] = Y;
+    pts[3 * p + 2] = Z;
+}
+
+int launch_reproject_batch(const float *disp, int batch, int W, int H, const double *Q16, const double *XR9, const double *XT3, unsigned char *dmap, double *points,
+                           hipStream_t st) {
+    ReprojectArgs a;
+    for (int i = 0; i < 16; i++) a.Q[i] = Q16[i];
+    a.has_xf = (XR9 || XT3) ? 1 : 0;
+    for (int i = 0; i < 9; i++) a.XR[i] = XR9 ? XR9[i] : (i % 4 == 0 ? 1.0 : 0.0);
+    for (int i = 0; i < 3; i++) a.XT[i] = XT3 ? XT3[i] : 0.0;
+    hipLaunchKernelGGL(k_reproject_batch, dim3((W + 255) / 256, H, batch), dim3(256), 0, st, disp, dmap, points, a, W, H);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 }  // namespace sv

@@ -56,6 +56,16 @@ _STAGE_DTYPES = {"desc1": np.uint8, "desc2": np.uint8, "dcan_raw": np.int16, "dc
                  "tri_id1": np.int32, "tri_id2": np.int32}
 
 
+def share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64; the library links the system one.  Whichever is loaded first serves both
+    (same SONAME), and only PyTorch's copy works for PyTorch: import torch first whenever it is installed, so that tensors
+    and the engine share one HIP runtime no matter in which order the application touches them."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def lib():
     """Loads the shared library (building it in-tree with hipcc if it is not there yet)."""
     global _lib
@@ -64,6 +74,7 @@ def lib():
     if not os.path.exists(LIB_PATH):
         from . import build as _build
         _build.build()
+    share_hip_runtime_with_torch()
     L = ctypes.CDLL(LIB_PATH)
     u8p, f32p, i32p = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p
     L.sv_params_init.argtypes = [ctypes.POINTER(SvParams), ctypes.c_int]
@@ -216,6 +227,30 @@ class StereoEngine:
         calls = (ctypes.c_int64 * cap)()
         n = lib().sv_kernel_times(self._h, names, ms, calls, cap)
         return {names[i].decode(): (ms[i], calls[i]) for i in range(n)}
+
+
+def reproject(disp, Q, XR=None, XT=None, want_dmap=True):
+    """Batched disparity -> (u8 x4 map, 3-D points) on the device (stereo_vision.cpp:316, :233-256; optional robot-frame transform of
+    the CUDA variant).  disp: CUDA float32 tensor [B,H,W]; Q: 4x4; returns (dmap uint8 [B,H,W] or None, points float64 [B,H,W,3])."""
+    import torch
+    assert disp.is_cuda and disp.dtype == torch.float32 and disp.dim() == 3
+    disp = disp.contiguous()
+    B, H, W = disp.shape
+    q = np.ascontiguousarray(Q, dtype=np.float64).reshape(16)
+    xr = None if XR is None else np.ascontiguousarray(XR, dtype=np.float64).reshape(9)
+    xt = None if XT is None else np.ascontiguousarray(XT, dtype=np.float64).reshape(3)
+    dmap = torch.empty((B, H, W), dtype=torch.uint8, device=disp.device) if want_dmap else None
+    pts = torch.empty((B, H, W, 3), dtype=torch.float64, device=disp.device)
+    torch.cuda.current_stream(disp.device).synchronize()
+    L = lib()
+    L.sv_reproject_batch_device.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p]
+    with torch.cuda.device(disp.device):
+        rc = L.sv_reproject_batch_device(disp.data_ptr(), B, W, H, q.ctypes.data, xr.ctypes.data if xr is not None else None,
+                                         xt.ctypes.data if xt is not None else None, dmap.data_ptr() if dmap is not None else None, pts.data_ptr())
+    if rc != 0:
+        raise StereoError("sv_reproject_batch_device failed (%d)" % rc)
+    return dmap, pts
 
 
 def host_support_filter(params, dcan, width, height):

@@ -33,6 +33,10 @@ class stereo_vision:
                  CAMERA_CALIBRATION_YAML=DEFAULT_CALIBRATION, subsampling=False):
         if not os.path.exists(so_lib_path):
             raise FileNotFoundError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`" % so_lib_path)
+        try:  # share one HIP runtime with PyTorch if the application also uses it (see engine.share_hip_runtime_with_torch)
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         self.sv = ctypes.CDLL(so_lib_path)
         self.width = width
         self.height = height

@@ -24,6 +24,7 @@ def test_header_symbols_exported(eng):
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = set(re.findall(r"\b(sv_[a-z_]+|generatePointCloud|clean|getColor)\s*\(", src))
     assert {"sv_create", "sv_process_batch_device", "generatePointCloud", "clean", "getColor"} <= names
+    eng.share_hip_runtime_with_torch()
     L = ctypes.CDLL(eng.LIB_PATH)
     missing = [n for n in sorted(names) if not hasattr(L, n)]
     assert not missing, missing

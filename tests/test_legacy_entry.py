@@ -11,6 +11,7 @@ from pyoracle import ElasParams
 
 
 def _q(eng, w, h, scale=1.0, variant=1):
+    eng.share_hip_runtime_with_torch()
     L = ctypes.CDLL(eng.LIB_PATH)
     L.sv_debug_stereo_rectify.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
     Q = np.zeros(16)
@@ -119,3 +120,35 @@ def test_generate_point_cloud_subsampling(oracle):
     want = np.clip(np.rint(buf * np.float32(4.0)), 0, 255).astype(np.uint8).reshape(H, W)
     assert np.array_equal(dmap, want)
     assert pts.shape == (W * H, 3)
+
+
+@pytest.mark.gpu
+def test_reproject_batch_device():
+    """Batched conversion + reprojection against the same arithmetic in numpy doubles (operation order of stereo_vision.cpp:233-256
+    and of projectParallel, stereo_vision.cu:200-211)."""
+    import torch
+
+    eng = util.pkg("engine")
+    rng = np.random.default_rng(4)
+    B, H, W = 3, 37, 101
+    d = rng.uniform(-12, 70, (B, H, W)).astype(np.float32)
+    d[0, :5] = -10
+    d[1, 3, 4] = 63.875  # x4 = 255.5 -> rounds to even 256 -> saturates
+    d[1, 3, 5] = 0.125   # x4 = 0.5 -> rounds to 0
+    d[1, 3, 6] = 0.375   # x4 = 1.5 -> rounds to 2
+    Q = np.array([[1, 0, 0, -50.5], [0, 1, 0, -18.25], [0, 0, 0, 721.5], [0, 0, 1.86, 0.01]])
+    XR = np.array([[0.1, -0.99, 0.02], [0.03, 0.2, -0.97], [0.99, 0.05, 0.11]])
+    XT = np.array([0.27, -0.08, 1.65])
+    want_u8 = np.clip(np.rint(d * np.float32(4.0)), 0, 255).astype(np.uint8)
+    jj, ii = np.mgrid[0:H, 0:W]
+    x, y, v = ii.astype(np.float64)[None], jj.astype(np.float64)[None], want_u8.astype(np.float64)
+    pos = [((Q[r, 0] * x + Q[r, 1] * y) + Q[r, 2] * v) + Q[r, 3] for r in range(4)]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        X, Y, Z = pos[0] / pos[3], pos[1] / pos[3], pos[2] / pos[3]
+        plain = np.stack([X, Y, Z], -1)
+        xf = np.stack([((XR[r, 0] * X + XR[r, 1] * Y) + XR[r, 2] * Z) + XT[r] for r in range(3)], -1)
+    dmap, pts = eng.reproject(torch.from_numpy(d).cuda(), Q)
+    assert np.array_equal(dmap.cpu().numpy(), want_u8)
+    assert np.array_equal(pts.cpu().numpy(), plain, equal_nan=True)
+    _, pts2 = eng.reproject(torch.from_numpy(d).cuda(), Q, XR, XT, want_dmap=False)
+    assert np.array_equal(pts2.cpu().numpy(), xf, equal_nan=True)
