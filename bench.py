@@ -187,7 +187,7 @@ def main():
     # batch-1 latency on rank 0 (ms/frame): one pair per call, one worker
     lat_ms = None
     if rank == 0:
-        e1 = eng.StereoEngine(W, H, params, device=local_rank, n_workers=2, chunk=1, n_streams=1, n_slots=2)
+        e1 = eng.StereoEngine(W, H, params, device=local_rank, n_workers=4, chunk=1, n_streams=1, n_slots=2)
         l1, r1 = left[:1].contiguous(), right[:1].contiguous()
         o1, o2 = d1[:1].clone(), d2[:1].clone()
         for _ in range(5):

@@ -136,6 +136,9 @@ void sv_kernel_timing_enable(sv_handle *h, int on);
  * triangulation (elas.cpp:442-501 -> Triangle "zQB"). */
 int sv_host_support_filter(const sv_params *p, int16_t *dcan, int width, int height, int32_t *support, int cap);
 int sv_host_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap);
+/* Same triangulation with the two halves of the top-level cut built by two threads, as the engine does in latency mode
+ * (chunk = 1); helper_delay_us > 0 delays the helper thread so that the caller ends up doing both halves itself. */
+int sv_host_delaunay_split(const int32_t *xy, int n, int32_t *tri_out, int cap, int helper_delay_us);
 
 /* ---- (A) the reference's exported symbols ------------------------------------------------------------- */
 

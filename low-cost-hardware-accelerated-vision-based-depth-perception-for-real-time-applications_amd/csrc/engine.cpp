@@ -98,6 +98,8 @@ struct Task {
     Slot *s;
     int pair;  // index inside the chunk
     int side;  // -1: filter stage (then triangulates side 0 and queues side 1); 1: triangulation of the right image
+    void (*fn)(void *) = nullptr;  // latency mode: a piece of a triangulation handed over by Delaunay::Spawn (then s == nullptr)
+    void *arg = nullptr;
 };
 
 
@@ -471,6 +473,18 @@ void pair_done(sv_handle *h, Slot *s) {
     if (s->pending.fetch_sub(1) == 1) chunk_host_done(h, s);
 }
 
+void spawn_to_pool(void *ctx, void (*fn)(void *), void *arg) {
+    sv_handle *h = static_cast<sv_handle *>(ctx);
+    {
+        std::lock_guard<std::mutex> lk(h->qmu);
+        Task t{nullptr, 0, 0};
+        t.fn = fn;
+        t.arg = arg;
+        h->queue.push_front(t);
+    }
+    h->qcv.notify_one();
+}
+
 // one Delaunay triangulation of a pair's support points; errors are recorded, never thrown (the completion accounting of
 // the caller must run in any case)
 void triangulate_side(sv_handle *h, HostScratch *sc, Slot *s, int j, int side) {
@@ -485,7 +499,9 @@ void triangulate_side(sv_handle *h, HostScratch *sc, Slot *s, int j, int side) {
         sc->xy[2 * q + 1] = sup[3 * q + 1];
     }
     const auto t0 = std::chrono::steady_clock::now();
-    const int nt = sc->dl.triangulate(sc->xy.data(), ns, blob + meta[3 + 2 * side], 2 * ns);
+    // latency mode: the halves of the top-level cut go to two threads (throughput mode keeps every core busy with whole pairs)
+    const Delaunay::Spawn spawn{spawn_to_pool, h};
+    const int nt = sc->dl.triangulate(sc->xy.data(), ns, blob + meta[3 + 2 * side], 2 * ns, (h->chunk == 1 && h->pool.size() >= 3) ? &spawn : nullptr);
     if (h->timing) h->host_delaunay_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     if (nt < 0 || nt > d.max_tri) {
         note_error(h, "triangle capacity exceeded");
@@ -496,6 +512,10 @@ void triangulate_side(sv_handle *h, HostScratch *sc, Slot *s, int j, int side) {
 }
 
 void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
+    if (t.fn) {
+        t.fn(t.arg);
+        return;
+    }
     Slot *s = t.s;
     const Dims &d = h->kp.d;
     const int lat = d.Wc * d.Hc;
@@ -1136,10 +1156,10 @@ int sv_process_batch_host(sv_handle *h, const uint8_t *left, const uint8_t *righ
         h->error = e.what();
         rc = SV_ERR_HIP;
     }
-    if (dl) hipFree(dl);
-    if (dr) hipFree(dr);
-    if (o1) hipFree(o1);
-    if (o2) hipFree(o2);
+    if (dl) (void)hipFree(dl);
+    if (dr) (void)hipFree(dr);
+    if (o1) (void)hipFree(o1);
+    if (o2) (void)hipFree(o2);
     return rc;
 }
 
@@ -1212,6 +1232,27 @@ int sv_host_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap) {
     if (!xy || !tri_out) return SV_ERR_ARG;
     Delaunay dl;
     return dl.triangulate(xy, n, tri_out, cap);
+}
+
+int sv_host_delaunay_split(const int32_t *xy, int n, int32_t *tri_out, int cap, int helper_delay_us) {
+    if (!xy || !tri_out) return SV_ERR_ARG;
+    struct Helper {
+        std::vector<std::thread> threads;
+        int delay_us;
+        static void run(void *ctx, void (*fn)(void *), void *arg) {
+            Helper *hp = static_cast<Helper *>(ctx);
+            const int delay = hp->delay_us;
+            hp->threads.emplace_back([fn, arg, delay] {
+                if (delay > 0) std::this_thread::sleep_for(std::chrono::microseconds(delay));
+                fn(arg);
+            });
+        }
+    } helper{{}, helper_delay_us};
+    const Delaunay::Spawn spawn{&Helper::run, &helper};
+    Delaunay dl;
+    const int nt = dl.triangulate(xy, n, tri_out, cap, &spawn);
+    for (std::thread &t : helper.threads) t.join();  // a late helper finds the work claimed and returns at once
+    return nt;
 }
 
 } /* extern "C" */

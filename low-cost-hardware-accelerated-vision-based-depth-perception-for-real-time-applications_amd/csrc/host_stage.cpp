@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -365,11 +366,11 @@ uint32_t Delaunay::rnd(uint32_t choices) {  // triangle.cpp:3833-3836; seed < 71
     return seed_ / (714025u / choices + 1);
 }
 
-Delaunay::H Delaunay::make() {  // triangle.cpp:2068-2101; slot 0 stands for "outer space"
-    Tri &t = tris_[n_slots_];
+Delaunay::H Delaunay::make(int &cursor) {  // triangle.cpp:2068-2101; slot 0 stands for "outer space"
+    Tri &t = tris_[cursor];
     t.nbr[0] = t.nbr[1] = t.nbr[2] = 0;
     t.vtx[0] = t.vtx[1] = t.vtx[2] = -1;
-    return (H)(n_slots_++) << 2;
+    return (H)(cursor++) << 2;
 }
 
 // sort keys: x and y are biased to unsigned 16-bit and packed as (x << 16 | y); the (y, x) order is the key rotated by 16
@@ -472,7 +473,7 @@ void Delaunay::alternate_cuts(Pt *a, int m) {
 }
 
 // triangle.cpp:5362-5651
-void Delaunay::merge(H &farleft, H &innerleft, H &innerright, H &farright, int axis) {
+void Delaunay::merge(H &farleft, H &innerleft, H &innerright, H &farright, int axis, int &cursor) {
     Tri *T = tris_.data();
     const int32_t *xy = xy_;
     int ild = DEST(innerleft), ila = APEX(innerleft);
@@ -524,7 +525,7 @@ void Delaunay::merge(H &farleft, H &innerleft, H &innerright, H &farright, int a
         }
     }
     H leftcand = SYM(innerleft), rightcand = SYM(innerright);
-    H base = make();
+    H base = make(cursor);
     T = tris_.data();
     BOND(base, innerleft);
     base = hnext(base);
@@ -539,7 +540,7 @@ void Delaunay::merge(H &farleft, H &innerleft, H &innerright, H &farright, int a
     for (;;) {
         const bool leftdone = orient(xy, ul, ll, lr) <= 0, rightdone = orient(xy, ur, ll, lr) <= 0;
         if (leftdone && rightdone) {
-            H top = make();
+            H top = make(cursor);
             T = tris_.data();
             ORG(top) = ll;
             DEST(top) = lr;
@@ -644,10 +645,10 @@ void Delaunay::merge(H &farleft, H &innerleft, H &innerright, H &farright, int a
 }
 
 // triangle.cpp:5670-5815
-void Delaunay::build(const Pt *p, int n, int axis, H &farleft, H &farright) {
+void Delaunay::build(const Pt *p, int n, int axis, H &farleft, H &farright, int &cursor) {
     const int a[3] = {p[0].id, p[1].id, n > 2 ? p[2].id : -1};
     if (n == 2) {
-        H l = make(), r = make();
+        H l = make(cursor), r = make(cursor);
         Tri *T = tris_.data();
         ORG(l) = a[0];
         DEST(l) = a[1];
@@ -663,7 +664,7 @@ void Delaunay::build(const Pt *p, int n, int axis, H &farleft, H &farright) {
         farright = r;
         farleft = hprev(r);
     } else if (n == 3) {
-        H mid = make(), t1 = make(), t2 = make(), t3 = make();
+        H mid = make(cursor), t1 = make(cursor), t2 = make(cursor), t3 = make(cursor);
         Tri *T = tris_.data();
         const int64_t area = orient(xy_, a[0], a[1], a[2]);
         if (area == 0) {
@@ -722,13 +723,18 @@ void Delaunay::build(const Pt *p, int n, int axis, H &farleft, H &farright) {
     } else {
         const int divider = n >> 1;
         H innerleft, innerright;
-        build(p, divider, 1 - axis, farleft, innerleft);
-        build(p + divider, n - divider, 1 - axis, innerright, farright);
-        merge(farleft, innerleft, innerright, farright, axis);
+        build(p, divider, 1 - axis, farleft, innerleft, cursor);
+        build(p + divider, n - divider, 1 - axis, innerright, farright, cursor);
+        merge(farleft, innerleft, innerright, farright, axis, cursor);
     }
 }
 
-int Delaunay::triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap) {
+// Slots a subproblem of n vertices allocates: 2 for a pair, 4 for a triple, 2 per merge.  It only depends on n, so the two
+// halves of the top-level cut can be built at the same time into disjoint, pre-computed slot ranges and still leave the
+// pool exactly as the sequential recursion does (the output order is the pool order).
+static int slots_of(int n) { return n == 2 ? 2 : n == 3 ? 4 : slots_of(n >> 1) + slots_of(n - (n >> 1)) + 2; }
+
+int Delaunay::triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap, const Spawn *spawn) {
     if (n < 3) return 0;
     xy_ = xy;
     seed_ = 1;  // triangle.cpp:3818: reseeded on every call
@@ -736,7 +742,7 @@ int Delaunay::triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap) {
     // leaves allocate <= 4 slots per 3 points (2 per 2), every merge 2 more: < 3n in total, + the outer-space slot
     if ((int)tris_.size() < 3 * n + 8) tris_.resize(3 * n + 8);
     n_slots_ = 0;
-    make();
+    make(n_slots_);
     Pt *a = order_.data();
     for (int i = 0; i < n; i++) {
         const int32_t x = xy[2 * i], y = xy[2 * i + 1];
@@ -753,7 +759,35 @@ int Delaunay::triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap) {
     if (m < 2) return 0;
     alternate_cuts(a, m);
     H hl, hr;
-    build(a, m, 0, hl, hr);
+    if (spawn && spawn->run && m >= 64) {
+        // latency mode: the right half of the top-level cut is built by another thread (or by this one afterwards if nobody
+        // picked it up: the closure is claimed with a compare-and-swap, so it runs exactly once and nobody can wait for ever)
+        const int divider = m >> 1;
+        struct Half {
+            Delaunay *self;
+            const Pt *p;
+            int n, cursor;
+            H l, r;
+            std::atomic<int> state;  // 0 queued, 1 claimed, 2 done
+            static void run(void *arg) {
+                Half *h = static_cast<Half *>(arg);
+                int expected = 0;
+                if (!h->state.compare_exchange_strong(expected, 1)) return;
+                h->self->build(h->p, h->n, 1, h->l, h->r, h->cursor);
+                h->state.store(2, std::memory_order_release);
+            }
+        } right{this, a + divider, m - divider, 1 + slots_of(divider), 0, 0, {0}};
+        spawn->run(spawn->ctx, &Half::run, &right);
+        H innerleft;
+        build(a, divider, 1, hl, innerleft, n_slots_);
+        Half::run(&right);  // no-op unless it is still unclaimed
+        while (right.state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
+        n_slots_ = right.cursor;
+        merge(hl, innerleft, right.l, right.r, 0, n_slots_);
+        hr = right.r;
+    } else {
+        build(a, m, 0, hl, hr, n_slots_);
+    }
     // Output in slot order (= pool order, triangle.cpp:7449-7500) skipping bounding triangles (what removeghosts,
     // :5817-5859, deletes): corners are org/dest/apex at orientation 0.
     int count = 0;

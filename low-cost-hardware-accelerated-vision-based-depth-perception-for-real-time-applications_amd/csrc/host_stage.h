@@ -30,9 +30,15 @@ int support_filter_t(const sv_params &p, int16_t *T, int W, int H, int32_t *out,
 // The object owns its scratch memory and is reused from pair to pair (no allocation in steady state).
 class Delaunay {
    public:
+    // Optional helper for latency mode: run(ctx, fn, arg) makes some other thread call fn(arg) soon.  fn may also be called by
+    // the triangulation itself; it does its work exactly once, and `arg` stays valid until triangulate() returns.
+    struct Spawn {
+        void (*run)(void *ctx, void (*fn)(void *), void *arg);
+        void *ctx;
+    };
     // xy: n points (x0,y0,x1,y1,...).  tri_out receives 3*count vertex indices; returns count (<= 2n), or -1 if cap
-    // (in triangles) is too small.
-    int triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap);
+    // (in triangles) is too small.  With `spawn` the two halves of the top-level cut are built concurrently.
+    int triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap, const Spawn *spawn = nullptr);
 
    private:
     struct Tri {
@@ -53,12 +59,12 @@ class Delaunay {
     int n_slots_ = 0;
     uint32_t seed_ = 1;
 
-    H make();
+    H make(int &cursor);
     void sort_xy(Pt *a, int n);
     void kd_order(uint64_t *xs, uint64_t *xalt, uint64_t *ys, uint64_t *yalt, int n, int axis, Pt *out);
     void alternate_cuts(Pt *a, int m);
-    void build(const Pt *a, int n, int axis, H &farleft, H &farright);
-    void merge(H &farleft, H &innerleft, H &innerright, H &farright, int axis);
+    void build(const Pt *a, int n, int axis, H &farleft, H &farright, int &cursor);
+    void merge(H &farleft, H &innerleft, H &innerright, H &farright, int axis, int &cursor);
     uint32_t rnd(uint32_t choices);
 };
 

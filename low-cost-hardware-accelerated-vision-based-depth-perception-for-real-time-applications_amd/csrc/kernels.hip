@@ -1241,6 +1241,16 @@ __device__ __forceinline__ int ccl_find(const int32_t *L, int x) {
     return x;
 }
 
+// the same walk on a forest that no longer changes (plain, cacheable loads)
+__device__ __forceinline__ int ccl_find_frozen(const int32_t *__restrict__ L, int x) {
+    int p = L[x];
+    while (p != x) {
+        x = p;
+        p = L[x];
+    }
+    return x;
+}
+
 __device__ __forceinline__ void ccl_union(int32_t *L, int a, int b) {
     for (;;) {
         a = ccl_find(L, a);
@@ -1475,7 +1485,7 @@ __device__ void ccl_legacy_map(const KParams &k, float *D, int32_t *label, int32
 
 // ---- second half of the run-based labelling: three small grid-wide passes over the run records ----
 // (a) unions across band borders: first row of band b against the last row of band b-1, one thread per 64-pixel mask word
-__global__ __launch_bounds__(256) void k_ccl_border(KParams k, int nproc, const int32_t *__restrict__ blob, CclWs ws) {
+__global__ __launch_bounds__(256) void k_ccl_border(int nproc, const int32_t *__restrict__ blob, CclWs ws) {
     const int m = blockIdx.y;
     if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m]) return;
     const int nch = ws.nch, cap = ws.cap, nb = ws.nb;
@@ -1497,7 +1507,7 @@ __global__ __launch_bounds__(256) void k_ccl_border(KParams k, int nproc, const 
 }
 
 // (b) component sizes at the global roots: every band-local root adds its component's pixel count
-__global__ __launch_bounds__(256) void k_ccl_total(KParams k, int nproc, const int32_t *__restrict__ blob, CclWs ws) {
+__global__ __launch_bounds__(256) void k_ccl_total(int nproc, const int32_t *__restrict__ blob, CclWs ws) {
     const int m = blockIdx.y, b = blockIdx.x;
     if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m]) return;
     const int cap = ws.cap, nb = ws.nb;
@@ -1508,7 +1518,7 @@ __global__ __launch_bounds__(256) void k_ccl_total(KParams k, int nproc, const i
     for (int i = threadIdx.x; i < T; i += 256) {
         const int4 r = RUNS[i];
         if (r.z != i) continue;
-        atomicAdd(&TOT[ccl_find(GP, b * cap + i)], r.w);
+        atomicAdd(&TOT[ccl_find_frozen(GP, b * cap + i)], r.w);
     }
 }
 
@@ -1525,7 +1535,7 @@ __global__ __launch_bounds__(256) void k_ccl_apply(KParams k, int nproc, const i
     for (int i = threadIdx.x; i < T; i += 256) {
         const int4 r = RUNS[i];
         if (r.y >= k.speckle_size) continue;  // a run that long is a large component by itself
-        if (TOT[ccl_find(GP, b * cap + r.z)] >= k.speckle_size) continue;
+        if (TOT[ccl_find_frozen(GP, b * cap + r.z)] >= k.speckle_size) continue;
         for (int q = 0; q < r.y; q++) D[r.x + q] = -10.0f;
     }
 }
@@ -1555,8 +1565,8 @@ void launch_speckle(const KParams &k, const SlotDev &s, int n, int nproc, hipStr
             g.store(lds);
     }
     SV_LAUNCH(K_CCL_BAND, k_ccl_band, dim3(ws.nb, maps), dim3(CCL_THREADS), lds, st, k, nproc, s.blob, s.disp, ws);
-    if (ws.nb > 1) SV_LAUNCH(K_CCL_FINISH, k_ccl_border, dim3(((ws.nb - 1) * ws.nch + 255) / 256, maps), dim3(256), 0, st, k, nproc, s.blob, ws);
-    SV_LAUNCH(K_CCL_FINISH, k_ccl_total, dim3(ws.nb, maps), dim3(256), 0, st, k, nproc, s.blob, ws);
+    if (ws.nb > 1) SV_LAUNCH(K_CCL_FINISH, k_ccl_border, dim3(((ws.nb - 1) * ws.nch + 255) / 256, maps), dim3(256), 0, st, nproc, s.blob, ws);
+    SV_LAUNCH(K_CCL_FINISH, k_ccl_total, dim3(ws.nb, maps), dim3(256), 0, st, nproc, s.blob, ws);
     SV_LAUNCH(K_CCL_FINISH, k_ccl_apply, dim3(ws.nb, maps), dim3(256), 0, st, k, nproc, s.blob, s.disp, ws);
     int32_t *cnt = reinterpret_cast<int32_t *>(s.tmp);  // slow path only: the filters' scratch map is free during speckle removal
     SV_LAUNCH(K_CCL_FINISH, k_ccl_slow, dim3(maps), dim3(1024), 0, st, k, nproc, s.blob, s.disp, ws, s.tri_id, s.csize, cnt);
@@ -1629,7 +1639,8 @@ void launch_gap_rows(const KParams &k, const SlotDev &s, int n, int nproc, hipSt
 
 // Columns: a workgroup owns 64 columns; its 4 wavefronts split the rows.  Pass 1 builds the per-column validity
 // bit masks in LDS (coalesced row reads), pass 2 resolves every invalid pixel on its own from the masks.
-__global__ __launch_bounds__(256) void k_gap_cols(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp) {
+#define GAPC_THREADS 512  // 8 wavefronts: one 64-row word each for maps up to 512 rows
+__global__ __launch_bounds__(GAPC_THREADS) void k_gap_cols(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp) {
     const Dims &d = k.d;
     const int m = blockIdx.y;
     if (blob[(m / nproc) * META_WORDS] < 3) return;
@@ -1639,11 +1650,11 @@ __global__ __launch_bounds__(256) void k_gap_cols(KParams k, int nproc, const in
     extern __shared__ unsigned long long cmask[];  // [nw][64]
     const int nw = (d.H + 63) / 64;
     const bool live = u < d.W;
-    for (int w = wave; w < nw; w += 4) {
+    for (int w = wave; w < nw; w += GAPC_THREADS / 64) {
         unsigned long long word = 0;
         const int vend = min(64, d.H - w * 64);
         const float *col = D + (size_t)(w * 64) * d.W + u;
-#pragma unroll 8
+#pragma unroll 16
         for (int b = 0; b < vend; b++) {
             const float val = live ? col[(size_t)b * d.W] : -1.0f;
             word |= (unsigned long long)(val >= 0) << b;
@@ -1653,7 +1664,7 @@ __global__ __launch_bounds__(256) void k_gap_cols(KParams k, int nproc, const in
     __syncthreads();
     if (!live) return;
     const int gw = k.gap_width;
-    for (int w = wave; w < nw; w += 4) {
+    for (int w = wave; w < nw; w += GAPC_THREADS / 64) {
         const unsigned long long word = cmask[w * 64 + lane];
         const int vend = min(64, d.H - w * 64);
         unsigned long long inval = ~word & (vend == 64 ? ~0ull : ((1ull << vend) - 1ull));
@@ -1703,7 +1714,7 @@ __global__ __launch_bounds__(256) void k_gap_cols(KParams k, int nproc, const in
 
 void launch_gap_cols(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st) {
     const size_t shmem = (size_t)((k.d.H + 63) / 64) * 64 * sizeof(unsigned long long);
-    SV_LAUNCH(K_GAP_COLS, k_gap_cols, dim3((k.d.W + 63) / 64, n * nproc), dim3(256), shmem, st, k, nproc, s.blob, s.disp);
+    SV_LAUNCH(K_GAP_COLS, k_gap_cols, dim3((k.d.W + 63) / 64, n * nproc), dim3(GAPC_THREADS), shmem, st, k, nproc, s.blob, s.disp);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -93,7 +93,7 @@ bool legacy_init(int width, int height, float scale, const char *yaml, bool subs
     cfg.width = width;
     cfg.height = height;
     cfg.device = 0;
-    cfg.n_workers = 2;
+    cfg.n_workers = 4;  // latency mode: two triangulations, each split over two threads
     cfg.n_streams = 1;
     cfg.n_slots = 2;
     cfg.chunk = 1;

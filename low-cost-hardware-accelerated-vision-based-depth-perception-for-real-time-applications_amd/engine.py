@@ -264,12 +264,18 @@ def host_support_filter(params, dcan, width, height):
     return out[:n].copy()
 
 
-def host_delaunay(xy):
-    """Product host stage: Delaunay triangulation of integer points (n,2) -> (nt,3) int32."""
+def host_delaunay(xy, split=False, helper_delay_us=0):
+    """Product host stage: Delaunay triangulation of integer points (n,2) -> (nt,3) int32.  split: build the two halves of
+    the top-level cut on two threads (what the engine does in latency mode)."""
     xy = np.ascontiguousarray(xy, dtype=np.int32)
     n = xy.shape[0]
     out = np.empty((2 * n + 8, 3), np.int32)
-    nt = lib().sv_host_delaunay(xy.ctypes.data, n, out.ctypes.data, 2 * n + 8)
+    if split:
+        L = lib()
+        L.sv_host_delaunay_split.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        nt = L.sv_host_delaunay_split(xy.ctypes.data, n, out.ctypes.data, 2 * n + 8, int(helper_delay_us))
+    else:
+        nt = lib().sv_host_delaunay(xy.ctypes.data, n, out.ctypes.data, 2 * n + 8)
     if nt < 0:
         raise StereoError("triangle capacity")
     return out[:nt].copy()

@@ -118,3 +118,20 @@ def test_host_filter_random_lattices(eng, oracle):
         n = L.orc_support_filter(ctypes.byref(po), a.ctypes.data, W, H, want.ctypes.data, want.shape[0])
         got = eng.host_support_filter(pe, d.copy(), W, H)
         assert n == got.shape[0] and np.array_equal(got, want[:n]), (it, W, H, step)
+
+
+def test_host_delaunay_split_halves(eng):
+    """Latency mode builds the two halves of the top-level cut on two threads into pre-computed slot ranges: same triangles,
+    same order - also when the helper comes too late and the caller builds both halves itself."""
+    rng = np.random.default_rng(17)
+    for it in range(60):
+        n = int(rng.integers(64, 3000))
+        if it % 3 == 0:
+            pts = rng.integers(0, 250, (n, 2)) * 5
+        elif it % 3 == 1:
+            pts = np.stack([rng.integers(-50, 1300, n), rng.integers(0, 75, n) * 5], 1)
+        else:
+            pts = rng.integers(0, 4000, (n, 2))
+        a = eng.host_delaunay(pts)
+        b = eng.host_delaunay(pts, split=True, helper_delay_us=0 if it % 2 else 20000)
+        assert a.shape == b.shape and np.array_equal(a, b), it

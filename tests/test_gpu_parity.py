@@ -180,7 +180,7 @@ def test_latency_mode_single_pairs(eng, monkeypatch, inline):
         monkeypatch.setenv("SV_NO_INLINE", "1")
     entry = DIG["kitti0_d128"]
     L, R = util.case_images(entry)
-    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=1, n_slots=2, n_streams=1, n_workers=2)
+    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=1, n_slots=2, n_streams=1, n_workers=4)  # 4 workers: split triangulations
     try:
         for rep in range(3):
             d1, d2, st = e.process_host(L, R)

@@ -6,7 +6,7 @@ eng = importlib.import_module(PKG + ".engine"); synth = importlib.import_module(
 W, H, D = 1242, 375, 128
 b = synth.make_batch(1000, 4, H, W, D)
 left = torch.from_numpy(np.ascontiguousarray(b[:, 0])).cuda(); right = torch.from_numpy(np.ascontiguousarray(b[:, 1])).cuda()
-e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), n_workers=2, chunk=1, n_streams=1, n_slots=2)
+e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), n_workers=int(os.environ.get("LAT_WORKERS", "4")), chunk=1, n_streams=1, n_slots=2)
 d1 = torch.zeros((1, H, W), dtype=torch.float32, device='cuda'); d2 = torch.zeros_like(d1)
 for i in range(20): e.process_device(left[i % 4:i % 4 + 1], right[i % 4:i % 4 + 1], d1, d2)
 ts = []
