@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--sync-steps", action="store_true", help="wait for each step before submitting the next (default: streamed submission)")
     ap.add_argument("--serial-kernels", action="store_true", help="extra pass with one slot / one stream (no kernel overlap) to get clean per-kernel times")
+    ap.add_argument("--real-pair", action="store_true", help="fill the batch with copies of the committed kitti_mini pair 0 instead of synthetic pairs (sanity check of the synthetic workload: real maps are more fragmented)")
     ap.add_argument("--subsampling", action="store_true", help="Elas::parameters::subsampling (the reference's s1 benchmark rows): half-resolution maps")
     ap.add_argument("--gather", action="store_true", help="after the timed region, also gather all left maps on rank 0 (RCCL) and report the time")
     args = ap.parse_args()
@@ -129,6 +130,14 @@ def main():
     # weak scaling: every rank owns B distinct pairs (seeds 1000 + rank*B + i); no data-path collective
     seeds = par.pair_seeds(rank, B, seed0=wseed)
     batch = synth.make_batch(seeds[0], B, H, W, D, scale=wscale)
+    data_desc = "synthetic"
+    if args.real_pair:
+        from PIL import Image
+        gl = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "kitti0_left.png")))
+        gr = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "kitti0_right.png")))
+        assert gl.shape == (H, W), "the committed pair is 1242x375"
+        batch[:, 0], batch[:, 1] = gl, gr
+        data_desc = "kitti_mini pair 0 replicated"
     left = torch.from_numpy(np.ascontiguousarray(batch[:, 0])).cuda()
     right = torch.from_numpy(np.ascontiguousarray(batch[:, 1])).cuda()
     params = eng.SvParams.driver(D - 1)
@@ -184,23 +193,32 @@ def main():
         serial_k = {k: round(1e3 * v[0] / B, 3) for k, v in sorted(kt.items(), key=lambda kv: -kv[1][0]) if v[1] > 0 and not k.startswith("host:")}
         serial_k["_sum"] = round(sum(serial_k.values()), 3)
 
-    # batch-1 latency on rank 0 (ms/frame): one pair per call, one worker
+    # batch-1 latency on rank 0 (ms/frame), SURVEY.md §8d config 2: pair 0 of kitti_mini (the committed gray fixture; the first
+    # synthetic pair if the fixture is absent), one pair per call, 200 timed calls after 20 warm-ups
     lat_ms = None
     if rank == 0:
         e1 = eng.StereoEngine(W, H, params, device=local_rank, n_workers=4, chunk=1, n_streams=1, n_slots=2)
-        l1, r1 = left[:1].contiguous(), right[:1].contiguous()
+        l1, r1, which = left[:1].contiguous(), right[:1].contiguous(), "synthetic seed %d" % seeds[0]
+        try:
+            from PIL import Image
+            gl = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "kitti0_left.png")))
+            gr = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "kitti0_right.png")))
+            if gl.shape == (H, W):
+                l1, r1, which = torch.from_numpy(np.ascontiguousarray(gl[None])).cuda(), torch.from_numpy(np.ascontiguousarray(gr[None])).cuda(), "kitti_mini pair 0"
+        except (OSError, ImportError):
+            pass
         o1, o2 = d1[:1].clone(), d2[:1].clone()
-        for _ in range(5):
+        for _ in range(20):
             e1.process_device(l1, r1, o1, o2)
         ts = []
-        for _ in range(50):
+        for _ in range(200):
             torch.cuda.synchronize()
             a = time.perf_counter()
             e1.process_device(l1, r1, o1, o2)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - a)
         e1.close()
-        lat_ms = {"median": round(1e3 * float(np.median(ts)), 3), "p99": round(1e3 * float(np.percentile(ts, 99)), 3)}
+        lat_ms = {"median": round(1e3 * float(np.median(ts)), 3), "p99": round(1e3 * float(np.percentile(ts, 99)), 3), "pair": which, "calls": 200}
     engine.close()
 
     if rank == 0:
@@ -212,7 +230,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
+            "dtype": "u8", "data": data_desc,
             "config": {"workload": "%s_%dx%d_D%d_batch%d_per_gpu_streamed" % (args.workload.split("_")[0], W, H, D, B), "width": W, "height": H, "disp_max": D - 1,
                        "preset": "driver(MIDDLEBURY+only_left+adaptive_mean+median)" + ("+subsampling" if args.subsampling else ""), "pairs_per_gpu_per_step": B,
                        "parallelism": "batch-sharded x%d, no data-path collective" % world},

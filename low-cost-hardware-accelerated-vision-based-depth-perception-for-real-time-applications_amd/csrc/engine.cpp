@@ -230,12 +230,13 @@ void fill_kparams(sv_handle *h) {
     k.speckle_size = p.speckle_size;
     k.gap_width = p.ipol_gap_width;
     k.add_corners = p.add_corners;
-    // run tables of the speckle stage (LDS of k_ccl_band, 16 B per run next to the band's bit masks): 2048 runs per 16-row band,
-    // more for wide images (a 4K band holds ~3x the pixels), within 144 KB of the CU's 160 KB
-    k.ccl_cap = std::max(2048, std::min(8192, ((d.W * 16 / 10 + 1023) / 1024) * 1024));
+    // run tables of the speckle stage (LDS of k_ccl_band, 12 B per run next to the band's bit masks).  Real disparity maps are
+    // fragmented: kitti_mini pair 0 has up to 170 runs per row, i.e. 1 400 per 8-row band.  4096 runs per band (512 per row) for
+    // images up to 2048 columns, more for wider ones, within 144 KB of the CU's 160 KB; beyond that a map takes the slow path.
+    k.ccl_cap = std::max(4096, std::min(8192, ((d.W * 2 + 1023) / 1024) * 1024));
     if (const char *e = getenv("SV_DEBUG_CCL_CAP")) k.ccl_cap = std::max(1, atoi(e));  // tests: force the per-pixel slow path
     {
-        const long room = (144L * 1024 - 256 - 16L * ((d.W + 63) / 64) * 28) / 16;
+        const long room = (144L * 1024 - 256 - 8L * ((d.W + 63) / 64) * 28) / 12;
         k.ccl_cap = (int)std::max(1L, std::min((long)k.ccl_cap, room));
     }
     k.rt_cap = 512;
@@ -1026,7 +1027,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     fill_kparams(h);
     int npool = cfg->n_workers > 0 ? cfg->n_workers : default_pool_size();
     // defaults: 64 pairs per launch, 8 slots, 4 phase-2 streams, scaled down so that the slots stay within a memory budget
-    // (about 80 bytes per pixel per pair in flight: 37 MB at KITTI size, 0.66 GB at 4K)
+    // (about 92 bytes per pixel per pair in flight: 43 MB at KITTI size, 0.76 GB at 4K)
     int np2 = cfg->n_streams > 0 ? cfg->n_streams : 4;
     int nslots = cfg->n_slots > 0 ? cfg->n_slots : 8;
     h->chunk = cfg->chunk > 0 ? cfg->chunk : 64;
@@ -1035,7 +1036,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         (void)hipSetDevice(cfg->device);
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
         const double budget = std::min(24.0 * (1 << 30), 0.25 * (double)free_b);
-        const double per_pair = 80.0 * (double)h->kp.d.N + 4.0e6;
+        const double per_pair = 92.0 * (double)h->kp.d.N + 4.0e6;
         while ((double)h->chunk * nslots * per_pair > budget) {
             if (cfg->chunk <= 0 && h->chunk > 1 && (h->chunk >= 2 * nslots || cfg->n_slots > 0 || nslots <= 3))
                 h->chunk = (h->chunk + 1) / 2;

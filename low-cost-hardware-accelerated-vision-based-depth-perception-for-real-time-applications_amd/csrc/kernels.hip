@@ -1169,8 +1169,8 @@ void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st, float 
 //       k_ccl_band    one workgroup per band of CCL_R rows.  Reads the band once, keeps three bit masks per row in LDS
 //                     (valid / run start / linked to the pixel above), numbers the runs by prefix pop-counts, unions
 //                     vertically adjacent runs in an LDS union-find (one thread per 64-pixel mask word, walking its set
-//                     bits), and writes one record per run (first pixel, length, band-local root, component size at
-//                     roots) plus the masks of its first and last row.
+//                     bits), and writes one record per run (first pixel, length, root, component size at band-local
+//                     roots; records are bump-allocated per map) plus the masks of its first and last row.
 //       k_ccl_border / k_ccl_total / k_ccl_apply  ("ccl_finish" in the timing report): three small grid-wide passes over the
 //                     run records - unions across band borders (global union-find over run records), component sizes
 //                     summed at the global roots, runs of components smaller than speckle_size overwritten with -10.
@@ -1183,18 +1183,22 @@ __device__ __forceinline__ size_t map_offset(const Dims &d, int m, int nproc) { 
     return (size_t)(pair * 2 + side) * d.N;
 }
 
-constexpr int CCL_R = 16;        // rows per band
+constexpr int CCL_R = 8;         // rows per band
 constexpr int CCL_THREADS = 512;
 
+// Run records of a map are bump-allocated (a band takes as many as it has runs), `rcap` per map: real disparity maps are far
+// more fragmented than smooth synthetic ones (kitti_mini pair 0: 49 000 runs, up to 170 per row), worst case one run per pixel.
 struct CclWs {  // workspace views of one launch (ccl_views lays them out)
-    int4 *runs;          // [maps][nb][cap]  (first pixel, length, band-local root, component size if root)
-    int32_t *gparent;    // [maps][nb][cap]  union-find over run records, node = band*cap + run
-    int32_t *total;      // [maps][nb][cap]  component size, accumulated at global roots
+    int4 *runs;          // [maps][rcap]     (first pixel, length, root as map-wide run index, component size if band-local root)
+    int32_t *gparent;    // [maps][rcap]     union-find over the run records
+    int32_t *total;      // [maps][rcap]     component size, accumulated at global roots
+    int32_t *nruns;      // [maps]           records handed out so far (bump allocator); cleared by k_ccl_slow
+    int32_t *boff;       // [maps][nb]       first record of each band
     int32_t *tcount;     // [maps][nb]       runs per band
     int32_t *flag;       // [maps]           1 = some band overflowed; cleared by k_ccl_slow
     uint64_t *bwords;    // [maps][nb][5][nch]  first row: start, valid, up-link masks; last row: start, valid masks
     int32_t *bbase;      // [maps][nb][2][nch]  run number before each 64-pixel word of the first / last row
-    int cap, nb, nch;
+    int cap, rcap, nb, nch;
 };
 
 static size_t ccl_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1202,25 +1206,32 @@ static size_t ccl_align(size_t x) { return (x + 255) & ~(size_t)255; }
 // carves the views out of the workspace; returns the bytes used
 static size_t ccl_views(const KParams &k, void *ws, int maps_cap, CclWs &w) {
     w.cap = k.ccl_cap;
-    w.nb = (k.d.H + CCL_R - 1) / CCL_R;
-    w.nch = (k.d.W + 63) / 64;
+    w.rcap = std::max(k.d.Nm / 4, 4096);
+    w.nb = (k.d.Hm + CCL_R - 1) / CCL_R;
+    w.nch = (k.d.Wm + 63) / 64;
+    // sized for the full-resolution map so that one workspace serves both modes of a handle
+    const size_t rcap_full = (size_t)std::max(k.d.N / 4, 4096), nb_full = (size_t)(k.d.H + CCL_R - 1) / CCL_R, nch_full = (size_t)(k.d.W + 63) / 64;
     uint8_t *base = static_cast<uint8_t *>(ws);
     size_t o = 0;
-    const size_t nodes = (size_t)maps_cap * w.nb * w.cap;
+    const size_t nodes = (size_t)maps_cap * rcap_full;
     w.runs = reinterpret_cast<int4 *>(base + o);
     o += ccl_align(nodes * sizeof(int4));
     w.gparent = reinterpret_cast<int32_t *>(base + o);
     o += ccl_align(nodes * 4);
     w.total = reinterpret_cast<int32_t *>(base + o);
     o += ccl_align(nodes * 4);
+    w.nruns = reinterpret_cast<int32_t *>(base + o);
+    o += ccl_align((size_t)maps_cap * 4);
+    w.boff = reinterpret_cast<int32_t *>(base + o);
+    o += ccl_align((size_t)maps_cap * nb_full * 4);
     w.tcount = reinterpret_cast<int32_t *>(base + o);
-    o += ccl_align((size_t)maps_cap * w.nb * 4);
+    o += ccl_align((size_t)maps_cap * nb_full * 4);
     w.flag = reinterpret_cast<int32_t *>(base + o);
     o += ccl_align((size_t)maps_cap * 4);
     w.bwords = reinterpret_cast<uint64_t *>(base + o);
-    o += ccl_align((size_t)maps_cap * w.nb * 5 * w.nch * 8);
+    o += ccl_align((size_t)maps_cap * nb_full * 5 * nch_full * 8);
     w.bbase = reinterpret_cast<int32_t *>(base + o);
-    o += ccl_align((size_t)maps_cap * w.nb * 2 * w.nch * 4);
+    o += ccl_align((size_t)maps_cap * nb_full * 2 * nch_full * 4);
     return o;
 }
 
@@ -1229,7 +1240,8 @@ size_t ccl_ws_bytes(const KParams &k, int maps_cap) {
     return ccl_views(k, nullptr, maps_cap, w);
 }
 
-size_t ccl_lds_bytes(const KParams &k) { return (size_t)CCL_R * ((k.d.W + 63) / 64) * (3 * 8 + 4) + (size_t)k.ccl_cap * 4 * 4; }
+// LDS of k_ccl_band: three bit masks and one run-number prefix per 64-pixel word of the band, 12 B per run
+size_t ccl_lds_bytes(const KParams &k) { return (size_t)CCL_R * ((k.d.W + 63) / 64) * (3 * 8 + 4) + (size_t)k.ccl_cap * 3 * 4; }
 
 // union-find with the smaller index as root; works on LDS and on global memory
 __device__ __forceinline__ int ccl_find(const int32_t *L, int x) {
@@ -1284,15 +1296,15 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
     const int v0 = band * CCL_R, rows = min(CCL_R, d.H - v0);
     uint64_t *Sm = ccl_lds, *Vm = Sm + CCL_R * nch, *Lm = Vm + CCL_R * nch;  // [CCL_R][nch] run-start / valid / up-link masks
     int32_t *base = reinterpret_cast<int32_t *>(Lm + CCL_R * nch);           // [CCL_R][nch] run starts of the row before the word
-    int32_t *parent = base + CCL_R * nch, *len = parent + cap, *size = len + cap, *start = size + cap;
+    int32_t *parent = base + CCL_R * nch, *len = parent + cap, *start = len + cap;
     __shared__ int32_t rowbase[CCL_R + 1];
+    __shared__ int32_t rec0;  // first run record of this band
     const float *D = disp + map_offset(d, m, nproc);
     const float thr = k.speckle_sim;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = CCL_THREADS / 64;
     for (int i = tid; i < cap; i += CCL_THREADS) {
         parent[i] = i;
         len[i] = 0;
-        size[i] = 0;
     }
     // masks: one wavefront per 64-pixel column strip; the strip's CCL_R+1 rows are requested at once, then reduced to masks
     for (int c = wave; c < nch; c += nw) {
@@ -1344,7 +1356,10 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
     __syncthreads();
     const int T = rowbase[rows];
     int32_t *tc = ws.tcount + (size_t)m * ws.nb + band;
-    if (T > cap) {  // too many runs for the LDS tables: the whole map goes the slow way
+    if (tid == 0) rec0 = T <= cap ? atomicAdd(&ws.nruns[m], T) : ws.rcap;
+    __syncthreads();
+    const int off = rec0;
+    if (T > cap || off + T > ws.rcap) {  // too many runs for the LDS tables / the map's record pool: the whole map goes the slow way
         if (tid == 0) {
             ws.flag[m] = 1;
             *tc = 0;
@@ -1380,19 +1395,27 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
         }
     }
     __syncthreads();
+    // flatten; the records take (first pixel, length, root); then the lengths of the non-roots are folded into their root's slot
+    // (a non-root's own slot is never a target), which leaves the component sizes at the roots
+    int4 *R = ws.runs + (size_t)m * ws.rcap + off;
+    int32_t *GP = ws.gparent + (size_t)m * ws.rcap + off, *TOT = ws.total + (size_t)m * ws.rcap + off;
     for (int i = tid; i < T; i += CCL_THREADS) {
         const int root = ccl_find(parent, i);
         parent[i] = root;
-        atomicAdd(&size[root], len[i]);
+        R[i] = make_int4(start[i], len[i], off + root, 0);
+        GP[i] = off + root;
+        TOT[i] = 0;
     }
     __syncthreads();
-    const size_t node0 = ((size_t)m * ws.nb + band) * cap;
-    for (int i = tid; i < T; i += CCL_THREADS) {
-        ws.runs[node0 + i] = make_int4(start[i], len[i], parent[i], size[i]);
-        ws.gparent[node0 + i] = band * cap + parent[i];
-        ws.total[node0 + i] = 0;
+    for (int i = tid; i < T; i += CCL_THREADS)
+        if (parent[i] != i) atomicAdd(&len[parent[i]], len[i]);
+    __syncthreads();
+    for (int i = tid; i < T; i += CCL_THREADS)
+        if (parent[i] == i) R[i].w = len[i];
+    if (tid == 0) {
+        *tc = T;
+        ws.boff[(size_t)m * ws.nb + band] = off;
     }
-    if (tid == 0) *tc = T;
     uint64_t *bw = ws.bwords + ((size_t)m * ws.nb + band) * 5 * nch;
     int32_t *bb = ws.bbase + ((size_t)m * ws.nb + band) * 2 * nch;
     for (int c = tid; c < nch; c += CCL_THREADS) {
@@ -1488,7 +1511,7 @@ __device__ void ccl_legacy_map(const KParams &k, float *D, int32_t *label, int32
 __global__ __launch_bounds__(256) void k_ccl_border(int nproc, const int32_t *__restrict__ blob, CclWs ws) {
     const int m = blockIdx.y;
     if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m]) return;
-    const int nch = ws.nch, cap = ws.cap, nb = ws.nb;
+    const int nch = ws.nch, nb = ws.nb;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= (nb - 1) * nch) return;
     const int b = 1 + idx / nch, c = idx - (b - 1) * nch;
@@ -1498,8 +1521,9 @@ __global__ __launch_bounds__(256) void k_ccl_border(int nproc, const int32_t *__
     const uint64_t S0 = bwb[c], V0 = bwb[nch + c], Sp = bwp[3 * nch + c], Vp = bwp[4 * nch + c];
     const uint64_t carry = c > 0 ? (bwb[2 * nch + c - 1] >> 63) : 0ull;
     const int32_t *bbb = ws.bbase + ((size_t)m * nb + b) * 2 * nch, *bbp = bbb - 2 * nch;
-    const int n0 = b * cap + bbb[c], np = (b - 1) * cap + bbp[nch + c];
-    int32_t *GP = ws.gparent + (size_t)m * nb * cap;
+    const int32_t *BO = ws.boff + (size_t)m * nb;
+    const int n0 = BO[b] + bbb[c], np = BO[b - 1] + bbp[nch + c];
+    int32_t *GP = ws.gparent + (size_t)m * ws.rcap;
     for (uint64_t F = ccl_new_links(L, V0 & ~S0, Vp & ~Sp, carry); F; F &= F - 1) {
         const uint64_t upto = bits_upto(ctz64(F));
         ccl_union(GP, n0 + __popcll(S0 & upto) - 1, np + __popcll(Sp & upto) - 1);
@@ -1510,15 +1534,14 @@ __global__ __launch_bounds__(256) void k_ccl_border(int nproc, const int32_t *__
 __global__ __launch_bounds__(256) void k_ccl_total(int nproc, const int32_t *__restrict__ blob, CclWs ws) {
     const int m = blockIdx.y, b = blockIdx.x;
     if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m]) return;
-    const int cap = ws.cap, nb = ws.nb;
-    const int T = ws.tcount[(size_t)m * nb + b];
-    const int32_t *GP = ws.gparent + (size_t)m * nb * cap;
-    int32_t *TOT = ws.total + (size_t)m * nb * cap;
-    const int4 *RUNS = ws.runs + ((size_t)m * nb + b) * cap;
+    const int T = ws.tcount[(size_t)m * ws.nb + b], off = ws.boff[(size_t)m * ws.nb + b];
+    const int32_t *GP = ws.gparent + (size_t)m * ws.rcap;
+    int32_t *TOT = ws.total + (size_t)m * ws.rcap;
+    const int4 *RUNS = ws.runs + (size_t)m * ws.rcap;
     for (int i = threadIdx.x; i < T; i += 256) {
-        const int4 r = RUNS[i];
-        if (r.z != i) continue;
-        atomicAdd(&TOT[ccl_find_frozen(GP, b * cap + i)], r.w);
+        const int4 r = RUNS[off + i];
+        if (r.z != off + i) continue;
+        atomicAdd(&TOT[ccl_find_frozen(GP, off + i)], r.w);
     }
 }
 
@@ -1527,15 +1550,14 @@ __global__ __launch_bounds__(256) void k_ccl_apply(KParams k, int nproc, const i
     const Dims &d = k.d;
     const int m = blockIdx.y, b = blockIdx.x;
     if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m]) return;
-    const int cap = ws.cap, nb = ws.nb;
-    const int T = ws.tcount[(size_t)m * nb + b];
-    const int32_t *GP = ws.gparent + (size_t)m * nb * cap, *TOT = ws.total + (size_t)m * nb * cap;
-    const int4 *RUNS = ws.runs + ((size_t)m * nb + b) * cap;
+    const int T = ws.tcount[(size_t)m * ws.nb + b], off = ws.boff[(size_t)m * ws.nb + b];
+    const int32_t *GP = ws.gparent + (size_t)m * ws.rcap, *TOT = ws.total + (size_t)m * ws.rcap;
+    const int4 *RUNS = ws.runs + (size_t)m * ws.rcap;
     float *D = disp + map_offset(d, m, nproc);
     for (int i = threadIdx.x; i < T; i += 256) {
-        const int4 r = RUNS[i];
+        const int4 r = RUNS[off + i];
         if (r.y >= k.speckle_size) continue;  // a run that long is a large component by itself
-        if (TOT[ccl_find_frozen(GP, b * cap + r.z)] >= k.speckle_size) continue;
+        if (TOT[ccl_find_frozen(GP, r.z)] >= k.speckle_size) continue;
         for (int q = 0; q < r.y; q++) D[r.x + q] = -10.0f;
     }
 }
@@ -1544,6 +1566,7 @@ __global__ __launch_bounds__(256) void k_ccl_apply(KParams k, int nproc, const i
 __global__ __launch_bounds__(1024) void k_ccl_slow(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp, CclWs ws,
                                                    int32_t *__restrict__ label, int32_t *__restrict__ csize, int32_t *__restrict__ cnt) {
     const int m = blockIdx.x;
+    if (threadIdx.x == 0) ws.nruns[m] = 0;  // the record pool is free again for the slot's next launch
     if (blob[(m / nproc) * META_WORDS] < 3 || !ws.flag[m]) return;
     const size_t off = map_offset(k.d, m, nproc);
     ccl_legacy_map(k, disp + off, label + off, csize + off, cnt + off);
