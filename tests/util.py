@@ -38,8 +38,8 @@ def case_images(entry):
     if "synth" in entry:
         return pkg("synth").make_pair(**entry["synth"])
     img = entry["image"]
-    if img == "kitti0":
-        return load_png("kitti0_left.png"), load_png("kitti0_right.png")
+    if img in ("kitti0", "kitti10", "kitti20"):
+        return load_png(img + "_left.png"), load_png(img + "_right.png")
     if img == "kitti0_crop":
         l, r = load_png("kitti0_left.png"), load_png("kitti0_right.png")
         return l[150:278, 400:720].copy(), r[150:278, 400:720].copy()
