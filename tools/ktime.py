@@ -18,11 +18,16 @@ ap.add_argument("--chunk", type=int, default=32)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--disp", type=int, default=128)
 ap.add_argument("--only", default="")
+ap.add_argument("--real", action="store_true", help="copies of the committed kitti_mini pair 0 instead of synthetic pairs")
 a = ap.parse_args()
 eng = importlib.import_module(PKG + ".engine")
 synth = importlib.import_module(PKG + ".synth")
 W, H, D = 1242, 375, a.disp
 b = synth.make_batch(1000, a.batch, H, W, D)
+if a.real:
+    from PIL import Image
+    b[:, 0] = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "kitti0_left.png")))
+    b[:, 1] = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "kitti0_right.png")))
 left = torch.from_numpy(np.ascontiguousarray(b[:, 0])).cuda()
 right = torch.from_numpy(np.ascontiguousarray(b[:, 1])).cuda()
 e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), chunk=a.chunk, n_streams=1, n_slots=1)
