@@ -78,6 +78,38 @@ __device__ __forceinline__ int sat_u8(int x) { return x < 0 ? 0 : (x > 255 ? 255
 // byte i (0..7) of the 8-byte little-endian pair (lo, hi)
 __device__ __forceinline__ uint32_t byte_of(uint32_t lo, uint32_t hi, int i) { return i < 4 ? (lo >> (8 * i)) & 0xFFu : (hi >> (8 * (i - 4))) & 0xFFu; }
 
+// The 16 descriptor bytes of pixel column c+J of a quad (descriptor.cpp:105-121) from the quad's du / dv words.  Each source
+// row is a 12-byte window (a, b, c) = columns c-4 .. c+7; the bytes one output word needs always lie inside 8 consecutive
+// window bytes, so a word is one or two v_perm_b32 (selector byte 0-3: low operand, 4-7: high operand, 0x0C: zero).
+struct DescWin {
+    uint32_t r0, r4;             // du rows y-2, y+2: columns c..c+3
+    uint32_t r1a, r1b, r1c;      // du row y-1
+    uint32_t r2a, r2b, r2c;      // du row y
+    uint32_t r3a, r3b, r3c;      // du row y+1
+    uint32_t v1, v3;             // dv rows y-1, y+1: columns c..c+3
+    uint32_t v2a, v2b, v2c;      // dv row y
+};
+
+template <int J>
+__device__ __forceinline__ uint4 desc_assemble(const DescWin &w) {
+    // triple (x-2, x, x+2): window bytes 2+J, 4+J, 6+J
+    constexpr bool t_hi = 6 + J >= 8;
+    constexpr uint32_t tb = t_hi ? 4 : 0, t0 = 2 + J - tb, t1 = 4 + J - tb, t2 = 6 + J - tb;
+    const uint32_t row1 = __builtin_amdgcn_perm(t_hi ? w.r1c : w.r1b, t_hi ? w.r1b : w.r1a, 0x0Cu | (t0 << 8) | (t1 << 16) | (t2 << 24));
+    const uint32_t row3 = __builtin_amdgcn_perm(t_hi ? w.r3c : w.r3b, t_hi ? w.r3b : w.r3a, t0 | (t1 << 8) | (t2 << 16) | (0x0Cu << 24));
+    // (x-1, x, x, x+1): window bytes 3+J, 4+J, 4+J, 5+J
+    constexpr bool m_hi = 5 + J >= 8;
+    constexpr uint32_t mb = m_hi ? 4 : 0, m0 = 3 + J - mb, m1 = 4 + J - mb, m2 = 5 + J - mb;
+    uint4 o;
+    o.x = __builtin_amdgcn_perm(row1, w.r0, (uint32_t)J | (5u << 8) | (6u << 16) | (7u << 24));                     // du (0,-2) (-2,-1) (0,-1) (2,-1)
+    o.y = __builtin_amdgcn_perm(m_hi ? w.r2c : w.r2b, m_hi ? w.r2b : w.r2a, m0 | (m1 << 8) | (m1 << 16) | (m2 << 24));  // du (-1,0) (0,0) (0,0) (1,0)
+    o.z = __builtin_amdgcn_perm(row3, w.r4, 4u | (5u << 8) | (6u << 16) | ((uint32_t)J << 24));                     // du (-2,1) (0,1) (2,1) (0,2)
+    const uint32_t mid = __builtin_amdgcn_perm(m_hi ? w.v2c : w.v2b, m_hi ? w.v2b : w.v2a, 0x0Cu | (m0 << 8) | (m2 << 16) | (0x0Cu << 24));
+    const uint32_t lowr = __builtin_amdgcn_perm(mid, w.v1, (uint32_t)J | (5u << 8) | (6u << 16) | (0x0Cu << 24));
+    o.w = __builtin_amdgcn_perm(lowr, w.v3, 4u | (5u << 8) | (6u << 16) | ((uint32_t)J << 24));                      // dv (0,-1) (-1,0) (1,0) (0,1)
+    return o;
+}
+
 __global__ __launch_bounds__(256) void k_descriptor(const uint8_t *__restrict__ left, const uint8_t *__restrict__ right, size_t in_pair_stride, int stride,
                                                     uint8_t *__restrict__ desc, Dims d) {
     const int img = blockIdx.z & 1, pair = blockIdx.z >> 1;
@@ -168,28 +200,13 @@ __global__ __launch_bounds__(256) void k_descriptor(const uint8_t *__restrict__ 
     // the four descriptors go to an LDS tile first so that the global stores below are fully coalesced (consecutive lanes ->
     // consecutive 16-byte descriptors); written straight from here each store instruction would touch 64-byte-strided pieces
     __shared__ uint4 otile[DESC_TH][DESC_TW];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int x = x0 + 4 * qx + j;
-        uint4 o = make_uint4(0, 0, 0, 0);
-        // descriptor.cpp:48-50: at half resolution only every second line, starting at 4, is computed
-        if (x >= 3 && x < d.W - 3 && y < d.H - 3 && (d.sub ? (y >= 4 && !(y & 1)) : y >= 3)) {
-            // byte k of the 12-byte window (a,b,c) starting at column c-4: column c+j+off is window byte 4+j+off
-#define WB(a, b, cc, off) ((4 + j + (off)) < 4 ? ((a) >> (8 * (4 + j + (off)))) & 0xFFu : (4 + j + (off)) < 8 ? ((b) >> (8 * (j + (off)))) & 0xFFu : ((cc) >> (8 * (j + (off) - 4))) & 0xFFu)
-            const uint32_t b0 = (r0 >> (8 * j)) & 0xFFu, b11 = (r4 >> (8 * j)) & 0xFFu;
-            const uint32_t b1 = WB(r1a, r1b, r1c, -2), b2 = WB(r1a, r1b, r1c, 0), b3 = WB(r1a, r1b, r1c, 2);
-            const uint32_t b4 = WB(r2a, r2b, r2c, -1), b5 = WB(r2a, r2b, r2c, 0), b7 = WB(r2a, r2b, r2c, 1);
-            const uint32_t b8 = WB(r3a, r3b, r3c, -2), b9 = WB(r3a, r3b, r3c, 0), b10 = WB(r3a, r3b, r3c, 2);
-            const uint32_t b12 = (v1 >> (8 * j)) & 0xFFu, b15 = (v3 >> (8 * j)) & 0xFFu;
-            const uint32_t b13 = WB(v2a, v2b, v2c, -1), b14 = WB(v2a, v2b, v2c, 1);
-#undef WB
-            o.x = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-            o.y = b4 | (b5 << 8) | (b5 << 16) | (b7 << 24);
-            o.z = b8 | (b9 << 8) | (b10 << 16) | (b11 << 24);
-            o.w = b12 | (b13 << 8) | (b14 << 16) | (b15 << 24);
-        }
-        otile[ry][4 * qx + j] = o;
-    }
+    const DescWin dw{r0, r4, r1a, r1b, r1c, r2a, r2b, r2c, r3a, r3b, r3c, v1, v3, v2a, v2b, v2c};
+    const bool row_ok = y < d.H - 3 && (d.sub ? (y >= 4 && !(y & 1)) : y >= 3);  // descriptor.cpp:48-50: every second line from 4 at half resolution
+    const int xq = x0 + 4 * qx;
+    otile[ry][4 * qx + 0] = (row_ok && xq + 0 >= 3 && xq + 0 < d.W - 3) ? desc_assemble<0>(dw) : make_uint4(0, 0, 0, 0);
+    otile[ry][4 * qx + 1] = (row_ok && xq + 1 >= 3 && xq + 1 < d.W - 3) ? desc_assemble<1>(dw) : make_uint4(0, 0, 0, 0);
+    otile[ry][4 * qx + 2] = (row_ok && xq + 2 >= 3 && xq + 2 < d.W - 3) ? desc_assemble<2>(dw) : make_uint4(0, 0, 0, 0);
+    otile[ry][4 * qx + 3] = (row_ok && xq + 3 >= 3 && xq + 3 < d.W - 3) ? desc_assemble<3>(dw) : make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int tw = min(DESC_TW, d.W - x0), th = min(DESC_TH, d.H - y0);
     for (int i = tid; i < th * DESC_TW; i += 256) {
