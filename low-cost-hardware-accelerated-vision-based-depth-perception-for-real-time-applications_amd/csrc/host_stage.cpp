@@ -761,30 +761,48 @@ int Delaunay::triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap, c
     H hl, hr;
     if (spawn && spawn->run && m >= 64) {
         // latency mode: the right half of the top-level cut is built by another thread (or by this one afterwards if nobody
-        // picked it up: the closure is claimed with a compare-and-swap, so it runs exactly once and nobody can wait for ever)
+        // picked it up: the work is claimed with a compare-and-swap, so it runs exactly once and nobody can wait for ever).
+        // The hand-over record is shared by the two parties and freed by whoever lets go of it last: a helper that shows up
+        // after this call has returned still finds valid memory (and nothing left to do).
         const int divider = m >> 1;
         struct Half {
             Delaunay *self;
             const Pt *p;
             int n, cursor;
             H l, r;
-            std::atomic<int> state;  // 0 queued, 1 claimed, 2 done
-            static void run(void *arg) {
-                Half *h = static_cast<Half *>(arg);
+            std::atomic<int> state{0};  // 0 queued, 1 claimed, 2 done
+            std::atomic<int> refs{2};
+            void work() {
                 int expected = 0;
-                if (!h->state.compare_exchange_strong(expected, 1)) return;
-                h->self->build(h->p, h->n, 1, h->l, h->r, h->cursor);
-                h->state.store(2, std::memory_order_release);
+                if (!state.compare_exchange_strong(expected, 1)) return;
+                self->build(p, n, 1, l, r, cursor);
+                state.store(2, std::memory_order_release);
             }
-        } right{this, a + divider, m - divider, 1 + slots_of(divider), 0, 0, {0}};
-        spawn->run(spawn->ctx, &Half::run, &right);
+            void release() {
+                if (refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this;
+            }
+            static void run(void *arg) {  // the helper's entry point
+                Half *h = static_cast<Half *>(arg);
+                h->work();
+                h->release();
+            }
+        };
+        Half *right = new Half();
+        right->self = this;
+        right->p = a + divider;
+        right->n = m - divider;
+        right->cursor = 1 + slots_of(divider);
+        right->l = right->r = 0;
+        spawn->run(spawn->ctx, &Half::run, right);
         H innerleft;
         build(a, divider, 1, hl, innerleft, n_slots_);
-        Half::run(&right);  // no-op unless it is still unclaimed
-        while (right.state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
-        n_slots_ = right.cursor;
-        merge(hl, innerleft, right.l, right.r, 0, n_slots_);
-        hr = right.r;
+        right->work();  // no-op unless it is still unclaimed
+        while (right->state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
+        n_slots_ = right->cursor;
+        H rl = right->l, rr = right->r;
+        right->release();
+        merge(hl, innerleft, rl, rr, 0, n_slots_);
+        hr = rr;
     } else {
         build(a, m, 0, hl, hr, n_slots_);
     }

@@ -1,0 +1,26 @@
+"""Host stage under AddressSanitizer + UBSan and under ThreadSanitizer (CPU build; the GPU pool offers no sanitizers)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+import util
+
+CSRC = os.path.join(util.ROOT, util.PKG, "csrc")
+
+
+@pytest.mark.parametrize("san", ["address,undefined", "thread"])
+def test_host_stage_sanitizers(tmp_path, san):
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "san_host")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-mavx2", "-fsanitize=" + san, "-fno-omit-frame-pointer", "-ffp-contract=off",
+           "-I" + os.path.join(util.ROOT, "include"), "-I" + CSRC, os.path.join(util.HERE, "san_host.cpp"), os.path.join(CSRC, "host_stage.cpp"),
+           "-o", exe, "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "sanitizer" in (r.stderr or "").lower() and "cannot find" in r.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "mismatches: 0" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
