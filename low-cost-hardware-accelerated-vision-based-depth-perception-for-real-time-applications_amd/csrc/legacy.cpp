@@ -50,7 +50,7 @@ struct Legacy {
     double *d_points = nullptr;
     Double3 *points = nullptr;          // host, library-owned (stereo_vision.cpp:89-93)
     std::vector<Uchar4> colors;         // last left image
-    std::vector<unsigned char> dmap;    // last u8 disparity image
+    unsigned char *h_dmap = nullptr;    // last u8 disparity image (host, page-locked)
     hipStream_t stream = nullptr;
 };
 
@@ -114,9 +114,12 @@ bool legacy_init(int width, int height, float scale, const char *yaml, bool subs
     L_TRY(hipMalloc((void **)&g.d_points, N * 3 * sizeof(double)));
     L_TRY(hipMalloc((void **)&g.d_Q, 16 * sizeof(double)));
     L_TRY(hipMemcpy(g.d_Q, g.rect.Q, 16 * sizeof(double), hipMemcpyHostToDevice));
-    g.points = (Double3 *)calloc(N, sizeof(Double3));
+    // page-locked: the 11 MB of points per frame come back at PCIe speed instead of through a pageable bounce buffer
+    L_TRY(hipHostMalloc((void **)&g.points, N * sizeof(Double3), hipHostMallocDefault));
+    memset(g.points, 0, N * sizeof(Double3));
+    L_TRY(hipHostMalloc((void **)&g.h_dmap, N, hipHostMallocDefault));
+    memset(g.h_dmap, 0, N);
     g.colors.assign(N, Uchar4{0, 0, 0, 0});
-    g.dmap.assign(N, 0);
     printf("Init done\n");
     return g.points != nullptr;
 }
@@ -136,7 +139,7 @@ bool legacy_frame(const unsigned char *left, const unsigned char *right) {
     }
     sv::launch_dmap_and_cloud(g.d_disp, g.d_dmap, g.d_points, g.d_Q, g.W, g.H, g.stream);
     L_TRY(hipMemcpyAsync(g.points, g.d_points, N * sizeof(Double3), hipMemcpyDeviceToHost, g.stream));
-    L_TRY(hipMemcpyAsync(g.dmap.data(), g.d_dmap, N, hipMemcpyDeviceToHost, g.stream));
+    L_TRY(hipMemcpyAsync(g.h_dmap, g.d_dmap, N, hipMemcpyDeviceToHost, g.stream));
     L_TRY(hipStreamSynchronize(g.stream));
     memcpy(g.colors.data(), left, N * 4);
     return true;
@@ -177,7 +180,8 @@ void clean(void) {
     for (void *p : dptrs)
         if (p) (void)hipFree(p);
     if (g.stream) (void)hipStreamDestroy(g.stream);
-    free(g.points);
+    if (g.points) (void)hipHostFree(g.points);
+    if (g.h_dmap) (void)hipHostFree(g.h_dmap);
     g = Legacy();
     printf("\n\nProgram exitted successfully!\n\n");  // stereo_vision.cpp:111 (the reference then calls exit(0); we return)
 }
@@ -187,7 +191,7 @@ Uchar4 *getColor(void) { return g.colors.empty() ? nullptr : g.colors.data(); }
 const unsigned char *sv_legacy_last_dmap(int *width, int *height) {
     if (width) *width = g.W;
     if (height) *height = g.H;
-    return g.dmap.empty() ? nullptr : g.dmap.data();
+    return g.h_dmap;
 }
 
 const double *sv_legacy_Q(void) { return g.ready ? g.rect.Q : nullptr; }

@@ -53,21 +53,32 @@ class stereo_vision:
         self.CAMERA_CALIBRATION_YAML = CAMERA_CALIBRATION_YAML
         self.subsampling = bool(subsampling)
         # reference: sv.py:180 lists 14 entries; the C function takes 16 (stereo_vision.cpp:566-581)
-        self.sv.generatePointCloud.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_bool,
+        self.sv.generatePointCloud.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_bool,
                                                ctypes.c_bool, ctypes.c_bool, ctypes.c_bool, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
                                                ctypes.c_char_p, ctypes.c_char_p, ctypes.c_bool, ctypes.c_bool]
         self.sv.clean.restype = None
         self._closed = False
+        self._bgra = None
 
     def generatePointCloud(self, left, right):
         left, right = np.asarray(left), np.asarray(right)
         if left.ndim != 3 or left.shape[2] != 3 or left.shape[:2] != (self.height, self.width) or right.shape != left.shape:
             raise ValueError("expected two BGR uint8 images of shape (%d, %d, 3)" % (self.height, self.width))
-        alpha = np.full(left.shape[:2] + (1,), 255, np.uint8)  # cv2.COLOR_BGR2BGRA
-        l = np.ascontiguousarray(np.concatenate([left.astype(np.uint8), alpha], axis=2)).tobytes()
-        r = np.ascontiguousarray(np.concatenate([right.astype(np.uint8), alpha], axis=2)).tobytes()
+        # cv2.COLOR_BGR2BGRA: a fourth channel of 255.  Pillow's C loop does it in ~0.3 ms per image (the channel order is left
+        # alone: "RGB" -> "RGBA" only appends alpha); plain numpy needs ~1.5 ms for the strided copy.  The library reads the
+        # buffers during the call only.
         try:
-            return self.sv.generatePointCloud(l, r, self.CAMERA_CALIBRATION_YAML.encode("utf-8"), self.width, self.height, self.defaultCalibFile,
+            from PIL import Image
+            self._bgra = (np.asarray(Image.fromarray(np.ascontiguousarray(left, dtype=np.uint8), "RGB").convert("RGBA")),
+                          np.asarray(Image.fromarray(np.ascontiguousarray(right, dtype=np.uint8), "RGB").convert("RGBA")))
+            self._bgra = tuple(np.ascontiguousarray(b) for b in self._bgra)
+        except ImportError:
+            if self._bgra is None or not self._bgra[0].flags.writeable:
+                self._bgra = (np.full(left.shape[:2] + (4,), 255, np.uint8), np.full(left.shape[:2] + (4,), 255, np.uint8))
+            self._bgra[0][:, :, :3] = left
+            self._bgra[1][:, :, :3] = right
+        try:
+            return self.sv.generatePointCloud(self._bgra[0].ctypes.data, self._bgra[1].ctypes.data, self.CAMERA_CALIBRATION_YAML.encode("utf-8"), self.width, self.height, self.defaultCalibFile,
                                               self.objectTracking, self.graphics, self.display, self.scale, self.pc_extrapolation,
                                               self.YOLO_CFG.encode("utf-8"), self.YOLO_WEIGHTS.encode("utf-8"), self.YOLO_CLASSES.encode("utf-8"),
                                               False, self.subsampling)
