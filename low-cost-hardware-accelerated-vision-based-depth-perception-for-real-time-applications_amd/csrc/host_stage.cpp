@@ -378,6 +378,32 @@ constexpr int KEY_BIAS_X = 4096, KEY_BIAS_Y = 4096;
 static inline uint32_t key_pack(int32_t x, int32_t y) { return ((uint32_t)(x + KEY_BIAS_X) << 16) | (uint32_t)(y + KEY_BIAS_Y); }
 static inline uint32_t key_yx(uint32_t k) { return (k << 16) | (k >> 16); }
 
+// Stable LSD radix sort of the packed keys, 11 bits per pass, through the `sorted_` scratch array.
+void Delaunay::radix_sort_xy(Pt *a, int n) {
+    if ((int)sorted_.size() < n) sorted_.resize(n);
+    Pt *b = sorted_.data();
+    uint32_t cnt[3][2048];
+    memset(cnt, 0, sizeof(cnt));
+    for (int i = 0; i < n; i++) {
+        const uint32_t k = a[i].key;
+        cnt[0][k & 2047]++;
+        cnt[1][(k >> 11) & 2047]++;
+        cnt[2][k >> 22]++;
+    }
+    for (int p = 0; p < 3; p++) {
+        uint32_t run = 0;
+        for (int d = 0; d < (p == 2 ? 1024 : 2048); d++) {
+            const uint32_t c = cnt[p][d];
+            cnt[p][d] = run;
+            run += c;
+        }
+    }
+    for (int i = 0; i < n; i++) b[cnt[0][a[i].key & 2047]++] = a[i];
+    for (int i = 0; i < n; i++) a[cnt[1][(b[i].key >> 11) & 2047]++] = b[i];
+    for (int i = 0; i < n; i++) b[cnt[2][a[i].key >> 22]++] = a[i];
+    memcpy(a, b, sizeof(Pt) * (size_t)n);
+}
+
 // Randomised quicksort by (x, y) with the reference's pivot sequence (triangle.cpp:5183-5229): which of two coincident
 // points survives the duplicate scan depends on it.
 void Delaunay::sort_xy(Pt *a, int n) {
@@ -749,7 +775,18 @@ int Delaunay::triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap, c
         if (x < -KEY_BIAS_X || x >= 65536 - KEY_BIAS_X || y < -KEY_BIAS_Y || y >= 65536 - KEY_BIAS_Y) return -2;  // outside the packed-key range
         a[i] = Pt{key_pack(x, y), i};
     }
-    sort_xy(a, n);
+    // Sorted (x, y) order.  Without coincident points it is unique, whatever the sorting method: a stable LSD radix sort (three
+    // 11-bit digits of the packed key) is 3x faster than the reference's randomised quicksort.  Only when two points coincide
+    // does the quicksort's pivot sequence decide which of them comes first and survives the duplicate scan below
+    // (triangle.cpp:5183-5229, :5890-5903) - then the array is rebuilt and sorted the reference's way.  Coincident points only
+    // arise in the right image (u - d equal on one row) and are rare.
+    radix_sort_xy(a, n);
+    bool coincident = false;
+    for (int j = 1; j < n; j++) coincident |= a[j].key == a[j - 1].key;
+    if (coincident) {
+        for (int i = 0; i < n; i++) a[i] = Pt{key_pack(xy[2 * i], xy[2 * i + 1]), i};
+        sort_xy(a, n);
+    }
     int m = 0;
     for (int j = 1; j < n; j++) {  // triangle.cpp:5890-5903: the first of a group of coincident points is kept
         if (a[m].key == a[j].key) continue;

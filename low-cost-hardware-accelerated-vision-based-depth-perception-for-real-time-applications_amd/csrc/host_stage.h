@@ -61,6 +61,7 @@ class Delaunay {
 
     H make(int &cursor);
     void sort_xy(Pt *a, int n);
+    void radix_sort_xy(Pt *a, int n);
     void kd_order(uint64_t *xs, uint64_t *xalt, uint64_t *ys, uint64_t *yalt, int n, int axis, Pt *out);
     void alternate_cuts(Pt *a, int m);
     void build(const Pt *a, int n, int axis, H &farleft, H &farright, int &cursor);
