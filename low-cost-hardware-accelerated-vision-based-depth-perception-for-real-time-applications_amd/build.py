@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstereo_vision_hip.so")
-SOURCES = ["kernels.hip", "legacy_kernels.hip", "engine.cpp", "host_stage.cpp", "legacy.cpp", "calib.cpp"]
+SOURCES = ["kernels.hip", "delaunay_gpu.hip", "legacy_kernels.hip", "engine.cpp", "host_stage.cpp", "legacy.cpp", "calib.cpp"]
 HEADERS = ["sv_kernels.h", "host_stage.h", "calib.h", os.path.join("..", "..", "include", "stereo_vision_hip.h")]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 HOST = ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]

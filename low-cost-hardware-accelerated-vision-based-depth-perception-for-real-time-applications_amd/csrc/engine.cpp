@@ -1235,6 +1235,59 @@ int sv_host_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap) {
     return dl.triangulate(xy, n, tri_out, cap);
 }
 
+// Test hook: the same triangulation with the divide-and-conquer phase on the GPU (delaunay_gpu.hip); sort, duplicate scan and
+// k-d ordering stay on the host.  `reps` identical sets are triangulated in one launch (throughput measurements); the first
+// result is returned.  Returns the triangle count, or < 0.
+int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int reps, double *kernel_ms) {
+    if (!xy || !tri_out || n < 3 || reps < 1) return SV_ERR_ARG;
+    if (n > delaunay_gpu_max_points()) return SV_ERR_UNSUPPORTED;
+    Delaunay dl;
+    std::vector<int32_t> ids(n);
+    const int m = dl.kd_ordered_ids(xy, n, ids.data());
+    if (m < 0) return m;
+    if (m < 3) return 0;
+    int32_t *d_order = nullptr, *d_xy = nullptr, *d_tri = nullptr, *d_cnt = nullptr;
+    int4 *d_sets = nullptr;
+    int rc = SV_OK, nt = 0;
+    const size_t tri_words = (size_t)3 * 2 * n;
+    try {
+        HIP_TRY(hipMalloc((void **)&d_order, sizeof(int32_t) * n));
+        HIP_TRY(hipMalloc((void **)&d_xy, sizeof(int32_t) * 2 * n));
+        HIP_TRY(hipMalloc((void **)&d_tri, sizeof(int32_t) * tri_words * reps));
+        HIP_TRY(hipMalloc((void **)&d_cnt, sizeof(int32_t) * reps));
+        HIP_TRY(hipMalloc((void **)&d_sets, sizeof(int4) * reps));
+        std::vector<int4> sets(reps);
+        for (int r = 0; r < reps; r++) sets[r] = make_int4(0, m, n, (int)(tri_words * r));
+        HIP_TRY(hipMemcpy(d_order, ids.data(), sizeof(int32_t) * m, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_xy, xy, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(d_sets, sets.data(), sizeof(int4) * reps, hipMemcpyHostToDevice));
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, nullptr));
+        if (launch_delaunay_gpu(d_sets, reps, d_order, d_xy, d_tri, d_cnt, delaunay_gpu_lds_bytes(m, n), nullptr) != 0) throw std::runtime_error("k_delaunay launch failed");
+        HIP_TRY(hipEventRecord(e1, nullptr));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        if (kernel_ms) *kernel_ms = ms;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        HIP_TRY(hipMemcpy(&nt, d_cnt, sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (nt > cap) {
+            rc = -1;
+        } else {
+            HIP_TRY(hipMemcpy(tri_out, d_tri, sizeof(int32_t) * 3 * (size_t)nt, hipMemcpyDeviceToHost));
+        }
+    } catch (const std::exception &e) {
+        g_create_error = e.what();
+        rc = SV_ERR_HIP;
+    }
+    for (void *p : {(void *)d_order, (void *)d_xy, (void *)d_tri, (void *)d_cnt, (void *)d_sets})
+        if (p) (void)hipFree(p);
+    return rc == SV_OK ? nt : rc;
+}
+
 int sv_host_delaunay_split(const int32_t *xy, int n, int32_t *tri_out, int cap, int helper_delay_us) {
     if (!xy || !tri_out) return SV_ERR_ARG;
     struct Helper {

@@ -760,15 +760,12 @@ void Delaunay::build(const Pt *p, int n, int axis, H &farleft, H &farright, int 
 // pool exactly as the sequential recursion does (the output order is the pool order).
 static int slots_of(int n) { return n == 2 ? 2 : n == 3 ? 4 : slots_of(n >> 1) + slots_of(n - (n >> 1)) + 2; }
 
-int Delaunay::triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap, const Spawn *spawn) {
-    if (n < 3) return 0;
+// Sort, duplicate scan and k-d ordering: fills order_[0..m) and returns m (< 2: nothing to triangulate; -2: coordinates
+// outside the packed-key range).
+int Delaunay::prepare(const int32_t *xy, int n) {
     xy_ = xy;
     seed_ = 1;  // triangle.cpp:3818: reseeded on every call
     if ((int)order_.size() < n) order_.resize(n);
-    // leaves allocate <= 4 slots per 3 points (2 per 2), every merge 2 more: < 3n in total, + the outer-space slot
-    if ((int)tris_.size() < 3 * n + 8) tris_.resize(3 * n + 8);
-    n_slots_ = 0;
-    make(n_slots_);
     Pt *a = order_.data();
     for (int i = 0; i < n; i++) {
         const int32_t x = xy[2 * i], y = xy[2 * i + 1];
@@ -793,8 +790,28 @@ int Delaunay::triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap, c
         a[++m] = a[j];
     }
     m++;
+    if (m >= 2) alternate_cuts(a, m);
+    return m;
+}
+
+// The vertex ids in the order the divide-and-conquer recursion consumes them (for the GPU triangulation, delaunay_gpu.hip).
+int Delaunay::kd_ordered_ids(const int32_t *xy, int n, int32_t *ids_out) {
+    if (n < 3) return 0;
+    const int m = prepare(xy, n);
+    for (int i = 0; i < m; i++) ids_out[i] = order_[i].id;
+    return m;
+}
+
+int Delaunay::triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap, const Spawn *spawn) {
+    if (n < 3) return 0;
+    // leaves allocate <= 4 slots per 3 points (2 per 2), every merge 2 more: < 3n in total, + the outer-space slot
+    if ((int)tris_.size() < 3 * n + 8) tris_.resize(3 * n + 8);
+    const int m = prepare(xy, n);
+    if (m < 0) return m;
     if (m < 2) return 0;
-    alternate_cuts(a, m);
+    n_slots_ = 0;
+    make(n_slots_);
+    Pt *a = order_.data();
     H hl, hr;
     if (spawn && spawn->run && m >= 64) {
         // latency mode: the right half of the top-level cut is built by another thread (or by this one afterwards if nobody

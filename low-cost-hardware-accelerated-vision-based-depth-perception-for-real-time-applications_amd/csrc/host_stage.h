@@ -39,6 +39,9 @@ class Delaunay {
     // xy: n points (x0,y0,x1,y1,...).  tri_out receives 3*count vertex indices; returns count (<= 2n), or -1 if cap
     // (in triangles) is too small.  With `spawn` the two halves of the top-level cut are built concurrently.
     int triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap, const Spawn *spawn = nullptr);
+    // Only the preparation (sort, duplicate scan, k-d ordering): the ids of the m surviving vertices in the order the recursion
+    // consumes them; the GPU triangulation (delaunay_gpu.hip) starts from there.  Returns m (or < 0 like triangulate).
+    int kd_ordered_ids(const int32_t *xy, int n, int32_t *ids_out);
 
    private:
     struct Tri {
@@ -59,6 +62,7 @@ class Delaunay {
     int n_slots_ = 0;
     uint32_t seed_ = 1;
 
+    int prepare(const int32_t *xy, int n);
     H make(int &cursor);
     void sort_xy(Pt *a, int n);
     void radix_sort_xy(Pt *a, int n);

@@ -83,6 +83,12 @@ void launch_amean(const KParams &k, const SlotDev &s, int n, int nproc, hipStrea
 void launch_median(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st, const float *src, float *dst, float *user_d1, float *user_d2);
 void launch_output(const KParams &k, const SlotDev &s, int n, const float *src, float *d1, float *d2, hipStream_t st);
 
+// GPU triangulation (delaunay_gpu.hip): one workgroup per vertex set, sets[s] = {first entry in order/xy, vertices after the
+// duplicate scan, entries of xy, offset of the set's triangle list in tri_out (in int32 units)}
+size_t delaunay_gpu_lds_bytes(int m, int npts);
+int delaunay_gpu_max_points();
+int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, size_t lds, hipStream_t st);
+
 // names of the kernels behind each wrapper, in launch order, for timing reports
 enum KernelId {
     K_DESCRIPTOR = 0, K_SUPPORT, K_SUPPORT_FILTER, K_GRID_MARK, K_GRID_DILATE, K_PLANES, K_TRIANGLES, K_TRIANGLES_FALLBACK, K_DENSE, K_LR,

@@ -264,6 +264,21 @@ def host_support_filter(params, dcan, width, height):
     return out[:n].copy()
 
 
+def gpu_delaunay(xy, reps=1):
+    """Triangulation with the divide-and-conquer phase on the GPU (test hook).  Returns (triangles (nt,3) int32, kernel ms)."""
+    share_hip_runtime_with_torch()
+    xy = np.ascontiguousarray(xy, dtype=np.int32)
+    n = xy.shape[0]
+    out = np.empty((2 * n + 8, 3), np.int32)
+    ms = ctypes.c_double(0.0)
+    L = lib()
+    L.sv_gpu_delaunay.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]
+    nt = L.sv_gpu_delaunay(xy.ctypes.data, n, out.ctypes.data, 2 * n + 8, int(reps), ctypes.byref(ms))
+    if nt < 0:
+        raise StereoError("sv_gpu_delaunay failed (%d): %s" % (nt, L.sv_last_error(None).decode()))
+    return out[:nt].copy(), ms.value
+
+
 def host_delaunay(xy, split=False, helper_delay_us=0):
     """Product host stage: Delaunay triangulation of integer points (n,2) -> (nt,3) int32.  split: build the two halves of
     the top-level cut on two threads (what the engine does in latency mode)."""

@@ -157,6 +157,34 @@ def test_raster_fallback_path(eng, oracle, monkeypatch):
     assert util.sha(d1) == entry["stages"]["final1"] and util.sha(d2) == entry["stages"]["final2"]
 
 
+def test_gpu_delaunay_matches_host(eng):
+    """csrc/delaunay_gpu.hip (the divide-and-conquer phase as one workgroup per vertex set, mesh in LDS) against the host
+    triangulation: random lattice / scattered / heavily co-circular sets up to the kernel's limit, and the support points of the
+    kitti_mini pair in both images; several sets in one launch."""
+    rng = np.random.default_rng(41)
+    for it in range(60):
+        n = int(rng.integers(3, 3900 if it % 10 == 0 else 500))
+        k = it % 4
+        if k == 0:
+            pts = rng.integers(0, 250, (n, 2)) * 5
+        elif k == 1:
+            pts = np.stack([rng.integers(-50, 1300, n), rng.integers(0, 75, n) * 5], 1)
+        elif k == 2:
+            pts = np.stack([rng.integers(0, 12, n) * 5, rng.integers(0, 12, n) * 5], 1)
+        else:
+            pts = rng.integers(0, 3000, (n, 2))
+        if len(np.unique(pts, axis=0)) < 3:
+            continue
+        a, (b, _) = eng.host_delaunay(pts), eng.gpu_delaunay(pts)
+        assert a.shape == b.shape and np.array_equal(a, b), (it, n)
+    g = util.golden_npz("kitti0_d128")
+    s = g["support"].reshape(-1, 3)
+    for side, want in ((0, g["tri1"]), (1, g["tri2"])):
+        pts = np.stack([s[:, 0] - (s[:, 2] if side else 0), s[:, 1]], 1)
+        got, _ = eng.gpu_delaunay(pts, reps=16)
+        assert np.array_equal(got.ravel(), want.ravel())
+
+
 def test_random_parameter_sets(eng, oracle):
     """Elas::parameters far from the three presets (tools/fuzz_params.py): both maps, batch path and latency path, bit-exact."""
     import sys

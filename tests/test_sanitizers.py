@@ -24,3 +24,20 @@ def test_host_stage_sanitizers(tmp_path, san):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "mismatches: 0" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_gpu_delaunay_logic_emulated_on_cpu(tmp_path):
+    """The device functions of csrc/delaunay_gpu.hip (leaf construction, merge, tree / slot arithmetic) compiled as plain C++ and
+    run depth by depth with the nodes of a depth in reversed order, against Delaunay::triangulate, under ASan + UBSan."""
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "emu_dg")
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-mavx2", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-ffp-contract=off", "-x", "c++",
+           "-I" + os.path.join(util.ROOT, "include"), "-I" + CSRC, os.path.join(util.HERE, "emu_delaunay_gpu.cpp"), os.path.join(CSRC, "host_stage.cpp"),
+           "-o", exe, "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "cannot find" in (r.stderr or ""):
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "mismatches: 0" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
