@@ -146,6 +146,7 @@ def main():
     d1 = torch.empty((B, Hm, Wm), dtype=torch.float32, device="cuda")
     d2 = torch.empty((B, Hm, Wm), dtype=torch.float32, device="cuda")
     engine = eng.StereoEngine(W, H, params, device=local_rank, n_workers=args.workers, chunk=args.chunk, n_streams=args.streams, n_slots=args.slots)
+    engine_info = engine.query()
 
     def barrier():
         torch.cuda.synchronize()
@@ -233,7 +234,7 @@ def main():
             "dtype": "u8", "data": data_desc,
             "config": {"workload": "%s_%dx%d_D%d_batch%d_per_gpu_streamed" % (args.workload.split("_")[0], W, H, D, B), "width": W, "height": H, "disp_max": D - 1,
                        "preset": "driver(MIDDLEBURY+only_left+adaptive_mean+median)" + ("+subsampling" if args.subsampling else ""), "pairs_per_gpu_per_step": B,
-                       "parallelism": "batch-sharded x%d, no data-path collective" % world},
+                       "parallelism": "batch-sharded x%d, no data-path collective" % world, "engine": engine_info},
             "latency_ms_batch1": lat_ms, "gather_ms": gather_ms, "serial_kernel_us_per_pair": serial_k,
             "valid_fraction": round(valid_frac, 4), "checksum_rank0": checksum,
         }

@@ -94,6 +94,15 @@ typedef struct sv_config {
 
 int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out);
 int sv_destroy(sv_handle *h);
+/* What the handle decided at creation (defaults depend on the image size, the free memory and the CPU quota). */
+enum sv_query_key {
+    SV_Q_HOST_THREADS = 0,       /* size of the host pool */
+    SV_Q_CHUNK = 1,              /* pairs per GPU launch */
+    SV_Q_SLOTS = 2,              /* chunks in flight */
+    SV_Q_GPU_LATTICE_FILTER = 3, /* 1: support-lattice filters on the GPU, 0: on the host pool */
+    SV_Q_GPU_TRIANGULATION = 4   /* 1: Delaunay divide-and-conquer on the GPU (few host threads), 0: on the host pool */
+};
+int sv_query(const sv_handle *h, int what);
 const char *sv_last_error(const sv_handle *h); /* h may be NULL: error of the last failed sv_create */
 
 /* B independent pairs, images and maps in DEVICE memory (HBM):

@@ -367,16 +367,16 @@ __device__ __forceinline__ void d_process_node(const Mesh &M, DG_LDS uint32_t *r
 }
 
 #ifndef DG_HOST_EMULATION
-// One workgroup per vertex set.  sets[s] = {offset of the set's first entry in `order` / `xy`, m (vertices after the duplicate
-// scan), n_points (entries of xy), offset of its triangle list in tri_out}.  order: vertex ids in k-d order; xy: (x, y) per id.
-__global__ __launch_bounds__(DG_THREADS) void k_delaunay(const int4 *__restrict__ sets, const int32_t *__restrict__ order, const int32_t *__restrict__ xy,
-                                                        int32_t *__restrict__ tri_out, int32_t *__restrict__ tri_count) {
+// The body of both kernels: one workgroup triangulates one vertex set.
+//   order[0..m)            vertex ids in k-d order (global memory)
+//   vertex i               x = xb[i*stride] - (db ? db[i*stride] : 0), y = yb[i*stride], i < npts
+//   out / count            triangle list (3 ids per triangle, pool order, no bounding triangles) and its length
+__device__ __forceinline__ void dg_triangulate(int m, int npts, const int32_t *__restrict__ order, const int32_t *__restrict__ xb, const int32_t *__restrict__ yb,
+                                               const int32_t *__restrict__ db, int stride, int32_t *__restrict__ out, int32_t *__restrict__ count) {
     extern __shared__ uint32_t dg_lds[];
-    const int4 st = sets[blockIdx.x];
-    const int m = st.y, npts = st.z;
     const int tid = threadIdx.x;
     if (m < 3) {
-        if (tid == 0) tri_count[blockIdx.x] = 0;
+        if (tid == 0) *count = 0;
         return;
     }
     const int nslots = 2 * m - 1;  // slot 0 + 2m - 2
@@ -387,10 +387,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_delaunay(const int4 *__restrict_
     DG_LDS int16_t *py = px + npts + (npts & 1);
     DG_LDS uint16_t *ord = (DG_LDS uint16_t *)(py + npts + (npts & 1));
     for (int i = tid; i < npts; i += DG_THREADS) {
-        px[i] = (int16_t)xy[2 * (st.x + i)];
-        py[i] = (int16_t)xy[2 * (st.x + i) + 1];
+        px[i] = (int16_t)(xb[(size_t)i * stride] - (db ? db[(size_t)i * stride] : 0));
+        py[i] = (int16_t)yb[(size_t)i * stride];
     }
-    for (int i = tid; i < m; i += DG_THREADS) ord[i] = (uint16_t)order[st.x + i];
+    for (int i = tid; i < m; i += DG_THREADS) ord[i] = (uint16_t)order[i];
     if (tid == 0) {
         T[0].nbr[0] = T[0].nbr[1] = T[0].nbr[2] = 0;
         T[0].vtx[0] = T[0].vtx[1] = T[0].vtx[2] = (uint16_t)GHOST;
@@ -421,7 +421,6 @@ __global__ __launch_bounds__(DG_THREADS) void k_delaunay(const int4 *__restrict_
     }
     __syncthreads();
     int pos = s_part[tid];
-    int32_t *out = tri_out + st.w;
     for (int t = t0; t < t1; t++) {
         if (T[t].vtx[0] == GHOST || T[t].vtx[1] == GHOST || T[t].vtx[2] == GHOST) continue;
         out[3 * pos] = T[t].vtx[1];
@@ -429,7 +428,30 @@ __global__ __launch_bounds__(DG_THREADS) void k_delaunay(const int4 *__restrict_
         out[3 * pos + 2] = T[t].vtx[0];
         pos++;
     }
-    if (tid == 0) tri_count[blockIdx.x] = s_total;
+    if (tid == 0) *count = s_total;
+}
+
+// Test-hook form: sets[s] = {offset of the set's first entry in `order` / `xy`, m (vertices after the duplicate scan), n_points
+// (entries of xy), offset of its triangle list in tri_out}.  order: vertex ids in k-d order; xy: (x, y) per id.
+__global__ __launch_bounds__(DG_THREADS) void k_delaunay(const int4 *__restrict__ sets, const int32_t *__restrict__ order, const int32_t *__restrict__ xy,
+                                                        int32_t *__restrict__ tri_out, int32_t *__restrict__ tri_count) {
+    const int4 st = sets[blockIdx.x];
+    dg_triangulate(st.y, st.z, order + st.x, xy + 2 * (size_t)st.x, xy + 2 * (size_t)st.x + 1, nullptr, 2, tri_out + st.w, tri_count + blockIdx.x);
+}
+
+// Pipeline form: blockIdx.x = pair * 2 + side.  The chunk's blob (engine.cpp) holds per pair the meta words, the support points
+// (u, v, d) and room for the two triangle lists; behind the second list the host stage has left, per side, [m, id_0 .. id_{m-1}]:
+// the k-d ordered vertex ids (m = -1: the host triangulated this side itself, nothing to do).  Left image: (u, v); right: (u - d, v).
+__global__ __launch_bounds__(DG_THREADS) void k_delaunay_blob(int32_t *__restrict__ blob) {
+    const int pair = blockIdx.x >> 1, side = blockIdx.x & 1;
+    int32_t *meta = blob + (size_t)pair * META_WORDS;
+    const int ns = meta[0];
+    if (ns < 3) return;
+    const int32_t *sup = blob + meta[1];
+    const int32_t *ord = blob + meta[5] + (size_t)2 * ns * 3 + (size_t)side * (ns + 1);
+    const int m = ord[0];
+    if (m < 0) return;
+    dg_triangulate(m, ns, ord + 1, sup, sup + 1, side ? sup + 2 : nullptr, 3, blob + meta[3 + 2 * side], meta + 2 + 2 * side);
 }
 
 #endif  // DG_HOST_EMULATION
@@ -460,6 +482,19 @@ int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const
     }
     hipLaunchKernelGGL(k_delaunay, dim3(nsets), dim3(DG_THREADS), lds, st, sets, order, xy, tri_out, tri_count);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Both triangulations of every pair of a chunk, straight into the chunk's device blob.
+void launch_delaunay_blob(int32_t *blob, int n_pairs, size_t lds, hipStream_t st) {
+    if (lds > 64 * 1024) {
+        static std::atomic<size_t> granted[64];  // per device
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<size_t> &g = granted[dev & 63];
+        if (lds > g.load() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_delaunay_blob), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
+            g.store(lds);
+    }
+    SV_LAUNCH(K_DELAUNAY, k_delaunay_blob, dim3(2 * n_pairs), dim3(DG_THREADS), lds, st, blob);
 }
 #endif  // DG_HOST_EMULATION
 

@@ -113,6 +113,7 @@ struct sv_handle {
     int nproc = 1;  // maps per pair that get post-processed
     int chunk = 1;
     bool block_sync = false;  // host waits on events sleep (throughput mode) instead of spinning (latency mode)
+    bool gpu_delaunay = false;  // divide-and-conquer phase of the triangulations on the GPU (delaunay_gpu.hip); the host only orders the vertices
     bool gpu_filter = false;  // lattice filters on the GPU (k_support_filter) instead of the host pool
     std::vector<Slot *> slots;
     hipStream_t sP1 = nullptr, sPF = nullptr;  // phase 1; lattice filter + its D2H
@@ -500,6 +501,21 @@ void triangulate_side(sv_handle *h, HostScratch *sc, Slot *s, int j, int side) {
         sc->xy[2 * q + 1] = sup[3 * q + 1];
     }
     const auto t0 = std::chrono::steady_clock::now();
+    if (h->gpu_delaunay) {
+        // only the preparation stays here: [m, ids in k-d order] behind the two triangle lists; k_delaunay_blob does the rest.
+        // Sets the kernel cannot hold (LDS) are triangulated here as usual and marked with m = -1.
+        int32_t *ord = blob + meta[5] + (size_t)2 * ns * 3 + (size_t)side * (ns + 1);
+        if (ns <= delaunay_gpu_max_points()) {
+            const int m = sc->dl.kd_ordered_ids(sc->xy.data(), ns, ord + 1);
+            if (h->timing) h->host_delaunay_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            if (m >= 0) {
+                ord[0] = m;
+                meta[2 + 2 * side] = 0;  // the kernel writes the count into the device copy
+                return;
+            }
+        }
+        ord[0] = -1;
+    }
     // latency mode: the halves of the top-level cut go to two threads (throughput mode keeps every core busy with whole pairs)
     const Delaunay::Spawn spawn{spawn_to_pool, h};
     const int nt = sc->dl.triangulate(sc->xy.data(), ns, blob + meta[3 + 2 * side], 2 * ns, (h->chunk == 1 && h->pool.size() >= 3) ? &spawn : nullptr);
@@ -564,7 +580,7 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
         return;
     }
     // 3*ns words of points + two triangle lists of at most 2*ns triangles each
-    const size_t need = (size_t)ns * 3 + 2 * ((size_t)2 * ns * 3);
+    const size_t need = (size_t)ns * 3 + 2 * ((size_t)2 * ns * 3) + (h->gpu_delaunay ? 2 * ((size_t)ns + 1) : 0);
     const size_t off = s->blob_off.fetch_add(need);
     if (off + need > s->blob_words) {
         note_error(h, "host blob overflow");
@@ -652,6 +668,11 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
         dbg_put(h, "tri2", blob + meta[5], (size_t)meta[4] * 3);
     }
     HIP_TRY(hipMemcpyAsync(s->dev.blob, blob, off * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (h->gpu_delaunay) {  // the triangle lists are still missing: built on the device from the vertex orders the host left in the blob
+        int ns_max = 3;
+        for (int j = 0; j < n; j++) ns_max = std::max(ns_max, std::min(blob[(size_t)j * META_WORDS], delaunay_gpu_max_points()));
+        launch_delaunay_blob(s->dev.blob, n, delaunay_gpu_lds_bytes(ns_max, ns_max), st);
+    }
     launch_grid(k, s->dev, n, st);
     launch_triangles(k, s->dev, n, st);
     launch_dense(k, s->dev, n, st);
@@ -772,7 +793,7 @@ void alloc_slot(sv_handle *h, Slot *sl) {
     s.cap = (int)cap;
     dev_alloc(s.desc, cap * 2 * d.N * 16);
     dev_alloc(s.dcan, cap * d.Wc * d.Hc);
-    sl->blob_words = cap * (META_WORDS + (size_t)d.max_pts * 3 + 2 * (size_t)d.max_tri * 3 + 64);
+    sl->blob_words = cap * (META_WORDS + (size_t)d.max_pts * 3 + 2 * (size_t)d.max_tri * 3 + 2 * ((size_t)d.max_pts + 1) + 64);
     dev_alloc(s.blob, sl->blob_words);
     dev_alloc(s.fsup, cap * (size_t)d.max_pts * 3);
     dev_alloc(s.fnsup, cap);
@@ -1052,6 +1073,10 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         h->chunk = 1;
     }
     if (h->chunk < 4 && !getenv("SV_GPU_FILTER")) h->gpu_filter = false;
+    // triangulation on the GPU: on request, or by itself when few host threads are available (it costs GPU time and LDS, and a
+    // single pair is faster on the host); never with keep_debug (the parity tests read the host's triangle lists)
+    h->gpu_delaunay = !cfg->keep_debug && h->chunk >= 4 && npool <= 9;  // measured: host mode wins from ~10 free threads per GPU on
+    if (const char *e = getenv("SV_GPU_DELAUNAY")) h->gpu_delaunay = atoi(e) != 0 && !cfg->keep_debug;
     h->block_sync = h->chunk >= 4;
     if (const char *e = getenv("SV_EVENT_SYNC")) h->block_sync = strcmp(e, "block") == 0;
     try {
@@ -1124,6 +1149,18 @@ int sv_submit_batch_device(sv_handle *h, const uint8_t *left, const uint8_t *rig
 }
 
 int sv_wait(sv_handle *h) { return wait_jobs(h); }
+
+int sv_query(const sv_handle *h, int what) {
+    if (!h) return SV_ERR_ARG;
+    switch (what) {
+        case SV_Q_HOST_THREADS: return (int)h->pool.size();
+        case SV_Q_CHUNK: return h->chunk;
+        case SV_Q_SLOTS: return (int)h->slots.size();
+        case SV_Q_GPU_LATTICE_FILTER: return h->gpu_filter ? 1 : 0;
+        case SV_Q_GPU_TRIANGULATION: return h->gpu_delaunay ? 1 : 0;
+        default: return SV_ERR_ARG;
+    }
+}
 
 int sv_process_batch_host(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status) {
     if (!h) return SV_ERR_ARG;

@@ -17,16 +17,10 @@ thread_local LaunchHook g_launch_hook = {nullptr, nullptr};
 
 const char *kernel_name(int id) {
     static const char *names[K_COUNT] = {"descriptor", "support_match", "support_filter", "grid_mark", "grid_dilate", "plane_fit", "triangles_raster", "triangles_raster_fallback", "dense_match", "lr_check",
-                                         "ccl_band", "ccl_finish", "gap_rows", "gap_cols", "adaptive_mean", "median", "output"};
+                                         "delaunay_gpu", "ccl_band", "ccl_finish", "gap_rows", "gap_cols", "adaptive_mean", "median", "output"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 
-#define SV_LAUNCH(id, kernel, grid, block, shmem, st, ...)                         \
-    do {                                                                           \
-        if (g_launch_hook.fn) g_launch_hook.fn(g_launch_hook.ctx, id, true, st);   \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);           \
-        if (g_launch_hook.fn) g_launch_hook.fn(g_launch_hook.ctx, id, false, st);  \
-    } while (0)
 
 // ------------------------------------------------------------------------------------------------------------
 // small device helpers

@@ -87,12 +87,13 @@ void launch_output(const KParams &k, const SlotDev &s, int n, const float *src, 
 // duplicate scan, entries of xy, offset of the set's triangle list in tri_out (in int32 units)}
 size_t delaunay_gpu_lds_bytes(int m, int npts);
 int delaunay_gpu_max_points();
+void launch_delaunay_blob(int32_t *blob, int n_pairs, size_t lds, hipStream_t st);
 int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, size_t lds, hipStream_t st);
 
 // names of the kernels behind each wrapper, in launch order, for timing reports
 enum KernelId {
     K_DESCRIPTOR = 0, K_SUPPORT, K_SUPPORT_FILTER, K_GRID_MARK, K_GRID_DILATE, K_PLANES, K_TRIANGLES, K_TRIANGLES_FALLBACK, K_DENSE, K_LR,
-    K_CCL_BAND, K_CCL_FINISH, K_GAP_ROWS, K_GAP_COLS, K_AMEAN, K_MEDIAN, K_OUTPUT, K_COUNT
+    K_DELAUNAY, K_CCL_BAND, K_CCL_FINISH, K_GAP_ROWS, K_GAP_COLS, K_AMEAN, K_MEDIAN, K_OUTPUT, K_COUNT
 };
 const char *kernel_name(int id);
 
@@ -102,5 +103,12 @@ struct LaunchHook {
     void *ctx;
 };
 extern thread_local LaunchHook g_launch_hook;
+
+#define SV_LAUNCH(id, kernel, grid, block, shmem, st, ...)                         \
+    do {                                                                           \
+        if (g_launch_hook.fn) g_launch_hook.fn(g_launch_hook.ctx, id, true, st);   \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);           \
+        if (g_launch_hook.fn) g_launch_hook.fn(g_launch_hook.ctx, id, false, st);  \
+    } while (0)
 
 }  // namespace sv

@@ -215,6 +215,13 @@ class StereoEngine:
         assert got == n
         return out
 
+    def query(self):
+        """What the handle decided at creation: host threads, chunk, slots, where the lattice filters and the triangulations run."""
+        L = lib()
+        L.sv_query.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        keys = ["host_threads", "chunk", "slots", "gpu_lattice_filter", "gpu_triangulation"]
+        return {k: int(L.sv_query(self._h, i)) for i, k in enumerate(keys)}
+
     def timing(self, on=True):
         lib().sv_kernel_timing_enable(self._h, int(on))
         lib().sv_kernel_times_reset(self._h)

@@ -185,6 +185,26 @@ def test_gpu_delaunay_matches_host(eng):
         assert np.array_equal(got.ravel(), want.ravel())
 
 
+@pytest.mark.parametrize("name", ["kitti0_d128", "kitti20_d128", "kitti0_d128_sub", "cones_crop_middlebury", "synth5000_4kstrip_d192"])
+def test_pipeline_with_gpu_triangulation(eng, oracle, monkeypatch, name):
+    """SV_GPU_DELAUNAY=1 (what a handle with few host threads chooses by itself): the host pool only orders the vertices, the
+    triangle lists are built on the device straight into the chunk's blob.  Same maps, bit for bit; the 4K strip's 7 500-point
+    sets exceed the kernel's LDS and take the per-set host fallback inside the same chunk."""
+    monkeypatch.setenv("SV_GPU_DELAUNAY", "1")
+    entry = DIG[name]
+    L, R = util.case_images(entry)
+    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=2, n_streams=2, n_workers=3)
+    try:
+        assert e.query()["gpu_triangulation"] == 1
+        d1, d2, st = e.process_host(np.stack([L] * 5), np.stack([R] * 5))
+    finally:
+        e.close()
+    assert (st == entry["n_support"]).all()
+    for i in range(5):
+        assert util.sha(d1[i]) == entry["stages"]["final1"]
+        assert util.sha(d2[i]) == entry["stages"]["final2"]
+
+
 def test_random_parameter_sets(eng, oracle):
     """Elas::parameters far from the three presets (tools/fuzz_params.py): both maps, batch path and latency path, bit-exact."""
     import sys
