@@ -27,23 +27,27 @@ namespace dg {
 
 constexpr uint32_t GHOST = 0xFFFFu;
 constexpr int DG_THREADS = 256;
-constexpr int DG_MAX_DEPTH = 11;  // leaves of 2 vertices at depth 11: up to 4096 vertices
 
 struct DTri {
     uint16_t nbr[3];  // neighbour handle across edge o: (slot << 2) | orientation; slot 0 = outer space
     uint16_t vtx[3];  // vertex ids, GHOST = the vertex at infinity of a bounding triangle
 };
 
-// The triangle array is accessed through a volatile pointer: hipcc's SLP vectoriser (ROCm 7.2, -O2 and above) fuses the 16-bit
+// The triangle array is accessed through a DG_VOLATILE pointer: hipcc's SLP vectoriser (ROCm 7.2, -O2 and above) fuses the 16-bit
 // field accesses of neighbouring statements into wider ones across stores that may hit the same triangle through another handle
 // and the merge then walks a stale mesh (reproduced on a 7-vertex set; -fno-slp-vectorize or -O1 give the right mesh).
+#ifdef DG_NO_VOLATILE  // experiment: rely on -fno-slp-vectorize instead
+#define DG_VOLATILE
+#else
+#define DG_VOLATILE volatile
+#endif
 #ifdef DG_HOST_EMULATION
 #define DG_LDS
 #else
 #define DG_LDS __attribute__((address_space(3)))  // explicit LDS pointers: ds_* instructions instead of flat_* ones
 #endif
 struct Mesh {
-    DG_LDS volatile DTri *T;
+    DG_LDS DG_VOLATILE DTri *T;
     DG_LDS const int16_t *px, *py;
 };
 
@@ -77,7 +81,7 @@ __device__ __forceinline__ int64_t d_incirc(const Mesh &M, uint32_t a, uint32_t 
 }
 
 __device__ __forceinline__ uint32_t d_make(const Mesh &M, uint32_t slot) {  // triangle.cpp:2068-2101
-    DG_LDS volatile DTri &t = M.T[slot];
+    DG_LDS DG_VOLATILE DTri &t = M.T[slot];
     t.nbr[0] = 0, t.nbr[1] = 0, t.nbr[2] = 0;
     t.vtx[0] = (uint16_t)GHOST, t.vtx[1] = (uint16_t)GHOST, t.vtx[2] = (uint16_t)GHOST;
     return slot << 2;
@@ -371,6 +375,13 @@ __device__ __forceinline__ void d_process_node(const Mesh &M, DG_LDS uint32_t *r
 //   order[0..m)            vertex ids in k-d order (global memory)
 //   vertex i               x = xb[i*stride] - (db ? db[i*stride] : 0), y = yb[i*stride], i < npts
 //   out / count            triangle list (3 ids per triangle, pool order, no bounding triangles) and its length
+// Depth of the deepest leaves: the smallest D with ceil(m / 2^D) <= 3.
+__host__ __device__ inline int dg_depth(int m) {
+    int D = 0;
+    while (((m + (1 << D) - 1) >> D) > 3) D++;
+    return D;
+}
+
 __device__ __forceinline__ void dg_triangulate(int m, int npts, const int32_t *__restrict__ order, const int32_t *__restrict__ xb, const int32_t *__restrict__ yb,
                                                const int32_t *__restrict__ db, int stride, int32_t *__restrict__ out, int32_t *__restrict__ count) {
     extern __shared__ uint32_t dg_lds[];
@@ -380,9 +391,10 @@ __device__ __forceinline__ void dg_triangulate(int m, int npts, const int32_t *_
         return;
     }
     const int nslots = 2 * m - 1;  // slot 0 + 2m - 2
+    const int depth = dg_depth(m);
     // LDS: results of the tree nodes (heap order), triangles, coordinates, k-d ordered ids
-    DG_LDS uint32_t *res = (DG_LDS uint32_t *)dg_lds;                             // [2 << DG_MAX_DEPTH]: farleft | farright << 16
-    DG_LDS volatile DTri *T = (DG_LDS volatile DTri *)(res + (2 << DG_MAX_DEPTH));  // [nslots]
+    DG_LDS uint32_t *res = (DG_LDS uint32_t *)dg_lds;                       // [2 << depth]: farleft | farright << 16
+    DG_LDS DG_VOLATILE DTri *T = (DG_LDS DG_VOLATILE DTri *)(res + (2 << depth));   // [nslots]
     DG_LDS int16_t *px = (DG_LDS int16_t *)(T + nslots + (nslots & 1));
     DG_LDS int16_t *py = px + npts + (npts & 1);
     DG_LDS uint16_t *ord = (DG_LDS uint16_t *)(py + npts + (npts & 1));
@@ -397,7 +409,7 @@ __device__ __forceinline__ void dg_triangulate(int m, int npts, const int32_t *_
     }
     __syncthreads();
     const Mesh M{T, px, py};
-    for (int d = DG_MAX_DEPTH; d >= 0; d--) {
+    for (int d = depth; d >= 0; d--) {
         for (int j = tid; j < (1 << d); j += DG_THREADS) d_process_node(M, res, ord, m, d, j);
         __syncthreads();
     }
@@ -463,7 +475,7 @@ using namespace dg;
 #ifndef DG_HOST_EMULATION
 size_t delaunay_gpu_lds_bytes(int m, int npts) {
     const size_t nslots = 2 * (size_t)m - 1;
-    return sizeof(uint32_t) * (2 << DG_MAX_DEPTH) + sizeof(DTri) * (nslots + (nslots & 1)) + sizeof(int16_t) * 2 * ((size_t)npts + (npts & 1)) + sizeof(uint16_t) * (size_t)m + 16;
+    return sizeof(uint32_t) * (2 << dg_depth(m)) + sizeof(DTri) * (nslots + (nslots & 1)) + sizeof(int16_t) * 2 * ((size_t)npts + (npts & 1)) + sizeof(uint16_t) * (size_t)m + 16;
 }
 
 int delaunay_gpu_max_points() { return 4000; }

@@ -30,7 +30,7 @@ int main() {
         const int m = dl2.kd_ordered_ids(xy.data(), n, ids.data());
         if (m < 3) { if (nw != 0) bad++; continue; }
         const int nslots = 2 * m - 1;
-        std::vector<uint32_t> res(2 << sv::dg::DG_MAX_DEPTH, 0);
+        std::vector<uint32_t> res(2 << 12, 0);
         std::vector<sv::dg::DTri> T(nslots);
         std::vector<int16_t> px(n), py(n);
         std::vector<uint16_t> ord(m);
@@ -39,7 +39,7 @@ int main() {
         memset((void *)&T[0], 0, sizeof(sv::dg::DTri));
         T[0].vtx[0] = T[0].vtx[1] = T[0].vtx[2] = 0xFFFF;
         const sv::dg::Mesh M{T.data(), px.data(), py.data()};
-        for (int d = sv::dg::DG_MAX_DEPTH; d >= 0; d--)
+        for (int d = 12; d >= 0; d--)
             for (int j = (1 << d) - 1; j >= 0; j--) sv::dg::d_process_node(M, res.data(), ord.data(), m, d, j);
         std::vector<int32_t> got;
         for (int t = 1; t < nslots; t++) {
