@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="pairs per launch (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=64, help="pairs timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement (profiling runs: keeps the per-kernel averages to the timed region's launches)")
     ap.add_argument("--sync-steps", action="store_true", help="wait for each step before submitting the next (default: streamed submission)")
     ap.add_argument("--serial-kernels", action="store_true", help="extra pass with one slot / one stream (no kernel overlap) to get clean per-kernel times")
     ap.add_argument("--real-pair", action="store_true", help="fill the batch with copies of the committed kitti_mini pair 0 instead of synthetic pairs (sanity check of the synthetic workload: real maps are more fragmented)")
@@ -197,7 +198,7 @@ def main():
     # batch-1 latency on rank 0 (ms/frame), SURVEY.md §8d config 2: pair 0 of kitti_mini (the committed gray fixture; the first
     # synthetic pair if the fixture is absent), one pair per call, 200 timed calls after 20 warm-ups
     lat_ms = None
-    if rank == 0:
+    if rank == 0 and not args.no_latency:
         e1 = eng.StereoEngine(W, H, params, device=local_rank, n_workers=4, chunk=1, n_streams=1, n_slots=2)
         l1, r1, which = left[:1].contiguous(), right[:1].contiguous(), "synthetic seed %d" % seeds[0]
         try:
@@ -205,7 +206,7 @@ def main():
             gl = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "kitti0_left.png")))
             gr = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "kitti0_right.png")))
             if gl.shape == (H, W):
-                l1, r1, which = torch.from_numpy(np.ascontiguousarray(gl[None])).cuda(), torch.from_numpy(np.ascontiguousarray(gr[None])).cuda(), "kitti_mini pair 0"
+                l1, r1, which = torch.from_numpy(np.array(gl[None])).cuda(), torch.from_numpy(np.array(gr[None])).cuda(), "kitti_mini pair 0"
         except (OSError, ImportError):
             pass
         o1, o2 = d1[:1].clone(), d2[:1].clone()
