@@ -80,6 +80,32 @@ __device__ __forceinline__ int64_t d_incirc(const Mesh &M, uint32_t a, uint32_t 
     return (adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) + (bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy) + (cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
 }
 
+// A vertex with its coordinates (the GHOST vertex has none: its coordinates are never used)
+struct DV {
+    uint32_t id;
+    int32_t x, y;
+};
+
+__device__ __forceinline__ DV d_vertex(const Mesh &M, uint32_t id) {
+    DV v;
+    v.id = id;
+    const uint32_t safe = id == GHOST ? 0u : id;
+    v.x = M.px[safe];
+    v.y = M.py[safe];
+    return v;
+}
+
+__device__ __forceinline__ int64_t dv_orient(const DV &a, const DV &b, const DV &c) {
+    return (int64_t)(a.x - c.x) * (b.y - c.y) - (int64_t)(a.y - c.y) * (b.x - c.x);
+}
+
+__device__ __forceinline__ int64_t dv_incirc(const DV &a, const DV &b, const DV &c, const DV &d) {
+    const int64_t adx = a.x - d.x, ady = a.y - d.y;
+    const int64_t bdx = b.x - d.x, bdy = b.y - d.y;
+    const int64_t cdx = c.x - d.x, cdy = c.y - d.y;
+    return (adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) + (bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy) + (cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
+}
+
 __device__ __forceinline__ uint32_t d_make(const Mesh &M, uint32_t slot) {  // triangle.cpp:2068-2101
     DG_LDS DG_VOLATILE DTri &t = M.T[slot];
     t.nbr[0] = 0, t.nbr[1] = 0, t.nbr[2] = 0;
@@ -223,14 +249,16 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
     D_DEST(base) = (uint16_t)ild;
     if (ild == D_ORG(farleft)) farleft = hnext(base);
     if (iro == D_DEST(farright)) farright = hprev(base);
-    uint32_t ll = ild, lr = iro;
-    uint32_t ul = D_APEX(leftcand), ur = D_APEX(rightcand);
+    // The seam loop keeps the coordinates of its four moving vertices in registers (a vertex is read from LDS once, when it
+    // enters the picture) instead of fetching them again for every predicate.
+    DV ll = d_vertex(M, ild), lr = d_vertex(M, iro);
+    DV ul = d_vertex(M, D_APEX(leftcand)), ur = d_vertex(M, D_APEX(rightcand));
     for (;;) {
-        const bool leftdone = d_orient(M, ul, ll, lr) <= 0, rightdone = d_orient(M, ur, ll, lr) <= 0;
+        const bool leftdone = dv_orient(ul, ll, lr) <= 0, rightdone = dv_orient(ur, ll, lr) <= 0;
         if (leftdone && rightdone) {
             uint32_t top = d_make(M, slot + 1);
-            D_ORG(top) = (uint16_t)ll;
-            D_DEST(top) = (uint16_t)lr;
+            D_ORG(top) = (uint16_t)ll.id;
+            D_DEST(top) = (uint16_t)lr.id;
             D_BOND(top, base);
             top = hnext(top);
             D_BOND(top, rightcand);
@@ -257,9 +285,9 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
         }
         if (!leftdone) {  // flip away left edges that the circle through ll, lr, ul invalidates
             uint32_t nx = D_SYM(hprev(leftcand));
-            uint32_t na = D_APEX(nx);
-            if (na != GHOST) {
-                bool bad = d_incirc(M, ll, lr, ul, na) > 0;
+            DV na = d_vertex(M, D_APEX(nx));
+            if (na.id != GHOST) {
+                bool bad = dv_incirc(ll, lr, ul, na) > 0;
                 while (bad) {
                     nx = hnext(nx);
                     const uint32_t topc = D_SYM(nx);
@@ -271,24 +299,24 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
                     const uint32_t outerc = D_SYM(leftcand);
                     nx = hprev(nx);
                     D_BOND(nx, outerc);
-                    D_ORG(leftcand) = (uint16_t)ll;
+                    D_ORG(leftcand) = (uint16_t)ll.id;
                     D_DEST(leftcand) = (uint16_t)GHOST;
-                    D_APEX(leftcand) = (uint16_t)na;
+                    D_APEX(leftcand) = (uint16_t)na.id;
                     D_ORG(nx) = (uint16_t)GHOST;
-                    D_DEST(nx) = (uint16_t)ul;
-                    D_APEX(nx) = (uint16_t)na;
+                    D_DEST(nx) = (uint16_t)ul.id;
+                    D_APEX(nx) = (uint16_t)na.id;
                     ul = na;
                     nx = sidec;
-                    na = D_APEX(nx);
-                    bad = na != GHOST && d_incirc(M, ll, lr, ul, na) > 0;
+                    na = d_vertex(M, D_APEX(nx));
+                    bad = na.id != GHOST && dv_incirc(ll, lr, ul, na) > 0;
                 }
             }
         }
         if (!rightdone) {
             uint32_t nx = D_SYM(hnext(rightcand));
-            uint32_t na = D_APEX(nx);
-            if (na != GHOST) {
-                bool bad = d_incirc(M, ll, lr, ur, na) > 0;
+            DV na = d_vertex(M, D_APEX(nx));
+            if (na.id != GHOST) {
+                bool bad = dv_incirc(ll, lr, ur, na) > 0;
                 while (bad) {
                     nx = hprev(nx);
                     const uint32_t topc = D_SYM(nx);
@@ -301,32 +329,32 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
                     nx = hnext(nx);
                     D_BOND(nx, outerc);
                     D_ORG(rightcand) = (uint16_t)GHOST;
-                    D_DEST(rightcand) = (uint16_t)lr;
-                    D_APEX(rightcand) = (uint16_t)na;
-                    D_ORG(nx) = (uint16_t)ur;
+                    D_DEST(rightcand) = (uint16_t)lr.id;
+                    D_APEX(rightcand) = (uint16_t)na.id;
+                    D_ORG(nx) = (uint16_t)ur.id;
                     D_DEST(nx) = (uint16_t)GHOST;
-                    D_APEX(nx) = (uint16_t)na;
+                    D_APEX(nx) = (uint16_t)na.id;
                     ur = na;
                     nx = sidec;
-                    na = D_APEX(nx);
-                    bad = na != GHOST && d_incirc(M, ll, lr, ur, na) > 0;
+                    na = d_vertex(M, D_APEX(nx));
+                    bad = na.id != GHOST && dv_incirc(ll, lr, ur, na) > 0;
                 }
             }
         }
-        if (leftdone || (!rightdone && d_incirc(M, ul, ll, lr, ur) > 0)) {
+        if (leftdone || (!rightdone && dv_incirc(ul, ll, lr, ur) > 0)) {
             D_BOND(base, rightcand);
             base = hprev(rightcand);
-            D_DEST(base) = (uint16_t)ll;
+            D_DEST(base) = (uint16_t)ll.id;
             lr = ur;
             rightcand = D_SYM(base);
-            ur = D_APEX(rightcand);
+            ur = d_vertex(M, D_APEX(rightcand));
         } else {
             D_BOND(base, leftcand);
             base = hnext(leftcand);
-            D_ORG(base) = (uint16_t)lr;
+            D_ORG(base) = (uint16_t)lr.id;
             ll = ul;
             leftcand = D_SYM(base);
-            ul = D_APEX(leftcand);
+            ul = d_vertex(M, D_APEX(leftcand));
         }
     }
 }
