@@ -50,6 +50,7 @@ def algorithmic_bytes_per_pair(N, Wc, Hc, Wimg, MW, ncell):
         "triangles_raster": 2 * 4 * N, "triangles_raster_fallback": 0,                        # one tri_id write per covered pixel, both sides
         "dense_match": 2 * desc + 2 * 4 * N + 2 * 2 * N,      # both descriptor images, tri_id in, int16 WTA out (both sides)
         "lr_check": 2 * 2 * N + 2 * 4 * N,                    # int16 WTA maps in; checked left map + the caller's right map out
+        "delaunay_gpu": 2 * (16 * 2200 + 12 * 4400),         # GPU triangulation mode: ~2.2k support points + vertex order in, ~4.4k triangles out, per side
         "ccl_band": 4 * N, "ccl_finish": 0,
         "gap_rows": 8 * N, "gap_cols": 8 * N, "adaptive_mean": 8 * N, "median": 8 * N + 4 * N,
         "output": 2 * 8 * N,
@@ -249,7 +250,8 @@ def main():
             ktimes = {k: v for k, v in ktimes.items() if not k.startswith("host:")}
             out["host_stage_cpu_ms_per_pair"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in host.items()}
             tot = {k: v[0] for k, v in ktimes.items() if v[1] > 0}
-            dom = max((kk for kk in tot if kk != "support_filter"), key=tot.get)  # the lattice filter is one workgroup per pair: latency, not throughput
+            # the lattice filter and the GPU triangulation are one workgroup per pair / vertex set: latency, not throughput
+            dom = max((kk for kk in tot if kk not in ("support_filter", "delaunay_gpu")), key=tot.get)
             ms, calls = ktimes[dom]
             pairs_per_launch = B * args.steps / calls  # rank 0's launches of this kernel each cover one chunk
             avg_s = 1e-3 * ms / calls
