@@ -35,6 +35,13 @@ __device__ __forceinline__ uint32_t sad16(const uint4 &a, const uint4 &b) {
     return sad4(a.w, b.w, s);
 }
 
+__device__ __forceinline__ uint32_t sad16(const uint4 &a, const uint4 &b, uint32_t s) {  // continues an accumulation
+    s = sad4(a.x, b.x, s);
+    s = sad4(a.y, b.y, s);
+    s = sad4(a.z, b.z, s);
+    return sad4(a.w, b.w, s);
+}
+
 // sum |byte - 128| over the 16 descriptor bytes (elas.cpp:296-298, 732-734)
 __device__ __forceinline__ uint32_t texture16(const uint4 &a) {
     const uint4 mid = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
@@ -224,77 +231,112 @@ void launch_descriptor(const KParams &k, const uint8_t *left, const uint8_t *rig
 // row: the forward search reads the right image over [u-2-dmax, u+2], the backward check the left image over
 // [u-d-2, u-d+2+dmax]; neighbouring lattice points (5 px apart) share almost all of it, so the run is made as long as an
 // LDS budget allows (the whole row at KITTI size).
-#define SUP_THREADS 512
+//
+// One LANE per lattice point and quarter of the disparity range (a workgroup = 64 consecutive lattice points x 4 wavefronts,
+// one per quarter), disparities scanned in ascending order like the reference's loop: no cross-lane reduction, only a merge of
+// four (best, runner-up) records per point through LDS.  The descriptor at u-d+2 is the one loaded four steps earlier for
+// u-(d-4)-2, so a four-deep register rotation halves the LDS reads (2 x ds_read_b128 + 16 x v_sad_u8 + 3 bookkeeping
+// instructions per disparity).  Consecutive lanes are `step` descriptors (80 bytes at step 5) apart: conflict-free for
+// 128-bit LDS reads.
+#define SUP_THREADS 256
+#define SUP_POINTS 64
+#define SUP_SPLIT (SUP_THREADS / SUP_POINTS)
 
 struct SupRows {            // one staged image: rows v-2 and v+2, columns [c0, c0+n)
     const uint4 *r0, *r1;
     int c0;
 };
 
-// Wavefront reduction with DPP row shifts (no LDS crossbar traffic): an inclusive scan over disjoint lane ranges
-// (row_shr 1,2,4,8, then row_bcast 15 / 31), total in lane 63.  The element is (k1, e2): k1 = smallest (energy<<16|d) key,
-// e2 = second smallest energy of the lanes merged so far; lanes without a source receive the identity.
-__device__ __forceinline__ void top2_merge(uint32_t &k1, uint32_t &e2, uint32_t ok, uint32_t oe) {
-    const uint32_t hi = (ok > k1 ? ok : k1) >> 16;  // energy of the larger key: runner-up of the merged pair
-    k1 = ok < k1 ? ok : k1;
-    e2 = min(min(e2, oe), hi);
+// (best key, runner-up key) of the keys seen so far, key = energy<<16 | d: the smallest key is the lowest energy at the lowest d
+// (first-wins under the reference's strict <, elas.cpp:352-360), the energy of the second smallest key is the second order
+// statistic of the energy multiset, which is what min_2_E ends as.
+__device__ __forceinline__ void top2_push(uint32_t &k1, uint32_t &k2, uint32_t key) {
+    uint32_t m;  // k1 <= k2: the median of the three is the new runner-up
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(k1), "v"(k2), "v"(key));
+    k2 = m;
+    k1 = min(k1, key);
 }
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ void top2_dpp_step(uint32_t &k1, uint32_t &e2) {
-    const uint32_t ok = (uint32_t)__builtin_amdgcn_update_dpp((int)0x7FFFFFFF, (int)k1, CTRL, ROW_MASK, 0xf, false);
-    const uint32_t oe = (uint32_t)__builtin_amdgcn_update_dpp((int)0x7FFF, (int)e2, CTRL, ROW_MASK, 0xf, false);
-    top2_merge(k1, e2, ok, oe);
-}
+constexpr uint32_t SUP_KEY_NONE = 0x7FFFFFFFu;  // energy 32767, d 0xFFFF: the reference's initial min_1_E / min_2_E
 
-__device__ __forceinline__ void wave_top2(uint32_t &k1, uint32_t &e2) {
-    top2_dpp_step<0x111, 0xf>(k1, e2);  // row_shr:1
-    top2_dpp_step<0x112, 0xf>(k1, e2);  // row_shr:2
-    top2_dpp_step<0x114, 0xf>(k1, e2);  // row_shr:4
-    top2_dpp_step<0x118, 0xf>(k1, e2);  // row_shr:8
-    top2_dpp_step<0x142, 0xa>(k1, e2);  // row_bcast:15 into rows 1 and 3
-    top2_dpp_step<0x143, 0xc>(k1, e2);  // row_bcast:31 into rows 2 and 3
-    k1 = (uint32_t)__builtin_amdgcn_readlane((int)k1, 63);
-    e2 = (uint32_t)__builtin_amdgcn_readlane((int)e2, 63);
-}
-
-__device__ __forceinline__ int support_match(const KParams &k, const uint8_t *__restrict__ Aimg, const SupRows &A, const SupRows &B, int u, int v, bool right_image,
-                                             int lane) {
-    const int W = k.d.W, H = k.d.H;
-    if (!(u >= 5 && u <= W - 6 && v >= 5 && v <= H - 6)) return -1;  // elas.cpp:279
-    const uint4 centre = ld16(Aimg + ((size_t)v * W + u) * 16);  // used after the search: its latency hides behind it
-    const int dmax = right_image ? min(k.d.disp_max, W - u - 5) : min(k.d.disp_max, u - 5);  // :318-323 (disp_min = 0)
-    if (dmax < 10) return -1;                                                                // :326
+// energies of the disparities [d_lo, d_hi] of the lattice point at column u of image A against image B (elas.cpp:341-360)
+template <bool RIGHT>
+__device__ __forceinline__ void support_scan(const SupRows &A, const SupRows &B, int u, int d_lo, int d_hi, uint32_t &k1, uint32_t &k2) {
     const int ua = u - A.c0;
     const uint4 a0 = A.r0[ua - 2], a1 = A.r0[ua + 2], a2 = A.r1[ua - 2], a3 = A.r1[ua + 2];
-    uint32_t e1 = 0x7FFFu, d1 = 0xFFFFu, e2 = 0x7FFFu;
-    for (int dd = lane; dd <= dmax; dd += 64) {
-        const int ub = (right_image ? u + dd : u - dd) - B.c0;
-        uint32_t e = sad16(a0, B.r0[ub - 2]) + sad16(a1, B.r0[ub + 2]) + sad16(a2, B.r1[ub - 2]) + sad16(a3, B.r1[ub + 2]);  // :341-349
-        if (e < e1) {  // :352-360, ascending d within a lane
-            e2 = e1;
-            e1 = e;
-            d1 = (uint32_t)dd;
-        } else if (e < e2) {
-            e2 = e;
-        }
+    // P(d) = B[u + dir*(d+2)] is loaded at step d; Q(d) = B[u + dir*(d-2)] = P(d-4) comes from the rotation
+    constexpr int dir = RIGHT ? 1 : -1;
+    const uint4 *b0 = B.r0 + (u - B.c0), *b1 = B.r1 + (u - B.c0);
+    uint4 p0[4], p1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        p0[j] = b0[dir * (d_lo + j - 2)];
+        p1[j] = b1[dir * (d_lo + j - 2)];
     }
-    // min over keys = lowest energy, then lowest d (first-wins under strict <); e2 ends as the second order statistic of the
-    // whole energy multiset
-    uint32_t best = (e1 << 16) | d1;
-    wave_top2(best, e2);
-    if ((int)texture16(centre) < k.support_texture) return -1;  // :296-300 (wave-uniform: every lane holds the same descriptor)
-    const float E1 = (float)(best >> 16), E2 = (float)e2;
-    if (E1 < k.support_threshold * E2) return (int)(best & 0xFFFFu);  // :364
-    return -1;
+    // step j of a block of four at disparity d + off + j: the descriptors the block before it loaded (o0/o1) are the rotated
+    // operands, the fresh ones go to n0/n1.  One accumulation chain, the older operands first: the loads have longer to land.
+#define SUP_STEP(j, off, o0, o1, n0, n1)                                                                                    \
+    {                                                                                                                       \
+        const uint4 q0 = o0[j], q1 = o1[j];                                                                                 \
+        n0[j] = b0[dir * (d + (off) + (j) + 2)];                                                                            \
+        n1[j] = b1[dir * (d + (off) + (j) + 2)];                                                                            \
+        const uint32_t e = RIGHT ? sad16(a3, n1[j], sad16(a1, n0[j], sad16(a2, q1, sad16(a0, q0))))                         \
+                                 : sad16(a2, n1[j], sad16(a0, n0[j], sad16(a3, q1, sad16(a1, q0))));                        \
+        top2_push(k1, k2, (e << 16) | (uint32_t)(d + (off) + (j)));                                                         \
+    }
+    uint4 r0[4], r1[4];
+    int d = d_lo;
+    for (; d + 7 <= d_hi; d += 8) {  // two blocks per trip, ping-ponging between the register sets: no copies
+        SUP_STEP(0, 0, p0, p1, r0, r1) SUP_STEP(1, 0, p0, p1, r0, r1) SUP_STEP(2, 0, p0, p1, r0, r1) SUP_STEP(3, 0, p0, p1, r0, r1)
+        SUP_STEP(0, 4, r0, r1, p0, p1) SUP_STEP(1, 4, r0, r1, p0, p1) SUP_STEP(2, 4, r0, r1, p0, p1) SUP_STEP(3, 4, r0, r1, p0, p1)
+    }
+    if (d + 3 <= d_hi) {
+        SUP_STEP(0, 0, p0, p1, r0, r1) SUP_STEP(1, 0, p0, p1, r0, r1) SUP_STEP(2, 0, p0, p1, r0, r1) SUP_STEP(3, 0, p0, p1, r0, r1)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            p0[j] = r0[j];
+            p1[j] = r1[j];
+        }
+        d += 4;
+    }
+    if (d <= d_hi) SUP_STEP(0, 0, p0, p1, p0, p1)
+    if (d + 1 <= d_hi) SUP_STEP(1, 0, p0, p1, p0, p1)
+    if (d + 2 <= d_hi) SUP_STEP(2, 0, p0, p1, p0, p1)
+#undef SUP_STEP
 }
 
-__global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, int cands, const uint8_t *__restrict__ desc, int16_t *__restrict__ dcan) {
+// the four partial records of a point -> (best, runner-up) of the whole range
+__device__ __forceinline__ uint2 support_merge(const uint2 *rec, int point) {
+    uint2 m = rec[point];
+#pragma unroll
+    for (int g = 1; g < SUP_SPLIT; ++g) {
+        const uint2 o = rec[g * SUP_POINTS + point];
+        m.y = min(min(m.y, o.y), max(m.x, o.x));
+        m.x = min(m.x, o.x);
+    }
+    return m;
+}
+
+// elas.cpp:279 (border), :318-326 (range; disp_min = 0): the highest disparity to scan, -1 = no match possible
+template <bool RIGHT>
+__device__ __forceinline__ int support_range(const Dims &d, int u, int v) {
+    if (!(u >= 5 && u <= d.W - 6 && v >= 5 && v <= d.H - 6)) return -1;
+    const int dmax = RIGHT ? min(d.disp_max, d.W - u - 5) : min(d.disp_max, u - 5);
+    return dmax < 10 ? -1 : dmax;
+}
+
+// elas.cpp:296-300 (texture of the centre descriptor), :364 (ratio test)
+__device__ __forceinline__ int support_decide(const KParams &k, const uint4 &centre, uint2 m) {
+    if ((int)texture16(centre) < k.support_texture) return -1;
+    const float E1 = (float)(m.x >> 16), E2 = (float)(m.y >> 16);
+    return E1 < k.support_threshold * E2 ? (int)(m.x & 0xFFFFu) : -1;
+}
+
+__global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, const uint8_t *__restrict__ desc, int16_t *__restrict__ dcan) {
     const Dims &d = k.d;
     extern __shared__ uint4 sup_lds[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int pair = blockIdx.z, vc = blockIdx.y + 1;
-    const int uc0 = 1 + blockIdx.x * cands, uc1 = min(uc0 + cands, d.Wc);  // candidates [uc0, uc1)
+    const int uc0 = 1 + blockIdx.x * SUP_POINTS, uc1 = min(uc0 + SUP_POINTS, d.Wc);  // candidates [uc0, uc1)
     const int v = vc * d.step;
     const uint8_t *d1 = desc + ((size_t)(pair * 2) * d.N) * 16, *d2 = d1 + (size_t)d.N * 16;
     const int u_lo = uc0 * d.step, u_hi = (uc1 - 1) * d.step;
@@ -302,7 +344,8 @@ __global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, int cands, c
     const int r_c0 = max(u_lo - 2 - d.disp_max, 0), r_c1 = min(u_hi + 2, d.W - 1);
     const int l_c0 = max(u_lo - 2 - d.disp_max, 0), l_c1 = min(u_hi + 2 + d.disp_max, d.W - 1);
     const int nR = r_c1 - r_c0 + 1, nL = l_c1 - l_c0 + 1;
-    uint4 *sR0 = sup_lds, *sR1 = sR0 + nR, *sL0 = sR1 + nR, *sL1 = sL0 + nL;
+    uint2 *rec = reinterpret_cast<uint2 *>(sup_lds);  // [2 passes][SUP_SPLIT][SUP_POINTS]
+    uint4 *sR0 = sup_lds + 2 * SUP_THREADS * sizeof(uint2) / sizeof(uint4), *sR1 = sR0 + nR, *sL0 = sR1 + nR, *sL1 = sL0 + nL;
     if (v - 2 >= 0 && v + 2 < d.H) {
         const uint4 *gR = reinterpret_cast<const uint4 *>(d2) + (size_t)v * d.W + r_c0, *gL = reinterpret_cast<const uint4 *>(d1) + (size_t)v * d.W + l_c0;
         const long up = -2L * d.W, dn = 2L * d.W;
@@ -317,30 +360,48 @@ __global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, int cands, c
     }
     __syncthreads();
     const SupRows L{sL0, sL1, l_c0}, R{sR0, sR1, r_c0};
-    for (int uc = uc0 + wave; uc < uc1; uc += SUP_THREADS / 64) {
-        const int u = uc * d.step;
-        int res = -1;
-        const int dd = support_match(k, d1, L, R, u, v, false, lane);
-        if (dd >= 0) {
-            const int d2v = support_match(k, d2, R, L, u - dd, v, true, lane);
-            if (d2v >= 0 && abs(dd - d2v) <= k.lr_threshold) res = dd;  // :404-409
-        }
-        if (lane == 0) dcan[(size_t)pair * d.Wc * d.Hc + (size_t)uc * d.Hc + vc] = (int16_t)res;  // transposed: the host filters scan u outer / v inner
+    const int point = threadIdx.x & (SUP_POINTS - 1), part = __builtin_amdgcn_readfirstlane(threadIdx.x / SUP_POINTS);  // wave-uniform
+    const int uc = uc0 + point, u = uc * d.step;
+    const int qlen = (d.disp_max + SUP_SPLIT) / SUP_SPLIT, d_lo = part * qlen;  // this wavefront's share of [0, disp_max]
+    // left -> right
+    const int dmax1 = uc < uc1 ? support_range<false>(d, u, v) : -1;
+    uint4 centre = make_uint4(0, 0, 0, 0);
+    if (dmax1 >= 0) centre = ld16(d1 + ((size_t)v * d.W + u) * 16);  // used after the search: its latency hides behind it
+    uint32_t k1 = SUP_KEY_NONE, k2 = SUP_KEY_NONE;
+    if (d_lo <= dmax1) support_scan<false>(L, R, u, d_lo, min(dmax1, d_lo + qlen - 1), k1, k2);
+    rec[threadIdx.x] = make_uint2(k1, k2);
+    __syncthreads();
+    const int dd = dmax1 >= 0 ? support_decide(k, centre, support_merge(rec, point)) : -1;
+    // right -> left from the match (elas.cpp:404-409)
+    const int u2 = u - dd;
+    const int dmax2 = dd >= 0 ? support_range<true>(d, u2, v) : -1;
+    if (dmax2 >= 0 && part == 0) centre = ld16(d2 + ((size_t)v * d.W + u2) * 16);
+    k1 = k2 = SUP_KEY_NONE;
+    if (d_lo <= dmax2) support_scan<true>(R, L, u2, d_lo, min(dmax2, d_lo + qlen - 1), k1, k2);
+    rec[SUP_THREADS + threadIdx.x] = make_uint2(k1, k2);
+    __syncthreads();
+    if (part == 0 && uc < uc1) {
+        const int d2v = dmax2 >= 0 ? support_decide(k, centre, support_merge(rec + SUP_THREADS, point)) : -1;
+        const int res = (d2v >= 0 && abs(dd - d2v) <= k.lr_threshold) ? dd : -1;
+        dcan[(size_t)pair * d.Wc * d.Hc + (size_t)uc * d.Hc + vc] = (int16_t)res;  // transposed: the host filters scan u outer / v inner
     }
 }
 
 void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
     // row 0 / column 0 of the calloc'd lattice stay 0 (elas.cpp:387): they count as valid d=0 neighbours in the filters
     (void)hipMemsetAsync(s.dcan, 0, sizeof(int16_t) * (size_t)n * k.d.Wc * k.d.Hc, st);
-    // longest run of lattice points whose two staged row pairs fit the LDS budget: 32 B * (2*span + 3*disp_max + 10) <= budget
-    const int budget = 40 * 1024;
-    int span = (budget / 32 - 3 * k.d.disp_max - 10) / 2;
-    int cands = span / k.d.step + 1;
-    cands = std::max(8, std::min(cands, k.d.Wc - 1));
-    span = (cands - 1) * k.d.step;
-    const size_t shmem = sizeof(uint4) * 2 * ((size_t)(span + k.d.disp_max + 5) + (size_t)(span + 2 * k.d.disp_max + 5));
-    dim3 grid((k.d.Wc - 1 + cands - 1) / cands, k.d.Hc - 1, n);
-    SV_LAUNCH(K_SUPPORT, k_support, grid, dim3(SUP_THREADS), shmem, st, k, cands, s.desc, s.dcan);
+    const int span = (SUP_POINTS - 1) * k.d.step;
+    const size_t shmem = 2 * SUP_THREADS * sizeof(uint2) + sizeof(uint4) * 2 * ((size_t)(span + k.d.disp_max + 5) + (size_t)(span + 2 * k.d.disp_max + 5));
+    if (shmem > 64 * 1024) {  // large disparity ranges: more than the default dynamic LDS limit
+        static std::atomic<size_t> granted[64];  // per device
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::atomic<size_t> &g = granted[dev & 63];
+        if (shmem > g.load() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_support), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) == hipSuccess)
+            g.store(shmem);
+    }
+    dim3 grid((k.d.Wc - 1 + SUP_POINTS - 1) / SUP_POINTS, k.d.Hc - 1, n);
+    SV_LAUNCH(K_SUPPORT, k_support, grid, dim3(SUP_THREADS), shmem, st, k, s.desc, s.dcan);
 }
 
 // ------------------------------------------------------------------------------------------------------------
