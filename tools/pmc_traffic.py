@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json (HBM bytes per pair and kernel, read by bench.py for roofline.traffic) from a table written by
+tools/summarize_rocprof.py with the FETCH_SIZE and WRITE_SIZE passes merged in:
+
+  python tools/pmc_traffic.py profiles/r01h_serial_kernel_stats_pmc.csv --pairs-per-launch 32 --note "tools/profile_run.py --chunk 32 --batch 64"
+"""
+import argparse
+import csv
+import json
+import os
+
+NAMES = {"k_support_filter": "support_filter", "k_dense": "dense_match", "k_support": "support_match", "k_descriptor": "descriptor", "k_amean": "adaptive_mean",
+         "k_amean_sub": "adaptive_mean", "k_raster_tiles": "triangles_raster", "k_lr": "lr_check", "k_median": "median", "k_planes": "plane_fit",
+         "k_ccl_band": "ccl_band", "k_gap_cols": "gap_cols", "k_gap_rows": "gap_rows", "k_grid_mark": "grid_mark", "k_grid_dilate": "grid_dilate",
+         "k_raster": "triangles_raster_fallback", "k_ccl_border": "ccl_finish", "k_ccl_total": "ccl_finish", "k_ccl_apply": "ccl_finish", "k_ccl_slow": "ccl_finish",
+         "dg::k_delaunay_blob": "delaunay_gpu"}
+ap = argparse.ArgumentParser()
+ap.add_argument("table")
+ap.add_argument("--pairs-per-launch", type=float, default=32)
+ap.add_argument("--note", default="")
+ap.add_argument("-o", "--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json"))
+a = ap.parse_args()
+out = {}
+for r in csv.DictReader(open(a.table)):
+    k = NAMES.get(r["kernel"])
+    if k is None or not r.get("FETCH_SIZE_per_launch"):
+        continue
+    kb = 2.0 * float(r["FETCH_SIZE_per_launch"]) + float(r["WRITE_SIZE_per_launch"])  # gfx950 correction, see _correction
+    out[k] = out.get(k, 0) + int(round(kb * 1024 / a.pairs_per_launch))
+json.dump({"_source": "%s (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, %s: %g pairs per launch, no kernel overlap)" % (a.table, a.note, a.pairs_per_launch),
+           "_correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports half of the bytes of 16-B-per-lane streaming reads (MI355X_MICROARCH.md, HBM section); exact for the two matching kernels and the descriptor kernel whose reads are dwordx4, an upper bound for the 4-B-per-lane map kernels",
+           "bytes_per_pair": out}, open(a.out, "w"), indent=1)
+print(json.dumps(out))
