@@ -256,20 +256,25 @@ def main():
             pairs_per_launch = B * args.steps / calls  # rank 0's launches of this kernel each cover one chunk
             avg_s = 1e-3 * ms / calls
             achieved = alg[dom] * pairs_per_launch / avg_s / 1e9
-            traffic, traffic_src = None, None
+            traffic, traffic_src, valu = None, None, None
             try:  # HBM bytes from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as the microarch guide prescribes)
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                     pmc = json.load(f)
                 if dom in pmc["bytes_per_pair"]:
                     traffic = int(pmc["bytes_per_pair"][dom] * pairs_per_launch)
                     traffic_src = pmc["_source"]
+                vi = pmc.get("valu_wave_insts_per_pair", {}).get(dom)
+                if vi:  # what bounds the matching kernels: VALU issue; 1024 SIMDs, 2.4 GHz, 2..4 cycles per instruction
+                    per_launch = vi * pairs_per_launch
+                    valu = {"wave_insts_per_launch": int(per_launch), "issue_time_us_at_2_and_4_cycles": [round(per_launch * c / (1024 * 2.4e9) * 1e6, 1) for c in (2, 4)],
+                            "source": "SQ_INSTS_VALU, profiles/pmc_traffic.json"}
             except (OSError, ValueError, KeyError):
                 pass
             out["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
                                "algorithmic_bytes_per_launch": int(alg[dom] * pairs_per_launch),
                                "avg_launch_us": round(1e6 * avg_s, 2), "pairs_per_launch": pairs_per_launch,
-                               "algorithmic_bytes_per_pair": alg[dom]}
+                               "algorithmic_bytes_per_pair": alg[dom], "valu": valu}
             out["roofline_by_kernel"] = {kk: {"achieved_GBps": round(alg.get(kk, 0) * (B * args.steps / ktimes[kk][1]) / (1e-3 * ktimes[kk][0] / ktimes[kk][1]) / 1e9, 1),
                                                "frac": round(alg.get(kk, 0) * (B * args.steps / ktimes[kk][1]) / (1e-3 * ktimes[kk][0] / ktimes[kk][1]) / 1e9 / HBM_PEAK_GBS, 4)}
                                          for kk in tot if alg.get(kk, 0) > 0}

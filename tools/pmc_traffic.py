@@ -20,14 +20,18 @@ ap.add_argument("--pairs-per-launch", type=float, default=32)
 ap.add_argument("--note", default="")
 ap.add_argument("-o", "--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json"))
 a = ap.parse_args()
-out = {}
+out, valu = {}, {}
 for r in csv.DictReader(open(a.table)):
     k = NAMES.get(r["kernel"])
     if k is None or not r.get("FETCH_SIZE_per_launch"):
         continue
     kb = 2.0 * float(r["FETCH_SIZE_per_launch"]) + float(r["WRITE_SIZE_per_launch"])  # gfx950 correction, see _correction
     out[k] = out.get(k, 0) + int(round(kb * 1024 / a.pairs_per_launch))
+    if r.get("SQ_INSTS_VALU_per_launch"):
+        valu[k] = valu.get(k, 0) + int(round(float(r["SQ_INSTS_VALU_per_launch"]) / a.pairs_per_launch))
 json.dump({"_source": "%s (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes, %s: %g pairs per launch, no kernel overlap)" % (a.table, a.note, a.pairs_per_launch),
            "_correction": "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports half of the bytes of 16-B-per-lane streaming reads (MI355X_MICROARCH.md, HBM section); exact for the two matching kernels and the descriptor kernel whose reads are dwordx4, an upper bound for the 4-B-per-lane map kernels",
-           "bytes_per_pair": out}, open(a.out, "w"), indent=1)
+           "bytes_per_pair": out,
+           "_valu": "SQ_INSTS_VALU of the same run (its own --pmc pass): wave64 VALU instructions per pair; tools/valu_rate.hip prices them at 2 (add/and/mov/fma) to 4 (sad/min/max/med3/three-operand) cycles of one of the 1024 SIMDs",
+           "valu_wave_insts_per_pair": valu}, open(a.out, "w"), indent=1)
 print(json.dumps(out))

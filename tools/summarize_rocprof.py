@@ -26,13 +26,13 @@ a = ap.parse_args()
 
 rows = collections.OrderedDict()
 if a.stats:
-    f = glob.glob(os.path.join(a.stats, "**", "*kernel_stats.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(a.stats, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)  # the newest run in the directory
     for r in csv.DictReader(open(f)):
         k = short(r["Name"])
         rows[k] = {"kernel": k, "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2), "min_us": round(float(r["MinNs"]) / 1e3, 2),
                    "max_us": round(float(r["MaxNs"]) / 1e3, 2), "pct": r["Percentage"], "us_per_pair": round(float(r["AverageNs"]) / 1e3 / a.pairs_per_launch, 3)}
 for d in a.pmc:
-    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     n = collections.defaultdict(collections.Counter)
     for r in csv.DictReader(open(f)):
