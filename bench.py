@@ -22,6 +22,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before the first HIP call: one hardware queue per engine stream (engine.py explains)
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -91,6 +93,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="pairs per launch (0 = library default)")
     ap.add_argument("--cpu-sample", type=int, default=64, help="pairs timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--time-all-kernels", action="store_true", help="HIP events around every kernel launch (the full per-kernel table; 1-2 %% of the rate) "
+                    "instead of the three largest kernels only")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurement (profiling runs: keeps the per-kernel averages to the timed region's launches)")
     ap.add_argument("--sync-steps", action="store_true", help="wait for each step before submitting the next (default: streamed submission)")
     ap.add_argument("--serial-kernels", action="store_true", help="extra pass with one slot / one stream (no kernel overlap) to get clean per-kernel times")
@@ -158,8 +162,8 @@ def main():
 
     for _ in range(args.warmup):
         engine.process_device(left, right, d1, d2)
-    if not args.no_kernel_timing:
-        engine.timing(True)
+    if not args.no_kernel_timing:  # HIP events on the engine's own streams, inside the timed region
+        engine.timing(True, only=None if args.time_all_kernels else ("dense_match", "support_match", "descriptor"))
     barrier()
     t0 = time.perf_counter()
     if args.sync_steps:

@@ -141,6 +141,9 @@ long sv_debug_get(sv_handle *h, const char *name, void *out, long cap);
 int sv_kernel_times(sv_handle *h, const char **names, double *total_ms, int64_t *calls, int cap);
 void sv_kernel_times_reset(sv_handle *h);
 void sv_kernel_timing_enable(sv_handle *h, int on);
+/* Restricts the timing to the named kernels ("dense_match,support_match", names as sv_kernel_times reports them; NULL or ""
+ * = all): every timed launch costs two event records on its stream (all kernels timed: 1-2 % of the throughput). */
+int sv_kernel_timing_select(sv_handle *h, const char *names);
 
 /* Host-side stages exposed for tests (they run on the CPU in the product as well, between the two GPU phases):
  * the in-place support-point filters + corner points (elas.cpp:152-264, 413-433) and the Delaunay

@@ -52,6 +52,8 @@ struct TimingCtx {  // per issuing thread
     std::vector<TimedLaunch> timed;
     std::vector<hipEvent_t> pool;
     size_t used = 0;
+    const std::atomic<uint32_t> *mask = nullptr;  // the handle's selection of kernels to time (bit = KernelId)
+    bool open = false;                            // the launch in flight got a start event
 };
 
 struct HostScratch {  // per pool thread
@@ -142,6 +144,7 @@ struct sv_handle {
     bool pool_quit = false;
     // timing
     bool timing = false;
+    std::atomic<uint32_t> timing_mask{0xFFFFFFFFu};  // kernels whose launches get events (sv_kernel_timing_select)
     TimingCtx tc_issue, tc_finish;
     std::mutex tmu;
     double k_ms[K_COUNT] = {0};
@@ -267,6 +270,8 @@ void fill_kparams(sv_handle *h) {
 void timing_hook(void *ctx, int id, bool before, hipStream_t st) {
     TimingCtx *t = (TimingCtx *)ctx;
     if (before) {
+        t->open = false;
+        if (t->mask && !((t->mask->load(std::memory_order_relaxed) >> id) & 1u)) return;
         if (t->used + 2 > t->pool.size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
@@ -276,8 +281,10 @@ void timing_hook(void *ctx, int id, bool before, hipStream_t st) {
         TimedLaunch tl{id, t->pool[t->used], t->pool[t->used + 1]};
         t->used += 2;
         t->timed.push_back(tl);
+        t->open = true;
         (void)hipEventRecord(tl.a, st);
-    } else if (!t->timed.empty()) {
+    } else if (t->open) {
+        t->open = false;
         (void)hipEventRecord(t->timed.back().b, st);
     }
 }
@@ -1043,6 +1050,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         return SV_ERR_ARG;
     }
     sv_handle *h = new sv_handle();
+    h->tc_issue.mask = h->tc_finish.mask = &h->timing_mask;
     h->p = *params;
     h->cfg = *cfg;
     fill_kparams(h);
@@ -1259,6 +1267,31 @@ void sv_kernel_times_reset(sv_handle *h) {
 
 void sv_kernel_timing_enable(sv_handle *h, int on) {
     if (h) h->timing = on != 0;
+}
+
+int sv_kernel_timing_select(sv_handle *h, const char *names) {
+    if (!h) return SV_ERR_ARG;
+    if (!names || !*names) {
+        h->timing_mask.store(0xFFFFFFFFu);
+        return SV_OK;
+    }
+    uint32_t mask = 0;
+    std::string all(names);
+    size_t pos = 0;
+    while (pos <= all.size()) {
+        const size_t end = std::min(all.find(',', pos), all.size());
+        const std::string one = all.substr(pos, end - pos);
+        bool found = one.empty();
+        for (int i = 0; i < K_COUNT; i++)
+            if (one == kernel_name(i)) {
+                mask |= 1u << i;
+                found = true;
+            }
+        if (!found) return SV_ERR_ARG;
+        pos = end + 1;
+    }
+    h->timing_mask.store(mask);
+    return SV_OK;
 }
 
 int sv_host_support_filter(const sv_params *p, int16_t *dcan, int width, int height, int32_t *support, int cap) {
