@@ -289,6 +289,28 @@ def test_robotics_preset_batch(eng, oracle):
         assert np.array_equal(d1[i].view(np.uint8), o1.view(np.uint8)) and np.array_equal(d2[i].view(np.uint8), o2.view(np.uint8)), i
 
 
+@pytest.mark.parametrize("disp_max", [300, 511])
+def test_wide_disparity_range(eng, oracle, disp_max):
+    """disp_max beyond 255: more than eight candidate-mask words per cell in the dense kernel, and (511) support matching with
+    more than 64 KB of LDS per workgroup (hipFuncSetAttribute path)."""
+    import torch
+    synth = util.pkg("synth")
+    H, W, B = 90, 700, 3
+    batch = synth.make_batch(4100, B, H, W, 64)
+    p = eng.SvParams.driver(disp_max)
+    e = eng.StereoEngine(W, H, p, chunk=2, n_slots=2)
+    try:
+        d1, d2 = e.process_device(torch.from_numpy(batch[:, 0].copy()).cuda(), torch.from_numpy(batch[:, 1].copy()).cuda())
+        torch.cuda.synchronize()
+        d1, d2 = d1.cpu().numpy(), d2.cpu().numpy()
+    finally:
+        e.close()
+    for i in range(B):
+        o1, o2, _ = oracle.process(ElasParams.driver(disp_max), batch[i, 0], batch[i, 1])
+        assert (o1 >= 0).mean() > 0.3  # a real match, not the "too few support points" early exit
+        assert np.array_equal(d1[i].view(np.uint8), o1.view(np.uint8)) and np.array_equal(d2[i].view(np.uint8), o2.view(np.uint8)), i
+
+
 def test_streamed_submission_equals_synchronous(eng):
     """sv_submit_batch_device x3 + sv_wait gives the same bytes as three synchronous calls (distinct output buffers)."""
     import torch
