@@ -1079,23 +1079,28 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
     const int sgn = side ? 1 : -1;  // candidate d lives at pu[-d] (left pixel) or pu[+d] (right pixel)
     int min_val = 10000, min_d = -1;
     const int b_lo = max(d_plane_min, a_lo), b_hi = min(d_plane_max, a_hi);
+    // away from the image's left / right border every lane of the wavefront may use the whole range (mask bits above disp_max
+    // are never set): the column-range clipping of the masks is skipped then
+    const bool clip = __builtin_amdgcn_ballot_w64(a_lo != 0 || a_hi != d.D - 1) != 0;
+    // the band (at most 2 * plane_radius + 1 <= 31 bits) as a 64-bit mask starting in mask word band_word
+    const int band_bits = d_plane_max - d_plane_min + 1, band_word = d_plane_min >> 5;
+    const uint64_t band = band_bits > 0 ? ((1ull << band_bits) - 1ull) << (d_plane_min & 31) : 0ull;
+    const uint32_t band_lo = (uint32_t)band, band_hi = (uint32_t)(band >> 32);
 #pragma unroll
     for (int w = 0; w < 8; w++) {  // grid candidates outside the band (:759-767 / :778-786), ascending d
         if (w >= d.MW) break;
         uint32_t m = mw[w];
         {  // keep [a_lo, a_hi], drop [d_plane_min, d_plane_max]
-            const int lo = a_lo - 32 * w, hi = a_hi - 32 * w;
-            uint32_t keep = 0;
-            if (lo <= 31 && hi >= 0 && lo <= hi) {
-                const int l = max(lo, 0), h = min(hi, 31);
-                keep = (h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u)) & ~((1u << l) - 1u);
+            if (clip) {
+                const int lo = a_lo - 32 * w, hi = a_hi - 32 * w;
+                uint32_t keep = 0;
+                if (lo <= 31 && hi >= 0 && lo <= hi) {
+                    const int l = max(lo, 0), h = min(hi, 31);
+                    keep = (h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u)) & ~((1u << l) - 1u);
+                }
+                m &= keep;
             }
-            m &= keep;
-            const int lo2 = d_plane_min - 32 * w, hi2 = d_plane_max - 32 * w;
-            if (lo2 <= 31 && hi2 >= 0 && lo2 <= hi2) {
-                const int l = max(lo2, 0), h = min(hi2, 31);
-                m &= ~((h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u)) & ~((1u << l) - 1u));
-            }
+            m &= ~(w == band_word ? band_lo : (w == band_word + 1 ? band_hi : 0u));
         }
         while (m) {
             const int b = __ffs((int)m) - 1;
