@@ -254,8 +254,11 @@ def main():
             ktimes = {k: v for k, v in ktimes.items() if not k.startswith("host:")}
             out["host_stage_cpu_ms_per_pair"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in host.items()}
             tot = {k: v[0] for k, v in ktimes.items() if v[1] > 0}
-            # the lattice filter and the GPU triangulation are one workgroup per pair / vertex set: latency, not throughput
-            dom = max((kk for kk in tot if kk not in ("support_filter", "delaunay_gpu")), key=tot.get)
+            # the roofline kernel is the largest of the three kernels whose grids fill the chip; the event time of the small
+            # latency-bound kernels (lattice filter, GPU triangulation, gap_cols, speckle passes) is mostly time spent starved
+            # beside another stream's kernel, not work
+            big = [kk for kk in ("dense_match", "support_match", "descriptor") if kk in tot]
+            dom = max(big or [kk for kk in tot if kk not in ("support_filter", "delaunay_gpu")], key=tot.get)
             ms, calls = ktimes[dom]
             pairs_per_launch = B * args.steps / calls  # rank 0's launches of this kernel each cover one chunk
             avg_s = 1e-3 * ms / calls
