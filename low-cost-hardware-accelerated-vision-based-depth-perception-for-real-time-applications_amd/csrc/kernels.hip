@@ -1331,7 +1331,7 @@ __device__ __forceinline__ int ccl_find(const int32_t *L, int x) {
 }
 
 // the same walk on a forest that no longer changes (plain, cacheable loads)
-__device__ __forceinline__ int ccl_find_frozen(const int32_t *__restrict__ L, int x) {
+__device__ __forceinline__ int ccl_find_frozen(const int32_t *L, int x) {
     int p = L[x];
     while (p != x) {
         x = p;
@@ -1344,6 +1344,36 @@ __device__ __forceinline__ void ccl_union(int32_t *L, int a, int b) {
     for (;;) {
         a = ccl_find(L, a);
         b = ccl_find(L, b);
+        if (a == b) return;
+        if (a < b) {
+            int x = a;
+            a = b;
+            b = x;
+        }
+        const int old = atomicMin(&L[a], b);  // a > b: hang the larger root under the smaller
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// Variant for the unions across band borders (global memory): a component that spans many bands grows into a chain of band
+// roots, and every hop is a dependent L2 access, so the walk halves the path as it goes.  atomicMin keeps the invariant
+// "parent <= node and parent is an ancestor": a grandparent is an ancestor for good, concurrent unions only add ancestors.
+__device__ __forceinline__ int ccl_find_halving(int32_t *L, int x) {
+    int p = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (p != x) {
+        const int g = __hip_atomic_load(&L[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (g != p) atomicMin(&L[x], g);
+        x = p;
+        p = g;
+    }
+    return x;
+}
+
+__device__ __forceinline__ void ccl_union_halving(int32_t *L, int a, int b) {
+    for (;;) {
+        a = ccl_find_halving(L, a);
+        b = ccl_find_halving(L, b);
         if (a == b) return;
         if (a < b) {
             int x = a;
@@ -1584,12 +1614,14 @@ __device__ void ccl_legacy_map(const KParams &k, float *D, int32_t *label, int32
 }
 
 // ---- second half of the run-based labelling: three small grid-wide passes over the run records ----
-// (a) unions across band borders: first row of band b against the last row of band b-1, one thread per 64-pixel mask word
+// (a) unions across band borders: first row of band b against the last row of band b-1.  One WAVEFRONT per 64-pixel mask word,
+// one lane per pixel: every union is a chain of dependent L2 accesses, so the links of a word are joined side by side, not one
+// after the other (a word of a real map has up to ten of them)
 __global__ __launch_bounds__(256) void k_ccl_border(int nproc, const int32_t *__restrict__ blob, CclWs ws) {
     const int m = blockIdx.y;
     if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m]) return;
     const int nch = ws.nch, nb = ws.nb;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave-uniform word index
     if (idx >= (nb - 1) * nch) return;
     const int b = 1 + idx / nch, c = idx - (b - 1) * nch;
     const uint64_t *bwb = ws.bwords + ((size_t)m * nb + b) * 5 * nch, *bwp = bwb - 5 * nch;
@@ -1597,41 +1629,47 @@ __global__ __launch_bounds__(256) void k_ccl_border(int nproc, const int32_t *__
     if (!L) return;
     const uint64_t S0 = bwb[c], V0 = bwb[nch + c], Sp = bwp[3 * nch + c], Vp = bwp[4 * nch + c];
     const uint64_t carry = c > 0 ? (bwb[2 * nch + c - 1] >> 63) : 0ull;
+    const uint64_t F = ccl_new_links(L, V0 & ~S0, Vp & ~Sp, carry);
+    if (!((F >> lane) & 1ull)) return;
     const int32_t *bbb = ws.bbase + ((size_t)m * nb + b) * 2 * nch, *bbp = bbb - 2 * nch;
     const int32_t *BO = ws.boff + (size_t)m * nb;
     const int n0 = BO[b] + bbb[c], np = BO[b - 1] + bbp[nch + c];
     int32_t *GP = ws.gparent + (size_t)m * ws.rcap;
-    for (uint64_t F = ccl_new_links(L, V0 & ~S0, Vp & ~Sp, carry); F; F &= F - 1) {
-        const uint64_t upto = bits_upto(ctz64(F));
-        ccl_union(GP, n0 + __popcll(S0 & upto) - 1, np + __popcll(Sp & upto) - 1);
-    }
+    const uint64_t upto = bits_upto(lane);
+    ccl_union_halving(GP, n0 + __popcll(S0 & upto) - 1, np + __popcll(Sp & upto) - 1);
 }
 
-// (b) component sizes at the global roots: every band-local root adds its component's pixel count
+// (b) component sizes at the global roots: every band-local root adds its component's pixel count.  CCL_SPLIT workgroups per
+// band: the walk to a root is a chain of dependent loads, so a thread should not have to do more than one or two of them
+constexpr int CCL_SPLIT = 4;
 __global__ __launch_bounds__(256) void k_ccl_total(int nproc, const int32_t *__restrict__ blob, CclWs ws) {
-    const int m = blockIdx.y, b = blockIdx.x;
+    const int m = blockIdx.y, b = blockIdx.x / CCL_SPLIT, part = blockIdx.x - b * CCL_SPLIT;
     if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m]) return;
     const int T = ws.tcount[(size_t)m * ws.nb + b], off = ws.boff[(size_t)m * ws.nb + b];
-    const int32_t *GP = ws.gparent + (size_t)m * ws.rcap;
+    int32_t *GP = ws.gparent + (size_t)m * ws.rcap;
     int32_t *TOT = ws.total + (size_t)m * ws.rcap;
     const int4 *RUNS = ws.runs + (size_t)m * ws.rcap;
-    for (int i = threadIdx.x; i < T; i += 256) {
+    for (int i = part * 256 + threadIdx.x; i < T; i += 256 * CCL_SPLIT) {
         const int4 r = RUNS[off + i];
         if (r.z != off + i) continue;
-        atomicAdd(&TOT[ccl_find_frozen(GP, off + i)], r.w);
+        const int root = ccl_find_frozen(GP, off + i);
+        atomicAdd(&TOT[root], r.w);
+        // a component that spans many bands is a chain of band roots: point this one at the global root so that k_ccl_apply
+        // gets there in one hop (no union runs any more; a concurrent walk sees the old parent or the root, both ancestors)
+        GP[off + i] = root;
     }
 }
 
 // (c) runs of components smaller than speckle_size are wiped (elas.cpp:1109-1114); nothing else is written
 __global__ __launch_bounds__(256) void k_ccl_apply(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp, CclWs ws) {
     const Dims &d = k.d;
-    const int m = blockIdx.y, b = blockIdx.x;
+    const int m = blockIdx.y, b = blockIdx.x / CCL_SPLIT, part = blockIdx.x - b * CCL_SPLIT;
     if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m]) return;
     const int T = ws.tcount[(size_t)m * ws.nb + b], off = ws.boff[(size_t)m * ws.nb + b];
     const int32_t *GP = ws.gparent + (size_t)m * ws.rcap, *TOT = ws.total + (size_t)m * ws.rcap;
     const int4 *RUNS = ws.runs + (size_t)m * ws.rcap;
     float *D = disp + map_offset(d, m, nproc);
-    for (int i = threadIdx.x; i < T; i += 256) {
+    for (int i = part * 256 + threadIdx.x; i < T; i += 256 * CCL_SPLIT) {
         const int4 r = RUNS[off + i];
         if (r.y >= k.speckle_size) continue;  // a run that long is a large component by itself
         if (TOT[ccl_find_frozen(GP, r.z)] >= k.speckle_size) continue;
@@ -1665,9 +1703,9 @@ void launch_speckle(const KParams &k, const SlotDev &s, int n, int nproc, hipStr
             g.store(lds);
     }
     SV_LAUNCH(K_CCL_BAND, k_ccl_band, dim3(ws.nb, maps), dim3(CCL_THREADS), lds, st, k, nproc, s.blob, s.disp, ws);
-    if (ws.nb > 1) SV_LAUNCH(K_CCL_FINISH, k_ccl_border, dim3(((ws.nb - 1) * ws.nch + 255) / 256, maps), dim3(256), 0, st, nproc, s.blob, ws);
-    SV_LAUNCH(K_CCL_FINISH, k_ccl_total, dim3(ws.nb, maps), dim3(256), 0, st, nproc, s.blob, ws);
-    SV_LAUNCH(K_CCL_FINISH, k_ccl_apply, dim3(ws.nb, maps), dim3(256), 0, st, k, nproc, s.blob, s.disp, ws);
+    if (ws.nb > 1) SV_LAUNCH(K_CCL_FINISH, k_ccl_border, dim3(((ws.nb - 1) * ws.nch + 3) / 4, maps), dim3(256), 0, st, nproc, s.blob, ws);
+    SV_LAUNCH(K_CCL_FINISH, k_ccl_total, dim3(ws.nb * CCL_SPLIT, maps), dim3(256), 0, st, nproc, s.blob, ws);
+    SV_LAUNCH(K_CCL_FINISH, k_ccl_apply, dim3(ws.nb * CCL_SPLIT, maps), dim3(256), 0, st, k, nproc, s.blob, s.disp, ws);
     int32_t *cnt = reinterpret_cast<int32_t *>(s.tmp);  // slow path only: the filters' scratch map is free during speckle removal
     SV_LAUNCH(K_CCL_FINISH, k_ccl_slow, dim3(maps), dim3(1024), 0, st, k, nproc, s.blob, s.disp, ws, s.tri_id, s.csize, cnt);
 }
