@@ -50,15 +50,6 @@ __device__ __forceinline__ uint32_t texture16(const uint4 &a) {
 
 __device__ __forceinline__ uint4 ld16(const uint8_t *p) { return *reinterpret_cast<const uint4 *>(p); }
 
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        uint32_t o = (uint32_t)__shfl_xor((int)v, off, 64);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-
 __device__ __forceinline__ int sat_u8(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
 
 // ------------------------------------------------------------------------------------------------------------
