@@ -42,6 +42,15 @@ __device__ __forceinline__ uint32_t sad16(const uint4 &a, const uint4 &b, uint32
     return sad4(a.w, b.w, s);
 }
 
+// acc + (SAD of the 16 bytes << 16): v_sad_hi_u8 adds its sum to the HIGH half, so a chain started with acc = tie-break bits builds
+// the comparison key (energy << 16 | tie-break) without a shift; acc may carry a (negative) additive energy term in its high half
+__device__ __forceinline__ int sad16_key(const uint4 &a, const uint4 &b, int acc) {
+    uint32_t s = __builtin_amdgcn_sad_hi_u8(a.x, b.x, (uint32_t)acc);
+    s = __builtin_amdgcn_sad_hi_u8(a.y, b.y, s);
+    s = __builtin_amdgcn_sad_hi_u8(a.z, b.z, s);
+    return (int)__builtin_amdgcn_sad_hi_u8(a.w, b.w, s);
+}
+
 // sum |byte - 128| over the 16 descriptor bytes (elas.cpp:296-298, 732-734)
 __device__ __forceinline__ uint32_t texture16(const uint4 &a) {
     const uint4 mid = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
@@ -1068,7 +1077,11 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
     // disparities whose warped column stays inside [2, W-3] (:763, :770 / :782, :789), as a range instead of a per-candidate test
     const int a_lo = side ? 0 : max(u - (d.W - 3), 0), a_hi = side ? min(d.W - 3 - u, d.D - 1) : min(u - 2, d.D - 1);
     const int sgn = side ? 1 : -1;  // candidate d lives at pu[-d] (left pixel) or pu[+d] (right pixel)
-    int min_val = 10000, min_d = -1;
+    // The reference keeps the FIRST minimum in evaluation order (strict <): grid candidates in ascending d, then the band in
+    // ascending d.  Here every candidate yields the signed key  energy << 16 | band << 15 | d  (sad16_key) and the smallest key
+    // wins: the same candidate, with one v_min_i32 per candidate instead of compare + two selects.
+    constexpr int KEY_NONE = 0x7FFF0000;  // energy 32767: above every real energy (<= 4080) and the reference's initial 10000
+    int best = KEY_NONE;
     const int b_lo = max(d_plane_min, a_lo), b_hi = min(d_plane_max, a_hi);
     // away from the image's left / right border every lane of the wavefront may use the whole range (mask bits above disp_max
     // are never set): the column-range clipping of the masks is skipped then
@@ -1093,27 +1106,20 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
             }
             m &= ~(w == band_word ? band_lo : (w == band_word + 1 ? band_hi : 0u));
         }
+        int best_w = KEY_NONE;  // keys of this word carry the bit index only; 32 * w is added once per word
         while (m) {
             const int b = __ffs((int)m) - 1;
             m &= m - 1;
-            const int dc = 32 * w + b;
-            const int val = (int)sad16(own, pu[sgn * dc]);
-            if (val < min_val) {
-                min_val = val;
-                min_d = dc;
-            }
+            best_w = min(best_w, sad16_key(own, pu[sgn * (32 * w + b)], b));
         }
+        best = min(best, best_w + 32 * w);
     }
     for (int w = 8; w < d.MW; w++) {  // disp_max > 255: remaining words straight from memory
         const uint32_t m = cell[w];
         for (int b = 0; b < 32; b++) {
             const int dc = 32 * w + b;
             if (!((m >> b) & 1u) || dc < a_lo || dc > a_hi || (dc >= d_plane_min && dc <= d_plane_max)) continue;
-            const int val = (int)sad16(own, pu[sgn * dc]);
-            if (val < min_val) {
-                min_val = val;
-                min_d = dc;
-            }
+            best = min(best, sad16_key(own, pu[sgn * dc], dc));
         }
     }
     // the band [d_plane - r, d_plane + r], ascending, with the plane prior (:768-774 / :787-793).  The offset o is uniform
@@ -1121,13 +1127,10 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
     for (int o = -k.plane_radius; o <= k.plane_radius; o++) {
         const int dc = d_plane + o;
         if (dc < b_lo || dc > b_hi) continue;
-        const int val = (int)sad16(own, pu[sgn * dc]) + (valid ? k.prior[o < 0 ? -o : o] : 0);
-        if (val < min_val) {
-            min_val = val;
-            min_d = dc;
-        }
+        const int prior = valid ? k.prior[o < 0 ? -o : o] : 0;
+        best = min(best, sad16_key(own, pu[sgn * dc], prior * 65536 + (0x8000 | dc)));
     }
-    return min_d >= 0 ? (float)min_d : -1.0f;  // :797-800
+    return best < (10000 << 16) ? (float)(best & 0x7FFF) : -1.0f;  // :797-800 (min_val starts at 10000, :752)
 }
 
 __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restrict__ desc, const int32_t *__restrict__ blob, const int32_t *__restrict__ tri_id,
