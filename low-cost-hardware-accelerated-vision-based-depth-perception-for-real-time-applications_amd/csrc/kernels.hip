@@ -280,9 +280,10 @@ __device__ __forceinline__ void support_scan(const SupRows &A, const SupRows &B,
         const uint4 q0 = o0[j], q1 = o1[j];                                                                                 \
         n0[j] = b0[dir * (d + (off) + (j) + 2)];                                                                            \
         n1[j] = b1[dir * (d + (off) + (j) + 2)];                                                                            \
-        const uint32_t e = RIGHT ? sad16(a3, n1[j], sad16(a1, n0[j], sad16(a2, q1, sad16(a0, q0))))                         \
-                                 : sad16(a2, n1[j], sad16(a0, n0[j], sad16(a3, q1, sad16(a1, q0))));                        \
-        top2_push(k1, k2, (e << 16) | (uint32_t)(d + (off) + (j)));                                                         \
+        const int dk = d + (off) + (j); /* the chain starts from d and adds the SADs to the high half: energy << 16 | d */   \
+        const int key = RIGHT ? sad16_key(a3, n1[j], sad16_key(a1, n0[j], sad16_key(a2, q1, sad16_key(a0, q0, dk))))        \
+                              : sad16_key(a2, n1[j], sad16_key(a0, n0[j], sad16_key(a3, q1, sad16_key(a1, q0, dk))));       \
+        top2_push(k1, k2, (uint32_t)key);                                                                                   \
     }
     uint4 r0[4], r1[4];
     int d = d_lo;
