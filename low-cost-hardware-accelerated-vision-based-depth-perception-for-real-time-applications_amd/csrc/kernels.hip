@@ -1108,10 +1108,13 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
             m &= ~(w == band_word ? band_lo : (w == band_word + 1 ? band_hi : 0u));
         }
         int best_w = KEY_NONE;  // keys of this word carry the bit index only; 32 * w is added once per word
-        while (m) {
-            const int b = __ffs((int)m) - 1;
+        while (m) {  // two candidates per trip: their LDS reads are in flight together (an odd last one is evaluated twice)
+            const int b1 = __ffs((int)m) - 1;
             m &= m - 1;
-            best_w = min(best_w, sad16_key(own, pu[sgn * (32 * w + b)], b));
+            const int b2 = m ? __ffs((int)m) - 1 : b1;
+            m &= m - 1;  // 0 stays 0
+            const uint4 c1 = pu[sgn * (32 * w + b1)], c2 = pu[sgn * (32 * w + b2)];
+            best_w = min(best_w, min(sad16_key(own, c1, b1), sad16_key(own, c2, b2)));
         }
         best = min(best, best_w + 32 * w);
     }
