@@ -331,3 +331,25 @@ def test_streamed_submission_equals_synchronous(eng):
             assert torch.equal(a1, b1) and torch.equal(a2, b2)
     finally:
         e.close()
+
+
+def test_kernel_timing_selection(eng):
+    """sv_kernel_timing_select: only the named kernels get HIP events; unknown names are refused."""
+    import torch
+    synth = util.pkg("synth")
+    H, W, D, B = 96, 256, 48, 4
+    batch = synth.make_batch(900, B, H, W, D)
+    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), chunk=4, n_slots=2)
+    try:
+        left, right = torch.from_numpy(batch[:, 0].copy()).cuda(), torch.from_numpy(batch[:, 1].copy()).cuda()
+        e.timing(True, only=("dense_match", "descriptor"))
+        e.process_device(left, right)
+        kt = {k: v for k, v in e.kernel_times().items() if not k.startswith("host:")}
+        assert kt["dense_match"][1] > 0 and kt["descriptor"][1] > 0
+        assert all(v[1] == 0 for k, v in kt.items() if k not in ("dense_match", "descriptor")), kt
+        with pytest.raises(ValueError):
+            e.timing(True, only=("no_such_kernel",))
+        e.timing(False)
+    finally:
+        e.close()
+
