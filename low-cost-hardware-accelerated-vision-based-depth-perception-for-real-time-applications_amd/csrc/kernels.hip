@@ -1164,6 +1164,14 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
             tt[side][j] = u < x1 ? tri_id[(size_t)(pair * 2 + side) * d.N + (size_t)v * d.W + u] : -1;
         }
     __syncthreads();
+    // grid cell of each of the thread's columns (elas.cpp:745-746), once for both sides; word offsets fit 32 bits
+    const uint32_t gy = (uint32_t)(int)floorf((float)v / (float)d.grid_size);
+    uint32_t cell_off[DENSE_TW / 256];
+#pragma unroll
+    for (int j = 0; j < DENSE_TW / 256; j++) {
+        const int u = min(x0 + j * 256 + (int)threadIdx.x, d.W - 1);
+        cell_off[j] = gy * (uint32_t)(d.gw * d.MW) + __umul24((uint32_t)(int)floorf((float)u / (float)d.grid_size), (uint32_t)d.MW);
+    }
 #pragma unroll
     for (int side = 0; side < 2; side++) {
         const int ps = pair * 2 + side;
@@ -1175,8 +1183,7 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
             float out = -10.0f;  // elas.cpp:823-824
             if (t >= 0 && u >= 2 && u < d.W - 2 && !(d.sub && (u & 1))) {
                 const float4 rec = trirec[(size_t)ps * d.max_tri + t];
-                const int gx = (int)floorf((float)u / (float)d.grid_size), gy = (int)floorf((float)v / (float)d.grid_size);
-                const uint32_t *cell = gB + ((size_t)ps * d.ncell + (size_t)gy * d.gw + gx) * d.MW;
+                const uint32_t *cell = gB + (size_t)ps * d.ncell * d.MW + cell_off[j];
                 uint32_t mw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 if ((d.MW & 3) == 0) {  // 16-byte aligned cells: one or two wide loads
                     const uint4 m0 = *reinterpret_cast<const uint4 *>(cell);
