@@ -384,13 +384,21 @@ __global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, const uint8_
     if (part == 0 && uc < uc1) {
         const int d2v = dmax2 >= 0 ? support_decide(k, centre, support_merge(rec + SUP_THREADS, point)) : -1;
         const int res = (d2v >= 0 && abs(dd - d2v) <= k.lr_threshold) ? dd : -1;
-        dcan[(size_t)pair * d.Wc * d.Hc + (size_t)uc * d.Hc + vc] = (int16_t)res;  // transposed: the host filters scan u outer / v inner
+        int16_t *lat = dcan + (size_t)pair * d.Wc * d.Hc;
+        lat[(size_t)uc * d.Hc + vc] = (int16_t)res;  // transposed: the host filters scan u outer / v inner
+        // row 0 / column 0 of the reference's calloc'd lattice stay 0 (elas.cpp:387; they count as valid d=0 neighbours in the
+        // filters): written here instead of by a memset in front of the kernel
+        if (vc == 1) lat[(size_t)uc * d.Hc] = 0;
+        if (uc == 1) lat[vc] = 0;
+        if (uc == 1 && vc == 1) lat[0] = 0;
     }
 }
 
 void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
-    // row 0 / column 0 of the calloc'd lattice stay 0 (elas.cpp:387): they count as valid d=0 neighbours in the filters
-    (void)hipMemsetAsync(s.dcan, 0, sizeof(int16_t) * (size_t)n * k.d.Wc * k.d.Hc, st);
+    if (k.d.Wc < 2 || k.d.Hc < 2) {  // no lattice point besides row 0 / column 0: nothing to match, the lattice is all zero
+        (void)hipMemsetAsync(s.dcan, 0, sizeof(int16_t) * (size_t)n * k.d.Wc * k.d.Hc, st);
+        return;
+    }
     const int span = (SUP_POINTS - 1) * k.d.step;
     const size_t shmem = 2 * SUP_THREADS * sizeof(uint2) + sizeof(uint4) * 2 * ((size_t)(span + k.d.disp_max + 5) + (size_t)(span + 2 * k.d.disp_max + 5));
     if (shmem > 64 * 1024) {  // large disparity ranges: more than the default dynamic LDS limit
