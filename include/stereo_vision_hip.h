@@ -124,10 +124,22 @@ int sv_process_batch_device(sv_handle *h, const uint8_t *left, const uint8_t *ri
 int sv_submit_batch_device(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status);
 int sv_wait(sv_handle *h);
 
-/* Same as sv_process_batch_device, host memory in and out (PCIe-inclusive). */
+/* Same call with HOST memory in and out - the form of the reference's seam, which takes host pointers (elas.h:162, call site
+ * stereo_vision.cpp:313).  The batch streams through the pipeline chunk by chunk: the images of chunk k+1 go up and the maps of
+ * chunk k-1 come down on copy streams while chunk k computes; nothing is allocated per call.  Page-locked ("pinned") caller
+ * memory - sv_host_alloc, hipHostMalloc, hipHostRegister, torch pin_memory() - is the DMA source / target itself; pageable
+ * memory is detected and goes through page-locked staging buffers of the handle (one extra host copy each way).  Maps of pairs
+ * with < 3 support points are not written (the reference leaves them untouched, elas.cpp:63-69).
+ * sv_submit_batch_host is the streaming form (buffers stay valid and untouched until sv_wait). */
 int sv_process_batch_host(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status);
+int sv_submit_batch_host(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status);
+/* Page-locked host memory for the calls above (NULL on failure). */
+void *sv_host_alloc(size_t bytes);
+void sv_host_free(void *p);
 
-/* Single pair with the exact argument meaning of Elas::process (elas.h:153-162): dims = {width, height, bytes per line}. */
+/* Single pair with the exact argument meaning of Elas::process (elas.h:153-162): dims = {width, height, bytes per line};
+ * host pointers, like the reference.  On a chunk = 1 handle the calling thread drives the pair itself through persistent
+ * device buffers (latency mode). */
 int sv_elas_process(sv_handle *h, const uint8_t *I1, const uint8_t *I2, float *D1, float *D2, const int32_t *dims);
 
 /* Per-stage intermediates of the last pair processed (cfg.keep_debug != 0).  Names and layouts follow
@@ -135,6 +147,11 @@ int sv_elas_process(sv_handle *h, const uint8_t *I1, const uint8_t *I2, float *D
  * speckle1 gap1 amean1 final1 ...  Returns the byte count, -1 unknown name, -2 cap too small. */
 long sv_debug_size(sv_handle *h, const char *name);
 long sv_debug_get(sv_handle *h, const char *name, void *out, long cap);
+
+/* Work counters of the two matching kernels (separate instantiations of the kernels; off by default).  mode 1: enable and
+ * reset, 0: disable, -1: leave as is; out (may be NULL) receives uint64[4] = {dense candidates evaluated (16-byte SADs),
+ * dense pixels matched, support energies evaluated (64-byte SADs), 0} since the last reset.  Waits for submitted work. */
+int sv_debug_counters(sv_handle *h, int mode, uint64_t *out);
 
 /* Per-kernel device timings (HIP events on the worker streams) accumulated since the last reset.
  * names/ms/calls are parallel arrays written up to cap entries; returns the number of kernels known. */

@@ -526,14 +526,8 @@ int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const
 
 // Both triangulations of every pair of a chunk, straight into the chunk's device blob.
 void launch_delaunay_blob(int32_t *blob, int n_pairs, size_t lds, hipStream_t st) {
-    if (lds > 64 * 1024) {
-        static std::atomic<size_t> granted[64];  // per device
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::atomic<size_t> &g = granted[dev & 63];
-        if (lds > g.load() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_delaunay_blob), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
-            g.store(lds);
-    }
+    static std::atomic<size_t> granted[64];
+    ensure_dynamic_lds(k_delaunay_blob, lds, granted, "delaunay_gpu");
     SV_LAUNCH(K_DELAUNAY, k_delaunay_blob, dim3(2 * n_pairs), dim3(DG_THREADS), lds, st, blob);
 }
 #endif  // DG_HOST_EMULATION

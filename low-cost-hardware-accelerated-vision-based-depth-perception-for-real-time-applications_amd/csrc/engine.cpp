@@ -72,6 +72,11 @@ struct Job {
     int32_t *status = nullptr;
     int nchunks = 0;
     int issued2 = 0;  // chunks whose second GPU phase has been enqueued (guarded by sv_handle::mu)
+    // host-memory jobs (sv_submit_batch_host): left/right/d1/d2 are HOST pointers; images go through the slot's device
+    // staging buffers, maps come back from them.  Page-locked caller memory is the DMA source / target itself, pageable
+    // memory goes through the slot's page-locked staging buffers.
+    bool host = false, pin_in = false, pin_out = false;
+    int drained = 0;  // chunks whose maps have reached the caller (guarded by sv_handle::mu)
 };
 
 enum SlotState { SLOT_FREE = 0, SLOT_BUSY = 1, SLOT_DRAINING = 2 };  // DRAINING: phase 2 issued, ev_free recorded
@@ -85,6 +90,17 @@ struct Slot {
     int32_t *h_blob = nullptr;  // pinned
     size_t blob_words = 0;
     hipEvent_t ev_p1 = nullptr, ev_free = nullptr, ev_sup = nullptr;
+    // host-memory jobs: device staging (images in, maps out), page-locked staging for pageable callers, copy events
+    uint8_t *d_in = nullptr;   // [2][cap][H][W]   gray rows, packed (left block, right block)
+    float *d_out = nullptr;    // [2][cap][Nm]     final maps (left block, right block)
+    uint8_t *h_in = nullptr;   // page-locked, same layout as d_in
+    float *h_out = nullptr;    // page-locked, same layout as d_out
+    hipEvent_t ev_in = nullptr, ev_lr = nullptr, ev_p2 = nullptr, ev_out = nullptr;
+    // inputs of phase 1 for the chunk in flight (device pointers: the job's own, or the staging buffers)
+    const uint8_t *in_left = nullptr, *in_right = nullptr;
+    size_t in_pair = 0;
+    int in_stride = 0;
+    bool out_enqueued = false;  // host-memory jobs: phase 2 and the map downloads were enqueued (ev_out is pending)
     int state = SLOT_FREE;
     // chunk in flight
     Job *job = nullptr;
@@ -120,8 +136,11 @@ struct sv_handle {
     std::vector<Slot *> slots;
     hipStream_t sP1 = nullptr, sPF = nullptr;  // phase 1; lattice filter + its D2H
     std::vector<hipStream_t> sP2;
+    hipStream_t sIn = nullptr, sOut = nullptr;  // host-memory jobs: image uploads / map downloads, overlapping the kernels
+    bool host_dev_ready = false, host_pin_in_ready = false, host_pin_out_ready = false;  // lazily allocated staging (guarded by host_mu)
+    std::mutex host_mu;
     // control threads + queues
-    std::thread t_issue, t_dispatch, t_finish;
+    std::thread t_issue, t_dispatch, t_finish, t_drain;
     std::mutex mu;  // guards: job queue + counters, quit, slot states, q1, q2, error
     std::condition_variable cv;
     std::deque<Job *> jobs;       // submitted, not yet picked up by the issuer
@@ -131,8 +150,9 @@ struct sv_handle {
     bool quit = false;
     std::deque<Slot *> q1;  // phase 1 issued, waiting for the dispatcher
     std::deque<Slot *> q2;  // host stage complete, waiting for phase 2
+    std::deque<Slot *> q3;  // host-memory jobs: phase 2 and the map downloads enqueued, waiting for the drainer
     std::string error;
-    bool failed = false;
+    std::atomic<bool> failed{false};
     // host pool
     std::vector<std::thread> pool;
     std::vector<HostScratch *> scratch;
@@ -152,6 +172,7 @@ struct sv_handle {
     std::atomic<int64_t> host_filter_ns{0}, host_delaunay_ns{0}, host_tasks{0};
     // debug
     std::map<std::string, std::vector<uint8_t>> dbg;
+    unsigned long long *d_counters = nullptr;  // work counters of the matching kernels (sv_debug_counters)
 };
 
 namespace {
@@ -386,10 +407,8 @@ void dbg_grid(sv_handle *h, hipStream_t st, Slot *s, int j) {
 void issue_phase1(sv_handle *h, Slot *s) {
     const KParams &k = h->kp;
     const Dims &d = k.d;
-    const Job &job = *s->job;
-    const size_t in_pair = (size_t)d.H * job.stride;
     const int lat = d.Wc * d.Hc;
-    launch_descriptor(k, job.left + (size_t)s->i0 * in_pair, job.right + (size_t)s->i0 * in_pair, in_pair, job.stride, s->dev, s->n, h->sP1);
+    launch_descriptor(k, s->in_left, s->in_right, s->in_pair, s->in_stride, s->dev, s->n, h->sP1);
     launch_support(k, s->dev, s->n, h->sP1);
     hipStream_t tail = h->sP1;
     if (h->gpu_filter) {
@@ -405,6 +424,7 @@ void issue_phase1(sv_handle *h, Slot *s) {
     }
     if (!h->gpu_filter || h->cfg.keep_debug)
         HIP_TRY(hipMemcpyAsync(s->h_dcan, s->dev.dcan, sizeof(int16_t) * (size_t)s->n * lat, hipMemcpyDeviceToHost, tail));
+    HIP_TRY(hipGetLastError());  // a rejected phase-1 launch must not leave the previous chunk's lattices to the host stage
     HIP_TRY(hipEventRecord(s->ev_p1, tail));
     if (h->cfg.keep_debug) {
         const int j = s->n - 1;
@@ -421,6 +441,184 @@ void issue_phase1(sv_handle *h, Slot *s) {
         int32_t dd[2] = {d.Wc, d.Hc};
         dbg_put(h, "dcan_dims", dd, 2);
     }
+}
+
+// ---- host-memory jobs: staging and copies ------------------------------------------------------------------------------
+void spawn_to_pool(void *ctx, void (*fn)(void *), void *arg);
+
+// A large host-side copy shared between the calling thread and idle pool threads: pieces are claimed from an atomic counter,
+// so the caller never waits for a helper that is busy with a triangulation (it just ends up copying more itself).
+struct CopyJob {
+    struct Piece {
+        void *dst;
+        const void *src;
+        size_t bytes;
+    };
+    std::vector<Piece> pieces;
+    std::atomic<int> next{0}, done{0}, refs{1};
+    static void work(CopyJob *c) {
+        const int n = (int)c->pieces.size();
+        for (;;) {
+            const int i = c->next.fetch_add(1);
+            if (i >= n) break;
+            memcpy(c->pieces[i].dst, c->pieces[i].src, c->pieces[i].bytes);
+            c->done.fetch_add(1, std::memory_order_release);
+        }
+    }
+    static void helper(void *arg) {
+        CopyJob *c = static_cast<CopyJob *>(arg);
+        work(c);
+        if (c->refs.fetch_sub(1) == 1) delete c;
+    }
+};
+
+constexpr size_t COPY_PIECE = (size_t)512 << 10;
+
+struct CopyList {  // collects (dst, src, bytes) ranges, cut into pieces of at most COPY_PIECE
+    CopyJob *job = new CopyJob();
+    void add(void *dst, const void *src, size_t bytes) {
+        for (size_t o = 0; o < bytes; o += COPY_PIECE)
+            job->pieces.push_back({static_cast<uint8_t *>(dst) + o, static_cast<const uint8_t *>(src) + o, std::min(COPY_PIECE, bytes - o)});
+    }
+    // runs the copies; returns when every byte has landed
+    void run(sv_handle *h, int max_helpers) {
+        CopyJob *c = job;
+        job = nullptr;
+        const int n = (int)c->pieces.size();
+        const int helpers = std::max(0, std::min({max_helpers, n - 1, (int)h->pool.size()}));
+        c->refs.store(1 + helpers);
+        for (int i = 0; i < helpers; i++) spawn_to_pool(h, CopyJob::helper, c);
+        CopyJob::work(c);
+        while (c->done.load(std::memory_order_acquire) < n) __builtin_ia32_pause();
+        if (c->refs.fetch_sub(1) == 1) delete c;
+    }
+    ~CopyList() { delete job; }
+};
+
+// true when [p, p + bytes) is page-locked host memory the device can DMA from / to (hipHostMalloc, hipHostRegister, sv_host_alloc)
+bool is_pinned_host(const void *p, size_t bytes) {
+    if (!p || bytes == 0) return false;
+    for (const uint8_t *q : {static_cast<const uint8_t *>(p), static_cast<const uint8_t *>(p) + bytes - 1}) {
+        hipPointerAttribute_t a;
+        memset(&a, 0, sizeof(a));
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) {
+            (void)hipGetLastError();  // plain pageable memory: the query fails and leaves a sticky error behind
+            return false;
+        }
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
+// Staging of the host-memory path, allocated at the first host job (device-memory users never pay for it): per slot the
+// packed gray images of a chunk and its two final maps on the device, and - only when a caller hands over pageable memory -
+// page-locked mirrors of both.
+void ensure_host_staging(sv_handle *h, bool need_pin_in, bool need_pin_out) {
+    std::lock_guard<std::mutex> lk(h->host_mu);
+    const Dims &d = h->kp.d;
+    const size_t cap = (size_t)h->chunk;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    if (!h->host_dev_ready) {
+        HIP_TRY(hipStreamCreateWithFlags(&h->sIn, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&h->sOut, hipStreamNonBlocking));
+        const unsigned evf = hipEventDisableTiming | (h->block_sync ? hipEventBlockingSync : 0u);
+        for (Slot *sl : h->slots) {
+            HIP_TRY(hipMalloc((void **)&sl->d_in, 2 * cap * (size_t)d.N));
+            HIP_TRY(hipMalloc((void **)&sl->d_out, 2 * cap * (size_t)d.Nm * sizeof(float)));
+            HIP_TRY(hipEventCreateWithFlags(&sl->ev_in, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&sl->ev_lr, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&sl->ev_p2, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&sl->ev_out, evf));
+        }
+        h->host_dev_ready = true;
+    }
+    if (need_pin_in && !h->host_pin_in_ready) {
+        for (Slot *sl : h->slots) HIP_TRY(hipHostMalloc((void **)&sl->h_in, 2 * cap * (size_t)d.N, hipHostMallocDefault));
+        h->host_pin_in_ready = true;
+    }
+    if (need_pin_out && !h->host_pin_out_ready) {
+        for (Slot *sl : h->slots) HIP_TRY(hipHostMalloc((void **)&sl->h_out, 2 * cap * (size_t)d.Nm * sizeof(float), hipHostMallocDefault));
+        h->host_pin_out_ready = true;
+    }
+}
+
+// Upload of a chunk's images on `st` (stream sIn in the pipeline, the phase-1 stream itself in latency mode).  Device layout:
+// rows packed to W bytes, all left images of the chunk, then all right images.
+void upload_chunk(sv_handle *h, Slot *s, hipStream_t st, int copy_helpers) {
+    const Dims &d = h->kp.d;
+    const Job &job = *s->job;
+    const size_t cap = (size_t)s->dev.cap, img = (size_t)d.N, src_pair = (size_t)d.H * job.stride;
+    const uint8_t *src[2] = {job.left + (size_t)s->i0 * src_pair, job.right + (size_t)s->i0 * src_pair};
+    for (int side = 0; side < 2; side++) {
+        uint8_t *dev = s->d_in + side * cap * img;
+        if (job.pin_in) {  // DMA straight from the caller's page-locked memory
+            if (job.stride == d.W)
+                HIP_TRY(hipMemcpyAsync(dev, src[side], (size_t)s->n * img, hipMemcpyHostToDevice, st));
+            else
+                HIP_TRY(hipMemcpy2DAsync(dev, (size_t)d.W, src[side], (size_t)job.stride, (size_t)d.W, (size_t)s->n * d.H, hipMemcpyHostToDevice, st));
+            continue;
+        }
+        uint8_t *stage = s->h_in + side * cap * img;  // pageable: pack into the page-locked mirror first, one image side at a
+        CopyList cl;                                  // time so that the DMA of the left images overlaps the packing of the right
+        if (job.stride == d.W) {
+            cl.add(stage, src[side], (size_t)s->n * img);
+        } else {
+            for (int j = 0; j < s->n; j++)
+                for (int y = 0; y < d.H; y++) cl.job->pieces.push_back({stage + (size_t)j * img + (size_t)y * d.W, src[side] + (size_t)j * src_pair + (size_t)y * job.stride, (size_t)d.W});
+        }
+        cl.run(h, copy_helpers);
+        HIP_TRY(hipMemcpyAsync(dev, stage, (size_t)s->n * img, hipMemcpyHostToDevice, st));
+    }
+    s->in_left = s->d_in;
+    s->in_right = s->d_in + cap * img;
+    s->in_pair = img;
+    s->in_stride = d.W;
+}
+
+// Download of one finished map block (side 0: left maps, 1: right maps) of a chunk on `st`.  Pairs with fewer than 3 support
+// points are skipped: the reference leaves the caller's maps untouched for them (elas.cpp:63-69).
+void download_maps(sv_handle *h, Slot *s, int side, hipStream_t st) {
+    const Dims &d = h->kp.d;
+    const Job &job = *s->job;
+    float *user = side ? job.d2 : job.d1;
+    if (!user) return;
+    const size_t cap = (size_t)s->dev.cap, Nm = (size_t)d.Nm;
+    const float *dev = s->d_out + side * cap * Nm;
+    float *dst = job.pin_out ? user + (size_t)s->i0 * Nm : s->h_out + side * cap * Nm;
+    for (int j = 0; j < s->n;) {  // maximal runs of processed pairs
+        if (s->h_blob[(size_t)j * META_WORDS] < 3) {
+            j++;
+            continue;
+        }
+        int e = j + 1;
+        while (e < s->n && s->h_blob[(size_t)e * META_WORDS] >= 3) e++;
+        HIP_TRY(hipMemcpyAsync(dst + (size_t)j * Nm, dev + (size_t)j * Nm, (size_t)(e - j) * Nm * sizeof(float), hipMemcpyDeviceToHost, st));
+        j = e;
+    }
+}
+
+// Pageable callers: the maps of a chunk from the page-locked mirror into the caller's arrays (after ev_out)
+void deliver_maps(sv_handle *h, Slot *s, int copy_helpers) {
+    const Dims &d = h->kp.d;
+    const Job &job = *s->job;
+    if (job.pin_out) return;
+    const size_t cap = (size_t)s->dev.cap, Nm = (size_t)d.Nm;
+    CopyList cl;
+    for (int side = 0; side < 2; side++) {
+        float *user = side ? job.d2 : job.d1;
+        if (!user) continue;
+        for (int j = 0; j < s->n; j++)
+            if (s->h_blob[(size_t)j * META_WORDS] >= 3) cl.add(user + (size_t)(s->i0 + j) * Nm, s->h_out + side * cap * Nm + (size_t)j * Nm, Nm * sizeof(float));
+    }
+    if (!cl.job->pieces.empty()) cl.run(h, copy_helpers);
+}
+
+void set_chunk_inputs(sv_handle *h, Slot *s) {  // device-memory jobs read the caller's tensors in place
+    const Job &job = *s->job;
+    s->in_pair = (size_t)h->kp.d.H * job.stride;
+    s->in_left = job.left + (size_t)s->i0 * s->in_pair;
+    s->in_right = job.right + (size_t)s->i0 * s->in_pair;
+    s->in_stride = job.stride;
 }
 
 void issuer_main(sv_handle *h) {
@@ -452,7 +650,16 @@ void issuer_main(sv_handle *h) {
             s->n = std::min(h->chunk, job->batch - s->i0);
             try {
                 if (drain) HIP_TRY(hipEventSynchronize(s->ev_free));
-                if (!h->failed) issue_phase1(h, s);
+                if (!h->failed) {
+                    if (job->host) {  // images: caller -> (page-locked mirror ->) device on the upload stream; phase 1 waits for them
+                        upload_chunk(h, s, h->sIn, 3);
+                        HIP_TRY(hipEventRecord(s->ev_in, h->sIn));
+                        HIP_TRY(hipStreamWaitEvent(h->sP1, s->ev_in, 0));
+                    } else {
+                        set_chunk_inputs(h, s);
+                    }
+                    issue_phase1(h, s);
+                }
             } catch (const std::exception &e) {
                 note_error(h, e.what());
             }
@@ -609,6 +816,7 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
 }
 
 void pool_main(sv_handle *h, HostScratch *sc) {
+    (void)hipSetDevice(h->cfg.device);  // run_task may fetch a long support list from the handle's device
     for (;;) {
         Task t;
         {
@@ -684,9 +892,18 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
     launch_triangles(k, s->dev, n, st);
     launch_dense(k, s->dev, n, st);
     float *u1 = job.d1 + (size_t)s->i0 * d.Nm, *u2 = job.d2 ? job.d2 + (size_t)s->i0 * d.Nm : nullptr;  // the caller's maps are [batch][Hm][Wm]
+    if (job.host) {  // host-memory job: the maps are written to the slot's device staging and downloaded from there
+        u1 = s->d_out;
+        u2 = job.d2 ? s->d_out + (size_t)s->dev.cap * d.Nm : nullptr;
+    }
     const bool only_left = h->nproc == 1;
     // with postprocess_only_left the checked right map is final: it goes straight to the caller (or nowhere)
     launch_lr(km, s->dev, n, st, only_left ? u2 : nullptr, !only_left || dbg);
+    if (job.host && only_left && u2) {  // ... and its download overlaps the rest of phase 2
+        HIP_TRY(hipEventRecord(s->ev_lr, st));
+        HIP_TRY(hipStreamWaitEvent(h->sOut, s->ev_lr, 0));
+        download_maps(h, s, 1, h->sOut);
+    }
     const bool active = dbg && blob[(size_t)(n - 1) * META_WORDS] >= 3;
     if (active) {
         const int j = n - 1;
@@ -720,6 +937,13 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
     if (active) dbg_maps_nproc(h, st, "final", cur, s->dev.disp, n - 1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev_free, st));
+    if (job.host) {
+        HIP_TRY(hipEventRecord(s->ev_p2, st));
+        HIP_TRY(hipStreamWaitEvent(h->sOut, s->ev_p2, 0));
+        download_maps(h, s, 0, h->sOut);
+        if (!only_left) download_maps(h, s, 1, h->sOut);
+        HIP_TRY(hipEventRecord(s->ev_out, h->sOut));
+    }
 }
 
 void finisher_main(sv_handle *h) {
@@ -747,8 +971,42 @@ void finisher_main(sv_handle *h) {
         }
         {
             std::lock_guard<std::mutex> lk(h->mu);
-            s->state = recorded ? SLOT_DRAINING : SLOT_FREE;
-            if (++s->job->issued2 == s->job->nchunks) h->jobs_finished++;
+            if (s->job->host) {  // the slot stays busy until the drainer has seen its maps arrive
+                s->job->issued2++;
+                s->out_enqueued = recorded;
+                h->q3.push_back(s);
+            } else {
+                s->state = recorded ? SLOT_DRAINING : SLOT_FREE;
+                if (++s->job->issued2 == s->job->nchunks) h->jobs_finished++;
+            }
+        }
+        h->cv.notify_all();
+    }
+}
+
+// ---- stage 4 (host-memory jobs only): drainer ---------------------------------------------------------------------------
+// Waits for a chunk's map downloads, hands pageable callers their maps, frees the slot and counts the job's chunks.
+void drainer_main(sv_handle *h) {
+    (void)hipSetDevice(h->cfg.device);
+    for (;;) {
+        Slot *s = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(h->mu);
+            h->cv.wait(lk, [&] { return h->quit || !h->q3.empty(); });
+            if (h->quit) return;
+            s = h->q3.front();
+            h->q3.pop_front();
+        }
+        if (s->out_enqueued) {
+            if (hipEventSynchronize(s->ev_out) != hipSuccess)
+                note_error(h, "hipEventSynchronize(map download) failed");
+            else if (!h->failed)
+                deliver_maps(h, s, 3);
+        }
+        {
+            std::lock_guard<std::mutex> lk(h->mu);
+            s->state = SLOT_FREE;
+            if (++s->job->drained == s->job->nchunks) h->jobs_finished++;
         }
         h->cv.notify_all();
     }
@@ -853,6 +1111,12 @@ void free_slot(Slot *sl) {
     if (sl->ev_p1) (void)hipEventDestroy(sl->ev_p1);
     if (sl->ev_free) (void)hipEventDestroy(sl->ev_free);
     if (sl->ev_sup) (void)hipEventDestroy(sl->ev_sup);
+    if (sl->d_in) (void)hipFree(sl->d_in);
+    if (sl->d_out) (void)hipFree(sl->d_out);
+    if (sl->h_in) (void)hipHostFree(sl->h_in);
+    if (sl->h_out) (void)hipHostFree(sl->h_out);
+    for (hipEvent_t e : {sl->ev_in, sl->ev_lr, sl->ev_p2, sl->ev_out})
+        if (e) (void)hipEventDestroy(e);
 }
 
 void free_handle_resources(sv_handle *h) {
@@ -867,9 +1131,30 @@ void free_handle_resources(sv_handle *h) {
     if (h->sP1) (void)hipStreamDestroy(h->sP1);
     if (h->sPF) (void)hipStreamDestroy(h->sPF);
     for (hipStream_t st : h->sP2) (void)hipStreamDestroy(st);
+    if (h->d_counters) (void)hipFree(h->d_counters);
+    if (h->sIn) (void)hipStreamDestroy(h->sIn);
+    if (h->sOut) (void)hipStreamDestroy(h->sOut);
 }
 
-int submit_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status) {
+// host-memory jobs: classify the caller's memory and make sure the staging buffers exist
+int prepare_host_job(sv_handle *h, Job *job) {
+    const Dims &d = h->kp.d;
+    job->host = true;
+    const size_t in_bytes = (size_t)job->batch * d.H * job->stride, out_bytes = (size_t)job->batch * d.Nm * sizeof(float);
+    (void)hipSetDevice(h->cfg.device);
+    job->pin_in = is_pinned_host(job->left, in_bytes) && is_pinned_host(job->right, in_bytes);
+    job->pin_out = is_pinned_host(job->d1, out_bytes) && (!job->d2 || is_pinned_host(job->d2, out_bytes));
+    if (getenv("SV_HOST_FORCE_STAGING")) job->pin_in = job->pin_out = false;  // tests: the pageable route with page-locked buffers
+    try {
+        ensure_host_staging(h, !job->pin_in, !job->pin_out);
+    } catch (const std::exception &e) {
+        h->error = e.what();
+        return SV_ERR_HIP;
+    }
+    return SV_OK;
+}
+
+int submit_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status, bool host = false) {
     if (!h) return SV_ERR_ARG;
     if (!left || !right || !d1 || batch < 0 || stride < h->cfg.width) {
         h->error = "bad argument (null pointer, negative batch, or stride < width)";
@@ -885,6 +1170,13 @@ int submit_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batc
     job->d2 = d2;
     job->status = status;
     job->nchunks = (batch + h->chunk - 1) / h->chunk;
+    if (host) {
+        const int rc = prepare_host_job(h, job);
+        if (rc != SV_OK) {
+            delete job;
+            return rc;
+        }
+    }
     {
         std::lock_guard<std::mutex> lk(h->mu);
         if (h->live.empty()) h->failed = false;
@@ -907,6 +1199,8 @@ int wait_jobs(sv_handle *h) {
     bool ok = hipStreamSynchronize(h->sP1) == hipSuccess;
     ok = (hipStreamSynchronize(h->sPF) == hipSuccess) && ok;
     for (hipStream_t st : h->sP2) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
+    for (hipStream_t st : {h->sIn, h->sOut})
+        if (st) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
     if (!ok) note_error(h, "stream synchronisation failed");
     if (h->timing) {
         collect_timing(h, &h->tc_issue);
@@ -921,7 +1215,7 @@ int wait_jobs(sv_handle *h) {
 // Latency mode: one pair, chunk 1, nothing in flight.  The calling thread issues phase 1, spins on its event, runs the lattice
 // filter and the left triangulation itself (the right one goes to a pool thread meanwhile), issues phase 2 and waits for it:
 // no hand-over between the three control threads, which costs more than the kernels of a single pair.
-int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stride, float *d1, float *d2, int32_t *status) {
+int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stride, float *d1, float *d2, int32_t *status, bool host) {
     Job job;
     job.left = left;
     job.right = right;
@@ -931,6 +1225,10 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
     job.d2 = d2;
     job.status = status;
     job.nchunks = 1;
+    if (host) {
+        const int rc = prepare_host_job(h, &job);
+        if (rc != SV_OK) return rc;
+    }
     Slot *s = h->slots[0];
     h->failed = false;
     s->job = &job;
@@ -943,6 +1241,10 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
     try {
         g_launch_hook.fn = h->timing ? timing_hook : nullptr;
         g_launch_hook.ctx = &h->tc_issue;
+        if (host)
+            upload_chunk(h, s, h->sP1, 2);  // on the phase-1 stream itself: in order, no event
+        else
+            set_chunk_inputs(h, s);
         issue_phase1(h, s);
         HIP_TRY(hipEventSynchronize(s->ev_p1));
         s->blob_off.store((size_t)s->dev.cap * META_WORDS);
@@ -951,7 +1253,12 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
         while (!s->inline_done.load(std::memory_order_acquire)) __builtin_ia32_pause();
         g_launch_hook.ctx = &h->tc_finish;
         issue_phase2(h, s, h->sP2[0]);
-        HIP_TRY(hipStreamSynchronize(h->sP2[0]));
+        if (host) {  // the downloads were enqueued by issue_phase2 (right map right after the L/R check)
+            HIP_TRY(hipEventSynchronize(s->ev_out));
+            deliver_maps(h, s, 3);
+        } else {
+            HIP_TRY(hipStreamSynchronize(h->sP2[0]));
+        }
     } catch (const std::exception &e) {
         note_error(h, e.what());
         while (s->pending.load() > 0 && !s->inline_done.load()) __builtin_ia32_pause();  // a queued right-side task still refers to the slot
@@ -966,16 +1273,16 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
     return h->failed ? SV_ERR_HIP : SV_OK;
 }
 
-int run_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status) {
+int run_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status, bool host = false) {
     if (h && batch == 1 && h->chunk == 1 && !h->cfg.keep_debug && !h->gpu_filter && left && right && d1 && stride >= h->cfg.width && h->inline_ok) {
         bool idle;
         {
             std::lock_guard<std::mutex> lk(h->mu);
             idle = h->live.empty() && h->jobs.empty();
         }
-        if (idle) return run_inline(h, left, right, stride, d1, d2, status);
+        if (idle) return run_inline(h, left, right, stride, d1, d2, status, host);
     }
-    const int rc = submit_job(h, left, right, batch, stride, d1, d2, status);
+    const int rc = submit_job(h, left, right, batch, stride, d1, d2, status, host);
     if (rc != SV_OK) return rc;
     return wait_jobs(h);
 }
@@ -1118,6 +1425,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     h->t_issue = std::thread(issuer_main, h);
     h->t_dispatch = std::thread(dispatcher_main, h);
     h->t_finish = std::thread(finisher_main, h);
+    h->t_drain = std::thread(drainer_main, h);
     *out = h;
     return SV_OK;
 }
@@ -1130,7 +1438,7 @@ int sv_destroy(sv_handle *h) {
         h->quit = true;
     }
     h->cv.notify_all();
-    for (std::thread *t : {&h->t_issue, &h->t_dispatch, &h->t_finish})
+    for (std::thread *t : {&h->t_issue, &h->t_dispatch, &h->t_finish, &h->t_drain})
         if (t->joinable()) t->join();
     {
         std::lock_guard<std::mutex> lk(h->qmu);
@@ -1170,43 +1478,25 @@ int sv_query(const sv_handle *h, int what) {
     }
 }
 
+// Host memory in and out: the batch streams through the same pipeline, chunk by chunk - images up on a copy stream while
+// earlier chunks compute, maps down on another while later chunks compute (a pair = gray L+R in host memory ->
+// D1 back in host memory).  No allocation, no device-wide synchronisation per call (staging is allocated at the first call).
 int sv_process_batch_host(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status) {
-    if (!h) return SV_ERR_ARG;
-    if (!left || !right || !d1 || batch < 0 || stride < h->cfg.width) {
-        h->error = "bad argument";
-        return SV_ERR_ARG;
-    }
-    if (batch == 0) return SV_OK;
-    const Dims &d = h->kp.d;
-    const size_t in_bytes = (size_t)batch * d.H * stride, out_bytes = (size_t)batch * d.Nm * sizeof(float);  // maps: [batch][Hm][Wm]
-    uint8_t *dl = nullptr, *dr = nullptr;
-    float *o1 = nullptr, *o2 = nullptr;
-    int rc = SV_OK;
-    try {
-        HIP_TRY(hipSetDevice(h->cfg.device));
-        HIP_TRY(hipMalloc((void **)&dl, in_bytes));
-        HIP_TRY(hipMalloc((void **)&dr, in_bytes));
-        HIP_TRY(hipMalloc((void **)&o1, out_bytes));
-        if (d2) HIP_TRY(hipMalloc((void **)&o2, out_bytes));
-        HIP_TRY(hipMemcpy(dl, left, in_bytes, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(dr, right, in_bytes, hipMemcpyHostToDevice));
-        // pairs the reference would leave untouched (<3 support points) must keep the caller's values
-        HIP_TRY(hipMemcpy(o1, d1, out_bytes, hipMemcpyHostToDevice));
-        if (d2) HIP_TRY(hipMemcpy(o2, d2, out_bytes, hipMemcpyHostToDevice));
-        rc = run_job(h, dl, dr, batch, stride, o1, o2, status);
-        if (rc == SV_OK) {
-            HIP_TRY(hipMemcpy(d1, o1, out_bytes, hipMemcpyDeviceToHost));
-            if (d2) HIP_TRY(hipMemcpy(d2, o2, out_bytes, hipMemcpyDeviceToHost));
-        }
-    } catch (const std::exception &e) {
-        h->error = e.what();
-        rc = SV_ERR_HIP;
-    }
-    if (dl) (void)hipFree(dl);
-    if (dr) (void)hipFree(dr);
-    if (o1) (void)hipFree(o1);
-    if (o2) (void)hipFree(o2);
-    return rc;
+    return run_job(h, left, right, batch, stride, d1, d2, status, true);
+}
+
+int sv_submit_batch_host(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status) {
+    return submit_job(h, left, right, batch, stride, d1, d2, status, true);
+}
+
+void *sv_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void sv_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int sv_elas_process(sv_handle *h, const uint8_t *I1, const uint8_t *I2, float *D1, float *D2, const int32_t *dims) {
@@ -1216,6 +1506,27 @@ int sv_elas_process(sv_handle *h, const uint8_t *I1, const uint8_t *I2, float *D
         return SV_ERR_ARG;
     }
     return sv_process_batch_host(h, I1, I2, 1, dims[2], D1, D2, nullptr);
+}
+
+int sv_debug_counters(sv_handle *h, int mode, uint64_t *out) {
+    if (!h) return SV_ERR_ARG;
+    (void)wait_jobs(h);  // the slots' counter pointer only changes while nothing is in flight
+    if (hipSetDevice(h->cfg.device) != hipSuccess) return SV_ERR_HIP;
+    if (mode == 1) {
+        if (!h->d_counters && hipMalloc((void **)&h->d_counters, sizeof(unsigned long long) * CNT_COUNT) != hipSuccess) return SV_ERR_HIP;
+        if (hipMemset(h->d_counters, 0, sizeof(unsigned long long) * CNT_COUNT) != hipSuccess) return SV_ERR_HIP;
+    }
+    if (mode == 0 || mode == 1)
+        for (Slot *sl : h->slots) sl->dev.counters = mode ? h->d_counters : nullptr;
+    if (out) {
+        unsigned long long v[CNT_COUNT] = {0};
+        if (h->d_counters && hipMemcpy(v, h->d_counters, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return SV_ERR_HIP;
+        out[0] = v[CNT_DENSE_CANDIDATES];
+        out[1] = v[CNT_DENSE_PIXELS];
+        out[2] = v[CNT_SUPPORT_ENERGIES];
+        out[3] = 0;
+    }
+    return SV_OK;
 }
 
 long sv_debug_size(sv_handle *h, const char *name) {

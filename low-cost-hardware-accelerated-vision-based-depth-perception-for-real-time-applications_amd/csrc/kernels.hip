@@ -59,6 +59,13 @@ __device__ __forceinline__ uint32_t texture16(const uint4 &a) {
 
 __device__ __forceinline__ uint4 ld16(const uint8_t *p) { return *reinterpret_cast<const uint4 *>(p); }
 
+// work counters (sv_debug_counters): one atomic per wavefront, only in the COUNT instantiations of the matching kernels
+__device__ __forceinline__ void count_add(unsigned long long *slot, int mine) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(slot, (unsigned long long)mine);
+}
+
 __device__ __forceinline__ int sat_u8(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -333,7 +340,8 @@ __device__ __forceinline__ int support_decide(const KParams &k, const uint4 &cen
     return E1 < k.support_threshold * E2 ? (int)(m.x & 0xFFFFu) : -1;
 }
 
-__global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, const uint8_t *__restrict__ desc, int16_t *__restrict__ dcan) {
+template <bool COUNT>
+__global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, const uint8_t *__restrict__ desc, int16_t *__restrict__ dcan, unsigned long long *__restrict__ counters) {
     const Dims &d = k.d;
     extern __shared__ uint4 sup_lds[];
     const int pair = blockIdx.z, vc = blockIdx.y + 1;
@@ -380,6 +388,8 @@ __global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, const uint8_
     k1 = k2 = SUP_KEY_NONE;
     if (d_lo <= dmax2) support_scan<true>(R, L, u2, d_lo, min(dmax2, d_lo + qlen - 1), k1, k2);
     rec[SUP_THREADS + threadIdx.x] = make_uint2(k1, k2);
+    if (COUNT)  // 64-byte energies evaluated by this lane: its share of [0, dmax] in both directions
+        count_add(counters + CNT_SUPPORT_ENERGIES, (d_lo <= dmax1 ? min(dmax1, d_lo + qlen - 1) - d_lo + 1 : 0) + (d_lo <= dmax2 ? min(dmax2, d_lo + qlen - 1) - d_lo + 1 : 0));
     __syncthreads();
     if (part == 0 && uc < uc1) {
         const int d2v = dmax2 >= 0 ? support_decide(k, centre, support_merge(rec + SUP_THREADS, point)) : -1;
@@ -401,16 +411,15 @@ void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
     }
     const int span = (SUP_POINTS - 1) * k.d.step;
     const size_t shmem = 2 * SUP_THREADS * sizeof(uint2) + sizeof(uint4) * 2 * ((size_t)(span + k.d.disp_max + 5) + (size_t)(span + 2 * k.d.disp_max + 5));
-    if (shmem > 64 * 1024) {  // large disparity ranges: more than the default dynamic LDS limit
-        static std::atomic<size_t> granted[64];  // per device
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::atomic<size_t> &g = granted[dev & 63];
-        if (shmem > g.load() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_support), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem) == hipSuccess)
-            g.store(shmem);
-    }
+    static std::atomic<size_t> granted[64], granted_c[64];
     dim3 grid((k.d.Wc - 1 + SUP_POINTS - 1) / SUP_POINTS, k.d.Hc - 1, n);
-    SV_LAUNCH(K_SUPPORT, k_support, grid, dim3(SUP_THREADS), shmem, st, k, s.desc, s.dcan);
+    if (s.counters) {
+        ensure_dynamic_lds(k_support<true>, shmem, granted_c, "support_match");
+        SV_LAUNCH(K_SUPPORT, k_support<true>, grid, dim3(SUP_THREADS), shmem, st, k, s.desc, s.dcan, s.counters);
+        return;
+    }
+    ensure_dynamic_lds(k_support<false>, shmem, granted, "support_match");  // large disparity ranges: more than the default dynamic LDS limit
+    SV_LAUNCH(K_SUPPORT, k_support<false>, grid, dim3(SUP_THREADS), shmem, st, k, s.desc, s.dcan, s.counters);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -697,6 +706,8 @@ size_t support_filter_lds_bytes(const KParams &k) {
 }
 
 void launch_support_filter(const KParams &k, int win, int thr, int need, const SlotDev &s, int n, hipStream_t st) {
+    static std::atomic<size_t> granted[64];
+    ensure_dynamic_lds(k_support_filter, support_filter_lds_bytes(k), granted, "support_filter");
     SV_LAUNCH(K_SUPPORT_FILTER, k_support_filter, dim3(n), dim3(FLT_THREADS), support_filter_lds_bytes(k), st, k, win, thr, need, s.dcan, s.fsup, s.fnsup);
 }
 
@@ -1075,8 +1086,9 @@ void launch_triangles(const KParams &k, const SlotDev &s, int n, hipStream_t st)
 // instead of ~2.5 times with one pass per launch.
 #define DENSE_TW 512
 
+template <bool COUNT>
 __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, int v, const uint4 own, const uint4 *pu, const float4 rec, const uint32_t *mw,
-                                             const uint32_t *cell) {
+                                             const uint32_t *cell, int &ncand) {
     const Dims &d = k.d;
     if ((int)texture16(own) < k.match_texture) return -10.0f;                   // elas.cpp:732-736 (the map keeps its -10)
     const int d_plane = (int)(rec.x * (float)u + rec.y * (float)v + rec.z);      // :739, ((a*u)+(b*v))+c without contraction
@@ -1115,6 +1127,7 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
             }
             m &= ~(w == band_word ? band_lo : (w == band_word + 1 ? band_hi : 0u));
         }
+        if (COUNT) ncand += __popc(m);
         int best_w = KEY_NONE;  // keys of this word carry the bit index only; 32 * w is added once per word
         while (m) {  // two candidates per trip: their LDS reads are in flight together (an odd last one is evaluated twice)
             const int b1 = __ffs((int)m) - 1;
@@ -1131,6 +1144,7 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
         for (int b = 0; b < 32; b++) {
             const int dc = 32 * w + b;
             if (!((m >> b) & 1u) || dc < a_lo || dc > a_hi || (dc >= d_plane_min && dc <= d_plane_max)) continue;
+            if (COUNT) ncand++;
             best = min(best, sad16_key(own, pu[sgn * dc], dc));
         }
     }
@@ -1139,14 +1153,17 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
     for (int o = -k.plane_radius; o <= k.plane_radius; o++) {
         const int dc = d_plane + o;
         if (dc < b_lo || dc > b_hi) continue;
+        if (COUNT) ncand++;
         const int prior = valid ? k.prior[o < 0 ? -o : o] : 0;
         best = min(best, sad16_key(own, pu[sgn * dc], prior * 65536 + (0x8000 | dc)));
     }
     return best < (10000 << 16) ? (float)(best & 0x7FFF) : -1.0f;  // :797-800 (min_val starts at 10000, :752)
 }
 
+template <bool COUNT>
 __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restrict__ desc, const int32_t *__restrict__ blob, const int32_t *__restrict__ tri_id,
-                                               const float4 *__restrict__ trirec, const uint32_t *__restrict__ gB, int16_t *__restrict__ wta) {
+                                               const float4 *__restrict__ trirec, const uint32_t *__restrict__ gB, int16_t *__restrict__ wta,
+                                               unsigned long long *__restrict__ counters) {
     const Dims &d = k.d;
     extern __shared__ uint4 dense_lds[];
     const int pair = blockIdx.z;
@@ -1180,6 +1197,7 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
         const int u = min(x0 + j * 256 + (int)threadIdx.x, d.W - 1);
         cell_off[j] = gy * (uint32_t)(d.gw * d.MW) + __umul24((uint32_t)(int)floorf((float)u / (float)d.grid_size), (uint32_t)d.MW);
     }
+    int ncand = 0, npix = 0;
 #pragma unroll
     for (int side = 0; side < 2; side++) {
         const int ps = pair * 2 + side;
@@ -1206,7 +1224,8 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
                 }
                 const uint4 own = side ? sR[u - r0] : sL[u - l0];
                 const uint4 *pu = side ? sL + (u - l0) : sR + (u - r0);  // the other image at the pixel's own column
-                out = dense_pixel(k, side, u, v, own, pu, rec, mw, cell);
+                out = dense_pixel<COUNT>(k, side, u, v, own, pu, rec, mw, cell, ncand);
+                if (COUNT) npix++;
             }
             // integer-valued: a disparity, -1 or -10.  Half resolution (elas.cpp:707-711): only even (u, v) are matched, result at (u/2, v/2)
             if (!d.sub)
@@ -1215,11 +1234,23 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
                 wta[(size_t)ps * d.Nm + (size_t)(v >> 1) * d.Wm + (u >> 1)] = (int16_t)out;
         }
     }
+    if (COUNT) {
+        count_add(counters + CNT_DENSE_CANDIDATES, ncand);
+        count_add(counters + CNT_DENSE_PIXELS, npix);
+    }
 }
 
 void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
     const size_t shmem = sizeof(uint4) * 2 * (size_t)(DENSE_TW + k.d.disp_max);
-    SV_LAUNCH(K_DENSE, k_dense, dim3((k.d.W + DENSE_TW - 1) / DENSE_TW, k.d.sub ? (k.d.H + 1) / 2 : k.d.H, n), dim3(256), shmem, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta);
+    const dim3 grid((k.d.W + DENSE_TW - 1) / DENSE_TW, k.d.sub ? (k.d.H + 1) / 2 : k.d.H, n);
+    static std::atomic<size_t> granted[64], granted_c[64];
+    if (s.counters) {
+        ensure_dynamic_lds(k_dense<true>, shmem, granted_c, "dense_match");
+        SV_LAUNCH(K_DENSE, k_dense<true>, grid, dim3(256), shmem, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
+        return;
+    }
+    ensure_dynamic_lds(k_dense<false>, shmem, granted, "dense_match");
+    SV_LAUNCH(K_DENSE, k_dense<false>, grid, dim3(256), shmem, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1710,14 +1741,8 @@ void launch_speckle(const KParams &k, const SlotDev &s, int n, int nproc, hipStr
     CclWs ws;
     ccl_views(k, s.ccl_ws, s.cap * 2, ws);
     const size_t lds = ccl_lds_bytes(k);
-    if (lds > 64 * 1024) {  // wide images: larger run tables than the default dynamic-LDS limit allows
-        static std::atomic<size_t> granted[64];  // per device: the attribute belongs to the function's code object on that device
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        std::atomic<size_t> &g = granted[dev & 63];
-        if (lds > g.load() && hipFuncSetAttribute(reinterpret_cast<const void *>(k_ccl_band), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)
-            g.store(lds);
-    }
+    static std::atomic<size_t> granted[64];
+    ensure_dynamic_lds(k_ccl_band, lds, granted, "ccl_band");  // wide images: larger run tables than the default dynamic-LDS limit allows
     SV_LAUNCH(K_CCL_BAND, k_ccl_band, dim3(ws.nb, maps), dim3(CCL_THREADS), lds, st, k, nproc, s.blob, s.disp, ws);
     if (ws.nb > 1) SV_LAUNCH(K_CCL_FINISH, k_ccl_border, dim3(((ws.nb - 1) * ws.nch + 3) / 4, maps), dim3(256), 0, st, nproc, s.blob, ws);
     SV_LAUNCH(K_CCL_FINISH, k_ccl_total, dim3(ws.nb * CCL_SPLIT, maps), dim3(256), 0, st, nproc, k.speckle_size, s.blob, ws);

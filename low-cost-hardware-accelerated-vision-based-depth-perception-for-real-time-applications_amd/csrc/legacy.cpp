@@ -163,12 +163,22 @@ Double3 *generatePointCloud(unsigned char *left, unsigned char *right, char *CAM
     std::lock_guard<std::mutex> lk(g_mu);
     if (!left || !right) return nullptr;
     if (!g.ready && !g.failed) {  // function-static init of the reference (stereo_vision.cpp:582): first call freezes the state
+        if (width < 32 || height < 32 || scale < 1) {  // K1/K2 are divided by scale (:364-376); the reference would divide by zero
+            fprintf(stderr, "stereo_vision_hip: bad width/height/scale (%d, %d, %d)\n", width, height, scale);
+            return nullptr;
+        }
         if (objectTracking) printf("\n** Object tracking requested: not provided by this library (detector weights are not part of the hot path)\n");
         else printf("\n** Object tracking disabled\n");
         g.ready = legacy_init(width, height, (float)scale, CAMERA_CALIBRATION_YAML, subsampling);
         g.failed = !g.ready;
     }
     if (!g.ready) return nullptr;
+    // The reference wraps each call's width x height buffers and resizes them to the frozen out_img_size (:587-591).  There is
+    // no resize here: a frame of another size is refused instead of reading W*H*4 bytes from buffers that may be smaller.
+    if (width != g.W || height != g.H) {
+        fprintf(stderr, "stereo_vision_hip: frame is %dx%d but the first call froze %dx%d (stereo_vision.cpp:582); call clean() first\n", width, height, g.W, g.H);
+        return nullptr;
+    }
     if (!legacy_frame(left, right)) return nullptr;
     return g.points;
 }

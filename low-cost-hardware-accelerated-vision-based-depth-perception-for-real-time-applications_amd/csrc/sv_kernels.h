@@ -5,6 +5,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <stdexcept>
+#include <string>
+
 namespace sv {
 
 // Geometry of one stereo pair as the kernels see it.  All maps are dense row-major [H][W].
@@ -63,7 +67,10 @@ struct SlotDev {
     float *tmp;         // [cap][2][N]  second map buffer: the fused filters ping-pong disp <-> tmp (CCL counters before that)
     int32_t *csize;     // [cap][2][N]  slow-path CCL only: run lengths (at run-start pixels); component sizes accumulate in `tmp`
     void *ccl_ws;       // run records, union-find and border masks of the speckle stage (ccl_ws_bytes)
+    unsigned long long *counters;  // work counters of the matching kernels (CounterId), nullptr = not counting (the normal case)
 };
+
+enum CounterId { CNT_DENSE_CANDIDATES = 0, CNT_DENSE_PIXELS, CNT_SUPPORT_ENERGIES, CNT_COUNT = 8 };
 
 // ---- launch wrappers (kernels.hip).  `n` = pairs in this launch; `nproc` = maps per pair to post-process (1 or 2).
 void launch_descriptor(const KParams &k, const uint8_t *left, const uint8_t *right, size_t in_pair_stride, int stride, const SlotDev &s, int n, hipStream_t st);
@@ -103,6 +110,21 @@ struct LaunchHook {
     void *ctx;
 };
 extern thread_local LaunchHook g_launch_hook;
+
+// Dynamic LDS above the 64 KB default needs the function attribute raised once per device (the attribute belongs to the
+// function's code object on that device).  Throws when the runtime refuses: launching anyway would fail silently and leave
+// the previous chunk's results in the output buffers.
+template <class Kernel>
+inline void ensure_dynamic_lds(Kernel kernel, size_t bytes, std::atomic<size_t> (&granted)[64], const char *name) {
+    if (bytes <= 64 * 1024) return;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::atomic<size_t> &g = granted[dev & 63];
+    if (bytes <= g.load()) return;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) throw std::runtime_error(std::string(name) + ": " + std::to_string(bytes) + " bytes of LDS refused: " + hipGetErrorString(e));
+    g.store(bytes);
+}
 
 #define SV_LAUNCH(id, kernel, grid, block, shmem, st, ...)                         \
     do {                                                                           \

@@ -93,7 +93,13 @@ def lib():
     L.sv_last_error.restype = ctypes.c_char_p
     L.sv_wait.argtypes = [ctypes.c_void_p]
     L.sv_wait.restype = ctypes.c_int
-    for name in ("sv_process_batch_device", "sv_process_batch_host", "sv_submit_batch_device"):
+    L.sv_host_alloc.argtypes = [ctypes.c_size_t]
+    L.sv_host_alloc.restype = ctypes.c_void_p
+    L.sv_host_free.argtypes = [ctypes.c_void_p]
+    L.sv_host_free.restype = None
+    L.sv_query.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sv_query.restype = ctypes.c_int
+    for name in ("sv_process_batch_device", "sv_process_batch_host", "sv_submit_batch_device", "sv_submit_batch_host"):
         f = getattr(L, name)
         f.argtypes = [ctypes.c_void_p, u8p, u8p, ctypes.c_int, ctypes.c_int, f32p, f32p, i32p]
         f.restype = ctypes.c_int
@@ -159,17 +165,39 @@ class StereoEngine:
             raise StereoError("libstereo_vision_hip error %d: %s" % (rc, lib().sv_last_error(self._h).decode()))
 
     # ---- device path (inputs resident in HBM)
+    def _check_device_batch(self, left, right, d1, d2, status):
+        """The engine reads and writes raw pointers on its own streams: everything the kernels assume is checked here, and work
+        pending on torch's current stream (an H2D copy of the inputs, a fill of the outputs) is waited for."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        for t, dt, name in ((left, torch.uint8, "left"), (right, torch.uint8, "right"), (d1, torch.float32, "d1"), (d2, torch.float32, "d2")):
+            if t is None and name == "d2":
+                continue
+            if not (isinstance(t, torch.Tensor) and t.is_cuda and t.device == dev):
+                raise ValueError("%s must be a CUDA tensor on %s (the handle's device)" % (name, dev))
+            if t.dtype != dt or not t.is_contiguous() or t.dim() != 3:
+                raise ValueError("%s must be a contiguous %s tensor [B,H,W]" % (name, dt))
+        B = left.shape[0]
+        if tuple(left.shape) != (B, self.height, self.width) or right.shape != left.shape:
+            raise ValueError("images must be [B,%d,%d], got %s / %s" % (self.height, self.width, tuple(left.shape), tuple(right.shape)))
+        for t, name in ((d1, "d1"), (d2, "d2")):
+            if t is not None and tuple(t.shape) != (B, self.map_height, self.map_width):
+                raise ValueError("%s must be [%d,%d,%d], got %s" % (name, B, self.map_height, self.map_width, tuple(t.shape)))
+        if status is not None and not (isinstance(status, np.ndarray) and status.dtype == np.int32 and status.flags.c_contiguous and status.size >= B):
+            raise ValueError("status must be a contiguous int32 numpy array with at least B entries")
+        torch.cuda.current_stream(dev).synchronize()
+        return B
+
     def process_device(self, left, right, d1=None, d2=None, want_d2=True, status=None):
         import torch
-        assert left.is_cuda and right.is_cuda and left.dtype == torch.uint8 and right.dtype == torch.uint8
-        assert left.dim() == 3 and left.shape == right.shape and left.shape[1] == self.height and left.shape[2] == self.width
-        left, right = left.contiguous(), right.contiguous()
+        if isinstance(left, torch.Tensor) and isinstance(right, torch.Tensor):
+            left, right = left.contiguous(), right.contiguous()
         B = left.shape[0]
         if d1 is None:
             d1 = torch.zeros((B, self.map_height, self.map_width), dtype=torch.float32, device=left.device)
         if d2 is None and want_d2:
             d2 = torch.zeros((B, self.map_height, self.map_width), dtype=torch.float32, device=left.device)
-        torch.cuda.current_stream(left.device).synchronize()  # inputs/outputs are handed to the engine's own streams
+        self._check_device_batch(left, right, d1, d2, status)
         st = status.ctypes.data_as(ctypes.c_void_p) if status is not None else None
         self._check(lib().sv_process_batch_device(self._h, left.data_ptr(), right.data_ptr(), B, self.width, d1.data_ptr(),
                                                   d2.data_ptr() if d2 is not None else None, st))
@@ -178,29 +206,49 @@ class StereoEngine:
     def submit_device(self, left, right, d1, d2=None, status=None):
         """Streaming form: enqueue a device-resident batch and return at once (call wait() before touching d1/d2).
         Successive batches flow through the pipeline back to back."""
-        import torch
-        assert left.is_cuda and left.dtype == torch.uint8 and left.is_contiguous() and right.is_contiguous() and d1.is_contiguous()
+        B = self._check_device_batch(left, right, d1, d2, status)
         st = status.ctypes.data_as(ctypes.c_void_p) if status is not None else None
-        self._check(lib().sv_submit_batch_device(self._h, left.data_ptr(), right.data_ptr(), left.shape[0], self.width, d1.data_ptr(),
+        self._check(lib().sv_submit_batch_device(self._h, left.data_ptr(), right.data_ptr(), B, self.width, d1.data_ptr(),
                                                  d2.data_ptr() if d2 is not None else None, st))
 
     def wait(self):
         self._check(lib().sv_wait(self._h))
 
-    # ---- host path (numpy in / out, PCIe inclusive)
-    def process_host(self, left, right, want_d2=True):
+    # ---- host path (numpy in / out, PCIe inclusive): streamed through the pipeline, no allocation per call
+    def _host_args(self, left, right, d1, d2, want_d2):
         left = np.ascontiguousarray(left, dtype=np.uint8)
         right = np.ascontiguousarray(right, dtype=np.uint8)
         if left.ndim == 2:
             left, right = left[None], right[None]
         B, H, W = left.shape
-        assert (H, W) == (self.height, self.width) and right.shape == left.shape
-        d1 = np.zeros((B, self.map_height, self.map_width), np.float32)
-        d2 = np.zeros((B, self.map_height, self.map_width), np.float32) if want_d2 else None
+        if (H, W) != (self.height, self.width) or right.shape != left.shape:
+            raise ValueError("images must be [B,%d,%d]" % (self.height, self.width))
+        shape = (B, self.map_height, self.map_width)
+        if d1 is None:
+            d1 = np.zeros(shape, np.float32)
+        if d2 is None and want_d2:
+            d2 = np.zeros(shape, np.float32)
+        for m, name in ((d1, "d1"), (d2, "d2")):
+            if m is not None and not (isinstance(m, np.ndarray) and m.dtype == np.float32 and m.flags.c_contiguous and m.shape == shape):
+                raise ValueError("%s must be a contiguous float32 array %s" % (name, shape))
+        return left, right, d1, d2, B
+
+    def process_host(self, left, right, want_d2=True, d1=None, d2=None):
+        """numpy [B,H,W] uint8 in, float32 maps out.  Page-locked arrays (pinned_array) skip the staging copies."""
+        left, right, d1, d2, B = self._host_args(left, right, d1, d2, want_d2)
         status = np.zeros(B, np.int32)
-        self._check(lib().sv_process_batch_host(self._h, left.ctypes.data, right.ctypes.data, B, W, d1.ctypes.data,
+        self._check(lib().sv_process_batch_host(self._h, left.ctypes.data, right.ctypes.data, B, self.width, d1.ctypes.data,
                                                 d2.ctypes.data if d2 is not None else None, status.ctypes.data))
         return d1, d2, status
+
+    def submit_host(self, left, right, d1, d2=None, status=None):
+        """Streaming form of process_host: returns at once; the arrays must stay alive and untouched until wait()."""
+        left_c, right_c, d1, d2, B = self._host_args(left, right, d1, d2, False)
+        if left_c is not left and not np.shares_memory(left_c, left) or right_c is not right and not np.shares_memory(right_c, right):
+            raise ValueError("submit_host needs contiguous uint8 arrays (a temporary copy would be freed before the engine reads it)")
+        st = status.ctypes.data_as(ctypes.c_void_p) if status is not None else None
+        self._check(lib().sv_submit_batch_host(self._h, left_c.ctypes.data, right_c.ctypes.data, B, self.width, d1.ctypes.data,
+                                               d2.ctypes.data if d2 is not None else None, st))
 
     def elas_process(self, I1, I2):
         """Elas::process(I1, I2, D1, D2, dims) for one pair (elas.h:153-162)."""
@@ -226,7 +274,6 @@ class StereoEngine:
     def query(self):
         """What the handle decided at creation: host threads, chunk, slots, where the lattice filters and the triangulations run."""
         L = lib()
-        L.sv_query.argtypes = [ctypes.c_void_p, ctypes.c_int]
         keys = ["host_threads", "chunk", "slots", "gpu_lattice_filter", "gpu_triangulation"]
         return {k: int(L.sv_query(self._h, i)) for i, k in enumerate(keys)}
 
@@ -237,6 +284,15 @@ class StereoEngine:
         lib().sv_kernel_timing_enable(self._h, int(on))
         lib().sv_kernel_times_reset(self._h)
 
+    def counters(self, enable=None):
+        """Work counters of the matching kernels.  counters(True) enables and resets them, counters(False) disables;
+        counters() returns {dense_candidates, dense_pixels, support_energies} since the last reset."""
+        L = lib()
+        L.sv_debug_counters.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
+        out = (ctypes.c_uint64 * 4)()
+        self._check(L.sv_debug_counters(self._h, -1 if enable is None else int(bool(enable)), out))
+        return {"dense_candidates": int(out[0]), "dense_pixels": int(out[1]), "support_energies": int(out[2])}
+
     def kernel_times(self):
         """{kernel: (total_ms, calls)} accumulated since timing(True)."""
         cap = 64
@@ -245,6 +301,29 @@ class StereoEngine:
         calls = (ctypes.c_int64 * cap)()
         n = lib().sv_kernel_times(self._h, names, ms, calls, cap)
         return {names[i].decode(): (ms[i], calls[i]) for i in range(n)}
+
+
+class _PinnedBlock:
+    def __init__(self, nbytes):
+        self.ptr = lib().sv_host_alloc(max(int(nbytes), 1))
+        if not self.ptr:
+            raise StereoError("sv_host_alloc(%d) failed" % nbytes)
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().sv_host_free(self.ptr)
+            self.ptr = None
+
+
+def pinned_array(shape, dtype):
+    """numpy array in page-locked host memory (sv_host_alloc): the engine's host path moves it by DMA without a staging copy.
+    The memory lives as long as the array (or any view of it)."""
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape)) * dt.itemsize
+    block = _PinnedBlock(n)
+    buf = (ctypes.c_uint8 * max(n, 1)).from_address(block.ptr)
+    buf._sv_block = block  # keeps the allocation alive: the array's base chain holds the ctypes buffer
+    return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
 
 
 def reproject(disp, Q, XR=None, XT=None, want_dmap=True):

@@ -58,6 +58,10 @@ def main():
     k0r = gray_cv4(REF + "/datasets/kitti_mini/image_03/data/0000000000.png")
     Image.fromarray(k0l).save(os.path.join(HERE, "kitti0_left.png"), optimize=True)
     Image.fromarray(k0r).save(os.path.join(HERE, "kitti0_right.png"), optimize=True)
+    # colour crop of pair 0 (the region of the kitti0_crop cases): input of the BGRA -> gray test of the legacy entry point
+    for side, cam in (("left", "image_02"), ("right", "image_03")):
+        rgb = np.asarray(Image.open(REF + "/datasets/kitti_mini/%s/data/0000000000.png" % cam).convert("RGB"))[150:278, 400:720].copy()
+        Image.fromarray(rgb).save(os.path.join(HERE, "kitti0_crop_color_%s.png" % side), optimize=True)
     cl = np.asarray(Image.open(REF + "/datasets/profile/cones_left.pgm"))[200:500, 300:700].copy()
     cr = np.asarray(Image.open(REF + "/datasets/profile/cones_right.pgm"))[200:500, 300:700].copy()
     Image.fromarray(cl).save(os.path.join(HERE, "cones_crop_left.png"), optimize=True)

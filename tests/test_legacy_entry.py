@@ -152,3 +152,44 @@ def test_reproject_batch_device():
     assert np.array_equal(pts.cpu().numpy(), plain, equal_nan=True)
     _, pts2 = eng.reproject(torch.from_numpy(d).cuda(), Q, XR, XT, want_dmap=False)
     assert np.array_equal(pts2.cpu().numpy(), xf, equal_nan=True)
+
+
+def _gray_cv4(rgb):
+    a = rgb.astype(np.int64)  # OpenCV 4.x BGR2GRAY, 15-bit fixed point (tests/golden/make_golden.py:gray_cv4)
+    return ((a[..., 2] * 3735 + a[..., 1] * 19235 + a[..., 0] * 9798 + 16384) >> 15).astype(np.uint8)
+
+
+def test_colour_crop_fixture_matches_gray_fixture():
+    """The committed colour crop of kitti_mini pair 0 and the committed gray pair are the same pixels: gray_cv4(colour) == gray."""
+    for side in ("left", "right"):
+        rgb = util.load_png("kitti0_crop_color_%s.png" % side)
+        assert rgb.shape == (128, 320, 3)
+        assert (rgb[..., 0] != rgb[..., 2]).mean() > 0.9  # R != B almost everywhere: a swapped channel order cannot pass
+        assert np.array_equal(_gray_cv4(rgb), util.load_png("kitti0_%s.png" % side)[150:278, 400:720])
+
+
+@pytest.mark.gpu
+def test_generate_point_cloud_colour_input(oracle):
+    """Distinct B, G, R through k_bgra_to_gray (stereo_vision.cpp:338-339): the u8 disparity image equals the oracle's result on
+    gray_cv4 of the same colour images (disp_max 255 as the driver runs it) - a B/R swap or wrong weights change the gray
+    image and with it the map.  Also: the first call freezes the size (stereo_vision.cpp:582); another size is refused."""
+    svmod = util.pkg("stereo_vision")
+    rgb_l, rgb_r = util.load_png("kitti0_crop_color_left.png"), util.load_png("kitti0_crop_color_right.png")
+    H, W = rgb_l.shape[:2]
+    gl, gr = _gray_cv4(rgb_l), _gray_cv4(rgb_r)
+    swapped = _gray_cv4(rgb_l[..., ::-1])
+    assert (swapped != gl).mean() > 0.5  # the test has teeth
+    s = svmod.stereo_vision(objectTracking=False, width=W, height=H)
+    try:
+        pts = s.generatePointCloud(rgb_l[..., ::-1], rgb_r[..., ::-1])  # BGR, as cv2.imread hands images to the reference's wrapper
+        assert pts.shape == (W * H, 3)
+        dmap = s.last_disparity_u8()
+        with pytest.raises(ValueError):  # NULL return: the frozen size is W x H, the buffers of another size are not touched
+            s.sv.generatePointCloud(s._bgra[0].ctypes.data, s._bgra[1].ctypes.data, s.CAMERA_CALIBRATION_YAML.encode(), W + 8, H, True, False, False, False, 1, 0,
+                                    b"", b"", b"", False, False)
+    finally:
+        s.close()
+    d1, _, _ = oracle.process(ElasParams.driver(255), gl, gr)
+    want = np.clip(np.rint(d1 * np.float32(4.0)), 0, 255).astype(np.uint8)
+    assert (want > 0).mean() > 0.3
+    assert np.array_equal(dmap, want)
