@@ -1524,7 +1524,9 @@ int sv_debug_counters(sv_handle *h, int mode, uint64_t *out) {
         out[0] = v[CNT_DENSE_CANDIDATES];
         out[1] = v[CNT_DENSE_PIXELS];
         out[2] = v[CNT_SUPPORT_ENERGIES];
-        out[3] = 0;
+        out[3] = v[CNT_DENSE_BAND_FULL];
+        out[4] = v[CNT_DENSE_BAND_PART];
+        out[5] = v[CNT_DENSE_BAND_SLOW];
     }
     return SV_OK;
 }

@@ -207,19 +207,25 @@ __global__ __launch_bounds__(256) void k_descriptor(const uint8_t *__restrict__ 
 #undef LDW
     // the four descriptors go to an LDS tile first so that the global stores below are fully coalesced (consecutive lanes ->
     // consecutive 16-byte descriptors); written straight from here each store instruction would touch 64-byte-strided pieces
-    __shared__ uint4 otile[DESC_TH][DESC_TW];
+    // Layout: four planes, plane j = pixel j of every quad, [ry][qx] inside a plane.  A ds_write_b128 is serviced in groups of 8
+    // contiguous lanes over 32 banks: the 8 quads of a group are 128 contiguous bytes of one plane = conflict-free (a [row][pixel]
+    // tile puts them 64 B apart: 4-way).  The read-out (ds_read_b128: 16-lane groups {0-3,12-15,20-27}, ... over 64 banks) takes
+    // pixel cx from plane cx & 3, quad cx >> 2; planes 4 slots (64 B) out of step make every group hit 16 distinct 16-byte slots.
+    constexpr int OPLANE = DESC_TH * (DESC_TW / 4) + 4;
+    __shared__ uint4 otile[4 * OPLANE];
     const DescWin dw{r0, r4, r1a, r1b, r1c, r2a, r2b, r2c, r3a, r3b, r3c, v1, v3, v2a, v2b, v2c};
     const bool row_ok = y < d.H - 3 && (d.sub ? (y >= 4 && !(y & 1)) : y >= 3);  // descriptor.cpp:48-50: every second line from 4 at half resolution
     const int xq = x0 + 4 * qx;
-    otile[ry][4 * qx + 0] = (row_ok && xq + 0 >= 3 && xq + 0 < d.W - 3) ? desc_assemble<0>(dw) : make_uint4(0, 0, 0, 0);
-    otile[ry][4 * qx + 1] = (row_ok && xq + 1 >= 3 && xq + 1 < d.W - 3) ? desc_assemble<1>(dw) : make_uint4(0, 0, 0, 0);
-    otile[ry][4 * qx + 2] = (row_ok && xq + 2 >= 3 && xq + 2 < d.W - 3) ? desc_assemble<2>(dw) : make_uint4(0, 0, 0, 0);
-    otile[ry][4 * qx + 3] = (row_ok && xq + 3 >= 3 && xq + 3 < d.W - 3) ? desc_assemble<3>(dw) : make_uint4(0, 0, 0, 0);
+    uint4 *oq = otile + ry * (DESC_TW / 4) + qx;
+    oq[0 * OPLANE] = (row_ok && xq + 0 >= 3 && xq + 0 < d.W - 3) ? desc_assemble<0>(dw) : make_uint4(0, 0, 0, 0);
+    oq[1 * OPLANE] = (row_ok && xq + 1 >= 3 && xq + 1 < d.W - 3) ? desc_assemble<1>(dw) : make_uint4(0, 0, 0, 0);
+    oq[2 * OPLANE] = (row_ok && xq + 2 >= 3 && xq + 2 < d.W - 3) ? desc_assemble<2>(dw) : make_uint4(0, 0, 0, 0);
+    oq[3 * OPLANE] = (row_ok && xq + 3 >= 3 && xq + 3 < d.W - 3) ? desc_assemble<3>(dw) : make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int tw = min(DESC_TW, d.W - x0), th = min(DESC_TH, d.H - y0);
     for (int i = tid; i < th * DESC_TW; i += 256) {
         const int r = i / DESC_TW, cx = i - r * DESC_TW;
-        if (cx < tw) *reinterpret_cast<uint4 *>(out + ((size_t)(y0 + r) * d.W + x0 + cx) * 16) = otile[r][cx];
+        if (cx < tw) *reinterpret_cast<uint4 *>(out + ((size_t)(y0 + r) * d.W + x0 + cx) * 16) = otile[(cx & 3) * OPLANE + r * (DESC_TW / 4) + (cx >> 2)];
     }
 }
 
@@ -1085,10 +1091,29 @@ void launch_triangles(const KParams &k, const SlotDev &s, int n, hipStream_t st)
 // passes and also holds every pixel's own descriptor, so each descriptor row segment is fetched ~(TW+disp_max)/TW times
 // instead of ~2.5 times with one pass per launch.
 #define DENSE_TW 512
+#define DENSE_MASK_WORDS 8  // mask words per cell kept in LDS / registers (disp_max <= 255); further words are read from memory
+
+// All 2R+1 band candidates of a pixel (slots pb[0..2R], see dense_pixel): relative keys (energy + prior) << 16 | o'
+template <int R>
+__device__ __forceinline__ int dense_band_full(const KParams &k, int side, const uint4 own, const uint4 *pb, uint32_t vmask) {
+    uint4 c[2 * R + 1];
+#pragma unroll
+    for (int s = 0; s <= 2 * R; s++) c[s] = pb[s];
+    int key[2 * R + 1];
+#pragma unroll
+    for (int s = 0; s <= 2 * R; s++) {
+        const int o = side ? s : 2 * R - s, ao = s < R ? R - s : s - R;
+        key[s] = sad16_key(own, c[s], (int)(vmask & (((uint32_t)k.prior[ao] << 16) | (uint32_t)o)));
+    }
+    int bb = key[0];
+#pragma unroll
+    for (int s = 1; s + 1 <= 2 * R; s += 2) bb = min(bb, min(key[s], key[s + 1]));  // v_min3
+    return bb;
+}
 
 template <bool COUNT>
 __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, int v, const uint4 own, const uint4 *pu, const float4 rec, const uint32_t *mw,
-                                             const uint32_t *cell, int &ncand) {
+                                             const uint32_t *cell, int &ncand, int (&npath)[3]) {
     const Dims &d = k.d;
     if ((int)texture16(own) < k.match_texture) return -10.0f;                   // elas.cpp:732-736 (the map keeps its -10)
     const int d_plane = (int)(rec.x * (float)u + rec.y * (float)v + rec.z);      // :739, ((a*u)+(b*v))+c without contraction
@@ -1112,7 +1137,7 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
     const uint64_t band = band_bits > 0 ? ((1ull << band_bits) - 1ull) << (d_plane_min & 31) : 0ull;
     const uint32_t band_lo = (uint32_t)band, band_hi = (uint32_t)(band >> 32);
 #pragma unroll
-    for (int w = 0; w < 8; w++) {  // grid candidates outside the band (:759-767 / :778-786), ascending d
+    for (int w = 0; w < DENSE_MASK_WORDS; w++) {  // grid candidates outside the band (:759-767 / :778-786), ascending d
         if (w >= d.MW) break;
         uint32_t m = mw[w];
         {  // keep [a_lo, a_hi], drop [d_plane_min, d_plane_max]
@@ -1139,7 +1164,7 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
         }
         best = min(best, best_w + 32 * w);
     }
-    for (int w = 8; w < d.MW; w++) {  // disp_max > 255: remaining words straight from memory
+    for (int w = DENSE_MASK_WORDS; w < d.MW; w++) {  // disp_max > 255: remaining words straight from memory
         const uint32_t m = cell[w];
         for (int b = 0; b < 32; b++) {
             const int dc = 32 * w + b;
@@ -1148,20 +1173,64 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
             best = min(best, sad16_key(own, pu[sgn * dc], dc));
         }
     }
-    // the band [d_plane - r, d_plane + r], ascending, with the plane prior (:768-774 / :787-793).  The offset o is uniform
-    // over the wavefront, so the prior is a scalar operand and the LDS reads do not depend on earlier iterations.
-    for (int o = -k.plane_radius; o <= k.plane_radius; o++) {
-        const int dc = d_plane + o;
-        if (dc < b_lo || dc > b_hi) continue;
-        if (COUNT) ncand++;
-        const int prior = valid ? k.prior[o < 0 ? -o : o] : 0;
-        best = min(best, sad16_key(own, pu[sgn * dc], prior * 65536 + (0x8000 | dc)));
+    // the band [d_plane - r, d_plane + r], ascending, with the plane prior (:768-774 / :787-793)
+    const int r = k.plane_radius;
+    // o' = d - (d_plane - r) in [0, 2r]; the lane's valid candidates are o' in [lo_o, hi_o] (empty when lo_o > hi_o)
+    const int lo_o = b_lo - (d_plane - r), hi_o = b_hi - (d_plane - r);
+    const int lo_u = __builtin_amdgcn_readfirstlane(lo_o), hi_u = __builtin_amdgcn_readfirstlane(hi_o);
+#ifndef DENSE_BAND_FAST
+#define DENSE_BAND_FAST 1
+#endif
+#ifndef DENSE_WAVES_ATTR
+#define DENSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
+    if (DENSE_BAND_FAST && r <= 3 && __builtin_amdgcn_ballot_w64(lo_o != lo_u || hi_o != hi_u) == 0) {
+        // Fast path (almost every wavefront): all lanes clip the band the same way, so the loop bounds are scalar, the seven
+        // candidates are consecutive LDS slots at immediate offsets from one base, and nothing per candidate is left but the
+        // read, one v_and_or for the key's start value and the SAD chain.  Keys are relative here (tie-break = o'); the band
+        // bit and the band's first disparity are added once at the end (no carry: 0x8000 | d < 0x10000).
+        if (lo_u <= hi_u) {
+            if (COUNT) ncand += hi_u - lo_u + 1;
+            // LDS slot s of the band: pb[s], s = o' (right pixel) or 2r - o' (left pixel: its candidates run towards lower columns)
+            const uint4 *pb = side ? pu + (d_plane - r) : pu - (d_plane + r);
+            const uint32_t vmask = valid ? 0xFFFFFFFFu : 0x0000FFFFu;  // the prior counts only for a valid plane (:771)
+            int bb;
+            if (COUNT) npath[(lo_u == 0 && hi_u == 2 * r && (r == 3 || r == 2)) ? 0 : 1]++;
+            if (lo_u == 0 && hi_u == 2 * r && r == 3)       // the whole band (the usual case): straight-line code, reads in flight together
+                bb = dense_band_full<3>(k, side, own, pb, vmask);
+            else if (lo_u == 0 && hi_u == 2 * r && r == 2)
+                bb = dense_band_full<2>(k, side, own, pb, vmask);
+            else {
+                const int p0 = k.prior[0], p1 = k.prior[1], p2 = k.prior[2], p3 = k.prior[3];
+                bb = KEY_NONE;
+#pragma unroll
+                for (int s = 0; s <= 6; s++) {
+                    const int o = side ? s : 2 * r - s;                // all scalar
+                    if (s > 2 * r || o < lo_u || o > hi_u) continue;
+                    const int ao = s < r ? r - s : s - r;              // |o' - r|
+                    const int pa = ao == 0 ? p0 : (ao == 1 ? p1 : (ao == 2 ? p2 : p3));
+                    const uint32_t start = ((uint32_t)pa << 16) | (uint32_t)o;  // scalar: (prior << 16) | o'
+                    bb = min(bb, sad16_key(own, pb[s], (int)(vmask & start)));
+                }
+            }
+            best = min(best, bb + (0x8000 + d_plane - r));
+        }
+    } else {
+        // the offset o is uniform over the wavefront, so the prior is a scalar operand and the LDS reads do not depend on earlier iterations
+        if (COUNT) npath[2]++;
+        for (int o = -r; o <= r; o++) {
+            const int dc = d_plane + o;
+            if (dc < b_lo || dc > b_hi) continue;
+            if (COUNT) ncand++;
+            const int prior = valid ? k.prior[o < 0 ? -o : o] : 0;
+            best = min(best, sad16_key(own, pu[sgn * dc], prior * 65536 + (0x8000 | dc)));
+        }
     }
     return best < (10000 << 16) ? (float)(best & 0x7FFF) : -1.0f;  // :797-800 (min_val starts at 10000, :752)
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restrict__ desc, const int32_t *__restrict__ blob, const int32_t *__restrict__ tri_id,
+__global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const uint8_t *__restrict__ desc, const int32_t *__restrict__ blob, const int32_t *__restrict__ tri_id,
                                                const float4 *__restrict__ trirec, const uint32_t *__restrict__ gB, int16_t *__restrict__ wta,
                                                unsigned long long *__restrict__ counters) {
     const Dims &d = k.d;
@@ -1189,7 +1258,8 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
             tt[side][j] = u < x1 ? tri_id[(size_t)(pair * 2 + side) * d.N + (size_t)v * d.W + u] : -1;
         }
     __syncthreads();
-    // grid cell of each of the thread's columns (elas.cpp:745-746), once for both sides; word offsets fit 32 bits
+    // grid cell of each of the thread's columns (elas.cpp:745-746), once for both sides; word offsets fit 32 bits.  (Staging the
+    // tile's cell masks in LDS instead of one global gather per pixel was measured: 10.4 against 9.2 us per pair.)
     const uint32_t gy = (uint32_t)(int)floorf((float)v / (float)d.grid_size);
     uint32_t cell_off[DENSE_TW / 256];
 #pragma unroll
@@ -1197,7 +1267,7 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
         const int u = min(x0 + j * 256 + (int)threadIdx.x, d.W - 1);
         cell_off[j] = gy * (uint32_t)(d.gw * d.MW) + __umul24((uint32_t)(int)floorf((float)u / (float)d.grid_size), (uint32_t)d.MW);
     }
-    int ncand = 0, npix = 0;
+    int ncand = 0, npix = 0, npath[3] = {0, 0, 0};
 #pragma unroll
     for (int side = 0; side < 2; side++) {
         const int ps = pair * 2 + side;
@@ -1210,7 +1280,7 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
             if (t >= 0 && u >= 2 && u < d.W - 2 && !(d.sub && (u & 1))) {
                 const float4 rec = trirec[(size_t)ps * d.max_tri + t];
                 const uint32_t *cell = gB + (size_t)ps * d.ncell * d.MW + cell_off[j];
-                uint32_t mw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                uint32_t mw[DENSE_MASK_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
                 if ((d.MW & 3) == 0) {  // 16-byte aligned cells: one or two wide loads
                     const uint4 m0 = *reinterpret_cast<const uint4 *>(cell);
                     mw[0] = m0.x, mw[1] = m0.y, mw[2] = m0.z, mw[3] = m0.w;
@@ -1220,11 +1290,11 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
                     }
                 } else {
 #pragma unroll
-                    for (int w = 0; w < 8; w++) mw[w] = w < d.MW ? cell[w] : 0u;
+                    for (int w = 0; w < DENSE_MASK_WORDS; w++) mw[w] = w < d.MW ? cell[w] : 0u;
                 }
                 const uint4 own = side ? sR[u - r0] : sL[u - l0];
                 const uint4 *pu = side ? sL + (u - l0) : sR + (u - r0);  // the other image at the pixel's own column
-                out = dense_pixel<COUNT>(k, side, u, v, own, pu, rec, mw, cell, ncand);
+                out = dense_pixel<COUNT>(k, side, u, v, own, pu, rec, mw, cell, ncand, npath);
                 if (COUNT) npix++;
             }
             // integer-valued: a disparity, -1 or -10.  Half resolution (elas.cpp:707-711): only even (u, v) are matched, result at (u/2, v/2)
@@ -1237,11 +1307,16 @@ __global__ __launch_bounds__(256) void k_dense(KParams k, const uint8_t *__restr
     if (COUNT) {
         count_add(counters + CNT_DENSE_CANDIDATES, ncand);
         count_add(counters + CNT_DENSE_PIXELS, npix);
+        count_add(counters + CNT_DENSE_BAND_FULL, npath[0]);
+        count_add(counters + CNT_DENSE_BAND_PART, npath[1]);
+        count_add(counters + CNT_DENSE_BAND_SLOW, npath[2]);
     }
 }
 
+static size_t dense_lds_bytes(const KParams &k) { return sizeof(uint4) * 2 * (size_t)(DENSE_TW + k.d.disp_max); }
+
 void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
-    const size_t shmem = sizeof(uint4) * 2 * (size_t)(DENSE_TW + k.d.disp_max);
+    const size_t shmem = dense_lds_bytes(k);
     const dim3 grid((k.d.W + DENSE_TW - 1) / DENSE_TW, k.d.sub ? (k.d.H + 1) / 2 : k.d.H, n);
     static std::atomic<size_t> granted[64], granted_c[64];
     if (s.counters) {
@@ -1374,10 +1449,19 @@ __device__ __forceinline__ int ccl_find(const int32_t *L, int x) {
     return x;
 }
 
-// the same walk on a forest that no longer changes (plain, cacheable loads)
+// In the union-find over the run records of a whole map (gparent) the index CCL_LARGE = -1 is a super-root: "belongs to a
+// component that is already known to have >= speckle_size pixels".  k_ccl_band points every run of a band-local component
+// of that size at it, and since unions hang the larger root under the smaller, anything joined with such a run ends up there
+// too.  Only "is the component small?" is ever asked (elas.cpp:1109), so the large components need no identity - and the one
+// component that spans a real map (hundreds of band pieces, each large by itself) costs one load per border link instead of
+// a walk along a chain of band roots plus contended atomics.
+constexpr int CCL_LARGE = -1;
+
+// the same walk on a forest that no longer changes (plain, cacheable loads); CCL_LARGE for members of large components
 __device__ __forceinline__ int ccl_find_frozen(const int32_t *L, int x) {
     int p = L[x];
     while (p != x) {
+        if (p < 0) return CCL_LARGE;
         x = p;
         p = L[x];
     }
@@ -1404,10 +1488,12 @@ __device__ __forceinline__ void ccl_union(int32_t *L, int a, int b) {
 // roots, and every hop is a dependent L2 access, so the walk halves the path as it goes.  atomicMin keeps the invariant
 // "parent <= node and parent is an ancestor": a grandparent is an ancestor for good, concurrent unions only add ancestors.
 __device__ __forceinline__ int ccl_find_halving(int32_t *L, int x) {
+    if (x < 0) return CCL_LARGE;
     int p = __hip_atomic_load(&L[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (p != x) {
+        if (p < 0) return CCL_LARGE;
         const int g = __hip_atomic_load(&L[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (g != p) atomicMin(&L[x], g);
+        if (g != p) atomicMin(&L[x], g);  // g may be CCL_LARGE: x then belongs to the large ones directly
         x = p;
         p = g;
     }
@@ -1418,13 +1504,13 @@ __device__ __forceinline__ void ccl_union_halving(int32_t *L, int a, int b) {
     for (;;) {
         a = ccl_find_halving(L, a);
         b = ccl_find_halving(L, b);
-        if (a == b) return;
+        if (a == b) return;  // the same component, or both large already
         if (a < b) {
             int x = a;
             a = b;
             b = x;
         }
-        const int old = atomicMin(&L[a], b);  // a > b: hang the larger root under the smaller
+        const int old = atomicMin(&L[a], b);  // a > b >= CCL_LARGE: hang the larger root under the smaller (or under "large")
         if (old == a) return;
         a = old;
     }
@@ -1561,8 +1647,10 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
     for (int i = tid; i < T; i += CCL_THREADS)
         if (parent[i] != i) atomicAdd(&len[parent[i]], len[i]);
     __syncthreads();
-    for (int i = tid; i < T; i += CCL_THREADS)
+    for (int i = tid; i < T; i += CCL_THREADS) {
         if (parent[i] == i) R[i].w = len[i];
+        if (len[parent[i]] >= k.speckle_size) GP[i] = CCL_LARGE;  // a band-local component of that size: large whatever it joins
+    }
     if (tid == 0) {
         *tc = T;
         ws.boff[(size_t)m * ws.nb + band] = off;
@@ -1695,14 +1783,17 @@ __global__ __launch_bounds__(256) void k_ccl_total(int nproc, int speckle_size, 
     const int4 *RUNS = ws.runs + (size_t)m * ws.rcap;
     for (int i = part * 256 + threadIdx.x; i < T; i += 256 * CCL_SPLIT) {
         const int4 r = RUNS[off + i];
-        if (r.z != off + i) continue;
+        if (r.z != off + i || r.w >= speckle_size) continue;  // band-local roots of small components only (the others are CCL_LARGE)
         const int root = ccl_find_frozen(GP, off + i);
+        if (root < 0) {  // joined a large component across some border
+            GP[off + i] = CCL_LARGE;
+            continue;
+        }
         // Only "total >= speckle_size" is ever asked (k_ccl_apply) and totals only grow: once a root has reached the threshold
-        // further adds are skipped.  The largest component of a real map has hundreds of band roots, whose atomics would
-        // otherwise queue up on one address (73 -> 37 us per 32-pair launch of kitti_mini pairs).
+        // further adds are skipped
         if (__hip_atomic_load(&TOT[root], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < speckle_size) atomicAdd(&TOT[root], r.w);
-        // a component that spans many bands is a chain of band roots: point this one at the global root so that k_ccl_apply
-        // gets there in one hop (no union runs any more; a concurrent walk sees the old parent or the root, both ancestors)
+        // a component made of many small band pieces is a chain of band roots: point this one at the global root so that
+        // k_ccl_apply gets there in one hop (no union runs any more; a concurrent walk sees the old parent or the root, both ancestors)
         GP[off + i] = root;
     }
 }
@@ -1719,7 +1810,8 @@ __global__ __launch_bounds__(256) void k_ccl_apply(KParams k, int nproc, const i
     for (int i = part * 256 + threadIdx.x; i < T; i += 256 * CCL_SPLIT) {
         const int4 r = RUNS[off + i];
         if (r.y >= k.speckle_size) continue;  // a run that long is a large component by itself
-        if (TOT[ccl_find_frozen(GP, r.z)] >= k.speckle_size) continue;
+        const int root = ccl_find_frozen(GP, off + i);  // (its own entry: CCL_LARGE at once for runs of large band components)
+        if (root < 0 || TOT[root] >= k.speckle_size) continue;
         for (int q = 0; q < r.y; q++) D[r.x + q] = -10.0f;
     }
 }

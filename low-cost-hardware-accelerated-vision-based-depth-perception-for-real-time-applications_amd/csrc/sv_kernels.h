@@ -70,7 +70,7 @@ struct SlotDev {
     unsigned long long *counters;  // work counters of the matching kernels (CounterId), nullptr = not counting (the normal case)
 };
 
-enum CounterId { CNT_DENSE_CANDIDATES = 0, CNT_DENSE_PIXELS, CNT_SUPPORT_ENERGIES, CNT_COUNT = 8 };
+enum CounterId { CNT_DENSE_CANDIDATES = 0, CNT_DENSE_PIXELS, CNT_SUPPORT_ENERGIES, CNT_DENSE_BAND_FULL, CNT_DENSE_BAND_PART, CNT_DENSE_BAND_SLOW, CNT_COUNT = 8 };
 
 // ---- launch wrappers (kernels.hip).  `n` = pairs in this launch; `nproc` = maps per pair to post-process (1 or 2).
 void launch_descriptor(const KParams &k, const uint8_t *left, const uint8_t *right, size_t in_pair_stride, int stride, const SlotDev &s, int n, hipStream_t st);

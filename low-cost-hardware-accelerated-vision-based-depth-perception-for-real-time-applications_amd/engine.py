@@ -289,9 +289,10 @@ class StereoEngine:
         counters() returns {dense_candidates, dense_pixels, support_energies} since the last reset."""
         L = lib()
         L.sv_debug_counters.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64)]
-        out = (ctypes.c_uint64 * 4)()
+        out = (ctypes.c_uint64 * 8)()
         self._check(L.sv_debug_counters(self._h, -1 if enable is None else int(bool(enable)), out))
-        return {"dense_candidates": int(out[0]), "dense_pixels": int(out[1]), "support_energies": int(out[2])}
+        return {"dense_candidates": int(out[0]), "dense_pixels": int(out[1]), "support_energies": int(out[2]),
+                "dense_band_full": int(out[3]), "dense_band_partial": int(out[4]), "dense_band_per_lane": int(out[5])}
 
     def kernel_times(self):
         """{kernel: (total_ms, calls)} accumulated since timing(True)."""
