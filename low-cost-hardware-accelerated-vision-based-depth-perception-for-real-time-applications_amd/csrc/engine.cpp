@@ -63,7 +63,8 @@ struct HostScratch {  // per pool thread
     std::vector<int16_t> lattice;
 };
 
-constexpr int FSUP_COPY_PTS = 4096;  // support points per pair fetched with the bulk D2H (more are fetched on demand)
+// support points per pair fetched with the bulk D2H (more are fetched on demand): a sixth of the lattice, at least 4096
+static int fsup_copy_pts(const Dims &d) { return std::min(d.max_pts, std::max(4096, d.Wc * d.Hc / 6)); }
 
 struct Job {
     const uint8_t *left = nullptr, *right = nullptr;
@@ -85,7 +86,7 @@ struct Slot {
     int id = 0;
     SlotDev dev{};
     int16_t *h_dcan = nullptr;  // pinned [cap][Hc*Wc]
-    int32_t *h_fsup = nullptr;  // pinned [cap][FSUP_COPY_PTS][3]: head of the GPU-filtered support lists
+    int32_t *h_fsup = nullptr;  // pinned [cap][fsup_copy_pts][3]: head of the GPU-filtered support lists
     int32_t *h_fnsup = nullptr; // pinned [cap]
     int32_t *h_blob = nullptr;  // pinned
     size_t blob_words = 0;
@@ -100,7 +101,7 @@ struct Slot {
     const uint8_t *in_left = nullptr, *in_right = nullptr;
     size_t in_pair = 0;
     int in_stride = 0;
-    bool out_enqueued = false;  // host-memory jobs: phase 2 and the map downloads were enqueued (ev_out is pending)
+    bool out_enqueued = false;  // host-memory jobs: phase 2 was enqueued (ev_lr / ev_p2 are pending), the maps can be downloaded
     int state = SLOT_FREE;
     // chunk in flight
     Job *job = nullptr;
@@ -150,7 +151,7 @@ struct sv_handle {
     bool quit = false;
     std::deque<Slot *> q1;  // phase 1 issued, waiting for the dispatcher
     std::deque<Slot *> q2;  // host stage complete, waiting for phase 2
-    std::deque<Slot *> q3;  // host-memory jobs: phase 2 and the map downloads enqueued, waiting for the drainer
+    std::deque<Slot *> q3;  // host-memory jobs: phase 2 enqueued, waiting for the drainer (downloads the maps)
     std::string error;
     std::atomic<bool> failed{false};
     // host pool
@@ -278,12 +279,11 @@ void fill_kparams(sv_handle *h) {
         km.gap_width = p.ipol_gap_width / 2 + 1;
     }
     h->nproc = p.postprocess_only_left ? 1 : 2;
-    // the on-GPU lattice filter keeps the whole lattice (+ state) of a pair in the LDS of one workgroup and resolves a
-    // point's earlier neighbours with one 64-lane ballot: needs incon_window_size <= 5 and a lattice that fits
+    // the on-GPU lattice filter unrolls the 11 x 11 window and resolves a point's earlier neighbours with one 64-lane ballot:
+    // needs incon_window_size <= 5 (any lattice size: its state lives in global memory)
     const char *force_host = getenv("SV_HOST_FILTER");
     h->gpu_filter = !(force_host && atoi(force_host) != 0) && p.incon_window_size >= 0 && p.incon_window_size <= 5 &&
-                    p.incon_min_support >= 0 && p.incon_min_support <= 60 && p.incon_threshold >= 0 &&  // c_late lives in 6 bits
-                    (size_t)d.Wc * d.Hc < 65536 && support_filter_lds_bytes(k) <= 140 * 1024;
+                    p.incon_min_support >= 0 && p.incon_min_support <= 60 && p.incon_threshold >= 0;  // c_late lives in 6 bits
     // (sv_create additionally keeps the filters on the host for chunk < 4: the GPU version is a ~0.4 ms latency chain,
     //  worth it only when many pairs share it)
 }
@@ -418,8 +418,8 @@ void issue_phase1(sv_handle *h, Slot *s) {
         tail = h->sPF;
         launch_support_filter(k, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s->dev, s->n, tail);
         HIP_TRY(hipMemcpyAsync(s->h_fnsup, s->dev.fnsup, sizeof(int32_t) * (size_t)s->n, hipMemcpyDeviceToHost, tail));
-        const size_t w = sizeof(int32_t) * 3 * (size_t)std::min(FSUP_COPY_PTS, d.max_pts);
-        HIP_TRY(hipMemcpy2DAsync(s->h_fsup, sizeof(int32_t) * 3 * FSUP_COPY_PTS, s->dev.fsup, sizeof(int32_t) * 3 * (size_t)d.max_pts, w, (size_t)s->n,
+        const size_t w = sizeof(int32_t) * 3 * (size_t)fsup_copy_pts(d);
+        HIP_TRY(hipMemcpy2DAsync(s->h_fsup, w, s->dev.fsup, sizeof(int32_t) * 3 * (size_t)d.max_pts, w, (size_t)s->n,
                                  hipMemcpyDeviceToHost, tail));
     }
     if (!h->gpu_filter || h->cfg.keep_debug)
@@ -765,8 +765,8 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
             note_error(h, "corrupt support count from the GPU filter");
             ns = 0;
         }
-        if (ns <= FSUP_COPY_PTS) {
-            memcpy(sc->sup.data(), s->h_fsup + (size_t)t.pair * FSUP_COPY_PTS * 3, sizeof(int32_t) * 3 * (size_t)ns);
+        if (ns <= fsup_copy_pts(d)) {
+            memcpy(sc->sup.data(), s->h_fsup + (size_t)t.pair * fsup_copy_pts(d) * 3, sizeof(int32_t) * 3 * (size_t)ns);
         } else if (hipMemcpy(sc->sup.data(), s->dev.fsup + (size_t)t.pair * d.max_pts * 3, sizeof(int32_t) * 3 * (size_t)ns, hipMemcpyDeviceToHost) != hipSuccess) {
             note_error(h, "hipMemcpy of a long support list failed");
             ns = 0;
@@ -899,11 +899,7 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
     const bool only_left = h->nproc == 1;
     // with postprocess_only_left the checked right map is final: it goes straight to the caller (or nowhere)
     launch_lr(km, s->dev, n, st, only_left ? u2 : nullptr, !only_left || dbg);
-    if (job.host && only_left && u2) {  // ... and its download overlaps the rest of phase 2
-        HIP_TRY(hipEventRecord(s->ev_lr, st));
-        HIP_TRY(hipStreamWaitEvent(h->sOut, s->ev_lr, 0));
-        download_maps(h, s, 1, h->sOut);
-    }
+    if (job.host && only_left && u2) HIP_TRY(hipEventRecord(s->ev_lr, st));  // ... and its download may overlap the rest of phase 2
     const bool active = dbg && blob[(size_t)(n - 1) * META_WORDS] >= 3;
     if (active) {
         const int j = n - 1;
@@ -937,13 +933,24 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
     if (active) dbg_maps_nproc(h, st, "final", cur, s->dev.disp, n - 1);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev_free, st));
-    if (job.host) {
-        HIP_TRY(hipEventRecord(s->ev_p2, st));
-        HIP_TRY(hipStreamWaitEvent(h->sOut, s->ev_p2, 0));
-        download_maps(h, s, 0, h->sOut);
-        if (!only_left) download_maps(h, s, 1, h->sOut);
-        HIP_TRY(hipEventRecord(s->ev_out, h->sOut));
+    if (job.host) HIP_TRY(hipEventRecord(s->ev_p2, st));
+}
+
+// Host-memory jobs: the maps of a chunk from the device staging to the caller (or the page-locked mirror), after issue_phase2.
+// Issued by the drainer thread (the calling thread in latency mode), NOT by the finisher: hipMemcpyAsync may hold its caller
+// until the copy has been handed to a DMA engine, and the finisher has the next chunk's kernels to enqueue meanwhile.
+void download_chunk(sv_handle *h, Slot *s) {
+    const Job &job = *s->job;
+    const bool only_left = h->nproc == 1;
+    if (only_left && job.d2) {  // final since the L/R check: usually long done when the drainer gets here
+        HIP_TRY(hipStreamWaitEvent(h->sOut, s->ev_lr, 0));
+        download_maps(h, s, 1, h->sOut);
     }
+    HIP_TRY(hipStreamWaitEvent(h->sOut, s->ev_p2, 0));
+    download_maps(h, s, 0, h->sOut);
+    if (!only_left) download_maps(h, s, 1, h->sOut);
+    HIP_TRY(hipEventRecord(s->ev_out, h->sOut));
+    HIP_TRY(hipEventSynchronize(s->ev_out));
 }
 
 void finisher_main(sv_handle *h) {
@@ -997,11 +1004,13 @@ void drainer_main(sv_handle *h) {
             s = h->q3.front();
             h->q3.pop_front();
         }
-        if (s->out_enqueued) {
-            if (hipEventSynchronize(s->ev_out) != hipSuccess)
-                note_error(h, "hipEventSynchronize(map download) failed");
-            else if (!h->failed)
+        if (s->out_enqueued && !h->failed) {
+            try {
+                download_chunk(h, s);
                 deliver_maps(h, s, 3);
+            } catch (const std::exception &e) {
+                note_error(h, e.what());
+            }
         }
         {
             std::lock_guard<std::mutex> lk(h->mu);
@@ -1062,7 +1071,12 @@ void alloc_slot(sv_handle *h, Slot *sl) {
     dev_alloc(s.blob, sl->blob_words);
     dev_alloc(s.fsup, cap * (size_t)d.max_pts * 3);
     dev_alloc(s.fnsup, cap);
-    HIP_TRY(hipHostMalloc((void **)&sl->h_fsup, sizeof(int32_t) * cap * FSUP_COPY_PTS * 3, hipHostMallocDefault));
+    {
+        uint8_t *w = nullptr;
+        dev_alloc(w, support_filter_ws_bytes(h->kp, (int)cap));
+        s.flt_ws = w;
+    }
+    HIP_TRY(hipHostMalloc((void **)&sl->h_fsup, sizeof(int32_t) * cap * fsup_copy_pts(d) * 3, hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&sl->h_fnsup, sizeof(int32_t) * cap, hipHostMallocDefault));
     dev_alloc(s.trirec, cap * 2 * d.max_tri);
     {
@@ -1101,7 +1115,7 @@ void alloc_slot(sv_handle *h, Slot *sl) {
 
 void free_slot(Slot *sl) {
     SlotDev &s = sl->dev;
-    void *dptrs[] = {s.desc, s.dcan, s.fsup, s.fnsup, s.blob, s.rrec, s.tile_cnt, s.tile_list, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize, s.ccl_ws};
+    void *dptrs[] = {s.desc, s.dcan, s.fsup, s.fnsup, s.flt_ws, s.blob, s.rrec, s.tile_cnt, s.tile_list, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize, s.ccl_ws};
     for (void *p : dptrs)
         if (p) (void)hipFree(p);
     if (sl->h_dcan) (void)hipHostFree(sl->h_dcan);
@@ -1253,8 +1267,8 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
         while (!s->inline_done.load(std::memory_order_acquire)) __builtin_ia32_pause();
         g_launch_hook.ctx = &h->tc_finish;
         issue_phase2(h, s, h->sP2[0]);
-        if (host) {  // the downloads were enqueued by issue_phase2 (right map right after the L/R check)
-            HIP_TRY(hipEventSynchronize(s->ev_out));
+        if (host) {
+            download_chunk(h, s);
             deliver_maps(h, s, 3);
         } else {
             HIP_TRY(hipStreamSynchronize(h->sP2[0]));

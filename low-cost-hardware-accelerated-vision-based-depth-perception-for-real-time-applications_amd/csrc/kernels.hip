@@ -429,7 +429,7 @@ void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// K2b support lattice -> support point list, on the GPU (one workgroup per pair, lattice in LDS)
+// K2b support lattice -> support point list, on the GPU, for lattices of any size
 //     reference: elas.cpp:152-176 (removeInconsistentSupportPoints), :178-233 (removeRedundantSupportPoints x2, :419-420),
 //                :422-433 (collect, u outer / v inner), :235-264 (addCornerSupportPoints)
 //     The reference's filters are sequential in-place scans.  The inconsistency pass is made parallel by classification:
@@ -437,9 +437,15 @@ void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
 //        c_late  = consistent neighbours later-or-equal in scan order (exact at visit time)
 //        c_all   = consistent neighbours in the original lattice (upper bound at visit time)
 //     c_late >= min_support -> certainly kept; c_all < min_support -> certainly dropped; only the rest ("uncertain") depend
-//     on the fate of earlier points and are resolved one after the other, in scan order, by one wavefront that counts the
-//     <= 60 earlier neighbours with a ballot.  The redundancy passes only couple points of one column / one row, so they
-//     run one lane per column / row.  Lattice layout: transposed, T[u*Hc + v] (scan order == index order).
+//     on the fate of earlier points: a few parallel refinement rounds settle most of them, what remains is resolved one after
+//     the other, in scan order, by one wavefront that counts the <= 60 earlier neighbours with a ballot.  The redundancy
+//     passes only couple points of one column / one row: one lane walks one line.
+//     Four launches, all state in global memory (L2-resident: 11 bytes per lattice point), no size limit:
+//       k_filter_classify   grid-wide, one thread per lattice point (the 121-neighbour counts: 60 % of the old one-workgroup kernel)
+//       k_filter_resolve    one workgroup per pair: refinement rounds + sequential rest; writes the lattice without the dropped points
+//       k_filter_vertical   grid-wide, one lane per lattice column
+//       k_filter_collect    one workgroup per pair: horizontal pass (one lane per lattice row), ordered compaction, corner points
+//     Lattice layout: transposed, T[u*Hc + v] (scan order == index order).
 // ------------------------------------------------------------------------------------------------------------
 #define FST_NONE 0
 #define FST_KEEP 1
@@ -467,7 +473,7 @@ __device__ __forceinline__ int block_exclusive_scan(int val, int *s_scan, int *t
 
 // order-preserving compaction of the lattice indices that satisfy `pred` (each thread owns a contiguous index range)
 template <class Pred>
-__device__ __forceinline__ int compact_indices(int lat, uint16_t *list, int *s_scan, Pred pred) {
+__device__ __forceinline__ int compact_indices(int lat, uint32_t *list, int *s_scan, Pred pred) {
     const int tid = threadIdx.x;
     const int per = (lat + FLT_THREADS - 1) / FLT_THREADS;
     const int i_lo = min(tid * per, lat), i_hi = min(i_lo + per, lat);
@@ -476,7 +482,8 @@ __device__ __forceinline__ int compact_indices(int lat, uint16_t *list, int *s_s
     int total;
     int pos = block_exclusive_scan(mine, s_scan, &total);
     for (int i = i_lo; i < i_hi; i++)
-        if (pred(i)) list[pos++] = (uint16_t)i;
+        if (pred(i)) list[pos++] = (uint32_t)i;
+    __threadfence_block();
     __syncthreads();
     return total;
 }
@@ -494,29 +501,27 @@ __device__ __forceinline__ bool redundant_here(const int w[11]) {
     return (lo & hi) != 0;
 }
 
-__global__ __launch_bounds__(FLT_THREADS) void k_support_filter(KParams k, int win, int thr, int need, const int16_t *__restrict__ dcan, int32_t *__restrict__ fsup,
-                                                                int32_t *__restrict__ fnsup) {
-    const Dims &d = k.d;
-    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int Wc = d.Wc, Hc = d.Hc, lat = Wc * Hc;
-    extern __shared__ unsigned char flt_lds[];
-    int16_t *T = reinterpret_cast<int16_t *>(flt_lds);
-    uint16_t *list = reinterpret_cast<uint16_t *>(T + lat + (lat & 1));
-    uint8_t *st = reinterpret_cast<uint8_t *>(list + lat + (lat & 1));
-    __shared__ int s_scan[FLT_THREADS];
+// ---- (1) classification (elas.cpp:152-176), one thread per lattice point.  A block of 256 consecutive indices needs the
+// contiguous index span [first - 5*Hc - 5, last + 5*Hc + 5] of the transposed lattice: staged in LDS once, then the 11x11 window
+// (win <= 5, fully unrolled: independent reads, all in flight together) comes from there.
+#define FCL_THREADS 256
+__global__ __launch_bounds__(FCL_THREADS) void k_filter_classify(Dims d, int win, int thr, int need, const int16_t *__restrict__ dcan, uint8_t *__restrict__ fst) {
+    extern __shared__ int16_t fcl_lds[];
+    const int pair = blockIdx.y, Hc = d.Hc, Wc = d.Wc, lat = Wc * Hc;
     const int16_t *G = dcan + (size_t)pair * lat;
-    for (int i = tid; i < lat; i += FLT_THREADS) {
-        T[i] = G[i];
-        st[i] = FST_NONE;
+    const int first = blockIdx.x * FCL_THREADS, margin = 5 * Hc + 5;
+    const int s0 = first - margin, span = FCL_THREADS + 2 * margin;
+    for (int i = threadIdx.x; i < span; i += FCL_THREADS) {
+        const int g = s0 + i;
+        fcl_lds[i] = (g >= 0 && g < lat) ? G[g] : (int16_t)-1;
     }
     __syncthreads();
-
-    // ---- inconsistency pass, classification (elas.cpp:152-176) over the compacted valid points; the 11x11 window
-    // (win <= 5) is fully unrolled, so the LDS reads of one point are independent and all in flight together
-    const int n_valid = compact_indices(lat, list, s_scan, [&](int i) { return T[i] >= 0; });
-    for (int q = tid; q < n_valid; q += FLT_THREADS) {
-        const int idx = list[q];
-        const int dd = T[idx];
+    const int idx = first + threadIdx.x;
+    if (idx >= lat) return;
+    const int16_t *T = fcl_lds - s0;  // T[g] for g inside the span
+    const int dd = T[idx];
+    uint8_t state = FST_NONE;
+    if (dd >= 0) {
         const int u = idx / Hc, v = idx - u * Hc;
         int c_late = 0, c_early = 0;
 #pragma unroll
@@ -536,18 +541,32 @@ __global__ __launch_bounds__(FLT_THREADS) void k_support_filter(KParams k, int w
                     c_early += hit;
             }
         }
-        st[idx] = (uint8_t)(c_late >= need ? FST_KEEP : (c_late + c_early < need) ? FST_DROP : (FST_UNC | (c_late << 2)));
+        state = (uint8_t)(c_late >= need ? FST_KEEP : (c_late + c_early < need) ? FST_DROP : (FST_UNC | (c_late << 2)));
     }
-    __syncthreads();
-    // refinement rounds over the compacted uncertain points, still fully parallel: earlier neighbours that are certainly
-    // kept count for sure, earlier neighbours that are certainly dropped never count.  (A round only reads states of
-    // EARLIER points and only turns UNC into KEEP/DROP; both decisions stay valid whatever the remaining UNC points
-    // become, so concurrent updates are benign.)
+    fst[(size_t)pair * lat + idx] = state;
+}
+
+// ---- (2) the uncertain points: parallel refinement rounds, then the rest in scan order by one wavefront; output = the lattice
+// with the inconsistent points removed.  One workgroup per pair; T / st / list live in global memory (L2).
+__global__ __launch_bounds__(FLT_THREADS) void k_filter_resolve(Dims d, int win, int thr, int need, const int16_t *__restrict__ dcan, uint8_t *fst, uint32_t *flist,
+                                                                int16_t *__restrict__ latA) {
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int Wc = d.Wc, Hc = d.Hc, lat = Wc * Hc;
+    const int16_t *T = dcan + (size_t)pair * lat;
+    uint8_t *st = fst + (size_t)pair * lat;
+    uint32_t *list = flist + (size_t)pair * lat;
+    int16_t *A = latA + (size_t)pair * lat;
+    __shared__ int s_scan[FLT_THREADS];
+    (void)Wc;
+    // refinement rounds over the compacted uncertain points, fully parallel: earlier neighbours that are certainly kept count
+    // for sure, earlier neighbours that are certainly dropped never count.  (A round only reads states of EARLIER points and
+    // only turns UNC into KEEP/DROP; both decisions stay valid whatever the remaining UNC points become, so concurrent
+    // updates are benign.)
     int n_unc = compact_indices(lat, list, s_scan, [&](int i) { return (st[i] & 3) == FST_UNC; });
     for (int round = 0; round < 3 && n_unc > 0; round++) {
         for (int q = tid; q < n_unc; q += FLT_THREADS) {
-            const int idx = list[q];
-            const int s0 = st[idx];
+            const int idx = (int)list[q];
+            const int s0 = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((s0 & 3) != FST_UNC) continue;
             const int dd = T[idx], c_late = s0 >> 2;
             const int u = idx / Hc, v = idx - u * Hc;
@@ -562,17 +581,18 @@ __global__ __launch_bounds__(FLT_THREADS) void k_support_filter(KParams k, int w
                     const int v2 = v + dv;
                     const bool ok = col_ok && dv >= -win && dv <= win && v2 >= 0 && v2 < Hc;
                     const int j = (ok ? u2 : u) * Hc + (ok ? v2 : v);
-                    const int d2 = T[j], s2 = st[j] & 3;
+                    const int d2 = T[j], s2 = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 3;
                     const int cons = ok & (d2 >= 0) & (abs(dd - d2) <= thr);
                     sure += cons & (s2 == FST_KEEP);
                     maybe += cons & (s2 == FST_UNC);
                 }
             }
             if (c_late + sure >= need)
-                st[idx] = FST_KEEP;
+                __hip_atomic_store(&st[idx], (uint8_t)FST_KEEP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else if (c_late + sure + maybe < need)
-                st[idx] = FST_DROP;
+                __hip_atomic_store(&st[idx], (uint8_t)FST_DROP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        __threadfence_block();
         __syncthreads();
     }
     // what is still uncertain is resolved in scan order by one wavefront: lanes = the earlier neighbours
@@ -581,69 +601,87 @@ __global__ __launch_bounds__(FLT_THREADS) void k_support_filter(KParams k, int w
     if (tid < 64) {
         const int rowlen = 2 * win + 1, n_early = win * rowlen + win;
         for (int i = 0; i < n_unc; i++) {
-            const int idx = list[i];
+            const int idx = (int)list[i];
             const int u = idx / Hc, v = idx - u * Hc;
-            const int dd = T[idx], c_late = st[idx] >> 2;
+            const int dd = T[idx], c_late = st[idx] >> 2;  // (its own entry is only written below)
             bool ok = false;
             if (lane < n_early) {
                 const int u2 = lane < win * rowlen ? u - win + lane / rowlen : u;
                 const int v2 = lane < win * rowlen ? v - win + lane % rowlen : v - win + (lane - win * rowlen);
                 if (u2 >= 0 && v2 >= 0 && v2 < Hc) {
                     const int d2 = T[u2 * Hc + v2];
-                    ok = d2 >= 0 && abs(dd - d2) <= thr && (st[u2 * Hc + v2] & 3) == FST_KEEP;
+                    ok = d2 >= 0 && abs(dd - d2) <= thr && (__hip_atomic_load(&st[u2 * Hc + v2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 3) == FST_KEEP;
                 }
             }
             const int c = (int)__popcll(__ballot(ok));
-            if (lane == 0) st[idx] = (uint8_t)((c_late + c >= need) ? FST_KEEP : FST_DROP);
+            if (lane == 0) __hip_atomic_store(&st[idx], (uint8_t)((c_late + c >= need) ? FST_KEEP : FST_DROP), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
     }
+    __threadfence_block();
     __syncthreads();
-    for (int i = tid; i < lat; i += FLT_THREADS)
-        if ((st[i] & 3) == FST_DROP) T[i] = -1;
-    __syncthreads();
+    for (int i = tid; i < lat; i += FLT_THREADS) A[i] = (st[i] & 3) == FST_DROP ? (int16_t)-1 : T[i];
+}
 
-    // ---- redundancy passes (elas.cpp:178-233; max_dist 5, threshold 1).  Only points of one column (vertical pass) or
-    // one row (horizontal pass) interact, so one lane walks one line; it keeps the 11 values around the current position
-    // in registers (positions behind reflect its own earlier invalidations) and reads one new value per step.
-    for (int u = tid; u < Wc; u += FLT_THREADS) {
-        int16_t *col = T + u * Hc;
-        int w[11];
+// ---- (3) redundancy pass along the columns (elas.cpp:178-233 with vertical = true; max_dist 5, threshold 1).  Only points of
+// one line interact, so one lane walks one line; it keeps the 11 values around the current position in registers (positions
+// behind reflect its own earlier invalidations) and reads one new value per step.  Out of place: the loads never depend on the
+// walk, so the compiler can issue them ahead.
+__global__ __launch_bounds__(64) void k_filter_vertical(Dims d, const int16_t *__restrict__ latA, int16_t *__restrict__ latB) {
+    const int pair = blockIdx.y, u = blockIdx.x * 64 + threadIdx.x;
+    const int Wc = d.Wc, Hc = d.Hc;
+    if (u >= Wc) return;
+    const int16_t *col = latA + (size_t)pair * Wc * Hc + (size_t)u * Hc;
+    int16_t *out = latB + (size_t)pair * Wc * Hc + (size_t)u * Hc;
+    int w[11];
 #pragma unroll
-        for (int j = 0; j < 11; j++) w[j] = (j >= 5 && j - 5 < Hc) ? (int)col[j - 5] : -1;
-        for (int v = 0; v < Hc; v++) {
-            if (redundant_here(w)) {
-                col[v] = -1;
-                w[5] = -1;
-            }
+    for (int j = 0; j < 11; j++) w[j] = (j >= 5 && j - 5 < Hc) ? (int)col[j - 5] : -1;
+#pragma unroll 8
+    for (int v = 0; v < Hc; v++) {
+        const int nxt = v + 6 < Hc ? (int)col[v + 6] : -1;
+        if (redundant_here(w)) w[5] = -1;
+        out[v] = (int16_t)w[5];
 #pragma unroll
-            for (int j = 0; j < 10; j++) w[j] = w[j + 1];
-            w[10] = v + 6 < Hc ? (int)col[v + 6] : -1;
-        }
+        for (int j = 0; j < 10; j++) w[j] = w[j + 1];
+        w[10] = nxt;
     }
-    __syncthreads();
-    for (int v = tid; v < Hc; v += FLT_THREADS) {
+}
+
+// ---- (4) redundancy pass along the rows, collection in scan order (elas.cpp:424-428; lattice row / column 0 excluded), corner
+// points (elas.cpp:235-264).  One workgroup per pair.
+__global__ __launch_bounds__(FLT_THREADS) void k_filter_collect(KParams k, const int16_t *__restrict__ latB, int16_t *latC, uint32_t *flist, int32_t *__restrict__ fsup,
+                                                                int32_t *__restrict__ fnsup) {
+    const Dims &d = k.d;
+    const int pair = blockIdx.x, tid = threadIdx.x;
+    const int Wc = d.Wc, Hc = d.Hc, lat = Wc * Hc;
+    const int16_t *B = latB + (size_t)pair * lat;
+    int16_t *T = latC + (size_t)pair * lat;
+    uint32_t *list = flist + (size_t)pair * lat;
+    __shared__ int s_scan[FLT_THREADS];
+    __shared__ int s_dist[FLT_THREADS], s_idx[FLT_THREADS];
+    for (int v = tid; v < Hc; v += FLT_THREADS) {  // consecutive lanes = consecutive rows: every step is one coalesced access
         int w[11];
 #pragma unroll
-        for (int j = 0; j < 11; j++) w[j] = (j >= 5 && j - 5 < Wc) ? (int)T[(j - 5) * Hc + v] : -1;
+        for (int j = 0; j < 11; j++) w[j] = (j >= 5 && j - 5 < Wc) ? (int)B[(j - 5) * Hc + v] : -1;
+#pragma unroll 8
         for (int u = 0; u < Wc; u++) {
-            if (redundant_here(w)) {
-                T[u * Hc + v] = -1;
-                w[5] = -1;
-            }
+            const int nxt = u + 6 < Wc ? (int)B[(u + 6) * Hc + v] : -1;
+            if (redundant_here(w)) w[5] = -1;
+            T[u * Hc + v] = (int16_t)w[5];
 #pragma unroll
             for (int j = 0; j < 10; j++) w[j] = w[j + 1];
-            w[10] = u + 6 < Wc ? (int)T[(u + 6) * Hc + v] : -1;
+            w[10] = nxt;
         }
     }
+    __threadfence_block();
     __syncthreads();
 
-    // ---- collect in scan order (elas.cpp:424-428; lattice row / column 0 excluded)
     int32_t *out = fsup + (size_t)pair * d.max_pts * 3;
     const int n_main = compact_indices(lat, list, s_scan, [&](int i) { return T[i] >= 0 && i >= Hc && (i % Hc) != 0; });
     for (int q = tid; q < n_main; q += FLT_THREADS) {
-        const int i = list[q];
+        const int i = (int)list[q];
         const int u = i / Hc, v = i - u * Hc;
         out[3 * q] = u * d.step;
         out[3 * q + 1] = v * d.step;
@@ -651,27 +689,28 @@ __global__ __launch_bounds__(FLT_THREADS) void k_support_filter(KParams k, int w
     }
     int n_total = n_main;
     if (k.add_corners) {  // elas.cpp:235-264: the four image corners take the disparity of the nearest point (first minimum)
-        __syncthreads();
         const int bu[4] = {0, 0, d.W - 1, d.W - 1}, bv[4] = {0, d.H - 1, 0, d.H - 1};
-        int cd[4];
-        int *s_dist = s_scan;                          // reuse: FLT_THREADS ints
-        int *s_idx = reinterpret_cast<int *>(st);      // the state bytes are no longer needed (lat >= 4*FLT_THREADS is not assumed:
-                                                       // see the size check at launch)
+        int best[4], bidx[4];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            int best = 10000000, bidx = 0x7FFFFFFF;
-            for (int q = tid; q < n_main; q += FLT_THREADS) {  // ascending q within a thread: strict < keeps the first minimum
-                const int i = list[q];
-                const int pu = (i / Hc) * d.step, pv = (i % Hc) * d.step;
+        for (int c = 0; c < 4; c++) best[c] = 10000000, bidx[c] = 0x7FFFFFFF;
+        for (int q = tid; q < n_main; q += FLT_THREADS) {  // ascending q within a thread: strict < keeps the first minimum
+            const int i = (int)list[q];
+            const int pu = (i / Hc) * d.step, pv = (i % Hc) * d.step;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
                 const int du = bu[c] - pu, dv = bv[c] - pv;
                 const int dist = du * du + dv * dv;
-                if (dist < best) {
-                    best = dist;
-                    bidx = q;
+                if (dist < best[c]) {
+                    best[c] = dist;
+                    bidx[c] = q;
                 }
             }
-            s_dist[tid] = best;
-            s_idx[tid] = bidx;
+        }
+        int cd[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            s_dist[tid] = best[c];
+            s_idx[tid] = bidx[c];
             __syncthreads();
             for (int off = FLT_THREADS / 2; off >= 1; off >>= 1) {
                 if (tid < off) {
@@ -706,15 +745,24 @@ __global__ __launch_bounds__(FLT_THREADS) void k_support_filter(KParams k, int w
     if (tid == 0) fnsup[pair] = n_total;
 }
 
-size_t support_filter_lds_bytes(const KParams &k) {
+size_t support_filter_ws_bytes(const KParams &k, int cap) {  // per slot: state bytes, index list, three lattice copies
     const size_t lat = (size_t)k.d.Wc * k.d.Hc;
-    return (lat + (lat & 1)) * 2 * 2 + std::max(lat, (size_t)4 * FLT_THREADS) + 16;  // lattice, index list, state bytes (reused by the corner search)
+    return (size_t)cap * lat * (1 + 4 + 3 * 2) + 256;
 }
 
 void launch_support_filter(const KParams &k, int win, int thr, int need, const SlotDev &s, int n, hipStream_t st) {
+    const size_t lat = (size_t)k.d.Wc * k.d.Hc, cap = (size_t)s.cap;
+    uint8_t *base = static_cast<uint8_t *>(s.flt_ws);
+    uint32_t *flist = reinterpret_cast<uint32_t *>(base);
+    int16_t *latA = reinterpret_cast<int16_t *>(base + cap * lat * 4), *latB = latA + cap * lat, *latC = latB + cap * lat;
+    uint8_t *fst = reinterpret_cast<uint8_t *>(latC + cap * lat);
+    const size_t cl_lds = sizeof(int16_t) * (FCL_THREADS + 2 * (size_t)(5 * k.d.Hc + 5));
     static std::atomic<size_t> granted[64];
-    ensure_dynamic_lds(k_support_filter, support_filter_lds_bytes(k), granted, "support_filter");
-    SV_LAUNCH(K_SUPPORT_FILTER, k_support_filter, dim3(n), dim3(FLT_THREADS), support_filter_lds_bytes(k), st, k, win, thr, need, s.dcan, s.fsup, s.fnsup);
+    ensure_dynamic_lds(k_filter_classify, cl_lds, granted, "support_filter");
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_classify, dim3((unsigned)((lat + FCL_THREADS - 1) / FCL_THREADS), n), dim3(FCL_THREADS), cl_lds, st, k.d, win, thr, need, s.dcan, fst);
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_resolve, dim3(n), dim3(FLT_THREADS), 0, st, k.d, win, thr, need, s.dcan, fst, flist, latA);
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_vertical, dim3((k.d.Wc + 63) / 64, n), dim3(64), 0, st, k.d, latA, latB);
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_collect, dim3(n), dim3(FLT_THREADS), 0, st, k, latB, latC, flist, s.fsup, s.fnsup);
 }
 
 // ------------------------------------------------------------------------------------------------------------

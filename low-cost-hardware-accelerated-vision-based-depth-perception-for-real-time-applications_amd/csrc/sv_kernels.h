@@ -50,6 +50,7 @@ struct SlotDev {
     int16_t *dcan;      // [cap][Wc][Hc]     raw support lattice, TRANSPOSED (u major) for the host filters
     int32_t *fsup;      // [cap][max_pts][3] support points from the on-GPU lattice filter (when it is used)
     int32_t *fnsup;     // [cap]
+    void *flt_ws;       // workspace of the on-GPU lattice filter (support_filter_ws_bytes)
     int32_t *blob;      // host-stage results of the chunk, one H2D copy: [cap][8] meta words, then tightly packed data.
                         //   meta of pair p: [0] #support points  [1] offset of its (u,v,d) triples
                         //                   [2] #triangles left  [3] offset of their corner indices
@@ -75,7 +76,7 @@ enum CounterId { CNT_DENSE_CANDIDATES = 0, CNT_DENSE_PIXELS, CNT_SUPPORT_ENERGIE
 // ---- launch wrappers (kernels.hip).  `n` = pairs in this launch; `nproc` = maps per pair to post-process (1 or 2).
 void launch_descriptor(const KParams &k, const uint8_t *left, const uint8_t *right, size_t in_pair_stride, int stride, const SlotDev &s, int n, hipStream_t st);
 void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st);
-size_t support_filter_lds_bytes(const KParams &k);
+size_t support_filter_ws_bytes(const KParams &k, int cap);
 size_t ccl_ws_bytes(const KParams &k, int maps_cap);
 size_t ccl_lds_bytes(const KParams &k);
 void launch_support_filter(const KParams &k, int win, int thr, int need, const SlotDev &s, int n, hipStream_t st);
