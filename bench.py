@@ -55,6 +55,7 @@ METRIC = {
     "kitti_d256": "stereo pairs/sec, KITTI 1242x375 D=256 (LDS-pressure configuration; ms/frame at batch 1 in latency_ms_batch1)",
     "4k_d192": "stereo pairs/sec, synthetic 4K 3840x2160 D=192 (ms/frame at batch 1 in latency_ms_batch1)",
 }
+LATENCY_WORKERS = 7  # latency handles: the calling thread + 7 pool threads build the two triangulations as eight quarters
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # integer byte-absdiff peak: 1024 SIMDs x 64 lanes x 4 bytes per v_sad_u8, one wave instruction per 4 cycles (tools/valu_rate.hip), 2.4 GHz
 SAD_PEAK_BYTE_OPS = 1024 * 64 * 4 / 4 * 2.4e9
@@ -201,7 +202,7 @@ def host_latency(eng, params, l1, r1, pinned, calls=200):
     L, R, D1, D2 = alloc((H, W), np.uint8), alloc((H, W), np.uint8), alloc((Hm, Wm), np.float32), alloc((Hm, Wm), np.float32)
     L[:], R[:] = l1, r1
     dims = (ctypes.c_int32 * 3)(W, H, W)
-    e = eng.StereoEngine(W, H, params, n_workers=4, chunk=1, n_streams=1, n_slots=2)
+    e = eng.StereoEngine(W, H, params, n_workers=LATENCY_WORKERS, chunk=1, n_streams=1, n_slots=2)
     f = eng.lib().sv_elas_process
     args = (e._h, L.ctypes.data, R.ctypes.data, D1.ctypes.data, D2.ctypes.data, dims)
     try:
@@ -456,7 +457,7 @@ def main():
     # pair of the batch if the fixture is absent), one pair per call, 200 timed calls after 20 warm-ups, device memory in and out
     lat_ms = None
     if rank == 0 and not args.no_latency:
-        e1 = eng.StereoEngine(W, H, params, device=local_rank, n_workers=4, chunk=1, n_streams=1, n_slots=2)
+        e1 = eng.StereoEngine(W, H, params, device=local_rank, n_workers=LATENCY_WORKERS, chunk=1, n_streams=1, n_slots=2)
         l1 = torch.from_numpy(np.array(lat_pair[0][None])).cuda()
         r1 = torch.from_numpy(np.array(lat_pair[1][None])).cuda()
         which = "kitti_mini pair 0" if real is not None else "first pair of the batch"

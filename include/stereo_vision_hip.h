@@ -171,6 +171,9 @@ int sv_host_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap);
 /* Same triangulation with the two halves of the top-level cut built by two threads, as the engine does in latency mode
  * (chunk = 1); helper_delay_us > 0 delays the helper thread so that the caller ends up doing both halves itself. */
 int sv_host_delaunay_split(const int32_t *xy, int n, int32_t *tri_out, int cap, int helper_delay_us);
+/* Same with `depth` levels of the recursion shared (2: four quarters on four threads, what a latency handle with >= 7 pool
+ * threads does). */
+int sv_host_delaunay_par(const int32_t *xy, int n, int32_t *tri_out, int cap, int depth, int helper_delay_us);
 /* Test hook: the divide-and-conquer phase of that triangulation on the GPU (csrc/delaunay_gpu.hip; sort, duplicate scan and k-d
  * ordering on the host), `reps` copies of the set in one launch, kernel time in *kernel_ms (may be NULL).  n <= 4000. */
 int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int reps, double *kernel_ms);

@@ -101,6 +101,7 @@ struct Slot {
     const uint8_t *in_left = nullptr, *in_right = nullptr;
     size_t in_pair = 0;
     int in_stride = 0;
+    bool grid_issued = false;   // latency mode: the candidate grid of this chunk was launched while the host still triangulated
     bool out_enqueued = false;  // host-memory jobs: phase 2 was enqueued (ev_lr / ev_p2 are pending), the maps can be downloaded
     int state = SLOT_FREE;
     // chunk in flight
@@ -162,6 +163,7 @@ struct sv_handle {
     std::mutex qmu;
     std::condition_variable qcv;
     std::deque<Task> queue;
+    std::atomic<int> queue_len{0};  // == queue.size(); lets latency-mode pool threads poll for work without the lock
     bool pool_quit = false;
     // timing
     bool timing = false;
@@ -174,6 +176,9 @@ struct sv_handle {
     // debug
     std::map<std::string, std::vector<uint8_t>> dbg;
     unsigned long long *d_counters = nullptr;  // work counters of the matching kernels (sv_debug_counters)
+    bool lat_trace = false;                    // SV_LAT_TRACE=1: wall-clock split of the latency path, printed by sv_destroy
+    double lat_ns[8] = {0};
+    long lat_calls = 0;
 };
 
 namespace {
@@ -697,6 +702,7 @@ void spawn_to_pool(void *ctx, void (*fn)(void *), void *arg) {
         t.fn = fn;
         t.arg = arg;
         h->queue.push_front(t);
+        h->queue_len.fetch_add(1, std::memory_order_release);
     }
     h->qcv.notify_one();
 }
@@ -731,7 +737,8 @@ void triangulate_side(sv_handle *h, HostScratch *sc, Slot *s, int j, int side) {
         ord[0] = -1;
     }
     // latency mode: the halves of the top-level cut go to two threads (throughput mode keeps every core busy with whole pairs)
-    const Delaunay::Spawn spawn{spawn_to_pool, h};
+    // (two triangulations at a time: halves need 4 threads, quarters 8, counting the calling thread)
+    const Delaunay::Spawn spawn{spawn_to_pool, h, h->pool.size() >= 7 ? 2 : 1};
     const int nt = sc->dl.triangulate(sc->xy.data(), ns, blob + meta[3 + 2 * side], 2 * ns, (h->chunk == 1 && h->pool.size() >= 3) ? &spawn : nullptr);
     if (h->timing) h->host_delaunay_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     if (nt < 0 || nt > d.max_tri) {
@@ -806,9 +813,23 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
     meta[3] = (int32_t)(off + (size_t)ns * 3);
     meta[5] = (int32_t)(off + (size_t)ns * 3 + (size_t)2 * ns * 3);
     memcpy(blob + off, sc->sup.data(), sizeof(int32_t) * (size_t)ns * 3);
+    if (s->inline_mode && !h->gpu_delaunay) {
+        // latency mode (this is the calling thread): the candidate grid only needs the support points - upload them and launch
+        // it now, so that it runs while the two triangulations are built
+        try {
+            hipStream_t st = h->sP2[0];
+            HIP_TRY(hipMemcpyAsync(s->dev.blob, blob, sizeof(int32_t) * META_WORDS, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(s->dev.blob + off, blob + off, sizeof(int32_t) * (size_t)ns * 3, hipMemcpyHostToDevice, st));
+            launch_grid(h->kp, s->dev, 1, st);
+            s->grid_issued = true;
+        } catch (const std::exception &e) {
+            note_error(h, e.what());
+        }
+    }
     {
         std::lock_guard<std::mutex> lk(h->qmu);
         h->queue.push_front(Task{s, t.pair, 1});
+        h->queue_len.fetch_add(1, std::memory_order_release);
     }
     h->qcv.notify_one();
     triangulate_side(h, sc, s, t.pair, 0);
@@ -817,14 +838,20 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
 
 void pool_main(sv_handle *h, HostScratch *sc) {
     (void)hipSetDevice(h->cfg.device);  // run_task may fetch a long support list from the handle's device
+    // Latency mode (chunk 1): a frame hands over pieces of its two triangulations several times within ~0.2 ms, and waking a
+    // thread that sleeps on the condition variable costs 30-50 us each time.  There the pool polls the queue length for a
+    // while (about a frame period of continuous use) before it goes to sleep; throughput handles sleep at once.
+    const int spin_rounds = h->chunk == 1 && !getenv("SV_POOL_SLEEP") ? 400000 : 0;
     for (;;) {
         Task t;
+        for (int i = 0; i < spin_rounds && h->queue_len.load(std::memory_order_acquire) == 0; i++) __builtin_ia32_pause();
         {
             std::unique_lock<std::mutex> lk(h->qmu);
             h->qcv.wait(lk, [&] { return h->pool_quit || !h->queue.empty(); });
             if (h->pool_quit && h->queue.empty()) return;
             t = h->queue.front();
             h->queue.pop_front();
+            h->queue_len.fetch_sub(1, std::memory_order_relaxed);
         }
         run_task(h, sc, t);
     }
@@ -862,6 +889,7 @@ void dispatcher_main(sv_handle *h) {
         {
             std::lock_guard<std::mutex> lk(h->qmu);
             for (int j = 0; j < s->n; j++) h->queue.push_back(Task{s, j, -1});
+            h->queue_len.fetch_add(s->n, std::memory_order_release);
         }
         h->qcv.notify_all();
     }
@@ -888,7 +916,8 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
         for (int j = 0; j < n; j++) ns_max = std::max(ns_max, std::min(blob[(size_t)j * META_WORDS], delaunay_gpu_max_points()));
         launch_delaunay_blob(s->dev.blob, n, delaunay_gpu_lds_bytes(ns_max, ns_max), st);
     }
-    launch_grid(k, s->dev, n, st);
+    if (!s->grid_issued) launch_grid(k, s->dev, n, st);  // (latency mode launches it during the triangulations, run_task)
+    s->grid_issued = false;
     launch_triangles(k, s->dev, n, st);
     launch_dense(k, s->dev, n, st);
     float *u1 = job.d1 + (size_t)s->i0 * d.Nm, *u2 = job.d2 ? job.d2 + (size_t)s->i0 * d.Nm : nullptr;  // the caller's maps are [batch][Hm][Wm]
@@ -1249,29 +1278,43 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
     s->i0 = 0;
     s->n = 1;
     s->inline_done.store(0);
+    s->grid_issued = false;
     s->inline_mode = true;
     (void)hipSetDevice(h->cfg.device);
     const LaunchHook saved = g_launch_hook;
     try {
         g_launch_hook.fn = h->timing ? timing_hook : nullptr;
         g_launch_hook.ctx = &h->tc_issue;
+        using clk = std::chrono::steady_clock;
+        clk::time_point tp[7];
+        tp[0] = clk::now();
         if (host)
             upload_chunk(h, s, h->sP1, 2);  // on the phase-1 stream itself: in order, no event
         else
             set_chunk_inputs(h, s);
         issue_phase1(h, s);
+        tp[1] = clk::now();
         HIP_TRY(hipEventSynchronize(s->ev_p1));
+        tp[2] = clk::now();
         s->blob_off.store((size_t)s->dev.cap * META_WORDS);
         s->pending.store(1);
         run_task(h, h->inline_scratch, Task{s, 0, -1});
+        tp[3] = clk::now();
         while (!s->inline_done.load(std::memory_order_acquire)) __builtin_ia32_pause();
+        tp[4] = clk::now();
         g_launch_hook.ctx = &h->tc_finish;
         issue_phase2(h, s, h->sP2[0]);
+        tp[5] = clk::now();
         if (host) {
             download_chunk(h, s);
             deliver_maps(h, s, 3);
         } else {
             HIP_TRY(hipStreamSynchronize(h->sP2[0]));
+        }
+        tp[6] = clk::now();
+        if (h->lat_trace) {
+            for (int i = 0; i < 6; i++) h->lat_ns[i] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(tp[i + 1] - tp[i]).count();
+            h->lat_calls++;
         }
     } catch (const std::exception &e) {
         note_error(h, e.what());
@@ -1436,6 +1479,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     }
     h->inline_scratch = new HostScratch();
     h->inline_ok = getenv("SV_NO_INLINE") == nullptr;
+    h->lat_trace = getenv("SV_LAT_TRACE") != nullptr;
     h->t_issue = std::thread(issuer_main, h);
     h->t_dispatch = std::thread(dispatcher_main, h);
     h->t_finish = std::thread(finisher_main, h);
@@ -1447,6 +1491,12 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
 int sv_destroy(sv_handle *h) {
     if (!h) return SV_ERR_ARG;
     (void)wait_jobs(h);
+    if (h->lat_trace && h->lat_calls > 0) {
+        static const char *names[6] = {"enqueue phase 1", "wait phase 1", "filter + left triangulation", "wait right triangulation", "enqueue phase 2", "wait phase 2 (+ downloads)"};
+        fprintf(stderr, "latency path, %ld calls, us per call:", h->lat_calls);
+        for (int i = 0; i < 6; i++) fprintf(stderr, "  %s %.1f", names[i], 1e-3 * h->lat_ns[i] / (double)h->lat_calls);
+        fprintf(stderr, "\n");
+    }
     {
         std::lock_guard<std::mutex> lk(h->mu);
         h->quit = true;
@@ -1686,23 +1736,37 @@ int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int rep
 }
 
 int sv_host_delaunay_split(const int32_t *xy, int n, int32_t *tri_out, int cap, int helper_delay_us) {
-    if (!xy || !tri_out) return SV_ERR_ARG;
+    return sv_host_delaunay_par(xy, n, tri_out, cap, 1, helper_delay_us);
+}
+
+int sv_host_delaunay_par(const int32_t *xy, int n, int32_t *tri_out, int cap, int depth, int helper_delay_us) {
+    if (!xy || !tri_out || depth < 1 || depth > 8) return SV_ERR_ARG;
     struct Helper {
         std::vector<std::thread> threads;
+        std::mutex mu;  // at depth > 1 helpers spawn helpers
         int delay_us;
         static void run(void *ctx, void (*fn)(void *), void *arg) {
             Helper *hp = static_cast<Helper *>(ctx);
             const int delay = hp->delay_us;
+            std::lock_guard<std::mutex> lk(hp->mu);
             hp->threads.emplace_back([fn, arg, delay] {
                 if (delay > 0) std::this_thread::sleep_for(std::chrono::microseconds(delay));
                 fn(arg);
             });
         }
-    } helper{{}, helper_delay_us};
-    const Delaunay::Spawn spawn{&Helper::run, &helper};
+    } helper{{}, {}, helper_delay_us};
+    const Delaunay::Spawn spawn{&Helper::run, &helper, depth};
     Delaunay dl;
     const int nt = dl.triangulate(xy, n, tri_out, cap, &spawn);
-    for (std::thread &t : helper.threads) t.join();  // a late helper finds the work claimed and returns at once
+    for (size_t i = 0;; i++) {  // a late helper finds the work claimed and returns at once (joined by index: the vector may still grow)
+        std::thread t;
+        {
+            std::lock_guard<std::mutex> lk(helper.mu);
+            if (i >= helper.threads.size()) break;
+            t = std::move(helper.threads[i]);
+        }
+        t.join();
+    }
     return nt;
 }
 

@@ -802,6 +802,67 @@ int Delaunay::kd_ordered_ids(const int32_t *xy, int n, int32_t *ids_out) {
     return m;
 }
 
+// build() with the right half of the cut handed to another thread, `depth` levels deep (depth 2: four quarters on four threads).
+// The slots a subproblem allocates depend on its size only (slots_of), so the halves fill disjoint, pre-computed slot ranges
+// and the pool ends up exactly as the sequential recursion leaves it.  A half is claimed with a compare-and-swap: it runs
+// exactly once, by the helper or - if nobody picked it up in time - by the spawning thread itself, so nobody can wait for ever.
+// The hand-over record is shared by the two parties and freed by whoever lets go of it last: a helper that shows up after
+// the spawner has moved on still finds valid memory (and nothing left to do).
+void Delaunay::build_split(const Pt *p, int n, int axis, H &farleft, H &farright, int cursor0, int depth, const Spawn *spawn, int &cursor_end) {
+    if (depth <= 0 || n < 64) {
+        int c = cursor0;
+        build(p, n, axis, farleft, farright, c);
+        cursor_end = c;
+        return;
+    }
+    const int divider = n >> 1;
+    struct Half {
+        Delaunay *self;
+        const Pt *p;
+        const Spawn *spawn;
+        int n, axis, cursor0, depth, cursor_end;
+        H l, r;
+        std::atomic<int> state{0};  // 0 queued, 1 claimed, 2 done
+        std::atomic<int> refs{2};
+        void work() {
+            int expected = 0;
+            if (!state.compare_exchange_strong(expected, 1)) return;
+            self->build_split(p, n, axis, l, r, cursor0, depth, spawn, cursor_end);
+            state.store(2, std::memory_order_release);
+        }
+        void release() {
+            if (refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this;
+        }
+        static void run(void *arg) {  // the helper's entry point
+            Half *h = static_cast<Half *>(arg);
+            h->work();
+            h->release();
+        }
+    };
+    Half *right = new Half();
+    right->self = this;
+    right->p = p + divider;
+    right->spawn = spawn;  // (outlives the call: a late helper finds state != 0 and never touches it)
+    right->n = n - divider;
+    right->axis = 1 - axis;
+    right->cursor0 = cursor0 + slots_of(divider);
+    right->depth = depth - 1;
+    right->cursor_end = 0;
+    right->l = right->r = 0;
+    spawn->run(spawn->ctx, &Half::run, right);
+    H innerleft;
+    int left_end = cursor0;
+    build_split(p, divider, 1 - axis, farleft, innerleft, cursor0, depth - 1, spawn, left_end);
+    right->work();  // no-op unless it is still unclaimed
+    while (right->state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
+    int c = right->cursor_end;
+    H rl = right->l, rr = right->r;
+    right->release();
+    merge(farleft, innerleft, rl, rr, axis, c);
+    farright = rr;
+    cursor_end = c;
+}
+
 int Delaunay::triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap, const Spawn *spawn) {
     if (n < 3) return 0;
     // leaves allocate <= 4 slots per 3 points (2 per 2), every merge 2 more: < 3n in total, + the outer-space slot
@@ -814,49 +875,10 @@ int Delaunay::triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap, c
     Pt *a = order_.data();
     H hl, hr;
     if (spawn && spawn->run && m >= 64) {
-        // latency mode: the right half of the top-level cut is built by another thread (or by this one afterwards if nobody
-        // picked it up: the work is claimed with a compare-and-swap, so it runs exactly once and nobody can wait for ever).
-        // The hand-over record is shared by the two parties and freed by whoever lets go of it last: a helper that shows up
-        // after this call has returned still finds valid memory (and nothing left to do).
-        const int divider = m >> 1;
-        struct Half {
-            Delaunay *self;
-            const Pt *p;
-            int n, cursor;
-            H l, r;
-            std::atomic<int> state{0};  // 0 queued, 1 claimed, 2 done
-            std::atomic<int> refs{2};
-            void work() {
-                int expected = 0;
-                if (!state.compare_exchange_strong(expected, 1)) return;
-                self->build(p, n, 1, l, r, cursor);
-                state.store(2, std::memory_order_release);
-            }
-            void release() {
-                if (refs.fetch_sub(1, std::memory_order_acq_rel) == 1) delete this;
-            }
-            static void run(void *arg) {  // the helper's entry point
-                Half *h = static_cast<Half *>(arg);
-                h->work();
-                h->release();
-            }
-        };
-        Half *right = new Half();
-        right->self = this;
-        right->p = a + divider;
-        right->n = m - divider;
-        right->cursor = 1 + slots_of(divider);
-        right->l = right->r = 0;
-        spawn->run(spawn->ctx, &Half::run, right);
-        H innerleft;
-        build(a, divider, 1, hl, innerleft, n_slots_);
-        right->work();  // no-op unless it is still unclaimed
-        while (right->state.load(std::memory_order_acquire) != 2) __builtin_ia32_pause();
-        n_slots_ = right->cursor;
-        H rl = right->l, rr = right->r;
-        right->release();
-        merge(hl, innerleft, rl, rr, 0, n_slots_);
-        hr = rr;
+        // latency mode: the recursion's top levels are shared with other threads (build_split)
+        int end = n_slots_;
+        build_split(a, m, 0, hl, hr, n_slots_, spawn->depth > 0 ? spawn->depth : 1, spawn, end);
+        n_slots_ = end;
     } else {
         build(a, m, 0, hl, hr, n_slots_);
     }

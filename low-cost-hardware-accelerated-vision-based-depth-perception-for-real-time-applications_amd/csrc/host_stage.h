@@ -35,9 +35,10 @@ class Delaunay {
     struct Spawn {
         void (*run)(void *ctx, void (*fn)(void *), void *arg);
         void *ctx;
+        int depth = 1;  // levels of the recursion whose right halves are handed over: 1 = two halves, 2 = four quarters
     };
     // xy: n points (x0,y0,x1,y1,...).  tri_out receives 3*count vertex indices; returns count (<= 2n), or -1 if cap
-    // (in triangles) is too small.  With `spawn` the two halves of the top-level cut are built concurrently.
+    // (in triangles) is too small.  With `spawn` the halves (quarters, ...) of the top-level cuts are built concurrently.
     int triangulate(const int32_t *xy, int n, int32_t *tri_out, int cap, const Spawn *spawn = nullptr);
     // Only the preparation (sort, duplicate scan, k-d ordering): the ids of the m surviving vertices in the order the recursion
     // consumes them; the GPU triangulation (delaunay_gpu.hip) starts from there.  Returns m (or < 0 like triangulate).
@@ -69,6 +70,7 @@ class Delaunay {
     void kd_order(uint64_t *xs, uint64_t *xalt, uint64_t *ys, uint64_t *yalt, int n, int axis, Pt *out);
     void alternate_cuts(Pt *a, int m);
     void build(const Pt *a, int n, int axis, H &farleft, H &farright, int &cursor);
+    void build_split(const Pt *p, int n, int axis, H &farleft, H &farright, int cursor0, int depth, const Spawn *spawn, int &cursor_end);
     void merge(H &farleft, H &innerleft, H &innerright, H &farright, int axis, int &cursor);
     uint32_t rnd(uint32_t choices);
 };

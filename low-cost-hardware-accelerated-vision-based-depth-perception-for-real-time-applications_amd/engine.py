@@ -377,16 +377,16 @@ def gpu_delaunay(xy, reps=1):
     return out[:nt].copy(), ms.value
 
 
-def host_delaunay(xy, split=False, helper_delay_us=0):
-    """Product host stage: Delaunay triangulation of integer points (n,2) -> (nt,3) int32.  split: build the two halves of
-    the top-level cut on two threads (what the engine does in latency mode)."""
+def host_delaunay(xy, split=False, helper_delay_us=0, depth=1):
+    """Product host stage: Delaunay triangulation of integer points (n,2) -> (nt,3) int32.  split: build the halves (depth 2:
+    quarters) of the top-level cuts on other threads (what the engine does in latency mode)."""
     xy = np.ascontiguousarray(xy, dtype=np.int32)
     n = xy.shape[0]
     out = np.empty((2 * n + 8, 3), np.int32)
     if split:
         L = lib()
-        L.sv_host_delaunay_split.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
-        nt = L.sv_host_delaunay_split(xy.ctypes.data, n, out.ctypes.data, 2 * n + 8, int(helper_delay_us))
+        L.sv_host_delaunay_par.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        nt = L.sv_host_delaunay_par(xy.ctypes.data, n, out.ctypes.data, 2 * n + 8, int(depth), int(helper_delay_us))
     else:
         nt = lib().sv_host_delaunay(xy.ctypes.data, n, out.ctypes.data, 2 * n + 8)
     if nt < 0:

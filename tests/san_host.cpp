@@ -8,12 +8,15 @@
 #include <thread>
 #include <vector>
 using namespace sv;
+#include <mutex>
 struct Helper {
     std::vector<std::thread> threads;
+    std::mutex mu;  // at depth > 1 helpers spawn helpers
     int delay_us;
     static void run(void *ctx, void (*fn)(void *), void *arg) {
         Helper *hp = static_cast<Helper *>(ctx);
         const int delay = hp->delay_us;
+        std::lock_guard<std::mutex> lk(hp->mu);
         hp->threads.emplace_back([fn, arg, delay] {
             if (delay > 0) std::this_thread::sleep_for(std::chrono::microseconds(delay));
             fn(arg);
@@ -30,10 +33,18 @@ int main() {
         std::vector<int32_t> a(6 * n + 24), b(6 * n + 24);
         Delaunay d1, d2;
         int na = d1.triangulate(xy.data(), n, a.data(), 2 * n + 8);
-        Helper h{{}, (it % 3 == 0) ? 3000 : 0};
-        Delaunay::Spawn sp{&Helper::run, &h};
+        Helper h{{}, {}, (it % 3 == 0) ? 3000 : 0};
+        Delaunay::Spawn sp{&Helper::run, &h, 1 + it % 3};  // halves, quarters, eighths
         int nb = d2.triangulate(xy.data(), n, b.data(), 2 * n + 8, &sp);
-        for (auto &t : h.threads) t.join();
+        for (size_t i = 0;; i++) {  // joined by index: the vector may still grow while late helpers start
+            std::thread t;
+            {
+                std::lock_guard<std::mutex> lk(h.mu);
+                if (i >= h.threads.size()) break;
+                t = std::move(h.threads[i]);
+            }
+            t.join();
+        }
         if (na != nb || memcmp(a.data(), b.data(), sizeof(int32_t) * 3 * na)) bad++;
     }
     // lattice filter on random lattices (padding respected)

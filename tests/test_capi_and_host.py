@@ -135,3 +135,5 @@ def test_host_delaunay_split_halves(eng):
         a = eng.host_delaunay(pts)
         b = eng.host_delaunay(pts, split=True, helper_delay_us=0 if it % 2 else 20000)
         assert a.shape == b.shape and np.array_equal(a, b), it
+        c = eng.host_delaunay(pts, split=True, depth=2 + it % 2, helper_delay_us=0 if it % 4 < 2 else 3000)  # quarters / eighths
+        assert a.shape == c.shape and np.array_equal(a, c), it
