@@ -14,7 +14,12 @@ def short(name):
     name = name.split("(")[0]
     if name.startswith("void at::native"):
         return "torch::" + name.split("::")[2].split("<")[0]
-    return name.replace("sv::", "")
+    name = name.replace("sv::", "")
+    if name.startswith("void "):  # template instantiations: "void k_dense<false>" -> "k_dense" (the <true> variants are the counting builds)
+        name = name[5:]
+    if name.endswith("<false>"):
+        name = name[:-7]
+    return name
 
 
 ap = argparse.ArgumentParser()
