@@ -151,7 +151,8 @@ long sv_debug_get(sv_handle *h, const char *name, void *out, long cap);
 /* Work counters of the two matching kernels (separate instantiations of the kernels; off by default).  mode 1: enable and
  * reset, 0: disable, -1: leave as is; out (may be NULL) receives uint64[8] = {dense candidates evaluated (16-byte SADs),
  * dense pixels matched, support energies evaluated (64-byte SADs), pixels whose plane band took the straight-line path /
- * the scalar-bounded path / the per-lane path of dense_match, 0, 0} since the last reset.  Waits for submitted work. */
+ * the scalar-bounded path / the per-lane path of dense_match, trips of its grid-candidate loop per wavefront / per lane (two
+ * candidates per trip: lane trips / (64 x wavefront trips) = lane utilisation of that loop)} since the last reset.  Waits for submitted work. */
 int sv_debug_counters(sv_handle *h, int mode, uint64_t *out);
 
 /* Per-kernel device timings (HIP events on the worker streams) accumulated since the last reset.

@@ -820,7 +820,7 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
             hipStream_t st = h->sP2[0];
             HIP_TRY(hipMemcpyAsync(s->dev.blob, blob, sizeof(int32_t) * META_WORDS, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(s->dev.blob + off, blob + off, sizeof(int32_t) * (size_t)ns * 3, hipMemcpyHostToDevice, st));
-            launch_grid(h->kp, s->dev, 1, st);
+            launch_grid(h->kp, s->dev, 1, ns, st);
             s->grid_issued = true;
         } catch (const std::exception &e) {
             note_error(h, e.what());
@@ -916,9 +916,11 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
         for (int j = 0; j < n; j++) ns_max = std::max(ns_max, std::min(blob[(size_t)j * META_WORDS], delaunay_gpu_max_points()));
         launch_delaunay_blob(s->dev.blob, n, delaunay_gpu_lds_bytes(ns_max, ns_max), st);
     }
-    if (!s->grid_issued) launch_grid(k, s->dev, n, st);  // (latency mode launches it during the triangulations, run_task)
+    int max_points = 0;  // the chunk's largest support-point count: sizes the grids of the per-point / per-triangle kernels
+    for (int j = 0; j < n; j++) max_points = std::max(max_points, blob[(size_t)j * META_WORDS]);
+    if (!s->grid_issued) launch_grid(k, s->dev, n, max_points, st);  // (latency mode launches it during the triangulations, run_task)
     s->grid_issued = false;
-    launch_triangles(k, s->dev, n, st);
+    launch_triangles(k, s->dev, n, max_points, st);
     launch_dense(k, s->dev, n, st);
     float *u1 = job.d1 + (size_t)s->i0 * d.Nm, *u2 = job.d2 ? job.d2 + (size_t)s->i0 * d.Nm : nullptr;  // the caller's maps are [batch][Hm][Wm]
     if (job.host) {  // host-memory job: the maps are written to the slot's device staging and downloaded from there
@@ -1591,6 +1593,8 @@ int sv_debug_counters(sv_handle *h, int mode, uint64_t *out) {
         out[3] = v[CNT_DENSE_BAND_FULL];
         out[4] = v[CNT_DENSE_BAND_PART];
         out[5] = v[CNT_DENSE_BAND_SLOW];
+        out[6] = v[CNT_DENSE_GRID_WAVE_TRIPS];
+        out[7] = v[CNT_DENSE_GRID_LANE_TRIPS];
     }
     return SV_OK;
 }

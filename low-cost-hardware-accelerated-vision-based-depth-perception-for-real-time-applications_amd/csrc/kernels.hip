@@ -806,9 +806,12 @@ __global__ __launch_bounds__(256) void k_grid_dilate(KParams k, const uint32_t *
     gB[(size_t)ps * d.ncell * d.MW + i] = r;
 }
 
-void launch_grid(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
+// max_points: the largest support-point count of the chunk as the host knows it (it wrote the blob); the grids of the per-point
+// and per-triangle kernels are sized by it instead of by the capacity (a KITTI lattice holds 18 681 points, a pair has ~2 100)
+void launch_grid(const KParams &k, const SlotDev &s, int n, int max_points, hipStream_t st) {
     (void)hipMemsetAsync(s.gmaskA, 0, sizeof(uint32_t) * (size_t)n * 2 * k.d.ncell * k.d.MW, st);
-    SV_LAUNCH(K_GRID_MARK, k_grid_mark, dim3((k.d.max_pts + 255) / 256, 2, n), dim3(256), 0, st, k, s.blob, s.gmaskA);
+    const int np = std::max(1, std::min(max_points, k.d.max_pts));
+    SV_LAUNCH(K_GRID_MARK, k_grid_mark, dim3((np + 255) / 256, 2, n), dim3(256), 0, st, k, s.blob, s.gmaskA);
     SV_LAUNCH(K_GRID_DILATE, k_grid_dilate, dim3((k.d.ncell * k.d.MW + 255) / 256, n * 2), dim3(256), 0, st, k, s.gmaskA, s.gmaskB);
 }
 
@@ -1119,11 +1122,12 @@ __global__ __launch_bounds__(256) void k_raster(KParams k, const int32_t *__rest
     }
 }
 
-void launch_triangles(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
+void launch_triangles(const KParams &k, const SlotDev &s, int n, int max_points, hipStream_t st) {
     const int ntile = ((k.d.W + RT_W - 1) / RT_W) * ((k.d.H + RT_H - 1) / RT_H);
     (void)hipMemsetAsync(s.tile_cnt, 0, sizeof(int32_t) * ((size_t)n * 2 * ntile + (size_t)s.cap * 2), st);  // counters + overflow flags (contiguous)
     int32_t *ovf = s.tile_cnt + (size_t)s.cap * 2 * ntile;
-    SV_LAUNCH(K_PLANES, k_planes, dim3((k.d.max_tri + 255) / 256, 2, n), dim3(256), 0, st, k, s.blob, s.trirec, s.planes, (RasterRec *)s.rrec, s.tile_cnt, s.tile_list, ovf);
+    const int nt = std::max(1, std::min(2 * max_points, k.d.max_tri));  // a triangulation of p points has < 2p triangles
+    SV_LAUNCH(K_PLANES, k_planes, dim3((nt + 255) / 256, 2, n), dim3(256), 0, st, k, s.blob, s.trirec, s.planes, (RasterRec *)s.rrec, s.tile_cnt, s.tile_list, ovf);
     SV_LAUNCH(K_TRIANGLES, k_raster_tiles, dim3(ntile, 2, n), dim3(256), 0, st, k, s.blob, (const RasterRec *)s.rrec, s.tile_cnt, s.tile_list, ovf, s.tri_id);
     SV_LAUNCH(K_TRIANGLES_FALLBACK, k_raster, dim3(64, 2, n), dim3(256), 0, st, k, s.blob, (const RasterRec *)s.rrec, ovf, s.tri_id);
 }
@@ -1159,14 +1163,18 @@ __device__ __forceinline__ int dense_band_full(const KParams &k, int side, const
     return bb;
 }
 
-template <bool COUNT>
+// MWT / RT: mask words per cell and plane radius as compile-time constants (0 = read them from the parameters).  The kernel
+// has many wave-uniform decisions on them (which mask words exist, which band slots exist); as runtime values the compiler keeps
+// ~60 scalar conditions alive per workgroup, spills them to VGPR lanes and reloads them in the pixel loops.
+template <bool COUNT, int MWT, int RT>
 __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, int v, const uint4 own, const uint4 *pu, const float4 rec, const uint32_t *mw,
-                                             const uint32_t *cell, int &ncand, int (&npath)[3]) {
+                                             const uint32_t *cell, int &ncand, int (&npath)[5]) {
     const Dims &d = k.d;
+    const int MW = MWT ? MWT : d.MW, plane_radius = RT ? RT : k.plane_radius;
     if ((int)texture16(own) < k.match_texture) return -10.0f;                   // elas.cpp:732-736 (the map keeps its -10)
     const int d_plane = (int)(rec.x * (float)u + rec.y * (float)v + rec.z);      // :739, ((a*u)+(b*v))+c without contraction
-    const int d_plane_min = max(d_plane - k.plane_radius, 0);
-    const int d_plane_max = min(d_plane + k.plane_radius, d.D - 1);
+    const int d_plane_min = max(d_plane - plane_radius, 0);
+    const int d_plane_max = min(d_plane + plane_radius, d.D - 1);
     const bool valid = rec.w != 0.0f;
     // disparities whose warped column stays inside [2, W-3] (:763, :770 / :782, :789), as a range instead of a per-candidate test
     const int a_lo = side ? 0 : max(u - (d.W - 3), 0), a_hi = side ? min(d.W - 3 - u, d.D - 1) : min(u - 2, d.D - 1);
@@ -1186,7 +1194,7 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
     const uint32_t band_lo = (uint32_t)band, band_hi = (uint32_t)(band >> 32);
 #pragma unroll
     for (int w = 0; w < DENSE_MASK_WORDS; w++) {  // grid candidates outside the band (:759-767 / :778-786), ascending d
-        if (w >= d.MW) break;
+        if (w >= MW) break;
         uint32_t m = mw[w];
         {  // keep [a_lo, a_hi], drop [d_plane_min, d_plane_max]
             if (clip) {
@@ -1203,6 +1211,11 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
         if (COUNT) ncand += __popc(m);
         int best_w = KEY_NONE;  // keys of this word carry the bit index only; 32 * w is added once per word
         while (m) {  // two candidates per trip: their LDS reads are in flight together (an odd last one is evaluated twice)
+            if (COUNT) {  // loop trips: per wavefront (counted by its lowest active lane) and per lane
+                const unsigned long long act = __ballot(1);
+                npath[3] += ((int)(threadIdx.x & 63) == __ffsll((long long)act) - 1) ? 1 : 0;
+                npath[4]++;
+            }
             const int b1 = __ffs((int)m) - 1;
             m &= m - 1;
             const int b2 = m ? __ffs((int)m) - 1 : b1;
@@ -1212,7 +1225,7 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
         }
         best = min(best, best_w + 32 * w);
     }
-    for (int w = DENSE_MASK_WORDS; w < d.MW; w++) {  // disp_max > 255: remaining words straight from memory
+    for (int w = DENSE_MASK_WORDS; w < MW; w++) {  // disp_max > 255: remaining words straight from memory
         const uint32_t m = cell[w];
         for (int b = 0; b < 32; b++) {
             const int dc = 32 * w + b;
@@ -1222,7 +1235,7 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
         }
     }
     // the band [d_plane - r, d_plane + r], ascending, with the plane prior (:768-774 / :787-793)
-    const int r = k.plane_radius;
+    const int r = plane_radius;
     // o' = d - (d_plane - r) in [0, 2r]; the lane's valid candidates are o' in [lo_o, hi_o] (empty when lo_o > hi_o)
     const int lo_o = b_lo - (d_plane - r), hi_o = b_hi - (d_plane - r);
     const int lo_u = __builtin_amdgcn_readfirstlane(lo_o), hi_u = __builtin_amdgcn_readfirstlane(hi_o);
@@ -1277,11 +1290,12 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
     return best < (10000 << 16) ? (float)(best & 0x7FFF) : -1.0f;  // :797-800 (min_val starts at 10000, :752)
 }
 
-template <bool COUNT>
+template <bool COUNT, int MWT, int RT>
 __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const uint8_t *__restrict__ desc, const int32_t *__restrict__ blob, const int32_t *__restrict__ tri_id,
                                                const float4 *__restrict__ trirec, const uint32_t *__restrict__ gB, int16_t *__restrict__ wta,
                                                unsigned long long *__restrict__ counters) {
     const Dims &d = k.d;
+    const int MW = MWT ? MWT : d.MW;
     extern __shared__ uint4 dense_lds[];
     const int pair = blockIdx.z;
     if (blob[pair * META_WORDS] < 3) return;
@@ -1313,9 +1327,9 @@ __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const
 #pragma unroll
     for (int j = 0; j < DENSE_TW / 256; j++) {
         const int u = min(x0 + j * 256 + (int)threadIdx.x, d.W - 1);
-        cell_off[j] = gy * (uint32_t)(d.gw * d.MW) + __umul24((uint32_t)(int)floorf((float)u / (float)d.grid_size), (uint32_t)d.MW);
+        cell_off[j] = gy * (uint32_t)(d.gw * MW) + __umul24((uint32_t)(int)floorf((float)u / (float)d.grid_size), (uint32_t)MW);
     }
-    int ncand = 0, npix = 0, npath[3] = {0, 0, 0};
+    int ncand = 0, npix = 0, npath[5] = {0, 0, 0, 0, 0};
 #pragma unroll
     for (int side = 0; side < 2; side++) {
         const int ps = pair * 2 + side;
@@ -1327,22 +1341,22 @@ __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const
             float out = -10.0f;  // elas.cpp:823-824
             if (t >= 0 && u >= 2 && u < d.W - 2 && !(d.sub && (u & 1))) {
                 const float4 rec = trirec[(size_t)ps * d.max_tri + t];
-                const uint32_t *cell = gB + (size_t)ps * d.ncell * d.MW + cell_off[j];
+                const uint32_t *cell = gB + (size_t)ps * d.ncell * MW + cell_off[j];
                 uint32_t mw[DENSE_MASK_WORDS] = {0, 0, 0, 0, 0, 0, 0, 0};
-                if ((d.MW & 3) == 0) {  // 16-byte aligned cells: one or two wide loads
+                if ((MW & 3) == 0) {  // 16-byte aligned cells: one or two wide loads
                     const uint4 m0 = *reinterpret_cast<const uint4 *>(cell);
                     mw[0] = m0.x, mw[1] = m0.y, mw[2] = m0.z, mw[3] = m0.w;
-                    if (d.MW >= 8) {
+                    if (MW >= 8) {
                         const uint4 m1 = *reinterpret_cast<const uint4 *>(cell + 4);
                         mw[4] = m1.x, mw[5] = m1.y, mw[6] = m1.z, mw[7] = m1.w;
                     }
                 } else {
 #pragma unroll
-                    for (int w = 0; w < DENSE_MASK_WORDS; w++) mw[w] = w < d.MW ? cell[w] : 0u;
+                    for (int w = 0; w < DENSE_MASK_WORDS; w++) mw[w] = w < MW ? cell[w] : 0u;
                 }
                 const uint4 own = side ? sR[u - r0] : sL[u - l0];
                 const uint4 *pu = side ? sL + (u - l0) : sR + (u - r0);  // the other image at the pixel's own column
-                out = dense_pixel<COUNT>(k, side, u, v, own, pu, rec, mw, cell, ncand, npath);
+                out = dense_pixel<COUNT, MWT, RT>(k, side, u, v, own, pu, rec, mw, cell, ncand, npath);
                 if (COUNT) npix++;
             }
             // integer-valued: a disparity, -1 or -10.  Half resolution (elas.cpp:707-711): only even (u, v) are matched, result at (u/2, v/2)
@@ -1358,22 +1372,40 @@ __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const
         count_add(counters + CNT_DENSE_BAND_FULL, npath[0]);
         count_add(counters + CNT_DENSE_BAND_PART, npath[1]);
         count_add(counters + CNT_DENSE_BAND_SLOW, npath[2]);
+        count_add(counters + CNT_DENSE_GRID_WAVE_TRIPS, npath[3]);
+        count_add(counters + CNT_DENSE_GRID_LANE_TRIPS, npath[4]);
     }
 }
 
 static size_t dense_lds_bytes(const KParams &k) { return sizeof(uint4) * 2 * (size_t)(DENSE_TW + k.d.disp_max); }
 
+template <int MWT, int RT>
+static void launch_dense_as(const KParams &k, const SlotDev &s, const dim3 &grid, size_t shmem, hipStream_t st) {
+    static std::atomic<size_t> granted[64];
+    ensure_dynamic_lds(k_dense<false, MWT, RT>, shmem, granted, "dense_match");
+    SV_LAUNCH(K_DENSE, (k_dense<false, MWT, RT>), grid, dim3(256), shmem, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
+}
+
 void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
     const size_t shmem = dense_lds_bytes(k);
     const dim3 grid((k.d.W + DENSE_TW - 1) / DENSE_TW, k.d.sub ? (k.d.H + 1) / 2 : k.d.H, n);
-    static std::atomic<size_t> granted[64], granted_c[64];
     if (s.counters) {
-        ensure_dynamic_lds(k_dense<true>, shmem, granted_c, "dense_match");
-        SV_LAUNCH(K_DENSE, k_dense<true>, grid, dim3(256), shmem, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
+        static std::atomic<size_t> granted_c[64];
+        ensure_dynamic_lds(k_dense<true, 0, 0>, shmem, granted_c, "dense_match");
+        SV_LAUNCH(K_DENSE, (k_dense<true, 0, 0>), grid, dim3(256), shmem, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
         return;
     }
-    ensure_dynamic_lds(k_dense<false>, shmem, granted, "dense_match");
-    SV_LAUNCH(K_DENSE, k_dense<false>, grid, dim3(256), shmem, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
+    // the usual disparity ranges (64 / 128 / 192 / 256) with the presets' plane radii (2: ROBOTICS, 3: MIDDLEBURY) get kernels
+    // compiled for them; anything else the generic one
+    const int MW = k.d.MW, R = k.plane_radius;
+    if (MW == 4 && R == 3) return launch_dense_as<4, 3>(k, s, grid, shmem, st);
+    if (MW == 8 && R == 3) return launch_dense_as<8, 3>(k, s, grid, shmem, st);
+    if (MW == 2 && R == 3) return launch_dense_as<2, 3>(k, s, grid, shmem, st);
+    if (MW == 6 && R == 3) return launch_dense_as<6, 3>(k, s, grid, shmem, st);
+    if (MW == 4 && R == 2) return launch_dense_as<4, 2>(k, s, grid, shmem, st);
+    if (MW == 8 && R == 2) return launch_dense_as<8, 2>(k, s, grid, shmem, st);
+    if (MW == 2 && R == 2) return launch_dense_as<2, 2>(k, s, grid, shmem, st);
+    launch_dense_as<0, 0>(k, s, grid, shmem, st);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1864,8 +1896,11 @@ __global__ __launch_bounds__(256) void k_ccl_apply(KParams k, int nproc, const i
     }
 }
 
-// (d) maps whose bands overflowed the run tables: per-pixel union-find, one workgroup per flagged map (normally none)
-__global__ __launch_bounds__(1024) void k_ccl_slow(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp, CclWs ws,
+// (d) maps whose bands overflowed the run tables: per-pixel union-find, one workgroup per flagged map (normally none).  Four
+// wavefronts only: the launch is made for every chunk and normally returns at once, but a 16-wavefront workgroup has to wait for
+// half a CU to drain before it can do even that (78 us per launch beside the other streams' kernels, 5 us alone).
+#define CCL_SLOW_THREADS 256
+__global__ __launch_bounds__(CCL_SLOW_THREADS) void k_ccl_slow(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp, CclWs ws,
                                                    int32_t *__restrict__ label, int32_t *__restrict__ csize, int32_t *__restrict__ cnt) {
     const int m = blockIdx.x;
     if (threadIdx.x == 0) ws.nruns[m] = 0;  // the record pool is free again for the slot's next launch
@@ -1888,7 +1923,7 @@ void launch_speckle(const KParams &k, const SlotDev &s, int n, int nproc, hipStr
     SV_LAUNCH(K_CCL_FINISH, k_ccl_total, dim3(ws.nb * CCL_SPLIT, maps), dim3(256), 0, st, nproc, k.speckle_size, s.blob, ws);
     SV_LAUNCH(K_CCL_FINISH, k_ccl_apply, dim3(ws.nb * CCL_SPLIT, maps), dim3(256), 0, st, k, nproc, s.blob, s.disp, ws);
     int32_t *cnt = reinterpret_cast<int32_t *>(s.tmp);  // slow path only: the filters' scratch map is free during speckle removal
-    SV_LAUNCH(K_CCL_FINISH, k_ccl_slow, dim3(maps), dim3(1024), 0, st, k, nproc, s.blob, s.disp, ws, s.tri_id, s.csize, cnt);
+    SV_LAUNCH(K_CCL_FINISH, k_ccl_slow, dim3(maps), dim3(CCL_SLOW_THREADS), 0, st, k, nproc, s.blob, s.disp, ws, s.tri_id, s.csize, cnt);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -71,7 +71,7 @@ struct SlotDev {
     unsigned long long *counters;  // work counters of the matching kernels (CounterId), nullptr = not counting (the normal case)
 };
 
-enum CounterId { CNT_DENSE_CANDIDATES = 0, CNT_DENSE_PIXELS, CNT_SUPPORT_ENERGIES, CNT_DENSE_BAND_FULL, CNT_DENSE_BAND_PART, CNT_DENSE_BAND_SLOW, CNT_COUNT = 8 };
+enum CounterId { CNT_DENSE_CANDIDATES = 0, CNT_DENSE_PIXELS, CNT_SUPPORT_ENERGIES, CNT_DENSE_BAND_FULL, CNT_DENSE_BAND_PART, CNT_DENSE_BAND_SLOW, CNT_DENSE_GRID_WAVE_TRIPS, CNT_DENSE_GRID_LANE_TRIPS, CNT_COUNT = 8 };
 
 // ---- launch wrappers (kernels.hip).  `n` = pairs in this launch; `nproc` = maps per pair to post-process (1 or 2).
 void launch_descriptor(const KParams &k, const uint8_t *left, const uint8_t *right, size_t in_pair_stride, int stride, const SlotDev &s, int n, hipStream_t st);
@@ -80,8 +80,8 @@ size_t support_filter_ws_bytes(const KParams &k, int cap);
 size_t ccl_ws_bytes(const KParams &k, int maps_cap);
 size_t ccl_lds_bytes(const KParams &k);
 void launch_support_filter(const KParams &k, int win, int thr, int need, const SlotDev &s, int n, hipStream_t st);
-void launch_grid(const KParams &k, const SlotDev &s, int n, hipStream_t st);
-void launch_triangles(const KParams &k, const SlotDev &s, int n, hipStream_t st);
+void launch_grid(const KParams &k, const SlotDev &s, int n, int max_points, hipStream_t st);
+void launch_triangles(const KParams &k, const SlotDev &s, int n, int max_points, hipStream_t st);
 void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st);
 void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st, float *user_d2, bool keep_right);
 void launch_speckle(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st);

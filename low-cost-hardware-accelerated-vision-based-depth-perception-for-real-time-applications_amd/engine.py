@@ -292,7 +292,8 @@ class StereoEngine:
         out = (ctypes.c_uint64 * 8)()
         self._check(L.sv_debug_counters(self._h, -1 if enable is None else int(bool(enable)), out))
         return {"dense_candidates": int(out[0]), "dense_pixels": int(out[1]), "support_energies": int(out[2]),
-                "dense_band_full": int(out[3]), "dense_band_partial": int(out[4]), "dense_band_per_lane": int(out[5])}
+                "dense_band_full": int(out[3]), "dense_band_partial": int(out[4]), "dense_band_per_lane": int(out[5]),
+                "dense_grid_wave_trips": int(out[6]), "dense_grid_lane_trips": int(out[7])}
 
     def kernel_times(self):
         """{kernel: (total_ms, calls)} accumulated since timing(True)."""
