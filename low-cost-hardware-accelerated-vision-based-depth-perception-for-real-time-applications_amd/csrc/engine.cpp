@@ -176,6 +176,7 @@ struct sv_handle {
     // debug
     std::map<std::string, std::vector<uint8_t>> dbg;
     unsigned long long *d_counters = nullptr;  // work counters of the matching kernels (sv_debug_counters)
+    uint8_t *dbg_desc = nullptr;               // keep_debug: descriptor images [cap][2][N][16] for the stage snapshot
     bool lat_trace = false;                    // SV_LAT_TRACE=1: wall-clock split of the latency path, printed by sv_destroy
     double lat_ns[8] = {0};
     long lat_calls = 0;
@@ -413,7 +414,7 @@ void issue_phase1(sv_handle *h, Slot *s) {
     const KParams &k = h->kp;
     const Dims &d = k.d;
     const int lat = d.Wc * d.Hc;
-    launch_descriptor(k, s->in_left, s->in_right, s->in_pair, s->in_stride, s->dev, s->n, h->sP1);
+    launch_sobel(k, s->in_left, s->in_right, s->in_pair, s->in_stride, s->dev, s->n, h->sP1);
     launch_support(k, s->dev, s->n, h->sP1);
     hipStream_t tail = h->sP1;
     if (h->gpu_filter) {
@@ -434,8 +435,11 @@ void issue_phase1(sv_handle *h, Slot *s) {
     if (h->cfg.keep_debug) {
         const int j = s->n - 1;
         HIP_TRY(hipStreamSynchronize(tail));
-        dbg_from_device(h, h->sP1, "desc1", s->dev.desc + ((size_t)j * 2) * d.N * 16, (size_t)d.N * 16);
-        dbg_from_device(h, h->sP1, "desc2", s->dev.desc + ((size_t)j * 2 + 1) * d.N * 16, (size_t)d.N * 16);
+        // the descriptor images as the reference would hold them: assembled from the gradient planes by the same device
+        // function the matching kernels use (they are never stored otherwise)
+        launch_expand_debug(k, s->dev, s->n, h->dbg_desc, h->sP1);
+        dbg_from_device(h, h->sP1, "desc1", h->dbg_desc + ((size_t)j * 2) * d.N * 16, (size_t)d.N * 16);
+        dbg_from_device(h, h->sP1, "desc2", h->dbg_desc + ((size_t)j * 2 + 1) * d.N * 16, (size_t)d.N * 16);
         {
             std::vector<int16_t> rowmajor((size_t)lat);  // the oracle's layout is [Hc][Wc]; the device writes [Wc][Hc]
             const int16_t *T = s->h_dcan + (size_t)j * lat;
@@ -1096,7 +1100,9 @@ void alloc_slot(sv_handle *h, Slot *sl) {
     const size_t cap = (size_t)h->chunk;
     SlotDev &s = sl->dev;
     s.cap = (int)cap;
-    dev_alloc(s.desc, cap * 2 * d.N * 16);
+    dev_alloc(s.grad, cap * grad_bytes_per_pair(h->kp));
+    HIP_TRY(hipMemset(s.grad, 0, cap * grad_bytes_per_pair(h->kp)));  // the row margins are read (never used) and never written
+    if (h->cfg.keep_debug && !h->dbg_desc) dev_alloc(h->dbg_desc, cap * 2 * d.N * 16);
     dev_alloc(s.dcan, cap * d.Wc * d.Hc);
     sl->blob_words = cap * (META_WORDS + (size_t)d.max_pts * 3 + 2 * (size_t)d.max_tri * 3 + 2 * ((size_t)d.max_pts + 1) + 64);
     dev_alloc(s.blob, sl->blob_words);
@@ -1146,7 +1152,7 @@ void alloc_slot(sv_handle *h, Slot *sl) {
 
 void free_slot(Slot *sl) {
     SlotDev &s = sl->dev;
-    void *dptrs[] = {s.desc, s.dcan, s.fsup, s.fnsup, s.flt_ws, s.blob, s.rrec, s.tile_cnt, s.tile_list, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize, s.ccl_ws};
+    void *dptrs[] = {s.grad, s.dcan, s.fsup, s.fnsup, s.flt_ws, s.blob, s.rrec, s.tile_cnt, s.tile_list, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize, s.ccl_ws};
     for (void *p : dptrs)
         if (p) (void)hipFree(p);
     if (sl->h_dcan) (void)hipHostFree(sl->h_dcan);
@@ -1177,6 +1183,7 @@ void free_handle_resources(sv_handle *h) {
     if (h->sPF) (void)hipStreamDestroy(h->sPF);
     for (hipStream_t st : h->sP2) (void)hipStreamDestroy(st);
     if (h->d_counters) (void)hipFree(h->d_counters);
+    if (h->dbg_desc) (void)hipFree(h->dbg_desc);
     if (h->sIn) (void)hipStreamDestroy(h->sIn);
     if (h->sOut) (void)hipStreamDestroy(h->sOut);
 }
@@ -1422,7 +1429,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     fill_kparams(h);
     int npool = cfg->n_workers > 0 ? cfg->n_workers : default_pool_size();
     // defaults: 64 pairs per launch, 8 slots, 4 phase-2 streams, scaled down so that the slots stay within a memory budget
-    // (about 92 bytes per pixel per pair in flight: 43 MB at KITTI size, 0.76 GB at 4K)
+    // (about 66 bytes per pixel per pair in flight: 31 MB at KITTI size, 0.55 GB at 4K)
     int np2 = cfg->n_streams > 0 ? cfg->n_streams : 4;
     int nslots = cfg->n_slots > 0 ? cfg->n_slots : 8;
     h->chunk = cfg->chunk > 0 ? cfg->chunk : 64;
@@ -1431,7 +1438,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         (void)hipSetDevice(cfg->device);
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
         const double budget = std::min(24.0 * (1 << 30), 0.25 * (double)free_b);
-        const double per_pair = 92.0 * (double)h->kp.d.N + 4.0e6;
+        const double per_pair = 66.0 * (double)h->kp.d.N + 4.0e6;
         while ((double)h->chunk * nslots * per_pair > budget) {
             if (cfg->chunk <= 0 && h->chunk > 1 && (h->chunk >= 2 * nslots || cfg->n_slots > 0 || nslots <= 3))
                 h->chunk = (h->chunk + 1) / 2;

@@ -69,19 +69,98 @@ __device__ __forceinline__ void count_add(unsigned long long *slot, int mine) {
 __device__ __forceinline__ int sat_u8(int x) { return x < 0 ? 0 : (x > 255 ? 255 : x); }
 
 // ------------------------------------------------------------------------------------------------------------
-// K1  Sobel + 16-byte descriptors
+// K1  Sobel gradients; 16-byte descriptors are never stored
 //     reference: common_includes/elas/filter.cpp:416-424 (sobel3x3 = :380-413 + :235-275 + :183-229)
 //                common_includes/elas/descriptor.cpp:96-124
-//     One workgroup = 64x8 output pixels.  Gray tile (+3 halo) -> LDS, du/dv tile (+2 halo) -> LDS,
-//     then one 16-byte store per pixel (1 KiB per wavefront store instruction).  Pixels outside
-//     [3,W-3)x[3,H-3) get the canonical zero descriptor (the reference leaves them uninitialised).
+//     The reference materialises one 16-byte descriptor per pixel (12 du + 4 dv samples around it).  Here only the two
+//     gradient images are stored (2 bytes per pixel instead of 16), as byte planes with padded rows, and the matching
+//     kernels assemble the descriptors they stage in LDS from them (expand_quad): 32 B/px of descriptor stores and
+//     ~45 B/px of descriptor re-reads per pair become 4 B/px of stores and plane reads that mostly hit in L2 / MALL.
+//     Pixels outside [3,W-3)x[3,H-3) get the canonical zero descriptor (the reference leaves them uninitialised).
 // ------------------------------------------------------------------------------------------------------------
-// LDS tiles are byte images with word-aligned rows; tile column c <-> image column x0 - 4 + c, so every 4-pixel group
-// of the output tile starts on a word.  All LDS traffic is 32-bit; bytes are picked with v_perm_b32 / v_bfe.
-#define DESC_TW 64   // output tile width
-#define DESC_TH 16   // output tile height
-#define DESC_GS 76   // gray tile row stride in bytes (19 words)  : rows y0-3 .. y0+TH+2
-#define DESC_DS 72   // du/dv tile row stride in bytes (18 words) : rows y0-2 .. y0+TH+1
+// Plane geometry: [pair][image][du | dv][H][P] bytes, image column x at byte GRAD_MARGIN + x of its row; P is a multiple of
+// 16 and leaves >= 16 bytes on either side, so 4-byte words at columns c-4, c, c+4 (c a multiple of 4, 0 <= c < W+4) are
+// aligned and in bounds.  The margins are never written (zero from the allocation) and never reach a valid descriptor.
+#define GRAD_MARGIN 16
+__host__ __device__ inline int grad_pitch(int W) { return ((W + 15) & ~15) + 2 * GRAD_MARGIN; }
+__host__ __device__ inline size_t grad_plane_bytes(const Dims &d) { return (size_t)d.H * grad_pitch(d.W); }
+
+// LDS tile of k_sobel: byte image with word-aligned rows; tile column c <-> image column x0 - 4 + c
+#define SOB_TW 64   // output tile width
+#define SOB_TH 16   // output tile height
+#define SOB_GS 72   // gray tile row stride in bytes (18 words) : rows y0-1 .. y0+TH, columns x0-4 .. x0+67
+
+__global__ __launch_bounds__(256) void k_sobel(const uint8_t *__restrict__ left, const uint8_t *__restrict__ right, size_t in_pair_stride, int stride,
+                                               uint8_t *__restrict__ grad, Dims d) {
+    const int img = blockIdx.z & 1, pair = blockIdx.z >> 1;
+    const uint8_t *I = (img ? right : left) + (size_t)pair * in_pair_stride;
+    const int P = grad_pitch(d.W);
+    uint8_t *DU = grad + ((size_t)(pair * 2 + img) * 2) * grad_plane_bytes(d) + GRAD_MARGIN, *DV = DU + grad_plane_bytes(d);
+    const int x0 = blockIdx.x * SOB_TW, y0 = blockIdx.y * SOB_TH;
+    __shared__ __attribute__((aligned(16))) uint8_t g[(SOB_TH + 2) * SOB_GS];
+    const int tid = threadIdx.x;
+    // gray tile, one word (4 pixels) per item; pixels outside the image read as 0 (they never reach a valid descriptor)
+    for (int i = tid; i < (SOB_TH + 2) * (SOB_GS / 4); i += 256) {
+        const int r = i / (SOB_GS / 4), cw = i - r * (SOB_GS / 4);
+        const int y = y0 - 1 + r, xb = x0 - 4 + 4 * cw;
+        uint32_t w = 0;
+        if (y >= 0 && y < d.H) {
+            const uint8_t *row = I + (size_t)y * stride;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = xb + j;
+                if (x >= 0 && x < d.W) w |= (uint32_t)row[x] << (8 * j);
+            }
+        }
+        *reinterpret_cast<uint32_t *>(&g[r * SOB_GS + 4 * cw]) = w;
+    }
+    __syncthreads();
+    // one thread = 4 pixels of one row: gray rows r, r+1, r+2 of the tile (y-1, y, y+1), gray columns c-1 .. c+4
+    const int r = tid >> 4, cw = 1 + (tid & 15), c = 4 * cw;
+    const int y = y0 + r, x = x0 + 4 * (tid & 15);
+    uint32_t a[3][3];
+#pragma unroll
+    for (int rr = 0; rr < 3; rr++) {
+        const uint8_t *gr = &g[(r + rr) * SOB_GS];
+        a[rr][0] = *reinterpret_cast<const uint32_t *>(gr + c - 4);
+        a[rr][1] = *reinterpret_cast<const uint32_t *>(gr + c);
+        a[rr][2] = *reinterpret_cast<const uint32_t *>(gr + c + 4);
+    }
+    // column sums for gray columns c-1 .. c+4 (6 columns): S = (1,2,1) vertical, T = (1,0,-1) vertical
+    int S[6], T[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        int t0, t1, t2;
+        if (q == 0) {
+            t0 = (a[0][0] >> 24) & 0xFF, t1 = (a[1][0] >> 24) & 0xFF, t2 = (a[2][0] >> 24) & 0xFF;
+        } else if (q == 5) {
+            t0 = a[0][2] & 0xFF, t1 = a[1][2] & 0xFF, t2 = a[2][2] & 0xFF;
+        } else {
+            t0 = (a[0][1] >> (8 * (q - 1))) & 0xFF, t1 = (a[1][1] >> (8 * (q - 1))) & 0xFF, t2 = (a[2][1] >> (8 * (q - 1))) & 0xFF;
+        }
+        S[q] = t0 + 2 * t1 + t2;
+        T[q] = t0 - t2;
+    }
+    uint32_t du_w = 0, dv_w = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {  // pixel column c+j: neighbours are S/T index j (x-1), j+1 (x), j+2 (x+1)
+        const int du = sat_u8(((S[j] - S[j + 2]) >> 2) + 128);
+        const int dv = sat_u8(((T[j] + 2 * T[j + 1] + T[j + 2]) >> 2) + 128);
+        du_w |= (uint32_t)du << (8 * j);
+        dv_w |= (uint32_t)dv << (8 * j);
+    }
+    if (y < d.H && x < ((d.W + 3) & ~3)) {  // whole words: the bytes beyond W land in the row's right margin and are never used
+        *reinterpret_cast<uint32_t *>(DU + (size_t)y * P + x) = du_w;
+        *reinterpret_cast<uint32_t *>(DV + (size_t)y * P + x) = dv_w;
+    }
+}
+
+size_t grad_bytes_per_pair(const KParams &k) { return 4 * grad_plane_bytes(k.d); }
+
+void launch_sobel(const KParams &k, const uint8_t *left, const uint8_t *right, size_t in_pair_stride, int stride, const SlotDev &s, int n, hipStream_t st) {
+    dim3 grid((k.d.W + SOB_TW - 1) / SOB_TW, (k.d.H + SOB_TH - 1) / SOB_TH, n * 2);
+    SV_LAUNCH(K_DESCRIPTOR, k_sobel, grid, dim3(256), 0, st, left, right, in_pair_stride, stride, s.grad, k.d);
+}
 
 // byte i (0..7) of the 8-byte little-endian pair (lo, hi)
 __device__ __forceinline__ uint32_t byte_of(uint32_t lo, uint32_t hi, int i) { return i < 4 ? (lo >> (8 * i)) & 0xFFu : (hi >> (8 * (i - 4))) & 0xFFu; }
@@ -118,120 +197,69 @@ __device__ __forceinline__ uint4 desc_assemble(const DescWin &w) {
     return o;
 }
 
-__global__ __launch_bounds__(256) void k_descriptor(const uint8_t *__restrict__ left, const uint8_t *__restrict__ right, size_t in_pair_stride, int stride,
-                                                    uint8_t *__restrict__ desc, Dims d) {
-    const int img = blockIdx.z & 1, pair = blockIdx.z >> 1;
-    const uint8_t *I = (img ? right : left) + (size_t)pair * in_pair_stride;
-    uint8_t *out = desc + ((size_t)(pair * 2 + img) * d.N) * 16;
-    const int x0 = blockIdx.x * DESC_TW, y0 = blockIdx.y * DESC_TH;
-    __shared__ __attribute__((aligned(16))) uint8_t g[(DESC_TH + 6) * DESC_GS];
-    __shared__ __attribute__((aligned(16))) uint8_t sdu[(DESC_TH + 4) * DESC_DS];
-    __shared__ __attribute__((aligned(16))) uint8_t sdv[(DESC_TH + 4) * DESC_DS];
-    const int tid = threadIdx.x;
-    // phase A: gray tile, one word (4 pixels) per item; pixels outside the image read as 0 (they never reach a valid descriptor)
-    for (int i = tid; i < (DESC_TH + 6) * (DESC_GS / 4); i += 256) {
-        const int r = i / (DESC_GS / 4), cw = i - r * (DESC_GS / 4);
-        const int y = y0 - 3 + r, xb = x0 - 4 + 4 * cw;
-        uint32_t w = 0;
-        if (y >= 0 && y < d.H) {
-            const uint8_t *row = I + (size_t)y * stride;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int x = xb + j;
-                if (x >= 0 && x < d.W) w |= (uint32_t)row[x] << (8 * j);
-            }
-        }
-        *reinterpret_cast<uint32_t *>(&g[r * DESC_GS + 4 * cw]) = w;
-    }
-    __syncthreads();
-    // phase B: du/dv, one word (4 pixels) per item.  du/dv row r <-> y = y0-2+r uses gray rows r, r+1, r+2 (y-1, y, y+1);
-    // columns c..c+3 use gray columns c-1..c+4.
-    for (int i = tid; i < (DESC_TH + 4) * (DESC_DS / 4); i += 256) {
-        const int r = i / (DESC_DS / 4), cw = i - r * (DESC_DS / 4);
-        const int c = 4 * cw;
-        uint32_t du_w = 0, dv_w = 0;
-        if (cw >= 0) {
-            // 12 gray bytes per row: words c-4, c, c+4 (clamped inside the tile; the clamped ones only feed unused columns)
-            const int wl = max(c - 4, 0), wr = min(c + 4, DESC_GS - 4);
-            uint32_t a[3][3];
-#pragma unroll
-            for (int rr = 0; rr < 3; rr++) {
-                const uint8_t *gr = &g[(r + rr) * DESC_GS];
-                a[rr][0] = *reinterpret_cast<const uint32_t *>(gr + wl);
-                a[rr][1] = *reinterpret_cast<const uint32_t *>(gr + c);
-                a[rr][2] = *reinterpret_cast<const uint32_t *>(gr + wr);
-            }
-            // column sums for gray columns c-1 .. c+4 (6 columns): S = (1,2,1) vertical, T = (1,0,-1) vertical
-            int S[6], T[6];
-#pragma unroll
-            for (int q = 0; q < 6; q++) {
-                // gray column c-1+q: q=0 -> byte 3 of word 0; q=1..4 -> bytes 0..3 of word 1; q=5 -> byte 0 of word 2
-                int t0, t1, t2;
-                if (q == 0) {
-                    t0 = (a[0][0] >> 24) & 0xFF, t1 = (a[1][0] >> 24) & 0xFF, t2 = (a[2][0] >> 24) & 0xFF;
-                } else if (q == 5) {
-                    t0 = a[0][2] & 0xFF, t1 = a[1][2] & 0xFF, t2 = a[2][2] & 0xFF;
-                } else {
-                    t0 = (a[0][1] >> (8 * (q - 1))) & 0xFF, t1 = (a[1][1] >> (8 * (q - 1))) & 0xFF, t2 = (a[2][1] >> (8 * (q - 1))) & 0xFF;
-                }
-                S[q] = t0 + 2 * t1 + t2;
-                T[q] = t0 - t2;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {  // pixel column c+j: neighbours are S/T index j (x-1), j+1 (x), j+2 (x+1)
-                const int du = sat_u8(((S[j] - S[j + 2]) >> 2) + 128);
-                const int dv = sat_u8(((T[j] + 2 * T[j + 1] + T[j + 2]) >> 2) + 128);
-                du_w |= (uint32_t)du << (8 * j);
-                dv_w |= (uint32_t)dv << (8 * j);
-            }
-        }
-        *reinterpret_cast<uint32_t *>(&sdu[r * DESC_DS + c]) = du_w;
-        *reinterpret_cast<uint32_t *>(&sdv[r * DESC_DS + c]) = dv_w;
-    }
-    __syncthreads();
-    // phase C: each thread assembles the descriptors of 4 consecutive pixels of one row (descriptor.cpp:105-121)
-    const int qx = tid & 15, ry = tid >> 4;  // pixels x0+4qx .. +3, row y0+ry
-    const int y = y0 + ry;  // rows beyond the image compute harmless values that are never stored
-    const int c = 4 + 4 * qx;  // tile column of the quad's first pixel
-    // du rows y-2..y+2 are tile rows ry..ry+4 ; dv rows y-1..y+1 are tile rows ry+1..ry+3
-    const uint8_t *u0 = &sdu[(ry + 0) * DESC_DS + c], *u1 = &sdu[(ry + 1) * DESC_DS + c], *u2 = &sdu[(ry + 2) * DESC_DS + c];
-    const uint8_t *u3 = &sdu[(ry + 3) * DESC_DS + c], *u4 = &sdu[(ry + 4) * DESC_DS + c];
-    const uint8_t *w1 = &sdv[(ry + 1) * DESC_DS + c], *w2 = &sdv[(ry + 2) * DESC_DS + c], *w3 = &sdv[(ry + 3) * DESC_DS + c];
-#define LDW(p, off) (*reinterpret_cast<const uint32_t *>((p) + (off)))
-    const uint32_t r0 = LDW(u0, 0), r4 = LDW(u4, 0);
-    const uint32_t r1a = LDW(u1, -4), r1b = LDW(u1, 0), r1c = LDW(u1, 4);
-    const uint32_t r2a = LDW(u2, -4), r2b = LDW(u2, 0), r2c = LDW(u2, 4);
-    const uint32_t r3a = LDW(u3, -4), r3b = LDW(u3, 0), r3c = LDW(u3, 4);
-    const uint32_t v1 = LDW(w1, 0), v3 = LDW(w3, 0);
-    const uint32_t v2a = LDW(w2, -4), v2b = LDW(w2, 0), v2c = LDW(w2, 4);
-#undef LDW
-    // the four descriptors go to an LDS tile first so that the global stores below are fully coalesced (consecutive lanes ->
-    // consecutive 16-byte descriptors); written straight from here each store instruction would touch 64-byte-strided pieces
-    // Layout: four planes, plane j = pixel j of every quad, [ry][qx] inside a plane.  A ds_write_b128 is serviced in groups of 8
-    // contiguous lanes over 32 banks: the 8 quads of a group are 128 contiguous bytes of one plane = conflict-free (a [row][pixel]
-    // tile puts them 64 B apart: 4-way).  The read-out (ds_read_b128: 16-lane groups {0-3,12-15,20-27}, ... over 64 banks) takes
-    // pixel cx from plane cx & 3, quad cx >> 2; planes 4 slots (64 B) out of step make every group hit 16 distinct 16-byte slots.
-    constexpr int OPLANE = DESC_TH * (DESC_TW / 4) + 4;
-    __shared__ uint4 otile[4 * OPLANE];
-    const DescWin dw{r0, r4, r1a, r1b, r1c, r2a, r2b, r2c, r3a, r3b, r3c, v1, v3, v2a, v2b, v2c};
-    const bool row_ok = y < d.H - 3 && (d.sub ? (y >= 4 && !(y & 1)) : y >= 3);  // descriptor.cpp:48-50: every second line from 4 at half resolution
-    const int xq = x0 + 4 * qx;
-    uint4 *oq = otile + ry * (DESC_TW / 4) + qx;
-    oq[0 * OPLANE] = (row_ok && xq + 0 >= 3 && xq + 0 < d.W - 3) ? desc_assemble<0>(dw) : make_uint4(0, 0, 0, 0);
-    oq[1 * OPLANE] = (row_ok && xq + 1 >= 3 && xq + 1 < d.W - 3) ? desc_assemble<1>(dw) : make_uint4(0, 0, 0, 0);
-    oq[2 * OPLANE] = (row_ok && xq + 2 >= 3 && xq + 2 < d.W - 3) ? desc_assemble<2>(dw) : make_uint4(0, 0, 0, 0);
-    oq[3 * OPLANE] = (row_ok && xq + 3 >= 3 && xq + 3 < d.W - 3) ? desc_assemble<3>(dw) : make_uint4(0, 0, 0, 0);
-    __syncthreads();
-    const int tw = min(DESC_TW, d.W - x0), th = min(DESC_TH, d.H - y0);
-    for (int i = tid; i < th * DESC_TW; i += 256) {
-        const int r = i / DESC_TW, cx = i - r * DESC_TW;
-        if (cx < tw) *reinterpret_cast<uint4 *>(out + ((size_t)(y0 + r) * d.W + x0 + cx) * 16) = otile[(cx & 3) * OPLANE + r * (DESC_TW / 4) + (cx >> 2)];
-    }
+// Gradient planes of one image (k_sobel): DU / DV point at (row 0, column 0)
+struct GradImg {
+    const uint8_t *DU, *DV;
+    int P;
+};
+
+__device__ __forceinline__ GradImg grad_image(const uint8_t *grad, const Dims &d, int pair, int img) {
+    GradImg g;
+    g.P = grad_pitch(d.W);
+    g.DU = grad + ((size_t)(pair * 2 + img) * 2) * grad_plane_bytes(d) + GRAD_MARGIN;
+    g.DV = g.DU + grad_plane_bytes(d);
+    return g;
 }
 
-void launch_descriptor(const KParams &k, const uint8_t *left, const uint8_t *right, size_t in_pair_stride, int stride, const SlotDev &s, int n, hipStream_t st) {
-    dim3 grid((k.d.W + DESC_TW - 1) / DESC_TW, (k.d.H + DESC_TH - 1) / DESC_TH, n * 2);
-    SV_LAUNCH(K_DESCRIPTOR, k_descriptor, grid, dim3(256), 0, st, left, right, in_pair_stride, stride, s.desc, k.d);
+// descriptor.cpp:48-50, 96-98: rows that carry descriptors (every second line from 4 at half resolution)
+__device__ __forceinline__ bool desc_row_ok(const Dims &d, int y) { return y < d.H - 3 && (d.sub ? (y >= 4 && !(y & 1)) : y >= 3); }
+
+// The four descriptors of image columns c .. c+3 (c a multiple of 4) of row y -> out[0..3].  16 aligned word loads from the
+// planes (consecutive lanes = consecutive quads: every load instruction is one contiguous 256-byte piece), 32 v_perm_b32.
+__device__ __forceinline__ void expand_quad(const GradImg &g, const Dims &d, int y, int c, uint4 *out) {
+    if (!desc_row_ok(d, y)) {  // wave-uniform in every caller (one row per workgroup / loop trip)
+        out[0] = out[1] = out[2] = out[3] = make_uint4(0, 0, 0, 0);
+        return;
+    }
+#define LDW(base, row, off) (*reinterpret_cast<const uint32_t *>((base) + (size_t)(row) * g.P + c + (off)))
+    DescWin w;
+    w.r0 = LDW(g.DU, y - 2, 0), w.r4 = LDW(g.DU, y + 2, 0);
+    w.r1a = LDW(g.DU, y - 1, -4), w.r1b = LDW(g.DU, y - 1, 0), w.r1c = LDW(g.DU, y - 1, 4);
+    w.r2a = LDW(g.DU, y, -4), w.r2b = LDW(g.DU, y, 0), w.r2c = LDW(g.DU, y, 4);
+    w.r3a = LDW(g.DU, y + 1, -4), w.r3b = LDW(g.DU, y + 1, 0), w.r3c = LDW(g.DU, y + 1, 4);
+    w.v1 = LDW(g.DV, y - 1, 0), w.v3 = LDW(g.DV, y + 1, 0);
+    w.v2a = LDW(g.DV, y, -4), w.v2b = LDW(g.DV, y, 0), w.v2c = LDW(g.DV, y, 4);
+#undef LDW
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    out[0] = (c + 0 >= 3 && c + 0 < d.W - 3) ? desc_assemble<0>(w) : z;
+    out[1] = (c + 1 >= 3 && c + 1 < d.W - 3) ? desc_assemble<1>(w) : z;
+    out[2] = (c + 2 >= 3 && c + 2 < d.W - 3) ? desc_assemble<2>(w) : z;
+    out[3] = (c + 3 >= 3 && c + 3 < d.W - 3) ? desc_assemble<3>(w) : z;
+}
+
+// sum |byte - 128| over the 16 bytes of the descriptor at (x, y), a valid descriptor position (elas.cpp:296-298): straight from
+// the planes, byte by byte (the lattice points of the support search: a few thousand per pair)
+__device__ __forceinline__ uint32_t texture_at(const GradImg &g, int y, int x) {
+    auto a = [&](const uint8_t *base, int dx, int dy) { return (uint32_t)abs((int)base[(size_t)(y + dy) * g.P + x + dx] - 128); };
+    return a(g.DU, 0, -2) + a(g.DU, -2, -1) + a(g.DU, 0, -1) + a(g.DU, 2, -1) + a(g.DU, -1, 0) + 2u * a(g.DU, 0, 0) + a(g.DU, 1, 0) + a(g.DU, -2, 1) + a(g.DU, 0, 1) +
+           a(g.DU, 2, 1) + a(g.DU, 0, 2) + a(g.DV, 0, -1) + a(g.DV, -1, 0) + a(g.DV, 1, 0) + a(g.DV, 0, 1);
+}
+
+// Debug configuration only: the descriptor images the reference would hold, for the stage snapshot (same expand_quad)
+__global__ __launch_bounds__(256) void k_expand_all(const uint8_t *__restrict__ grad, uint8_t *__restrict__ desc, Dims d) {
+    const int img = blockIdx.z & 1, pair = blockIdx.z >> 1;
+    const int y = blockIdx.y, q = blockIdx.x * 256 + threadIdx.x;
+    if (4 * q >= d.W) return;
+    const GradImg g = grad_image(grad, d, pair, img);
+    uint4 o[4];
+    expand_quad(g, d, y, 4 * q, o);
+    uint4 *out = reinterpret_cast<uint4 *>(desc + ((size_t)(pair * 2 + img) * d.N + (size_t)y * d.W) * 16);
+    for (int j = 0; j < 4; j++)
+        if (4 * q + j < d.W) out[4 * q + j] = o[j];
+}
+
+void launch_expand_debug(const KParams &k, const SlotDev &s, int n, uint8_t *desc, hipStream_t st) {
+    hipLaunchKernelGGL(k_expand_all, dim3((k.d.W / 4 + 256) / 256, k.d.H, n * 2), dim3(256), 0, st, s.grad, desc, k.d);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -340,38 +368,35 @@ __device__ __forceinline__ int support_range(const Dims &d, int u, int v) {
 }
 
 // elas.cpp:296-300 (texture of the centre descriptor), :364 (ratio test)
-__device__ __forceinline__ int support_decide(const KParams &k, const uint4 &centre, uint2 m) {
-    if ((int)texture16(centre) < k.support_texture) return -1;
+__device__ __forceinline__ int support_decide(const KParams &k, uint32_t texture, uint2 m) {
+    if ((int)texture < k.support_texture) return -1;
     const float E1 = (float)(m.x >> 16), E2 = (float)(m.y >> 16);
     return E1 < k.support_threshold * E2 ? (int)(m.x & 0xFFFFu) : -1;
 }
 
 template <bool COUNT>
-__global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, const uint8_t *__restrict__ desc, int16_t *__restrict__ dcan, unsigned long long *__restrict__ counters) {
+__global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, const uint8_t *__restrict__ grad, int16_t *__restrict__ dcan, unsigned long long *__restrict__ counters) {
     const Dims &d = k.d;
     extern __shared__ uint4 sup_lds[];
     const int pair = blockIdx.z, vc = blockIdx.y + 1;
     const int uc0 = 1 + blockIdx.x * SUP_POINTS, uc1 = min(uc0 + SUP_POINTS, d.Wc);  // candidates [uc0, uc1)
     const int v = vc * d.step;
-    const uint8_t *d1 = desc + ((size_t)(pair * 2) * d.N) * 16, *d2 = d1 + (size_t)d.N * 16;
+    const GradImg g1 = grad_image(grad, d, pair, 0), g2 = grad_image(grad, d, pair, 1);
     const int u_lo = uc0 * d.step, u_hi = (uc1 - 1) * d.step;
-    // staged column ranges, clipped to the image
-    const int r_c0 = max(u_lo - 2 - d.disp_max, 0), r_c1 = min(u_hi + 2, d.W - 1);
-    const int l_c0 = max(u_lo - 2 - d.disp_max, 0), l_c1 = min(u_hi + 2 + d.disp_max, d.W - 1);
-    const int nR = r_c1 - r_c0 + 1, nL = l_c1 - l_c0 + 1;
+    // staged column ranges, clipped to the image; they start on a multiple of 4: descriptors are assembled four columns at a time
+    const int r_c0 = max(u_lo - 2 - d.disp_max, 0) & ~3, r_c1 = min(u_hi + 2, d.W - 1);
+    const int l_c0 = max(u_lo - 2 - d.disp_max, 0) & ~3, l_c1 = min(u_hi + 2 + d.disp_max, d.W - 1);
+    const int qR = (r_c1 - r_c0 + 4) >> 2, qL = (l_c1 - l_c0 + 4) >> 2;  // quads per staged row
+    const int nR = 4 * qR, nL = 4 * qL;
     uint2 *rec = reinterpret_cast<uint2 *>(sup_lds);  // [2 passes][SUP_SPLIT][SUP_POINTS]
     uint4 *sR0 = sup_lds + 2 * SUP_THREADS * sizeof(uint2) / sizeof(uint4), *sR1 = sR0 + nR, *sL0 = sR1 + nR, *sL1 = sL0 + nL;
-    if (v - 2 >= 0 && v + 2 < d.H) {
-        const uint4 *gR = reinterpret_cast<const uint4 *>(d2) + (size_t)v * d.W + r_c0, *gL = reinterpret_cast<const uint4 *>(d1) + (size_t)v * d.W + l_c0;
-        const long up = -2L * d.W, dn = 2L * d.W;
-        for (int i = threadIdx.x; i < nR; i += SUP_THREADS) {
-            sR0[i] = gR[up + i];
-            sR1[i] = gR[dn + i];
-        }
-        for (int i = threadIdx.x; i < nL; i += SUP_THREADS) {
-            sL0[i] = gL[up + i];
-            sL1[i] = gL[dn + i];
-        }
+    // rows v-2 and v+2 of both descriptor images, assembled from the gradient planes (rows without descriptors come out as zeros)
+    for (int i = threadIdx.x; i < 2 * (qR + qL); i += SUP_THREADS) {
+        const int row = i & 1, q = i >> 1;  // consecutive lanes alternate between the two rows of one quad column
+        if (q < qR)
+            expand_quad(g2, d, row ? v + 2 : v - 2, r_c0 + 4 * q, (row ? sR1 : sR0) + 4 * q);
+        else
+            expand_quad(g1, d, row ? v + 2 : v - 2, l_c0 + 4 * (q - qR), (row ? sL1 : sL0) + 4 * (q - qR));
     }
     __syncthreads();
     const SupRows L{sL0, sL1, l_c0}, R{sR0, sR1, r_c0};
@@ -380,17 +405,17 @@ __global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, const uint8_
     const int qlen = (d.disp_max + SUP_SPLIT) / SUP_SPLIT, d_lo = part * qlen;  // this wavefront's share of [0, disp_max]
     // left -> right
     const int dmax1 = uc < uc1 ? support_range<false>(d, u, v) : -1;
-    uint4 centre = make_uint4(0, 0, 0, 0);
-    if (dmax1 >= 0) centre = ld16(d1 + ((size_t)v * d.W + u) * 16);  // used after the search: its latency hides behind it
+    uint32_t texture = 0;  // of the centre descriptor (elas.cpp:296-300)
+    if (dmax1 >= 0) texture = texture_at(g1, v, u);  // used after the search: its latency hides behind it
     uint32_t k1 = SUP_KEY_NONE, k2 = SUP_KEY_NONE;
     if (d_lo <= dmax1) support_scan<false>(L, R, u, d_lo, min(dmax1, d_lo + qlen - 1), k1, k2);
     rec[threadIdx.x] = make_uint2(k1, k2);
     __syncthreads();
-    const int dd = dmax1 >= 0 ? support_decide(k, centre, support_merge(rec, point)) : -1;
+    const int dd = dmax1 >= 0 ? support_decide(k, texture, support_merge(rec, point)) : -1;
     // right -> left from the match (elas.cpp:404-409)
     const int u2 = u - dd;
     const int dmax2 = dd >= 0 ? support_range<true>(d, u2, v) : -1;
-    if (dmax2 >= 0 && part == 0) centre = ld16(d2 + ((size_t)v * d.W + u2) * 16);
+    if (dmax2 >= 0 && part == 0) texture = texture_at(g2, v, u2);
     k1 = k2 = SUP_KEY_NONE;
     if (d_lo <= dmax2) support_scan<true>(R, L, u2, d_lo, min(dmax2, d_lo + qlen - 1), k1, k2);
     rec[SUP_THREADS + threadIdx.x] = make_uint2(k1, k2);
@@ -398,7 +423,7 @@ __global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, const uint8_
         count_add(counters + CNT_SUPPORT_ENERGIES, (d_lo <= dmax1 ? min(dmax1, d_lo + qlen - 1) - d_lo + 1 : 0) + (d_lo <= dmax2 ? min(dmax2, d_lo + qlen - 1) - d_lo + 1 : 0));
     __syncthreads();
     if (part == 0 && uc < uc1) {
-        const int d2v = dmax2 >= 0 ? support_decide(k, centre, support_merge(rec + SUP_THREADS, point)) : -1;
+        const int d2v = dmax2 >= 0 ? support_decide(k, texture, support_merge(rec + SUP_THREADS, point)) : -1;
         const int res = (d2v >= 0 && abs(dd - d2v) <= k.lr_threshold) ? dd : -1;
         int16_t *lat = dcan + (size_t)pair * d.Wc * d.Hc;
         lat[(size_t)uc * d.Hc + vc] = (int16_t)res;  // transposed: the host filters scan u outer / v inner
@@ -416,16 +441,17 @@ void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
         return;
     }
     const int span = (SUP_POINTS - 1) * k.d.step;
-    const size_t shmem = 2 * SUP_THREADS * sizeof(uint2) + sizeof(uint4) * 2 * ((size_t)(span + k.d.disp_max + 5) + (size_t)(span + 2 * k.d.disp_max + 5));
+    // two rows per image; each staged range starts up to 3 columns early and ends on a whole quad
+    const size_t shmem = 2 * SUP_THREADS * sizeof(uint2) + sizeof(uint4) * 2 * ((size_t)(span + k.d.disp_max + 5 + 6) + (size_t)(span + 2 * k.d.disp_max + 5 + 6));
     static std::atomic<size_t> granted[64], granted_c[64];
     dim3 grid((k.d.Wc - 1 + SUP_POINTS - 1) / SUP_POINTS, k.d.Hc - 1, n);
     if (s.counters) {
         ensure_dynamic_lds(k_support<true>, shmem, granted_c, "support_match");
-        SV_LAUNCH(K_SUPPORT, k_support<true>, grid, dim3(SUP_THREADS), shmem, st, k, s.desc, s.dcan, s.counters);
+        SV_LAUNCH(K_SUPPORT, k_support<true>, grid, dim3(SUP_THREADS), shmem, st, k, s.grad, s.dcan, s.counters);
         return;
     }
     ensure_dynamic_lds(k_support<false>, shmem, granted, "support_match");  // large disparity ranges: more than the default dynamic LDS limit
-    SV_LAUNCH(K_SUPPORT, k_support<false>, grid, dim3(SUP_THREADS), shmem, st, k, s.desc, s.dcan, s.counters);
+    SV_LAUNCH(K_SUPPORT, k_support<false>, grid, dim3(SUP_THREADS), shmem, st, k, s.grad, s.dcan, s.counters);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1290,8 +1316,12 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
     return best < (10000 << 16) ? (float)(best & 0x7FFF) : -1.0f;  // :797-800 (min_val starts at 10000, :752)
 }
 
+// descriptors staged per image: DENSE_TW own columns + disp_max candidates beyond them, rounded so that the right image's
+// segment may start up to 3 columns early
+__host__ __device__ inline int dense_seg(const Dims &d) { return DENSE_TW + ((d.disp_max + 3) & ~3); }
+
 template <bool COUNT, int MWT, int RT>
-__global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const uint8_t *__restrict__ desc, const int32_t *__restrict__ blob, const int32_t *__restrict__ tri_id,
+__global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const uint8_t *__restrict__ grad, const int32_t *__restrict__ blob, const int32_t *__restrict__ tri_id,
                                                const float4 *__restrict__ trirec, const uint32_t *__restrict__ gB, int16_t *__restrict__ wta,
                                                unsigned long long *__restrict__ counters) {
     const Dims &d = k.d;
@@ -1301,15 +1331,21 @@ __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const
     if (blob[pair * META_WORDS] < 3) return;
     const int x0 = blockIdx.x * DENSE_TW, v = d.sub ? 2 * blockIdx.y : blockIdx.y;  // half resolution: even rows only (elas.cpp:919)
     const int x1 = min(x0 + DENSE_TW, d.W);  // tile columns [x0, x1)
-    const size_t line = (size_t)d.W * max(min(v, d.H - 3), 2);  // elas.cpp:718: descriptor row, clamped
-    const uint4 *gL = reinterpret_cast<const uint4 *>(desc + ((size_t)(pair * 2) * d.N) * 16) + line;
-    const uint4 *gR = gL + (size_t)d.N;
-    // staged column ranges
-    const int l0 = x0, l1 = min(x1 - 1 + d.disp_max, d.W - 1);   // left image  [l0, l1]
-    const int r0 = max(x0 - d.disp_max, 0), r1 = x1 - 1;         // right image [r0, r1]
-    uint4 *sL = dense_lds, *sR = dense_lds + (DENSE_TW + d.disp_max);
-    for (int i = threadIdx.x; i <= l1 - l0; i += 256) sL[i] = gL[l0 + i];
-    for (int i = threadIdx.x; i <= r1 - r0; i += 256) sR[i] = gR[r0 + i];
+    const int yd = max(min(v, d.H - 3), 2);  // elas.cpp:718: descriptor row, clamped (rows 2 and H-3 hold no descriptors: zeros)
+    // staged column ranges; both start on a multiple of 4 (x0 is one): descriptors are assembled four columns at a time
+    const int l0 = x0, l1 = min(x1 - 1 + d.disp_max, d.W - 1);         // left image  [l0, l1]
+    const int r0 = max(x0 - d.disp_max, 0) & ~3, r1 = x1 - 1;          // right image [r0, r1]
+    const int qL = (l1 - l0 + 4) >> 2, qR = (r1 - r0 + 4) >> 2;        // quads per image
+    uint4 *sL = dense_lds, *sR = dense_lds + dense_seg(d);
+    {
+        const GradImg gL = grad_image(grad, d, pair, 0), gR = grad_image(grad, d, pair, 1);
+        for (int q = threadIdx.x; q < qL + qR; q += 256) {
+            if (q < qL)
+                expand_quad(gL, d, yd, l0 + 4 * q, sL + 4 * q);
+            else
+                expand_quad(gR, d, yd, r0 + 4 * (q - qL), sR + 4 * (q - qL));
+        }
+    }
     // per-pixel global operands of this thread's pixels (two per side), requested before the barrier
     int tt[2][DENSE_TW / 256];
 #pragma unroll
@@ -1377,13 +1413,13 @@ __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const
     }
 }
 
-static size_t dense_lds_bytes(const KParams &k) { return sizeof(uint4) * 2 * (size_t)(DENSE_TW + k.d.disp_max); }
+static size_t dense_lds_bytes(const KParams &k) { return sizeof(uint4) * 2 * (size_t)dense_seg(k.d); }
 
 template <int MWT, int RT>
 static void launch_dense_as(const KParams &k, const SlotDev &s, const dim3 &grid, size_t shmem, hipStream_t st) {
     static std::atomic<size_t> granted[64];
     ensure_dynamic_lds(k_dense<false, MWT, RT>, shmem, granted, "dense_match");
-    SV_LAUNCH(K_DENSE, (k_dense<false, MWT, RT>), grid, dim3(256), shmem, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
+    SV_LAUNCH(K_DENSE, (k_dense<false, MWT, RT>), grid, dim3(256), shmem, st, k, s.grad, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
 }
 
 void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
@@ -1392,7 +1428,7 @@ void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
     if (s.counters) {
         static std::atomic<size_t> granted_c[64];
         ensure_dynamic_lds(k_dense<true, 0, 0>, shmem, granted_c, "dense_match");
-        SV_LAUNCH(K_DENSE, (k_dense<true, 0, 0>), grid, dim3(256), shmem, st, k, s.desc, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
+        SV_LAUNCH(K_DENSE, (k_dense<true, 0, 0>), grid, dim3(256), shmem, st, k, s.grad, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
         return;
     }
     // the usual disparity ranges (64 / 128 / 192 / 256) with the presets' plane radii (2: ROBOTICS, 3: MIDDLEBURY) get kernels

@@ -46,7 +46,8 @@ constexpr int META_WORDS = 8;
 
 struct SlotDev {
     int cap;
-    uint8_t *desc;      // [cap][2][N][16]   descriptors, image 0 = left, 1 = right
+    uint8_t *grad;      // [cap][2][2][H][P] Sobel gradient planes (image 0 = left, 1 = right; du, dv; padded rows, kernels.hip) -
+                        //                   the 16-byte descriptors are assembled from them in LDS, never stored
     int16_t *dcan;      // [cap][Wc][Hc]     raw support lattice, TRANSPOSED (u major) for the host filters
     int32_t *fsup;      // [cap][max_pts][3] support points from the on-GPU lattice filter (when it is used)
     int32_t *fnsup;     // [cap]
@@ -74,7 +75,9 @@ struct SlotDev {
 enum CounterId { CNT_DENSE_CANDIDATES = 0, CNT_DENSE_PIXELS, CNT_SUPPORT_ENERGIES, CNT_DENSE_BAND_FULL, CNT_DENSE_BAND_PART, CNT_DENSE_BAND_SLOW, CNT_DENSE_GRID_WAVE_TRIPS, CNT_DENSE_GRID_LANE_TRIPS, CNT_COUNT = 8 };
 
 // ---- launch wrappers (kernels.hip).  `n` = pairs in this launch; `nproc` = maps per pair to post-process (1 or 2).
-void launch_descriptor(const KParams &k, const uint8_t *left, const uint8_t *right, size_t in_pair_stride, int stride, const SlotDev &s, int n, hipStream_t st);
+void launch_sobel(const KParams &k, const uint8_t *left, const uint8_t *right, size_t in_pair_stride, int stride, const SlotDev &s, int n, hipStream_t st);
+size_t grad_bytes_per_pair(const KParams &k);
+void launch_expand_debug(const KParams &k, const SlotDev &s, int n, uint8_t *desc, hipStream_t st);  // debug: the descriptor images for the stage snapshot
 void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st);
 size_t support_filter_ws_bytes(const KParams &k, int cap);
 size_t ccl_ws_bytes(const KParams &k, int maps_cap);
