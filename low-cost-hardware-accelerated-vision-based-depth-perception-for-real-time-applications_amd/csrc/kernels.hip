@@ -85,10 +85,14 @@ __device__ __forceinline__ int sat_u8(int x) { return x < 0 ? 0 : (x > 255 ? 255
 __host__ __device__ inline int grad_pitch(int W) { return ((W + 15) & ~15) + 2 * GRAD_MARGIN; }
 __host__ __device__ inline size_t grad_plane_bytes(const Dims &d) { return (size_t)d.H * grad_pitch(d.W); }
 
-// LDS tile of k_sobel: byte image with word-aligned rows; tile column c <-> image column x0 - 4 + c
-#define SOB_TW 64   // output tile width
-#define SOB_TH 16   // output tile height
-#define SOB_GS 72   // gray tile row stride in bytes (18 words) : rows y0-1 .. y0+TH, columns x0-4 .. x0+67
+// LDS tile of k_sobel: gray words, tile column word cw <-> image columns x0 - 4 + 4*cw .. +3
+#define SOB_TW 256                 // output tile width: one wavefront = one row of 64 words
+#define SOB_TH 16                  // output tile height: four rows per wavefront
+#define SOB_GW (SOB_TW / 4 + 2)    // gray words per tile row: columns x0-4 .. x0+SOB_TW+3; rows y0-1 .. y0+SOB_TH
+
+struct __attribute__((packed)) UnalignedWord {  // caller's image rows have any alignment (stride 1242): one unaligned dword load
+    uint32_t v;
+};
 
 __global__ __launch_bounds__(256) void k_sobel(const uint8_t *__restrict__ left, const uint8_t *__restrict__ right, size_t in_pair_stride, int stride,
                                                uint8_t *__restrict__ grad, Dims d) {
@@ -97,61 +101,69 @@ __global__ __launch_bounds__(256) void k_sobel(const uint8_t *__restrict__ left,
     const int P = grad_pitch(d.W);
     uint8_t *DU = grad + ((size_t)(pair * 2 + img) * 2) * grad_plane_bytes(d) + GRAD_MARGIN, *DV = DU + grad_plane_bytes(d);
     const int x0 = blockIdx.x * SOB_TW, y0 = blockIdx.y * SOB_TH;
-    __shared__ __attribute__((aligned(16))) uint8_t g[(SOB_TH + 2) * SOB_GS];
+    __shared__ uint32_t g[(SOB_TH + 2) * SOB_GW];
     const int tid = threadIdx.x;
     // gray tile, one word (4 pixels) per item; pixels outside the image read as 0 (they never reach a valid descriptor)
-    for (int i = tid; i < (SOB_TH + 2) * (SOB_GS / 4); i += 256) {
-        const int r = i / (SOB_GS / 4), cw = i - r * (SOB_GS / 4);
+    for (int i = tid; i < (SOB_TH + 2) * SOB_GW; i += 256) {
+        const int r = i / SOB_GW, cw = i - r * SOB_GW;
         const int y = y0 - 1 + r, xb = x0 - 4 + 4 * cw;
         uint32_t w = 0;
         if (y >= 0 && y < d.H) {
             const uint8_t *row = I + (size_t)y * stride;
+            if (xb >= 0 && xb + 3 < d.W) {
+                w = reinterpret_cast<const UnalignedWord *>(row + xb)->v;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int x = xb + j;
-                if (x >= 0 && x < d.W) w |= (uint32_t)row[x] << (8 * j);
+                for (int j = 0; j < 4; j++) {
+                    const int x = xb + j;
+                    if (x >= 0 && x < d.W) w |= (uint32_t)row[x] << (8 * j);
+                }
             }
         }
-        *reinterpret_cast<uint32_t *>(&g[r * SOB_GS + 4 * cw]) = w;
+        g[i] = w;
     }
     __syncthreads();
-    // one thread = 4 pixels of one row: gray rows r, r+1, r+2 of the tile (y-1, y, y+1), gray columns c-1 .. c+4
-    const int r = tid >> 4, cw = 1 + (tid & 15), c = 4 * cw;
-    const int y = y0 + r, x = x0 + 4 * (tid & 15);
-    uint32_t a[3][3];
+    // one thread = 4 pixels (one word) of a row: gray rows r, r+1, r+2 of the tile (y-1, y, y+1), gray columns c-1 .. c+4
+    const int wq = tid & 63;
 #pragma unroll
-    for (int rr = 0; rr < 3; rr++) {
-        const uint8_t *gr = &g[(r + rr) * SOB_GS];
-        a[rr][0] = *reinterpret_cast<const uint32_t *>(gr + c - 4);
-        a[rr][1] = *reinterpret_cast<const uint32_t *>(gr + c);
-        a[rr][2] = *reinterpret_cast<const uint32_t *>(gr + c + 4);
-    }
-    // column sums for gray columns c-1 .. c+4 (6 columns): S = (1,2,1) vertical, T = (1,0,-1) vertical
-    int S[6], T[6];
+    for (int kk = 0; kk < SOB_TH / 4; kk++) {
+        const int r = (tid >> 6) + 4 * kk;
+        const int y = y0 + r, x = x0 + 4 * wq;
+        uint32_t a[3][3];
 #pragma unroll
-    for (int q = 0; q < 6; q++) {
-        int t0, t1, t2;
-        if (q == 0) {
-            t0 = (a[0][0] >> 24) & 0xFF, t1 = (a[1][0] >> 24) & 0xFF, t2 = (a[2][0] >> 24) & 0xFF;
-        } else if (q == 5) {
-            t0 = a[0][2] & 0xFF, t1 = a[1][2] & 0xFF, t2 = a[2][2] & 0xFF;
-        } else {
-            t0 = (a[0][1] >> (8 * (q - 1))) & 0xFF, t1 = (a[1][1] >> (8 * (q - 1))) & 0xFF, t2 = (a[2][1] >> (8 * (q - 1))) & 0xFF;
+        for (int rr = 0; rr < 3; rr++) {
+            const uint32_t *gr = &g[(r + rr) * SOB_GW + wq];
+            a[rr][0] = gr[0];
+            a[rr][1] = gr[1];
+            a[rr][2] = gr[2];
         }
-        S[q] = t0 + 2 * t1 + t2;
-        T[q] = t0 - t2;
-    }
-    uint32_t du_w = 0, dv_w = 0;
+        // column sums for gray columns c-1 .. c+4 (6 columns): S = (1,2,1) vertical, T = (1,0,-1) vertical
+        int S[6], T[6];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {  // pixel column c+j: neighbours are S/T index j (x-1), j+1 (x), j+2 (x+1)
-        const int du = sat_u8(((S[j] - S[j + 2]) >> 2) + 128);
-        const int dv = sat_u8(((T[j] + 2 * T[j + 1] + T[j + 2]) >> 2) + 128);
-        du_w |= (uint32_t)du << (8 * j);
-        dv_w |= (uint32_t)dv << (8 * j);
-    }
-    if (y < d.H && x < ((d.W + 3) & ~3)) {  // whole words: the bytes beyond W land in the row's right margin and are never used
-        *reinterpret_cast<uint32_t *>(DU + (size_t)y * P + x) = du_w;
-        *reinterpret_cast<uint32_t *>(DV + (size_t)y * P + x) = dv_w;
+        for (int q = 0; q < 6; q++) {
+            int t0, t1, t2;
+            if (q == 0) {
+                t0 = (a[0][0] >> 24) & 0xFF, t1 = (a[1][0] >> 24) & 0xFF, t2 = (a[2][0] >> 24) & 0xFF;
+            } else if (q == 5) {
+                t0 = a[0][2] & 0xFF, t1 = a[1][2] & 0xFF, t2 = a[2][2] & 0xFF;
+            } else {
+                t0 = (a[0][1] >> (8 * (q - 1))) & 0xFF, t1 = (a[1][1] >> (8 * (q - 1))) & 0xFF, t2 = (a[2][1] >> (8 * (q - 1))) & 0xFF;
+            }
+            S[q] = t0 + 2 * t1 + t2;
+            T[q] = t0 - t2;
+        }
+        uint32_t du_w = 0, dv_w = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {  // pixel column c+j: neighbours are S/T index j (x-1), j+1 (x), j+2 (x+1)
+            const int du = sat_u8(((S[j] - S[j + 2]) >> 2) + 128);
+            const int dv = sat_u8(((T[j] + 2 * T[j + 1] + T[j + 2]) >> 2) + 128);
+            du_w |= (uint32_t)du << (8 * j);
+            dv_w |= (uint32_t)dv << (8 * j);
+        }
+        if (y < d.H && x < ((d.W + 3) & ~3)) {  // whole words: the bytes beyond W land in the row's right margin and are never used
+            *reinterpret_cast<uint32_t *>(DU + (size_t)y * P + x) = du_w;
+            *reinterpret_cast<uint32_t *>(DV + (size_t)y * P + x) = dv_w;
+        }
     }
 }
 
