@@ -71,7 +71,7 @@ def algorithmic_bytes_8d(N):
     credit for redundant passes or materialised intermediates (descriptors, triangle ids, labels beyond the 8N the survey
     grants).  N = W*H of the map the stage works on.  Sum = 88N + the 2N the descriptor kernel's own gray read adds."""
     return {
-        "descriptor": 2 * N,                 # gray L,R in (the 16 B/px descriptors it writes are an intermediate: no credit)
+        "descriptor": 2 * N,                 # k_sobel: gray L,R in (the gradient planes it writes are an intermediate: no credit)
         "support_match": 2 * N,              # "support 2N (gray L,R)"
         "dense_match": 2 * N + 8 * N,        # "dense 2N read + 8N write (D1,D2 f32)"
         "lr_check": 8 * N + 4 * N,           # "LR 8N read + 4N write"
@@ -83,16 +83,16 @@ def algorithmic_bytes_8d(N):
 
 
 def interface_bytes_per_pair(N, Wc, Hc, Wimg, MW, ncell):
-    """HBM bytes each kernel must move for ONE pair given the buffers it is handed (materialised descriptors, triangle ids,
-    int16 WTA maps): what an ideal implementation of THIS kernel interface would move.  Reported as frac_interface."""
-    desc = 16 * N
+    """HBM bytes each kernel must move for ONE pair given the buffers it is handed (du/dv gradient planes of 2 B/px per image,
+    triangle ids, int16 WTA maps): what an ideal implementation of THIS kernel interface would move.  Reported as frac_interface."""
+    grad = 2 * N  # du + dv byte planes of one image
     return {
-        "descriptor": 2 * N + 2 * desc,
-        "support_match": 2 * (2 * (Hc - 1)) * Wimg * 16 + 2 * Wc * Hc,
+        "descriptor": 2 * N + 2 * grad,                      # k_sobel: gray L,R in, gradient planes out
+        "support_match": 2 * grad + 2 * Wc * Hc,             # both images' planes (every row is used by some lattice row), lattice out
         "support_filter": 2 * Wc * Hc + 12 * 2200,
         "grid_mark": 0, "grid_dilate": 2 * 2 * ncell * MW * 4, "plane_fit": 0,
         "triangles_raster": 2 * 4 * N, "triangles_raster_fallback": 0,
-        "dense_match": 2 * desc + 2 * 4 * N + 2 * 2 * N,
+        "dense_match": 2 * grad + 2 * 4 * N + 2 * 2 * N,     # planes, triangle ids in; int16 WTA maps out
         "lr_check": 2 * 2 * N + 2 * 4 * N,
         "delaunay_gpu": 2 * (16 * 2200 + 12 * 4400),
         "ccl_band": 4 * N, "ccl_finish": 0,
@@ -527,7 +527,7 @@ def main():
                 "bound": "hbm", "kernel": dom, "dominant_by_time": dom,
                 "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                 "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_pair": a8, "algorithmic_bytes_per_launch": int(a8 * ppl), "bytes_definition": "SURVEY.md 8(d) stage minimum (dense = 2N read + 8N write); no credit for materialised descriptors",
+                "algorithmic_bytes_per_pair": a8, "algorithmic_bytes_per_launch": int(a8 * ppl), "bytes_definition": "SURVEY.md 8(d) stage minimum (dense = 2N read + 8N write); no credit for intermediates (gradient planes, triangle ids)",
                 "avg_launch_us": round(1e6 * avg_s, 2), "pairs_per_launch": ppl, "duration_source": "HIP events on the launching stream, timed region (kernels of other streams overlap)",
                 "serial": {"avg_launch_us": round(1e6 * s_avg_s, 2), "pairs_per_launch": s_ppl, "achieved": round(s_achieved, 2), "frac": round(s_achieved / HBM_PEAK_GBS, 5),
                            "duration_source": "HIP events, one slot / one stream pass of this run (no kernel overlap)"},

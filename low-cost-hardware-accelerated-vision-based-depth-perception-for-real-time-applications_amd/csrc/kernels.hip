@@ -1060,6 +1060,16 @@ __device__ __forceinline__ int group16_min(int v) {
     for (int off = 8; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 16));
     return v;
 }
+__device__ __forceinline__ int group8_min(int v) {
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 8));
+    return v;
+}
+__device__ __forceinline__ int group8_max(int v) {
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 8));
+    return v;
+}
 __device__ __forceinline__ int group16_max(int v) {
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 16));
@@ -1080,33 +1090,31 @@ __global__ __launch_bounds__(256) void k_raster_tiles(KParams k, const int32_t *
     const bool ovf = tile_ovf[pair * 2 + side] != 0;  // overflow somewhere in this map: k_raster (global atomics) does the work
     const size_t gt = (size_t)(pair * 2 + side) * gridDim.x + blockIdx.x;
     const int cnt = ovf ? 0 : tile_cnt[gt];
-    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    // 8 lanes per triangle (a lattice triangle is ~5 columns wide), one lane per column of [A_u, C_u): the edge below / above
+    // the long edge AC is AB left of B_u and BC from B_u on (elas.cpp:913-925 and :928-940 are the two halves of this range)
+    const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
     const int x_end = min(tx0 + RT_W, d.W), y_end = min(ty0 + RT_H, d.H);
-    for (int i = grp; i < cnt; i += 16) {  // whole 16-lane groups walk the list together
+    for (int i = grp; i < cnt; i += 32) {  // whole 8-lane groups walk the list together
         const int t = tile_list[gt * RT_CAP + i];
         const RasterRec r = rrec[(size_t)(pair * 2 + side) * d.max_tri + t];
-#pragma unroll
-        for (int part = 0; part < 2; part++) {  // :913-925 (A->B, lines AC and AB) and :928-940 (B->C, lines AC and BC)
-            const int ua = part == 0 ? r.a_u : r.b_u, ub = part == 0 ? r.b_u : r.c_u;
-            if (ua == ub) continue;
-            const float e_a = part == 0 ? r.ab_a : r.bc_a, e_b = part == 0 ? r.ab_b : r.bc_b;
-            const int u_begin = max(max(ua, 0), tx0), u_end = min(min(ub, d.W), x_end);
-            for (int base = u_begin; base < u_end; base += 16) {
-                const int u = base + sub;
-                int lo = 0x7FFFFFFF, hi = -0x7FFFFFFF;
-                if (u < u_end) {
-                    const int v_1 = (int)(r.ac_a * (float)u + r.ac_b), v_2 = (int)(e_a * (float)u + e_b);
-                    lo = max(max(min(v_1, v_2), 0), ty0);
-                    hi = min(min(max(v_1, v_2), d.H), y_end);
-                    if (lo >= hi) {
-                        lo = 0x7FFFFFFF;
-                        hi = -0x7FFFFFFF;
-                    }
+        const int u_begin = max(max(r.a_u, 0), tx0), u_end = min(min(r.c_u, d.W), x_end);
+        for (int base = u_begin; base < u_end; base += 8) {
+            const int u = base + sub;
+            int lo = 0x7FFFFFFF, hi = -0x7FFFFFFF;
+            if (u < u_end) {
+                const bool second = u >= r.b_u;
+                const float e_a = second ? r.bc_a : r.ab_a, e_b = second ? r.bc_b : r.ab_b;
+                const int v_1 = (int)(r.ac_a * (float)u + r.ac_b), v_2 = (int)(e_a * (float)u + e_b);
+                lo = max(max(min(v_1, v_2), 0), ty0);
+                hi = min(min(max(v_1, v_2), d.H), y_end);
+                if (lo >= hi) {
+                    lo = 0x7FFFFFFF;
+                    hi = -0x7FFFFFFF;
                 }
-                const int glo = group16_min(lo), ghi = group16_max(hi);
-                for (int v = glo; v < ghi; v++)
-                    if (v >= lo && v < hi) atomicMax(&tile[v - ty0][u - tx0], t);
             }
+            const int glo = group8_min(lo), ghi = group8_max(hi);
+            for (int v = glo; v < ghi; v++)
+                if (v >= lo && v < hi) atomicMax(&tile[v - ty0][u - tx0], t);
         }
     }
     __syncthreads();
