@@ -965,7 +965,19 @@ __global__ __launch_bounds__(256) void k_planes(KParams k, const int32_t *__rest
     const int pair = blockIdx.z, side = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int32_t *meta = blob + pair * META_WORDS;
-    if (meta[0] < 3 || t >= meta[2 + 2 * side]) return;
+    if (meta[0] < 3) return;  // (the whole workgroup)
+    // Tile binning goes through the workgroup: counted per tile in LDS, one global atomic per (workgroup, tile) reserves the
+    // list slots, ranks inside the reservation again from LDS.  A workgroup's 256 consecutive triangles fall into a handful of
+    // tiles; with one global atomic per (triangle, tile) the ~200 increments per tile counter queued up at the L2 and the binning
+    // took twice as long as the two f64 solves (43 of the kernel's 64 us per 32-pair launch).
+    extern __shared__ int32_t pl_lds[];  // [2][ntile]: counts / ranks, reserved bases
+    const int ntx = (d.W + RT_W - 1) / RT_W, nty = (d.H + RT_H - 1) / RT_H, ntile = ntx * nty;
+    int32_t *s_cnt = pl_lds, *s_base = pl_lds + ntile;
+    for (int i = threadIdx.x; i < ntile; i += 256) s_cnt[i] = 0;
+    __syncthreads();
+    const bool active = t < meta[2 + 2 * side];
+    int ub = 0, ue = 0, vb = 0, ve = 0;  // the triangle's tile footprint (empty for idle threads)
+    if (active) {
     const size_t tbase = ((size_t)(pair * 2 + side) * d.max_tri + t);
     const int32_t *tc = blob + meta[3 + 2 * side] + (size_t)t * 3;
     const int32_t *support = blob + meta[1];
@@ -1035,22 +1047,31 @@ __global__ __launch_bounds__(256) void k_planes(KParams k, const int32_t *__rest
     r.bc_b = B_v - BC_a * B_u;
     rrec[tbase] = r;
     // bin into tiles: columns [max(A_u,0), min(C_u,W)), rows between the corners' v (+-1 for the float->int truncations)
-    const int ub = max(r.a_u, 0), ue = min(r.c_u, d.W);
+    ub = max(r.a_u, 0), ue = min(r.c_u, d.W);
     const float vlo = fminf(fminf(A_v, B_v), C_v), vhi = fmaxf(fmaxf(A_v, B_v), C_v);
-    const int vb = max((int)vlo - 1, 0), ve = min((int)vhi + 2, d.H);  // rows [vb, ve)
-    if (ub < ue && vb < ve) {
-        const int ntx = (d.W + RT_W - 1) / RT_W, nty = (d.H + RT_H - 1) / RT_H;
-        const size_t tb = (size_t)(pair * 2 + side) * ntx * nty;
-        for (int ty = vb / RT_H; ty <= (ve - 1) / RT_H; ty++)
-            for (int tx = ub / RT_W; tx <= (ue - 1) / RT_W; tx++) {
-                const size_t tile = tb + (size_t)ty * ntx + tx;
-                const int slot = atomicAdd(&tile_cnt[tile], 1);
-                if (slot < k.rt_cap)
-                    tile_list[tile * RT_CAP + slot] = t;
-                else
-                    tile_ovf[pair * 2 + side] = 1;
-            }
+    vb = max((int)vlo - 1, 0), ve = min((int)vhi + 2, d.H);  // rows [vb, ve)
     }
+    const bool bins = ub < ue && vb < ve;
+    const int tx_lo = ub / RT_W, tx_hi = bins ? (ue - 1) / RT_W : -1, ty_lo = vb / RT_H, ty_hi = bins ? (ve - 1) / RT_H : -1;
+    for (int ty = ty_lo; ty <= ty_hi; ty++)
+        for (int tx = tx_lo; tx <= tx_hi; tx++) atomicAdd(&s_cnt[ty * ntx + tx], 1);
+    __syncthreads();
+    const size_t tb = (size_t)(pair * 2 + side) * ntile;
+    for (int i = threadIdx.x; i < ntile; i += 256) {
+        const int c = s_cnt[i];
+        if (c > 0) s_base[i] = atomicAdd(&tile_cnt[tb + i], c);
+        s_cnt[i] = 0;
+    }
+    __syncthreads();
+    for (int ty = ty_lo; ty <= ty_hi; ty++)
+        for (int tx = tx_lo; tx <= tx_hi; tx++) {
+            const int tile = ty * ntx + tx;
+            const int slot = s_base[tile] + atomicAdd(&s_cnt[tile], 1);
+            if (slot < k.rt_cap)
+                tile_list[(tb + tile) * RT_CAP + slot] = t;
+            else
+                tile_ovf[pair * 2 + side] = 1;
+        }
 }
 
 // Scan conversion (elas.cpp:912-940): 16 lanes per triangle (lattice triangles are only a few columns wide), each lane
@@ -1173,7 +1194,10 @@ void launch_triangles(const KParams &k, const SlotDev &s, int n, int max_points,
     (void)hipMemsetAsync(s.tile_cnt, 0, sizeof(int32_t) * ((size_t)n * 2 * ntile + (size_t)s.cap * 2), st);  // counters + overflow flags (contiguous)
     int32_t *ovf = s.tile_cnt + (size_t)s.cap * 2 * ntile;
     const int nt = std::max(1, std::min(2 * max_points, k.d.max_tri));  // a triangulation of p points has < 2p triangles
-    SV_LAUNCH(K_PLANES, k_planes, dim3((nt + 255) / 256, 2, n), dim3(256), 0, st, k, s.blob, s.trirec, s.planes, (RasterRec *)s.rrec, s.tile_cnt, s.tile_list, ovf);
+    const size_t pl_lds = sizeof(int32_t) * 2 * (size_t)ntile;
+    static std::atomic<size_t> pl_granted[64];
+    ensure_dynamic_lds(k_planes, pl_lds, pl_granted, "plane_fit");
+    SV_LAUNCH(K_PLANES, k_planes, dim3((nt + 255) / 256, 2, n), dim3(256), pl_lds, st, k, s.blob, s.trirec, s.planes, (RasterRec *)s.rrec, s.tile_cnt, s.tile_list, ovf);
     SV_LAUNCH(K_TRIANGLES, k_raster_tiles, dim3(ntile, 2, n), dim3(256), 0, st, k, s.blob, (const RasterRec *)s.rrec, s.tile_cnt, s.tile_list, ovf, s.tri_id);
     SV_LAUNCH(K_TRIANGLES_FALLBACK, k_raster, dim3(64, 2, n), dim3(256), 0, st, k, s.blob, (const RasterRec *)s.rrec, ovf, s.tri_id);
 }
