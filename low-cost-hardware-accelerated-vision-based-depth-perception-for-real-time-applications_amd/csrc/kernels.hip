@@ -1512,8 +1512,40 @@ __global__ __launch_bounds__(256) void k_lr(KParams k, const int32_t *__restrict
     if (user_d2) user_d2[(size_t)pair * d.N + row + u] = o2;  // postprocess_only_left: the checked right map is already final
 }
 
+// Two pixels per thread for even map widths (every row then starts on a 4-byte boundary of the int16 maps and an 8-byte
+// boundary of the float maps): half the load / store instructions of this pure map kernel
+__global__ __launch_bounds__(256) void k_lr2(KParams k, const int32_t *__restrict__ blob, const int16_t *__restrict__ wta, float *__restrict__ disp,
+                                             float *__restrict__ user_d2, int keep_right) {
+    const Dims &d = k.d;
+    const int pair = blockIdx.z;
+    if (blob[pair * META_WORDS] < 3) return;
+    const int u = 2 * (blockIdx.x * 256 + threadIdx.x), v = blockIdx.y;
+    if (u >= d.W) return;
+    const int16_t *W1 = wta + (size_t)(pair * 2) * d.N, *W2 = W1 + d.N;
+    const size_t row = (size_t)v * d.W;
+    const short2 a = *reinterpret_cast<const short2 *>(W1 + row + u), b = *reinterpret_cast<const short2 *>(W2 + row + u);
+    const float thr = (float)k.lr_threshold;
+    float o1[2], o2[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const float d1 = (float)(j ? a.y : a.x), d2 = (float)(j ? b.y : b.x);
+        const int uj = u + j;
+        o1[j] = o2[j] = -10.0f;
+        // half resolution (elas.cpp:972-975): the map is half size, the disparities are still full-resolution pixels
+        const float uw1 = d.sub ? (float)uj - d1 / 2 : (float)uj - d1, uw2 = d.sub ? (float)uj + d2 / 2 : (float)uj + d2;
+        if (d1 >= 0 && uw1 >= 0 && uw1 < (float)d.W) o1[j] = (fabsf((float)W2[row + (int)uw1] - d1) > thr) ? -10.0f : d1;
+        if (d2 >= 0 && uw2 >= 0 && uw2 < (float)d.W) o2[j] = (fabsf((float)W1[row + (int)uw2] - d2) > thr) ? -10.0f : d2;
+    }
+    *reinterpret_cast<float2 *>(disp + (size_t)(pair * 2) * d.N + row + u) = make_float2(o1[0], o1[1]);
+    if (keep_right) *reinterpret_cast<float2 *>(disp + (size_t)(pair * 2 + 1) * d.N + row + u) = make_float2(o2[0], o2[1]);
+    if (user_d2) *reinterpret_cast<float2 *>(user_d2 + (size_t)pair * d.N + row + u) = make_float2(o2[0], o2[1]);
+}
+
 void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st, float *user_d2, bool keep_right) {
-    SV_LAUNCH(K_LR, k_lr, dim3((k.d.W + 255) / 256, k.d.H, n), dim3(256), 0, st, k, s.blob, s.wta, s.disp, user_d2, keep_right ? 1 : 0);
+    if ((k.d.W & 1) == 0 && (reinterpret_cast<uintptr_t>(user_d2) & 7) == 0)
+        SV_LAUNCH(K_LR, k_lr2, dim3((k.d.W / 2 + 255) / 256, k.d.H, n), dim3(256), 0, st, k, s.blob, s.wta, s.disp, user_d2, keep_right ? 1 : 0);
+    else
+        SV_LAUNCH(K_LR, k_lr, dim3((k.d.W + 255) / 256, k.d.H, n), dim3(256), 0, st, k, s.blob, s.wta, s.disp, user_d2, keep_right ? 1 : 0);
 }
 
 // ------------------------------------------------------------------------------------------------------------
