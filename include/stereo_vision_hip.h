@@ -202,6 +202,15 @@ Uchar4 *getColor(void); /* reference: stereo_vision.cpp:625-627 */
 const unsigned char *sv_legacy_last_dmap(int *width, int *height);
 /* The 4x4 disparity-to-depth matrix Q the legacy path uses (row major), NULL before the first frame. */
 const double *sv_legacy_Q(void);
+/* Rectification remap of the gray images in front of the matcher: findRectificationMap's initUndistortRectifyMap maps
+ * (stereo_vision.cpp:477-478) applied with cv::remap(INTER_LINEAR) - the call the reference has commented out at :341, so OFF
+ * by default here as well.  Call before the first generatePointCloud (the state is frozen there, :582).  OpenCV arithmetic
+ * restated (parity unpinned, like the gray conversion). */
+void sv_legacy_set_rectify(int on);
+/* The four maps lmapx, lmapy, rmapx, rmapy as [4][height][width] floats (host), NULL unless rectification is on. */
+const float *sv_legacy_rectify_maps(void);
+/* Test hook: the gray images of the last frame as the matcher received them (after the remap if it is on); [height][width] each. */
+int sv_legacy_last_gray(unsigned char *left, unsigned char *right);
 /* Batched disparity -> point cloud on the device, for callers of the batch API: the driver's conversion dmap = saturate(
  * round_half_even(4*d)) (stereo_vision.cpp:316) followed by publishPointCloud's reprojection pos = Q*[x y dmap 1]^T,
  * (X,Y,Z) = pos.xyz/pos.w in double (:233-256) for every pixel, and optionally the CUDA variant's robot-frame transform
@@ -224,6 +233,9 @@ int sv_legacy_box_means(const int32_t *boxes, int n, double *out);
 /* Test hook: Q (and P1,P2) of the stereoRectify restatement for a calibration file; K1,K2 are divided by `scale` first
  * (stereo_vision.cpp:364-376).  variant 1 = OpenCV 4.x rule set (the product), 0 = pre-3.4.2 rule set. */
 int sv_debug_stereo_rectify(const char *yaml, int image_w, int image_h, double scale, int variant, double *Q16, double *P1P2_24);
+
+/* Test hook: cv::initUndistortRectifyMap(K, D(k1,k2,p1,p2,k3), R, P(3x4), (w,h), CV_32F) as the legacy path restates it. */
+int sv_debug_undistort_map(const double *K9, const double *D5, const double *R9, const double *P12, int w, int h, float *mapx, float *mapy);
 
 #ifdef __cplusplus
 }

@@ -373,6 +373,52 @@ void stereo_rectify(const Calibration &c, int image_w, int image_h, int new_w, i
 }  // namespace sv
 
 // test hook (tests/test_calib.py): returns Q for a calibration file
+namespace sv {
+
+static bool mat3_inverse(const double *A, double *I) {
+    const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+    const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+    if (det == 0.0) return false;
+    const double id = 1.0 / det;
+    I[0] = c00 * id;
+    I[1] = (A[2] * A[7] - A[1] * A[8]) * id;
+    I[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    I[3] = c01 * id;
+    I[4] = (A[0] * A[8] - A[2] * A[6]) * id;
+    I[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    I[6] = c02 * id;
+    I[7] = (A[1] * A[6] - A[0] * A[7]) * id;
+    I[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+    return true;
+}
+
+// cv::initUndistortRectifyMap(K, D, R, P, size, CV_32F, mapx, mapy) (call sites: stereo_vision.cpp:477-478): for every pixel
+// (u, v) of the rectified image the position in the distorted source image.  Restates the documented algorithm (pinhole +
+// k1,k2,p1,p2,k3 model): [x y w]^T = (P[:, :3] * R)^-1 * [u v 1]^T, x /= w, y /= w, radial + tangential distortion, back through K.
+// Double arithmetic, row-wise increments like OpenCV's scalar loop.  OpenCV is not available here: parity unpinned.
+bool init_undistort_rectify_map(const double *K, const double *D, const double *R, const double *P, int w, int h, float *mapx, float *mapy) {
+    double Ar[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]}, ArR[9], ir[9];
+    mat3_mul(Ar, R, ArR);
+    if (!mat3_inverse(ArR, ir)) return false;
+    const double fx = K[0], fy = K[4], u0 = K[2], v0 = K[5];
+    const double k1 = D[0], k2 = D[1], p1 = D[2], p2 = D[3], k3 = D[4];
+    for (int i = 0; i < h; i++) {
+        double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+        for (int j = 0; j < w; j++, _x += ir[0], _y += ir[3], _w += ir[6]) {
+            const double iw = 1. / _w, x = _x * iw, y = _y * iw;
+            const double x2 = x * x, y2 = y * y, r2 = x2 + y2, _2xy = 2 * x * y;
+            const double kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2;
+            const double xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2);
+            const double yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy;
+            mapx[(size_t)i * w + j] = (float)(fx * xd + u0);
+            mapy[(size_t)i * w + j] = (float)(fy * yd + v0);
+        }
+    }
+    return true;
+}
+
+}  // namespace sv
+
 extern "C" int sv_debug_stereo_rectify(const char *yaml, int image_w, int image_h, double scale, int variant, double *Q16, double *P1P2_24) {
     sv::Calibration c;
     std::string err;
@@ -391,4 +437,9 @@ extern "C" int sv_debug_stereo_rectify(const char *yaml, int image_w, int image_
         memcpy(P1P2_24 + 12, r.P2, sizeof(r.P2));
     }
     return 0;
+}
+
+extern "C" int sv_debug_undistort_map(const double *K9, const double *D5, const double *R9, const double *P12, int w, int h, float *mapx, float *mapy) {
+    if (!K9 || !D5 || !R9 || !P12 || !mapx || !mapy || w < 1 || h < 1) return -1;
+    return sv::init_undistort_rectify_map(K9, D5, R9, P12, w, h, mapx, mapy) ? 0 : -1;
 }

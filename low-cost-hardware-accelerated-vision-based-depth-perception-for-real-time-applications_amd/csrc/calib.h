@@ -33,4 +33,7 @@ struct Rectification {
 // value for both, stereo_vision.cpp:524-525,547), alpha as cv::stereoRectify (the driver passes 0).
 void stereo_rectify(const Calibration &c, int image_w, int image_h, int new_w, int new_h, double alpha, Rectification &out);
 
+// cv::initUndistortRectifyMap(K, D, R, P, (w, h), CV_32F, mapx, mapy) (stereo_vision.cpp:477-478); maps are [h][w] floats.
+bool init_undistort_rectify_map(const double *K, const double *D, const double *R, const double *P, int w, int h, float *mapx, float *mapy);
+
 }  // namespace sv

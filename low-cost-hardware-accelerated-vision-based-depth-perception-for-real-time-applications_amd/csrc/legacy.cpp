@@ -32,6 +32,7 @@
 namespace sv {
 void launch_bgra_to_gray(const unsigned char *bgra_l, const unsigned char *bgra_r, unsigned char *gray_l, unsigned char *gray_r, int n, hipStream_t st);
 void launch_dmap_and_cloud(const float *disp, unsigned char *dmap, double *points, const double *Q16, int W, int H, hipStream_t st);
+void launch_remap_gray(const unsigned char *src, unsigned char *dst, const float *mapx, const float *mapy, int W, int H, hipStream_t st);
 int launch_reproject_batch(const float *disp, int batch, int W, int H, const double *Q16, const double *XR9, const double *XT3, unsigned char *dmap, double *points,
                            hipStream_t st);
 }  // namespace sv
@@ -48,6 +49,11 @@ struct Legacy {
     unsigned char *d_bgra_l = nullptr, *d_bgra_r = nullptr, *d_gray_l = nullptr, *d_gray_r = nullptr, *d_dmap = nullptr;
     float *d_disp = nullptr, *d_disp2 = nullptr;
     double *d_points = nullptr;
+    // rectification remap (stereo_vision.cpp:341, commented out in the reference; here: off unless sv_legacy_set_rectify(1))
+    bool rectify = false;
+    float *d_maps = nullptr;            // [4][H][W]: lmapx, lmapy, rmapx, rmapy (stereo_vision.cpp:477-478)
+    unsigned char *d_rect_l = nullptr, *d_rect_r = nullptr;
+    std::vector<float> h_maps;
     Double3 *points = nullptr;          // host, library-owned (stereo_vision.cpp:89-93)
     std::vector<Uchar4> colors;         // last left image
     unsigned char *h_dmap = nullptr;    // last u8 disparity image (host, page-locked)
@@ -56,6 +62,7 @@ struct Legacy {
 
 Legacy g;
 std::mutex g_mu;
+bool g_want_rectify = false;  // sv_legacy_set_rectify: read by the first generatePointCloud call
 
 #define L_TRY(expr)                                                                              \
     do {                                                                                         \
@@ -114,6 +121,19 @@ bool legacy_init(int width, int height, float scale, const char *yaml, bool subs
     L_TRY(hipMalloc((void **)&g.d_points, N * 3 * sizeof(double)));
     L_TRY(hipMalloc((void **)&g.d_Q, 16 * sizeof(double)));
     L_TRY(hipMemcpy(g.d_Q, g.rect.Q, 16 * sizeof(double), hipMemcpyHostToDevice));
+    g.rectify = g_want_rectify;
+    if (g.rectify) {  // findRectificationMap's two initUndistortRectifyMap calls (stereo_vision.cpp:477-478)
+        g.h_maps.assign(4 * N, 0.f);
+        if (!sv::init_undistort_rectify_map(c.K1, c.D1, g.rect.R1, g.rect.P1, width, height, g.h_maps.data(), g.h_maps.data() + N) ||
+            !sv::init_undistort_rectify_map(c.K2, c.D2, g.rect.R2, g.rect.P2, width, height, g.h_maps.data() + 2 * N, g.h_maps.data() + 3 * N)) {
+            fprintf(stderr, "stereo_vision_hip: singular rectification\n");
+            return false;
+        }
+        L_TRY(hipMalloc((void **)&g.d_maps, 4 * N * sizeof(float)));
+        L_TRY(hipMemcpy(g.d_maps, g.h_maps.data(), 4 * N * sizeof(float), hipMemcpyHostToDevice));
+        L_TRY(hipMalloc((void **)&g.d_rect_l, N));
+        L_TRY(hipMalloc((void **)&g.d_rect_r, N));
+    }
     // page-locked: the 11 MB of points per frame come back at PCIe speed instead of through a pageable bounce buffer
     L_TRY(hipHostMalloc((void **)&g.points, N * sizeof(Double3), hipHostMallocDefault));
     memset(g.points, 0, N * sizeof(Double3));
@@ -133,7 +153,14 @@ bool legacy_frame(const unsigned char *left, const unsigned char *right) {
     L_TRY(hipMemsetAsync(g.d_disp, 0, N * sizeof(float), g.stream));
     L_TRY(hipMemsetAsync(g.d_disp2, 0, N * sizeof(float), g.stream));
     L_TRY(hipStreamSynchronize(g.stream));
-    if (sv_process_batch_device(g.engine, g.d_gray_l, g.d_gray_r, 1, g.W, g.d_disp, g.d_disp2, nullptr) != SV_OK) {
+    const unsigned char *in_l = g.d_gray_l, *in_r = g.d_gray_r;
+    if (g.rectify) {  // remap(tmpL, img_left, lmapx, lmapy, INTER_LINEAR); remap(tmpR, img_right, rmapx, rmapy, INTER_LINEAR) (:341)
+        sv::launch_remap_gray(g.d_gray_l, g.d_rect_l, g.d_maps, g.d_maps + N, g.W, g.H, g.stream);
+        sv::launch_remap_gray(g.d_gray_r, g.d_rect_r, g.d_maps + 2 * N, g.d_maps + 3 * N, g.W, g.H, g.stream);
+        L_TRY(hipStreamSynchronize(g.stream));
+        in_l = g.d_rect_l, in_r = g.d_rect_r;
+    }
+    if (sv_process_batch_device(g.engine, in_l, in_r, 1, g.W, g.d_disp, g.d_disp2, nullptr) != SV_OK) {
         fprintf(stderr, "stereo_vision_hip: %s\n", sv_last_error(g.engine));
         return false;
     }
@@ -186,7 +213,7 @@ Double3 *generatePointCloud(unsigned char *left, unsigned char *right, char *CAM
 void clean(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g.engine) sv_destroy(g.engine);
-    void *dptrs[] = {g.d_bgra_l, g.d_bgra_r, g.d_gray_l, g.d_gray_r, g.d_dmap, g.d_disp, g.d_disp2, g.d_points, g.d_Q};
+    void *dptrs[] = {g.d_bgra_l, g.d_bgra_r, g.d_gray_l, g.d_gray_r, g.d_dmap, g.d_disp, g.d_disp2, g.d_points, g.d_Q, g.d_maps, g.d_rect_l, g.d_rect_r};
     for (void *p : dptrs)
         if (p) (void)hipFree(p);
     if (g.stream) (void)hipStreamDestroy(g.stream);
@@ -205,6 +232,22 @@ const unsigned char *sv_legacy_last_dmap(int *width, int *height) {
 }
 
 const double *sv_legacy_Q(void) { return g.ready ? g.rect.Q : nullptr; }
+
+void sv_legacy_set_rectify(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_want_rectify = on != 0;
+}
+
+const float *sv_legacy_rectify_maps(void) { return (g.ready && g.rectify) ? g.h_maps.data() : nullptr; }
+
+int sv_legacy_last_gray(unsigned char *left, unsigned char *right) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g.ready || !left || !right) return -1;
+    const size_t N = (size_t)g.W * g.H;
+    if (hipMemcpy(left, g.rectify ? g.d_rect_l : g.d_gray_l, N, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemcpy(right, g.rectify ? g.d_rect_r : g.d_gray_r, N, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return 0;
+}
 
 int sv_reproject_batch_device(const float *disp, int batch, int width, int height, const double *Q16, const double *XR9, const double *XT3, unsigned char *dmap_out,
                               double *points_out) {

@@ -21,6 +21,26 @@ void launch_bgra_to_gray(const unsigned char *bgra_l, const unsigned char *bgra_
     hipLaunchKernelGGL(k_bgra_to_gray, dim3((n + 255) / 256), dim3(256), 0, st, (const uchar4 *)bgra_l, (const uchar4 *)bgra_r, gray_l, gray_r, n);
 }
 
+// cv::remap(src, dst, mapx, mapy, INTER_LINEAR) for 8-bit single-channel images and CV_32FC1 maps, BORDER_CONSTANT(0)
+// (the call the reference has commented out at stereo_vision.cpp:341): OpenCV's fixed-point bilinear - the map converted to 5
+// fractional bits with round-half-even, weights (32-fx)(32-fy)*32 ... (they sum to 2^15 exactly), result (sum + 2^14) >> 15.
+__global__ __launch_bounds__(256) void k_remap_gray(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, const float *__restrict__ mapx, const float *__restrict__ mapy,
+                                                    int W, int H) {
+    const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
+    if (i >= W) return;
+    const size_t p = (size_t)j * W + i;
+    const int sx = __float2int_rn(mapx[p] * 32.0f), sy = __float2int_rn(mapy[p] * 32.0f);  // cvRound
+    const int ix = sx >> 5, iy = sy >> 5, fx = sx & 31, fy = sy & 31;
+    auto at = [&](int x, int y) -> int { return (x >= 0 && x < W && y >= 0 && y < H) ? (int)src[(size_t)y * W + x] : 0; };
+    const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    const int v = at(ix, iy) * w00 + at(ix + 1, iy) * w01 + at(ix, iy + 1) * w10 + at(ix + 1, iy + 1) * w11;
+    dst[p] = (uint8_t)((v + (1 << 14)) >> 15);
+}
+
+void launch_remap_gray(const unsigned char *src, unsigned char *dst, const float *mapx, const float *mapy, int W, int H, hipStream_t st) {
+    hipLaunchKernelGGL(k_remap_gray, dim3((W + 255) / 256, H), dim3(256), 0, st, src, dst, mapx, mapy, W, H);
+}
+
 __global__ __launch_bounds__(256) void k_dmap_cloud(const float *__restrict__ disp, uint8_t *__restrict__ dmap, double *__restrict__ pts, const double *__restrict__ Q, int W, int H) {
     const int i = blockIdx.x * 256 + threadIdx.x, j = blockIdx.y;
     if (i >= W) return;

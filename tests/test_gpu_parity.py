@@ -367,3 +367,29 @@ def test_kernel_timing_selection(eng):
     finally:
         e.close()
 
+
+
+def test_handle_on_second_device(eng, oracle):
+    """A handle on device 1 (bench.py --gpus N gives every rank its own ordinal): control threads, pool threads and the
+    lattice-filter fetch path all have to address that device.  Skipped on one-GPU boxes."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two visible GPUs")
+    synth = util.pkg("synth")
+    H, W, D, B = 120, 320, 64, 6
+    batch = synth.make_batch(640, B, H, W, D)
+    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), device=1, chunk=4, n_slots=2, n_workers=3)
+    try:
+        with torch.cuda.device(1):
+            left, right = torch.from_numpy(batch[:, 0].copy()).to("cuda:1"), torch.from_numpy(batch[:, 1].copy()).to("cuda:1")
+            d1, d2 = e.process_device(left, right)
+            torch.cuda.synchronize()
+        h1, h2, st = e.process_host(batch[:, 0], batch[:, 1])
+        d1, d2 = d1.cpu().numpy(), d2.cpu().numpy()
+    finally:
+        e.close()
+    assert np.array_equal(h1, d1) and np.array_equal(h2, d2) and (st >= 3).all()
+    po = ElasParams.driver(D - 1)
+    for i in range(B):
+        o1, o2, _ = oracle.process(po, batch[i, 0], batch[i, 1])
+        assert np.array_equal(d1[i].view(np.uint8), o1.view(np.uint8)) and np.array_equal(d2[i].view(np.uint8), o2.view(np.uint8)), i

@@ -193,3 +193,81 @@ def test_generate_point_cloud_colour_input(oracle):
     want = np.clip(np.rint(d1 * np.float32(4.0)), 0, 255).astype(np.uint8)
     assert (want > 0).mean() > 0.3
     assert np.array_equal(dmap, want)
+
+
+def _lib(eng):
+    eng.share_hip_runtime_with_torch()
+    return ctypes.CDLL(eng.LIB_PATH)
+
+
+def test_undistort_rectify_map_against_formula():
+    """initUndistortRectifyMap restatement (stereo_vision.cpp:477-478): identity camera -> identity map; with distortion and a
+    rotation -> the documented pinhole + (k1,k2,p1,p2,k3) formula evaluated directly in numpy (no OpenCV here: parity unpinned)."""
+    eng = util.pkg("engine")
+    util.pkg("build").build()
+    L = _lib(eng)
+    L.sv_debug_undistort_map.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    w, h = 97, 53
+    K = np.array([[420.0, 0, 48.5], [0, 415.0, 26.0], [0, 0, 1]])
+    P = np.hstack([K, np.zeros((3, 1))])
+    mx, my = np.zeros((h, w), np.float32), np.zeros((h, w), np.float32)
+    assert L.sv_debug_undistort_map(K.ctypes.data, np.zeros(5).ctypes.data, np.eye(3).ctypes.data, P.ctypes.data, w, h, mx.ctypes.data, my.ctypes.data) == 0
+    jj, ii = np.meshgrid(np.arange(w), np.arange(h))
+    assert np.abs(mx - jj).max() < 1e-3 and np.abs(my - ii).max() < 1e-3
+    D = np.array([-0.28, 0.09, 1e-3, -5e-4, -0.01])
+    a = 0.02
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    P2 = np.array([[400.0, 0, 50.0, -30.0], [0, 400.0, 25.0, 0], [0, 0, 1, 0]])
+    assert L.sv_debug_undistort_map(K.ctypes.data, D.ctypes.data, R.ctypes.data, P2.ctypes.data, w, h, mx.ctypes.data, my.ctypes.data) == 0
+    iR = np.linalg.inv(P2[:, :3] @ R)
+    xyz = iR @ np.stack([jj.ravel(), ii.ravel(), np.ones(w * h)]).astype(np.float64)
+    x, y = xyz[0] / xyz[2], xyz[1] / xyz[2]
+    r2 = x * x + y * y
+    kr = 1 + ((D[4] * r2 + D[1]) * r2 + D[0]) * r2
+    xd = x * kr + D[2] * 2 * x * y + D[3] * (r2 + 2 * x * x)
+    yd = y * kr + D[2] * (r2 + 2 * y * y) + D[3] * 2 * x * y
+    assert np.abs(mx.ravel() - (K[0, 0] * xd + K[0, 2])).max() < 2e-3 and np.abs(my.ravel() - (K[1, 1] * yd + K[1, 2])).max() < 2e-3
+
+
+def _remap_linear_u8(src, mapx, mapy):
+    """cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) for CV_8UC1 / CV_32FC1 maps: 5 fractional bits, weights sum to 2^15."""
+    H, W = src.shape
+    sx, sy = np.rint(mapx * np.float32(32)).astype(np.int64), np.rint(mapy * np.float32(32)).astype(np.int64)
+    ix, iy, fx, fy = sx >> 5, sy >> 5, sx & 31, sy & 31
+    pad = np.zeros((H + 2, W + 2), np.int64)
+
+    def at(x, y):
+        ok = (x >= 0) & (x < W) & (y >= 0) & (y < H)
+        return np.where(ok, src[np.clip(y, 0, H - 1), np.clip(x, 0, W - 1)].astype(np.int64), 0)
+
+    v = at(ix, iy) * (32 - fx) * (32 - fy) * 32 + at(ix + 1, iy) * fx * (32 - fy) * 32 + at(ix, iy + 1) * (32 - fx) * fy * 32 + at(ix + 1, iy + 1) * fx * fy * 32
+    del pad
+    return ((v + (1 << 14)) >> 15).astype(np.uint8)
+
+
+@pytest.mark.gpu
+def test_generate_point_cloud_with_rectification(oracle):
+    """sv_legacy_set_rectify(1): the remap the reference has commented out (stereo_vision.cpp:341) in front of the matcher.  The
+    gray images the matcher received equal the fixed-point bilinear remap of gray_cv4(colour) through the library's own maps, and
+    the disparity image equals the oracle's on exactly those images."""
+    svmod = util.pkg("stereo_vision")
+    rgb_l, rgb_r = util.load_png("kitti0_crop_color_left.png"), util.load_png("kitti0_crop_color_right.png")
+    H, W = rgb_l.shape[:2]
+    s = svmod.stereo_vision(objectTracking=False, width=W, height=H)
+    s.sv.sv_legacy_set_rectify(1)
+    try:
+        s.generatePointCloud(rgb_l[..., ::-1], rgb_r[..., ::-1])
+        dmap = s.last_disparity_u8()
+        s.sv.sv_legacy_rectify_maps.restype = ctypes.POINTER(ctypes.c_float)
+        maps = np.ctypeslib.as_array(s.sv.sv_legacy_rectify_maps(), shape=(4, H, W)).copy()
+        gl, gr = np.zeros((H, W), np.uint8), np.zeros((H, W), np.uint8)
+        s.sv.sv_legacy_last_gray.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        assert s.sv.sv_legacy_last_gray(gl.ctypes.data, gr.ctypes.data) == 0
+    finally:
+        s.close()
+        s.sv.sv_legacy_set_rectify(0)
+    want_l, want_r = _remap_linear_u8(_gray_cv4(rgb_l), maps[0], maps[1]), _remap_linear_u8(_gray_cv4(rgb_r), maps[2], maps[3])
+    assert (want_l != _gray_cv4(rgb_l)).mean() > 0.2  # the maps of this calibration at this size are not the identity
+    assert np.array_equal(gl, want_l) and np.array_equal(gr, want_r)
+    d1, _, _ = oracle.process(ElasParams.driver(255), gl, gr)
+    assert np.array_equal(dmap, np.clip(np.rint(d1 * np.float32(4.0)), 0, 255).astype(np.uint8))
