@@ -1262,22 +1262,26 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
     const int band_bits = d_plane_max - d_plane_min + 1, band_word = d_plane_min >> 5;
     const uint64_t band = band_bits > 0 ? ((1ull << band_bits) - 1ull) << (d_plane_min & 31) : 0ull;
     const uint32_t band_lo = (uint32_t)band, band_hi = (uint32_t)(band >> 32);
+    uint32_t mc[DENSE_MASK_WORDS];
+#pragma unroll
+    for (int w = 0; w < DENSE_MASK_WORDS; w++) mc[w] = mw[w];
+    if (clip) {  // image border only: keep [a_lo, a_hi] (one wave-uniform branch for all words)
+#pragma unroll
+        for (int w = 0; w < DENSE_MASK_WORDS; w++) {
+            if (w >= MW) break;
+            const int lo = a_lo - 32 * w, hi = a_hi - 32 * w;
+            uint32_t keep = 0;
+            if (lo <= 31 && hi >= 0 && lo <= hi) {
+                const int l = max(lo, 0), h = min(hi, 31);
+                keep = (h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u)) & ~((1u << l) - 1u);
+            }
+            mc[w] &= keep;
+        }
+    }
 #pragma unroll
     for (int w = 0; w < DENSE_MASK_WORDS; w++) {  // grid candidates outside the band (:759-767 / :778-786), ascending d
         if (w >= MW) break;
-        uint32_t m = mw[w];
-        {  // keep [a_lo, a_hi], drop [d_plane_min, d_plane_max]
-            if (clip) {
-                const int lo = a_lo - 32 * w, hi = a_hi - 32 * w;
-                uint32_t keep = 0;
-                if (lo <= 31 && hi >= 0 && lo <= hi) {
-                    const int l = max(lo, 0), h = min(hi, 31);
-                    keep = (h == 31 ? 0xFFFFFFFFu : ((1u << (h + 1)) - 1u)) & ~((1u << l) - 1u);
-                }
-                m &= keep;
-            }
-            m &= ~(w == band_word ? band_lo : (w == band_word + 1 ? band_hi : 0u));
-        }
+        uint32_t m = mc[w] & ~(w == band_word ? band_lo : (w == band_word + 1 ? band_hi : 0u));  // drop [d_plane_min, d_plane_max]
         if (COUNT) ncand += __popc(m);
         int best_w = KEY_NONE;  // keys of this word carry the bit index only; 32 * w is added once per word
         while (m) {  // two candidates per trip: their LDS reads are in flight together (an odd last one is evaluated twice)
