@@ -2053,37 +2053,64 @@ __device__ __forceinline__ float gap_value(float d1, float d2) {
 
 #define SV_MAX_LINE_WORDS 128  // lines up to 8192 pixels
 
-__global__ __launch_bounds__(64) void k_gap_rows(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp) {
+// One workgroup (4 wavefronts) per row: the wavefronts share the row's 64-pixel words, so a row is a chain of nch / 4 memory
+// latencies instead of nch (measured inside the one-wavefront version at batch 1: 5.8 us of dependent loads, 2.2 us of serial
+// scan by lane 0, 6.0 us of resolve for a 1242-pixel row)
+#define GAPR_THREADS 256
+__global__ __launch_bounds__(GAPR_THREADS) void k_gap_rows(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp) {
     const Dims &d = k.d;
     const int m = blockIdx.y;
     if (blob[(m / nproc) * META_WORDS] < 3) return;
     float *D = disp + map_offset(d, m, nproc) + (size_t)blockIdx.x * d.W;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = GAPR_THREADS / 64;
     const int nch = (d.W + 63) / 64;
     __shared__ unsigned long long mw[SV_MAX_LINE_WORDS];
     __shared__ int prevb[SV_MAX_LINE_WORDS], nextb[SV_MAX_LINE_WORDS];
-    for (int c = 0; c < nch; c++) {
+    for (int c = wave; c < nch; c += nw) {
         const int u = c * 64 + lane;
         const float val = u < d.W ? D[u] : -1.0f;
         const unsigned long long b = __ballot(val >= 0);
         if (lane == 0) mw[c] = b;
     }
     __syncthreads();
-    if (lane == 0) {
-        int pb = -1;
-        for (int c = 0; c < nch; c++) {
-            prevb[c] = pb;
-            if (mw[c]) pb = c * 64 + 63 - __clzll((long long)mw[c]);
+    // last valid pixel before / first valid pixel after each word: one lane per word, max / min scans across the wavefront
+    if (wave == 0) {
+        int carry = -1;
+        for (int c0 = 0; c0 < nch; c0 += 64) {
+            const int c = c0 + lane;
+            const unsigned long long w = c < nch ? mw[c] : 0ull;
+            int last = w ? c * 64 + 63 - __clzll((long long)w) : -1;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(last, o, 64);
+                if (lane >= o) last = max(last, t);
+            }
+            int excl = __shfl_up(last, 1, 64);
+            if (lane == 0) excl = -1;
+            if (c < nch) prevb[c] = max(excl, carry);
+            carry = max(carry, __shfl(last, 63, 64));
         }
-        int nb = -1;
-        for (int c = nch - 1; c >= 0; c--) {
-            nextb[c] = nb;
-            if (mw[c]) nb = c * 64 + __ffsll((long long)mw[c]) - 1;
+    } else if (wave == 1) {
+        int carry = 0x7FFFFFFF;
+        for (int c0 = ((nch - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
+            const int c = c0 + lane;
+            const unsigned long long w = c < nch ? mw[c] : 0ull;
+            int first = w ? c * 64 + __ffsll((long long)w) - 1 : 0x7FFFFFFF;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_down(first, o, 64);
+                if (lane + o < 64) first = min(first, t);
+            }
+            int excl = __shfl_down(first, 1, 64);
+            if (lane == 63) excl = 0x7FFFFFFF;
+            const int nb = min(excl, carry);
+            if (c < nch) nextb[c] = nb == 0x7FFFFFFF ? -1 : nb;
+            carry = min(carry, __shfl(first, 0, 64));
         }
     }
     __syncthreads();
     const int gw = k.gap_width;
-    for (int c = 0; c < nch; c++) {
+    for (int c = wave; c < nch; c += nw) {
         const int u = c * 64 + lane;
         const unsigned long long w = mw[c];
         if (u >= d.W || ((w >> lane) & 1ull)) continue;
@@ -2104,7 +2131,7 @@ __global__ __launch_bounds__(64) void k_gap_rows(KParams k, int nproc, const int
 }
 
 void launch_gap_rows(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st) {
-    SV_LAUNCH(K_GAP_ROWS, k_gap_rows, dim3(k.d.H, n * nproc), dim3(64), 0, st, k, nproc, s.blob, s.disp);
+    SV_LAUNCH(K_GAP_ROWS, k_gap_rows, dim3(k.d.H, n * nproc), dim3(GAPR_THREADS), 0, st, k, nproc, s.blob, s.disp);
 }
 
 // Columns: a workgroup owns 64 columns; its 4 wavefronts split the rows.  Pass 1 builds the per-column validity
