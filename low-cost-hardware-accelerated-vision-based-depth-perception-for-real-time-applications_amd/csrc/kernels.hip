@@ -1799,19 +1799,23 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
         }
         return;
     }
-    // run records (first pixel, length) and vertical unions: one THREAD per mask word, walking its set bits
-    for (int rc = tid; rc < rows * nch; rc += CCL_THREADS) {
+    // run records (first pixel, length) and vertical unions: one THREAD per quarter of a mask word (16 pixels), walking its set
+    // bits.  (One thread per word left 160 of the 512 threads with up to 64 dependent LDS atomics / union-find walks each: 11 of
+    // the kernel's 20 us on a real map.)
+    for (int task = tid; task < rows * nch * 4; task += CCL_THREADS) {
+        const int rc = task >> 2, q = task & 3;
+        const uint64_t qmask = 0xFFFFull << (16 * q), qbelow = (1ull << (16 * q)) - 1ull;
         const int r = rc / nch, c = rc - r * nch;
         const uint64_t V = Vm[rc], S = Sm[rc], L = Lm[rc];
         const int b0 = rowbase[r] + base[rc];  // number of the first run that starts in this word
         const int pix0 = (v0 + r) * d.W + c * 64;
         const uint64_t brk = S | ~V;           // a segment ends before the next start or invalid pixel
-        if ((V & 1ull) && !(S & 1ull)) {       // the run of the previous word continues into this one
+        if (q == 0 && (V & 1ull) && !(S & 1ull)) {  // the run of the previous word continues into this one
             const uint64_t bk = brk & ~1ull;
             atomicAdd(&len[b0 - 1], bk ? ctz64(bk) : 64);
         }
-        int j = b0;
-        for (uint64_t sb = S; sb; sb &= sb - 1, j++) {
+        int j = b0 + __popcll(S & qbelow);
+        for (uint64_t sb = S & qmask; sb; sb &= sb - 1, j++) {
             const int pos = ctz64(sb);
             const uint64_t bk = brk & ~bits_upto(pos);
             atomicAdd(&len[j], (bk ? ctz64(bk) : 64) - pos);
@@ -1821,7 +1825,7 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
             const uint64_t Vu = Vm[rc - nch], Su = Sm[rc - nch];
             const int bu = rowbase[r - 1] + base[rc - nch];
             const uint64_t carry = c > 0 ? (Lm[rc - 1] >> 63) : 0ull;
-            for (uint64_t F = ccl_new_links(L, V & ~S, Vu & ~Su, carry); F; F &= F - 1) {
+            for (uint64_t F = ccl_new_links(L, V & ~S, Vu & ~Su, carry) & qmask; F; F &= F - 1) {
                 const uint64_t upto = bits_upto(ctz64(F));
                 ccl_union(parent, b0 + __popcll(S & upto) - 1, bu + __popcll(Su & upto) - 1);
             }
