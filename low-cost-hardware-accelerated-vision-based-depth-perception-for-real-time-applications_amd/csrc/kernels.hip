@@ -2266,15 +2266,22 @@ __global__ __launch_bounds__(256) void k_amean(KParams k, int nproc, const int32
     const int x0 = blockIdx.x * PF_TW, y0 = blockIdx.y * PF_TH;
     __shared__ float sD[PF_TH + 7][PF_TW + 8];  // D_copy (:1307-1318): rows y0-4.., columns x0-4..; invalid -> -10
     __shared__ float sT[PF_TH + 7][PF_TW];      // D_tmp after the horizontal pass: rows y0-4.., columns x0..
-    for (int i = threadIdx.x; i < (PF_TH + 7) * (PF_TW + 8); i += 256) {
-        const int r = i / (PF_TW + 8), c = i - r * (PF_TW + 8);
-        const int y = y0 - 4 + r, x = x0 - 4 + c;
-        float val = -10.0f;
-        if (y >= 0 && y < d.H && x >= 0 && x < d.W) {
-            val = S[(size_t)y * d.W + x];
-            if (val < 0) val = -10.0f;
+    {  // all of a thread's tile loads are requested before the first one is used (one load per loop trip is a chain of latencies)
+        constexpr int NLD = ((PF_TH + 7) * (PF_TW + 8) + 255) / 256;
+        float val[NLD];
+#pragma unroll
+        for (int t = 0; t < NLD; t++) {
+            const int i = threadIdx.x + t * 256;
+            const int r = i / (PF_TW + 8), c = i - r * (PF_TW + 8);
+            const int y = y0 - 4 + r, x = x0 - 4 + c;
+            const bool in = i < (PF_TH + 7) * (PF_TW + 8) && y >= 0 && y < d.H && x >= 0 && x < d.W;
+            val[t] = in ? S[(size_t)y * d.W + x] : -10.0f;
         }
-        sD[r][c] = val;
+#pragma unroll
+        for (int t = 0; t < NLD; t++) {
+            const int i = threadIdx.x + t * 256;
+            if (i < (PF_TH + 7) * (PF_TW + 8)) (&sD[0][0])[i] = val[t] < 0 ? -10.0f : val[t];
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < (PF_TH + 7) * PF_TW; i += 256) {  // horizontal pass (:1402-1441)
@@ -2425,10 +2432,22 @@ __global__ __launch_bounds__(256) void k_median(KParams k, int nproc, const int3
     const int x0 = blockIdx.x * PF_TW, y0 = blockIdx.y * PF_TH;
     __shared__ float sD[PF_TH + 6][PF_TW + 8];  // rows y0-3.., columns x0-3.. (70 used)
     __shared__ float sT[PF_TH + 6][PF_TW];      // D_temp after the horizontal pass (:1515-1534): rows y0-3.., columns x0..
-    for (int i = threadIdx.x; i < (PF_TH + 6) * (PF_TW + 6); i += 256) {
-        const int r = i / (PF_TW + 6), c = i - r * (PF_TW + 6);
-        const int y = y0 - 3 + r, x = x0 - 3 + c;
-        sD[r][c] = (y >= 0 && y < d.H && x >= 0 && x < d.W) ? S[(size_t)y * d.W + x] : 0.0f;
+    {  // all of a thread's tile loads are requested before the first one is used
+        constexpr int NLD = ((PF_TH + 6) * (PF_TW + 6) + 255) / 256;
+        float val[NLD];
+#pragma unroll
+        for (int t = 0; t < NLD; t++) {
+            const int i = threadIdx.x + t * 256;
+            const int r = i / (PF_TW + 6), c = i - r * (PF_TW + 6);
+            const int y = y0 - 3 + r, x = x0 - 3 + c;
+            val[t] = (i < (PF_TH + 6) * (PF_TW + 6) && y >= 0 && y < d.H && x >= 0 && x < d.W) ? S[(size_t)y * d.W + x] : 0.0f;
+        }
+#pragma unroll
+        for (int t = 0; t < NLD; t++) {
+            const int i = threadIdx.x + t * 256;
+            const int r = i / (PF_TW + 6), c = i - r * (PF_TW + 6);
+            if (i < (PF_TH + 6) * (PF_TW + 6)) sD[r][c] = val[t];
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < (PF_TH + 6) * PF_TW; i += 256) {
