@@ -1115,9 +1115,18 @@ __global__ __launch_bounds__(256) void k_raster_tiles(KParams k, const int32_t *
     // the long edge AC is AB left of B_u and BC from B_u on (elas.cpp:913-925 and :928-940 are the two halves of this range)
     const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
     const int x_end = min(tx0 + RT_W, d.W), y_end = min(ty0 + RT_H, d.H);
-    for (int i = grp; i < cnt; i += 32) {  // whole 8-lane groups walk the list together
-        const int t = tile_list[gt * RT_CAP + i];
-        const RasterRec r = rrec[(size_t)(pair * 2 + side) * d.max_tri + t];
+    // whole 8-lane groups walk the list together, one trip ahead with the loads (list entry, then its record: two dependent
+    // memory accesses that would otherwise sit in front of every trip)
+    const RasterRec *recs = rrec + (size_t)(pair * 2 + side) * d.max_tri;
+    int t_next = grp < cnt ? tile_list[gt * RT_CAP + grp] : 0;
+    RasterRec r_next = recs[t_next];
+    for (int i = grp; i < cnt; i += 32) {
+        const int t = t_next;
+        const RasterRec r = r_next;
+        if (i + 32 < cnt) {
+            t_next = tile_list[gt * RT_CAP + i + 32];
+            r_next = recs[t_next];
+        }
         const int u_begin = max(max(r.a_u, 0), tx0), u_end = min(min(r.c_u, d.W), x_end);
         for (int base = u_begin; base < u_end; base += 8) {
             const int u = base + sub;
