@@ -1456,7 +1456,9 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     if (h->chunk < 4 && !getenv("SV_GPU_FILTER")) h->gpu_filter = false;
     // triangulation on the GPU: on request, or by itself when few host threads are available (it costs GPU time and LDS, and a
     // single pair is faster on the host); never with keep_debug (the parity tests read the host's triangle lists)
-    h->gpu_delaunay = !cfg->keep_debug && h->chunk >= 4 && npool <= 9;  // measured: host mode wins from ~10 free threads per GPU on
+    // (measured, round 2: 38 300 pairs/s in this mode with 4 or 8 host threads; the host triangulation needs 16 threads to feed the
+    //  same rate - 32 000 with 14 - and is then within the noise of it)
+    h->gpu_delaunay = !cfg->keep_debug && h->chunk >= 4 && npool < 16;
     if (const char *e = getenv("SV_GPU_DELAUNAY")) h->gpu_delaunay = atoi(e) != 0 && !cfg->keep_debug;
     h->block_sync = h->chunk >= 4;
     if (const char *e = getenv("SV_EVENT_SYNC")) h->block_sync = strcmp(e, "block") == 0;
