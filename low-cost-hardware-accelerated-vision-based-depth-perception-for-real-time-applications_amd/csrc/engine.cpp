@@ -1058,7 +1058,8 @@ void drainer_main(sv_handle *h) {
 
 // Host cores this process may use: the cgroup CPU quota when there is one, else the affinity mask; shared evenly between
 // the ranks of one node (LOCAL_WORLD_SIZE, set by torch.distributed.run).  Without a visible quota the pool stays at 16.
-int default_pool_size() {
+// cores this rank may use (cgroup quota or affinity mask, divided by the ranks of the node); *quota = a cgroup quota is set
+double host_cpu_share(bool *quota) {
     double cpus = 0.0;
     if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
         char q[64];
@@ -1086,7 +1087,13 @@ int default_pool_size() {
     if (!have_quota || cpus > aff) cpus = aff;
     int ranks = 1;
     if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
-    const int share = std::max(1, (int)(cpus / ranks));
+    if (quota) *quota = have_quota;
+    return cpus / ranks;
+}
+
+int default_pool_size() {
+    bool have_quota = false;
+    const int share = std::max(1, (int)host_cpu_share(&have_quota));
     return std::max(1, std::min(have_quota ? 32 : 16, share));
 }
 
@@ -1458,6 +1465,9 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     // single pair is faster on the host); never with keep_debug (the parity tests read the host's triangle lists)
     // (measured, round 2: 38 300 pairs/s in this mode with 4 or 8 host threads; the host triangulation needs 16 threads to feed the
     //  same rate - 32 000 with 14 - and is then within the noise of it)
+    //  With 16 threads the host mode is 2 % faster on average (38 400 - 40 300 against 38 000 - 38 700 on the same box) but
+    //  noisier: under a CPU quota that the pool alone fills, the control threads compete with it.  SV_GPU_DELAUNAY=1 forces the
+    //  GPU mode.
     h->gpu_delaunay = !cfg->keep_debug && h->chunk >= 4 && npool < 16;
     if (const char *e = getenv("SV_GPU_DELAUNAY")) h->gpu_delaunay = atoi(e) != 0 && !cfg->keep_debug;
     h->block_sync = h->chunk >= 4;
