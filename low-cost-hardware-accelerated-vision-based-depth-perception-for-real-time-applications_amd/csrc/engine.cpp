@@ -1128,13 +1128,14 @@ void alloc_slot(sv_handle *h, Slot *sl) {
         dev_alloc(r, cap * 2 * (size_t)d.max_tri * 36);
         s.rrec = r;
     }
-    {
-        const size_t ntile = (size_t)((d.W + 63) / 64) * ((d.H + 31) / 32);  // RT_W x RT_H tiles of kernels.hip
-        dev_alloc(s.tile_cnt, cap * 2 * ntile + cap * 2);
-        dev_alloc(s.tile_list, cap * 2 * ntile * 512);
-    }
+    dev_alloc(s.tile_list, cap * 2 * raster_tiles(h->kp) * 512);
     dev_alloc(s.planes, cap * 2 * d.max_tri * 6);
-    dev_alloc(s.gmaskA, cap * 2 * d.ncell * d.MW);
+    {  // cell masks + raster tile counters: one allocation, one clear per chunk
+        uint8_t *w = nullptr;
+        dev_alloc(w, grid_clear_bytes(h->kp, (int)cap));
+        s.gmaskA = reinterpret_cast<uint32_t *>(w);
+        s.tile_cnt = reinterpret_cast<int32_t *>(s.gmaskA + grid_masks_words(h->kp, (int)cap));
+    }
     dev_alloc(s.gmaskB, cap * 2 * d.ncell * d.MW);
     dev_alloc(s.tri_id, cap * 2 * d.N);
     dev_alloc(s.wta, cap * 2 * d.N);
@@ -1159,7 +1160,7 @@ void alloc_slot(sv_handle *h, Slot *sl) {
 
 void free_slot(Slot *sl) {
     SlotDev &s = sl->dev;
-    void *dptrs[] = {s.grad, s.dcan, s.fsup, s.fnsup, s.flt_ws, s.blob, s.rrec, s.tile_cnt, s.tile_list, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize, s.ccl_ws};
+    void *dptrs[] = {s.grad, s.dcan, s.fsup, s.fnsup, s.flt_ws, s.blob, s.rrec, s.tile_list, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize, s.ccl_ws};
     for (void *p : dptrs)
         if (p) (void)hipFree(p);
     if (sl->h_dcan) (void)hipHostFree(sl->h_dcan);

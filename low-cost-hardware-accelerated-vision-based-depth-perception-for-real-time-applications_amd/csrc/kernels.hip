@@ -16,7 +16,7 @@ namespace sv {
 thread_local LaunchHook g_launch_hook = {nullptr, nullptr};
 
 const char *kernel_name(int id) {
-    static const char *names[K_COUNT] = {"descriptor", "support_match", "support_filter", "grid_mark", "grid_dilate", "plane_fit", "triangles_raster", "triangles_raster_fallback", "dense_match", "lr_check",
+    static const char *names[K_COUNT] = {"descriptor", "support_match", "support_filter", "grid_mark", "grid_dilate", "plane_fit", "triangles_raster", "dense_match", "lr_check",
                                          "delaunay_gpu", "ccl_band", "ccl_finish", "gap_rows", "gap_cols", "adaptive_mean", "median", "output"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
@@ -844,10 +844,15 @@ __global__ __launch_bounds__(256) void k_grid_dilate(KParams k, const uint32_t *
     gB[(size_t)ps * d.ncell * d.MW + i] = r;
 }
 
+size_t grid_masks_words(const KParams &k, int cap) { return (size_t)cap * 2 * k.d.ncell * k.d.MW; }
+size_t raster_tiles(const KParams &k) { return (size_t)((k.d.W + 63) / 64) * ((k.d.H + 31) / 32); }  // RT_W x RT_H tiles
+size_t grid_clear_bytes(const KParams &k, int cap) { return sizeof(uint32_t) * (grid_masks_words(k, cap) + (size_t)cap * 2 * raster_tiles(k)); }
+
 // max_points: the largest support-point count of the chunk as the host knows it (it wrote the blob); the grids of the per-point
 // and per-triangle kernels are sized by it instead of by the capacity (a KITTI lattice holds 18 681 points, a pair has ~2 100)
 void launch_grid(const KParams &k, const SlotDev &s, int n, int max_points, hipStream_t st) {
-    (void)hipMemsetAsync(s.gmaskA, 0, sizeof(uint32_t) * (size_t)n * 2 * k.d.ncell * k.d.MW, st);
+    // one clear for the cell masks and the raster tile counters of the whole slot (they are one allocation: gmaskA, tile_cnt)
+    (void)hipMemsetAsync(s.gmaskA, 0, grid_clear_bytes(k, s.cap), st);
     const int np = std::max(1, std::min(max_points, k.d.max_pts));
     SV_LAUNCH(K_GRID_MARK, k_grid_mark, dim3((np + 255) / 256, 2, n), dim3(256), 0, st, k, s.blob, s.gmaskA);
     SV_LAUNCH(K_GRID_DILATE, k_grid_dilate, dim3((k.d.ncell * k.d.MW + 255) / 256, n * 2), dim3(256), 0, st, k, s.gmaskA, s.gmaskB);
@@ -960,7 +965,7 @@ struct RasterRec {
 #define RT_CAP 512
 
 __global__ __launch_bounds__(256) void k_planes(KParams k, const int32_t *__restrict__ blob, float4 *__restrict__ trirec, float *__restrict__ planes,
-                                                RasterRec *__restrict__ rrec, int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_list, int32_t *__restrict__ tile_ovf) {
+                                                RasterRec *__restrict__ rrec, int32_t *__restrict__ tile_cnt, int32_t *__restrict__ tile_list) {
     const Dims &d = k.d;
     const int pair = blockIdx.z, side = blockIdx.y;
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -1067,10 +1072,7 @@ __global__ __launch_bounds__(256) void k_planes(KParams k, const int32_t *__rest
         for (int tx = tx_lo; tx <= tx_hi; tx++) {
             const int tile = ty * ntx + tx;
             const int slot = s_base[tile] + atomicAdd(&s_cnt[tile], 1);
-            if (slot < k.rt_cap)
-                tile_list[(tb + tile) * RT_CAP + slot] = t;
-            else
-                tile_ovf[pair * 2 + side] = 1;
+            if (slot < k.rt_cap) tile_list[(tb + tile) * RT_CAP + slot] = t;  // (a tile whose count passes the cap walks all triangles)
         }
 }
 
@@ -1099,7 +1101,7 @@ __device__ __forceinline__ int group16_max(int v) {
 
 // elas.cpp:912-940 for the part of every binned triangle that falls into this workgroup's tile
 __global__ __launch_bounds__(256) void k_raster_tiles(KParams k, const int32_t *__restrict__ blob, const RasterRec *__restrict__ rrec, const int32_t *__restrict__ tile_cnt,
-                                                      const int32_t *__restrict__ tile_list, const int32_t *__restrict__ tile_ovf, int32_t *__restrict__ tri_id) {
+                                                      const int32_t *__restrict__ tile_list, int32_t *__restrict__ tri_id) {
     const Dims &d = k.d;
     const int pair = blockIdx.z, side = blockIdx.y;
     if (blob[pair * META_WORDS] < 3) return;
@@ -1108,9 +1110,12 @@ __global__ __launch_bounds__(256) void k_raster_tiles(KParams k, const int32_t *
     __shared__ int32_t tile[RT_H][RT_W];
     for (int i = threadIdx.x; i < RT_H * RT_W; i += 256) (&tile[0][0])[i] = -1;
     __syncthreads();
-    const bool ovf = tile_ovf[pair * 2 + side] != 0;  // overflow somewhere in this map: k_raster (global atomics) does the work
     const size_t gt = (size_t)(pair * 2 + side) * gridDim.x + blockIdx.x;
-    const int cnt = ovf ? 0 : tile_cnt[gt];
+    // A tile whose list overflowed (more than rt_cap triangles touch it: pathological triangulations) walks ALL triangles of its
+    // side instead - those outside the tile clip to nothing.  Decided per tile: no second kernel, no flag.
+    const int listed = tile_cnt[gt];
+    const bool all = listed > k.rt_cap;
+    const int cnt = all ? blob[pair * META_WORDS + 2 + 2 * side] : listed;
     // 8 lanes per triangle (a lattice triangle is ~5 columns wide), one lane per column of [A_u, C_u): the edge below / above
     // the long edge AC is AB left of B_u and BC from B_u on (elas.cpp:913-925 and :928-940 are the two halves of this range)
     const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
@@ -1118,13 +1123,14 @@ __global__ __launch_bounds__(256) void k_raster_tiles(KParams k, const int32_t *
     // whole 8-lane groups walk the list together, one trip ahead with the loads (list entry, then its record: two dependent
     // memory accesses that would otherwise sit in front of every trip)
     const RasterRec *recs = rrec + (size_t)(pair * 2 + side) * d.max_tri;
-    int t_next = grp < cnt ? tile_list[gt * RT_CAP + grp] : 0;
+    const int32_t *list = tile_list + gt * RT_CAP;
+    int t_next = grp < cnt ? (all ? grp : list[grp]) : 0;
     RasterRec r_next = recs[t_next];
     for (int i = grp; i < cnt; i += 32) {
         const int t = t_next;
         const RasterRec r = r_next;
         if (i + 32 < cnt) {
-            t_next = tile_list[gt * RT_CAP + i + 32];
+            t_next = all ? i + 32 : list[i + 32];
             r_next = recs[t_next];
         }
         const int u_begin = max(max(r.a_u, 0), tx0), u_end = min(min(r.c_u, d.W), x_end);
@@ -1155,60 +1161,15 @@ __global__ __launch_bounds__(256) void k_raster_tiles(KParams k, const int32_t *
     }
 }
 
-// Fallback for maps whose tile lists overflowed: 16 lanes per triangle straight on global memory (k_raster_tiles has
-// already filled such maps with -1).
-__global__ __launch_bounds__(256) void k_raster(KParams k, const int32_t *__restrict__ blob, const RasterRec *__restrict__ rrec, const int32_t *__restrict__ tile_ovf,
-                                                int32_t *__restrict__ tri_id) {
-    const Dims &d = k.d;
-    const int pair = blockIdx.z, side = blockIdx.y;
-    if (tile_ovf[pair * 2 + side] == 0) return;
-    const int sub = threadIdx.x & 15;
-    const int32_t *meta = blob + pair * META_WORDS;
-    if (meta[0] < 3) return;
-    int32_t *ids = tri_id + (size_t)(pair * 2 + side) * d.N;
-    const int ntri = meta[2 + 2 * side];
-    for (int t0 = blockIdx.x * 16; t0 < ntri; t0 += gridDim.x * 16) {
-    const int t = t0 + (threadIdx.x >> 4);
-    const bool live = t < ntri;  // whole 16-lane groups are live or not
-    RasterRec r;
-    if (live) r = rrec[(size_t)(pair * 2 + side) * d.max_tri + t];
-#pragma unroll
-    for (int part = 0; part < 2; part++) {
-        const int ua = part == 0 ? r.a_u : r.b_u, ub = part == 0 ? r.b_u : r.c_u;
-        const float e_a = part == 0 ? r.ab_a : r.bc_a, e_b = part == 0 ? r.ab_b : r.bc_b;
-        const int u_begin = live && ua != ub ? max(ua, 0) : 0, u_end = live && ua != ub ? min(ub, d.W) : 0;
-        const int width = group16_max(u_end - u_begin);
-        for (int base = 0; base < width; base += 16) {
-            const int u = u_begin + base + sub;
-            int lo = 0x7FFFFFFF, hi = -0x7FFFFFFF;
-            if (u < u_end) {
-                const int v_1 = (int)(r.ac_a * (float)u + r.ac_b), v_2 = (int)(e_a * (float)u + e_b);
-                lo = max(min(v_1, v_2), 0);
-                hi = min(max(v_1, v_2), d.H);
-                if (lo >= hi) {
-                    lo = 0x7FFFFFFF;
-                    hi = -0x7FFFFFFF;
-                }
-            }
-            const int glo = group16_min(lo), ghi = group16_max(hi);
-            for (int v = glo; v < ghi; v++)
-                if (v >= lo && v < hi) atomicMax(&ids[(size_t)v * d.W + u], t);
-        }
-    }
-    }
-}
-
 void launch_triangles(const KParams &k, const SlotDev &s, int n, int max_points, hipStream_t st) {
     const int ntile = ((k.d.W + RT_W - 1) / RT_W) * ((k.d.H + RT_H - 1) / RT_H);
-    (void)hipMemsetAsync(s.tile_cnt, 0, sizeof(int32_t) * ((size_t)n * 2 * ntile + (size_t)s.cap * 2), st);  // counters + overflow flags (contiguous)
-    int32_t *ovf = s.tile_cnt + (size_t)s.cap * 2 * ntile;
+    // (the tile counters were cleared together with the cell masks: launch_grid)
     const int nt = std::max(1, std::min(2 * max_points, k.d.max_tri));  // a triangulation of p points has < 2p triangles
     const size_t pl_lds = sizeof(int32_t) * 2 * (size_t)ntile;
     static std::atomic<size_t> pl_granted[64];
     ensure_dynamic_lds(k_planes, pl_lds, pl_granted, "plane_fit");
-    SV_LAUNCH(K_PLANES, k_planes, dim3((nt + 255) / 256, 2, n), dim3(256), pl_lds, st, k, s.blob, s.trirec, s.planes, (RasterRec *)s.rrec, s.tile_cnt, s.tile_list, ovf);
-    SV_LAUNCH(K_TRIANGLES, k_raster_tiles, dim3(ntile, 2, n), dim3(256), 0, st, k, s.blob, (const RasterRec *)s.rrec, s.tile_cnt, s.tile_list, ovf, s.tri_id);
-    SV_LAUNCH(K_TRIANGLES_FALLBACK, k_raster, dim3(64, 2, n), dim3(256), 0, st, k, s.blob, (const RasterRec *)s.rrec, ovf, s.tri_id);
+    SV_LAUNCH(K_PLANES, k_planes, dim3((nt + 255) / 256, 2, n), dim3(256), pl_lds, st, k, s.blob, s.trirec, s.planes, (RasterRec *)s.rrec, s.tile_cnt, s.tile_list);
+    SV_LAUNCH(K_TRIANGLES, k_raster_tiles, dim3(ntile, 2, n), dim3(256), 0, st, k, s.blob, (const RasterRec *)s.rrec, s.tile_cnt, s.tile_list, s.tri_id);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -58,7 +58,7 @@ struct SlotDev {
                         //                   [4] #triangles right [5] offset           (offsets in int32 units from blob)
     float4 *trirec;     // [cap][2][max_tri]  (a, b, c, valid) of the side's own plane
     void *rrec;         // [cap][2][max_tri]  raster records (k_planes -> raster kernels), 36 B each
-    int32_t *tile_cnt;  // [cap][2][ntile] triangles binned per 64x32 raster tile, followed by [cap][2] overflow flags
+    int32_t *tile_cnt;  // [cap][2][ntile] triangles binned per 64x32 raster tile (same allocation as gmaskA, right behind it)
     int32_t *tile_list; // [cap][2][ntile][512] their indices
     float *planes;      // [cap][2][max_tri][6] t1a t1b t1c t2a t2b t2c (kept for parity tests)
     uint32_t *gmaskA;   // [cap][2][ncell][MW] support marks
@@ -83,6 +83,9 @@ size_t support_filter_ws_bytes(const KParams &k, int cap);
 size_t ccl_ws_bytes(const KParams &k, int maps_cap);
 size_t ccl_lds_bytes(const KParams &k);
 void launch_support_filter(const KParams &k, int win, int thr, int need, const SlotDev &s, int n, hipStream_t st);
+size_t grid_masks_words(const KParams &k, int cap);  // gmaskA and tile_cnt are ONE allocation of grid_clear_bytes (cleared by one memset)
+size_t raster_tiles(const KParams &k);
+size_t grid_clear_bytes(const KParams &k, int cap);
 void launch_grid(const KParams &k, const SlotDev &s, int n, int max_points, hipStream_t st);
 void launch_triangles(const KParams &k, const SlotDev &s, int n, int max_points, hipStream_t st);
 void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st);
@@ -103,7 +106,7 @@ int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const
 
 // names of the kernels behind each wrapper, in launch order, for timing reports
 enum KernelId {
-    K_DESCRIPTOR = 0, K_SUPPORT, K_SUPPORT_FILTER, K_GRID_MARK, K_GRID_DILATE, K_PLANES, K_TRIANGLES, K_TRIANGLES_FALLBACK, K_DENSE, K_LR,
+    K_DESCRIPTOR = 0, K_SUPPORT, K_SUPPORT_FILTER, K_GRID_MARK, K_GRID_DILATE, K_PLANES, K_TRIANGLES, K_DENSE, K_LR,
     K_DELAUNAY, K_CCL_BAND, K_CCL_FINISH, K_GAP_ROWS, K_GAP_COLS, K_AMEAN, K_MEDIAN, K_OUTPUT, K_COUNT
 };
 const char *kernel_name(int id);
