@@ -297,8 +297,8 @@ def load_real_pair():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (0 = the workload's default: 256 for the headline)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kitti_d128", help="kitti_d128 is BASELINE.json's metric configuration")
     ap.add_argument("--workers", type=int, default=0, help="host pool threads (0 = library default)")

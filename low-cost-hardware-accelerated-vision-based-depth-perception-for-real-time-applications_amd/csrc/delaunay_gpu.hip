@@ -486,7 +486,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_delaunay_blob(int32_t *__restric
     const int pair = blockIdx.x >> 1, side = blockIdx.x & 1;
     int32_t *meta = blob + (size_t)pair * META_WORDS;
     const int ns = meta[0];
-    if (ns < 3) return;
+    if (ns < 3 || meta[7] == 0) return;  // meta[7]: this pair is triangulated here (the host pool did the others)
     const int32_t *sup = blob + meta[1];
     const int32_t *ord = blob + meta[5] + (size_t)2 * ns * 3 + (size_t)side * (ns + 1);
     const int m = ord[0];

@@ -134,6 +134,7 @@ struct sv_handle {
     int chunk = 1;
     bool block_sync = false;  // host waits on events sleep (throughput mode) instead of spinning (latency mode)
     bool gpu_delaunay = false;  // divide-and-conquer phase of the triangulations on the GPU (delaunay_gpu.hip); the host only orders the vertices
+    int gpu_delaunay_pct = 0;   // ... for this share of the pairs (100 in the GPU mode; a part in the host mode relieves the pool)
     bool gpu_filter = false;  // lattice filters on the GPU (k_support_filter) instead of the host pool
     std::vector<Slot *> slots;
     hipStream_t sP1 = nullptr, sPF = nullptr;  // phase 1; lattice filter + its D2H
@@ -725,7 +726,7 @@ void triangulate_side(sv_handle *h, HostScratch *sc, Slot *s, int j, int side) {
         sc->xy[2 * q + 1] = sup[3 * q + 1];
     }
     const auto t0 = std::chrono::steady_clock::now();
-    if (h->gpu_delaunay) {
+    if (meta[7]) {  // this pair's triangulations run on the GPU
         // only the preparation stays here: [m, ids in k-d order] behind the two triangle lists; k_delaunay_blob does the rest.
         // Sets the kernel cannot hold (LDS) are triangulated here as usual and marked with m = -1.
         int32_t *ord = blob + meta[5] + (size_t)2 * ns * 3 + (size_t)side * (ns + 1);
@@ -799,13 +800,17 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
     meta[0] = ns;
     meta[1] = meta[3] = meta[5] = 0;
     meta[2] = meta[4] = 0;
-    meta[6] = meta[7] = 0;
+    meta[6] = 0;
+    {  // which pairs are triangulated on the GPU: every pair in the GPU mode, an evenly spread share of them otherwise
+        const long idx = (long)s->i0 + t.pair, pct = h->gpu_delaunay_pct;
+        meta[7] = (pct >= 100 || ((idx + 1) * pct / 100 != idx * pct / 100)) && pct > 0 ? 1 : 0;
+    }
     if (ns < 3) {  // elas.cpp:63-69
         pair_done(h, s);
         return;
     }
     // 3*ns words of points + two triangle lists of at most 2*ns triangles each
-    const size_t need = (size_t)ns * 3 + 2 * ((size_t)2 * ns * 3) + (h->gpu_delaunay ? 2 * ((size_t)ns + 1) : 0);
+    const size_t need = (size_t)ns * 3 + 2 * ((size_t)2 * ns * 3) + (meta[7] ? 2 * ((size_t)ns + 1) : 0);
     const size_t off = s->blob_off.fetch_add(need);
     if (off + need > s->blob_words) {
         note_error(h, "host blob overflow");
@@ -817,7 +822,7 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
     meta[3] = (int32_t)(off + (size_t)ns * 3);
     meta[5] = (int32_t)(off + (size_t)ns * 3 + (size_t)2 * ns * 3);
     memcpy(blob + off, sc->sup.data(), sizeof(int32_t) * (size_t)ns * 3);
-    if (s->inline_mode && !h->gpu_delaunay) {
+    if (s->inline_mode && !meta[7]) {
         // latency mode (this is the calling thread): the candidate grid only needs the support points - upload them and launch
         // it now, so that it runs while the two triangulations are built
         try {
@@ -915,10 +920,11 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
         dbg_put(h, "tri2", blob + meta[5], (size_t)meta[4] * 3);
     }
     HIP_TRY(hipMemcpyAsync(s->dev.blob, blob, off * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    if (h->gpu_delaunay) {  // the triangle lists are still missing: built on the device from the vertex orders the host left in the blob
-        int ns_max = 3;
-        for (int j = 0; j < n; j++) ns_max = std::max(ns_max, std::min(blob[(size_t)j * META_WORDS], delaunay_gpu_max_points()));
-        launch_delaunay_blob(s->dev.blob, n, delaunay_gpu_lds_bytes(ns_max, ns_max), st);
+    if (h->gpu_delaunay_pct > 0) {  // triangle lists still missing: built on the device from the vertex orders the host left in the blob
+        int ns_max = 0;
+        for (int j = 0; j < n; j++)
+            if (blob[(size_t)j * META_WORDS + 7]) ns_max = std::max(ns_max, std::min(blob[(size_t)j * META_WORDS], delaunay_gpu_max_points()));
+        if (ns_max >= 3) launch_delaunay_blob(s->dev.blob, n, delaunay_gpu_lds_bytes(ns_max, ns_max), st);
     }
     int max_points = 0;  // the chunk's largest support-point count: sizes the grids of the per-point / per-triangle kernels
     for (int j = 0; j < n; j++) max_points = std::max(max_points, blob[(size_t)j * META_WORDS]);
@@ -1471,6 +1477,12 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     //  GPU mode.
     h->gpu_delaunay = !cfg->keep_debug && h->chunk >= 4 && npool < 16;
     if (const char *e = getenv("SV_GPU_DELAUNAY")) h->gpu_delaunay = atoi(e) != 0 && !cfg->keep_debug;
+    // A share of the pairs can go to the GPU kernel while the pool does the rest (SV_GPU_DELAUNAY_PCT, experiments only): measured
+    // with 16 pool threads 0 % -> 39 300 - 41 300 pairs/s, 15 % -> 39 700, 25 % -> 38 200, 40 % -> 33 600 - 39 000: every chunk
+    // then waits for the 0.8 ms latency chain of the triangulation kernel, which costs more than the relieved pool gains.
+    h->gpu_delaunay_pct = h->gpu_delaunay ? 100 : 0;
+    if (const char *e = getenv("SV_GPU_DELAUNAY_PCT")) h->gpu_delaunay_pct = (cfg->keep_debug || h->chunk < 4) ? 0 : std::max(0, std::min(100, atoi(e)));
+    if (h->gpu_delaunay_pct >= 100) h->gpu_delaunay = true;
     h->block_sync = h->chunk >= 4;
     if (const char *e = getenv("SV_EVENT_SYNC")) h->block_sync = strcmp(e, "block") == 0;
     try {
