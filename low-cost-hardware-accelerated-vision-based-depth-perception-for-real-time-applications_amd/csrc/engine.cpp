@@ -1100,7 +1100,10 @@ double host_cpu_share(bool *quota) {
 int default_pool_size() {
     bool have_quota = false;
     const int share = std::max(1, (int)host_cpu_share(&have_quota));
-    return std::max(1, std::min(have_quota ? 32 : 16, share));
+    // under a CPU quota the pool leaves two cores to the control threads and the caller: a pool that fills the quota gets the whole
+    // process throttled in bursts (sustained over 20 000 pairs: 37 300 - 38 600 pairs/s with 16 threads of a 16-CPU quota,
+    // 40 100 - 40 400 with 14)
+    return std::max(1, std::min(have_quota ? 32 : 16, have_quota && share > 4 ? share - 2 : share));
 }
 
 template <class T>
@@ -1470,17 +1473,13 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     if (h->chunk < 4 && !getenv("SV_GPU_FILTER")) h->gpu_filter = false;
     // triangulation on the GPU: on request, or by itself when few host threads are available (it costs GPU time and LDS, and a
     // single pair is faster on the host); never with keep_debug (the parity tests read the host's triangle lists)
-    // (measured, round 2: 38 300 pairs/s in this mode with 4 or 8 host threads; the host triangulation needs 16 threads to feed the
-    //  same rate - 32 000 with 14 - and is then within the noise of it)
-    //  With 16 threads the host mode is 2 % faster on average (38 400 - 40 300 against 38 000 - 38 700 on the same box) but
-    //  noisier: under a CPU quota that the pool alone fills, the control threads compete with it.  SV_GPU_DELAUNAY=1 forces the
-    //  GPU mode.
-    h->gpu_delaunay = !cfg->keep_debug && h->chunk >= 4 && npool < 16;
+    // Measured in round 2, sustained over 20 000 pairs: 38 100 - 38 500 pairs/s in the GPU mode with 4, 8 or 15 host threads; the host
+    // mode needs >= 14 threads for more (40 100 - 40 400 with 14, 33 000 with 13), and it is best with a small share of the pairs
+    // still going to the GPU kernel (10 - 20 %: 40 600 - 40 950, and steadier; 30 %: 40 100): the pool gets slack, and the 0.8 ms
+    // latency chain of the triangulation kernel is hidden beside the other streams as long as few chunks wait for it.
+    h->gpu_delaunay = !cfg->keep_debug && h->chunk >= 4 && npool < 12;
     if (const char *e = getenv("SV_GPU_DELAUNAY")) h->gpu_delaunay = atoi(e) != 0 && !cfg->keep_debug;
-    // A share of the pairs can go to the GPU kernel while the pool does the rest (SV_GPU_DELAUNAY_PCT, experiments only): measured
-    // with 16 pool threads 0 % -> 39 300 - 41 300 pairs/s, 15 % -> 39 700, 25 % -> 38 200, 40 % -> 33 600 - 39 000: every chunk
-    // then waits for the 0.8 ms latency chain of the triangulation kernel, which costs more than the relieved pool gains.
-    h->gpu_delaunay_pct = h->gpu_delaunay ? 100 : 0;
+    h->gpu_delaunay_pct = h->gpu_delaunay ? 100 : ((!cfg->keep_debug && h->chunk >= 4) ? 15 : 0);
     if (const char *e = getenv("SV_GPU_DELAUNAY_PCT")) h->gpu_delaunay_pct = (cfg->keep_debug || h->chunk < 4) ? 0 : std::max(0, std::min(100, atoi(e)));
     if (h->gpu_delaunay_pct >= 100) h->gpu_delaunay = true;
     h->block_sync = h->chunk >= 4;

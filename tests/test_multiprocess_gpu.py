@@ -57,6 +57,14 @@ def test_two_ranks_drive_the_engine(oracle, tmp_path):
     sys.path.insert(0, util.ROOT)
     import bench
     usable = bench.usable_cpus()
-    cap = 16 if alone == 16 and usable > 16 else 32  # engine.cpp:default_pool_size: at most 16 threads without a cgroup quota, 32 with one
-    assert alone == max(1, min(cap, usable))
-    assert int(r0["host_threads"]) == int(r1["host_threads"]) == max(1, min(cap, usable // 2))
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()[0] != "max"
+    except OSError:
+        quota = False
+
+    def expected(share):  # engine.cpp:default_pool_size: two cores stay free under a CPU quota; at most 16 threads without one, 32 with
+        share = max(1, share)
+        return max(1, min(32 if quota else 16, share - 2 if quota and share > 4 else share))
+
+    assert alone == expected(usable)
+    assert int(r0["host_threads"]) == int(r1["host_threads"]) == expected(usable // 2)
