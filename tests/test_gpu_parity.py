@@ -205,6 +205,27 @@ def test_pipeline_with_gpu_triangulation(eng, oracle, monkeypatch, name):
         assert util.sha(d2[i]) == entry["stages"]["final2"]
 
 
+def test_pipeline_with_mixed_triangulation(eng, oracle, monkeypatch):
+    """SV_GPU_DELAUNAY_PCT=40: inside one chunk some pairs are triangulated by the pool, the others by the GPU kernel (per-pair
+    flag in the blob's meta words); every pair still equals its own oracle result."""
+    monkeypatch.setenv("SV_GPU_DELAUNAY", "0")
+    monkeypatch.setenv("SV_GPU_DELAUNAY_PCT", "40")
+    synth = util.pkg("synth")
+    H, W, D, B = 120, 320, 64, 11
+    batch = synth.make_batch(260, B, H, W, D)
+    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), chunk=4, n_slots=2, n_streams=2, n_workers=3)
+    try:
+        assert e.query()["gpu_triangulation"] == 0
+        d1, d2, st = e.process_host(batch[:, 0], batch[:, 1])
+    finally:
+        e.close()
+    po = ElasParams.driver(D - 1)
+    for i in range(B):
+        o1, o2, _ = oracle.process(po, batch[i, 0], batch[i, 1])
+        assert st[i] >= 3
+        assert np.array_equal(d1[i].view(np.uint8), o1.view(np.uint8)) and np.array_equal(d2[i].view(np.uint8), o2.view(np.uint8)), i
+
+
 def test_random_parameter_sets(eng, oracle):
     """Elas::parameters far from the three presets (tools/fuzz_params.py): both maps, batch path and latency path, bit-exact."""
     import sys
