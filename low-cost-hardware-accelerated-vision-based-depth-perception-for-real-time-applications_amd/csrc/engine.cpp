@@ -139,7 +139,7 @@ struct sv_handle {
     std::vector<Slot *> slots;
     hipStream_t sP1 = nullptr, sPF = nullptr;  // phase 1; lattice filter + its D2H
     std::vector<hipStream_t> sP2;
-    hipStream_t sIn = nullptr, sOut = nullptr;  // host-memory jobs: image uploads / map downloads, overlapping the kernels
+    hipStream_t sIn = nullptr, sOut = nullptr, sOut2 = nullptr;  // host-memory jobs: image uploads / map downloads (two streams: two DMA engines), overlapping the kernels
     bool host_dev_ready = false, host_pin_in_ready = false, host_pin_out_ready = false;  // lazily allocated staging (guarded by host_mu)
     std::mutex host_mu;
     // control threads + queues
@@ -181,6 +181,8 @@ struct sv_handle {
     bool lat_trace = false;                    // SV_LAT_TRACE=1: wall-clock split of the latency path, printed by sv_destroy
     double lat_ns[8] = {0};
     long lat_calls = 0;
+    double drain_ns[3] = {0};  // drainer, per chunk: waiting for phase 2, downloading, handing pageable maps over
+    long drain_chunks = 0;
 };
 
 namespace {
@@ -531,6 +533,7 @@ void ensure_host_staging(sv_handle *h, bool need_pin_in, bool need_pin_out) {
     if (!h->host_dev_ready) {
         HIP_TRY(hipStreamCreateWithFlags(&h->sIn, hipStreamNonBlocking));
         HIP_TRY(hipStreamCreateWithFlags(&h->sOut, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&h->sOut2, hipStreamNonBlocking));
         const unsigned evf = hipEventDisableTiming | (h->block_sync ? hipEventBlockingSync : 0u);
         for (Slot *sl : h->slots) {
             HIP_TRY(hipMalloc((void **)&sl->d_in, 2 * cap * (size_t)d.N));
@@ -587,7 +590,7 @@ void upload_chunk(sv_handle *h, Slot *s, hipStream_t st, int copy_helpers) {
 
 // Download of one finished map block (side 0: left maps, 1: right maps) of a chunk on `st`.  Pairs with fewer than 3 support
 // points are skipped: the reference leaves the caller's maps untouched for them (elas.cpp:63-69).
-void download_maps(sv_handle *h, Slot *s, int side, hipStream_t st) {
+void download_maps(sv_handle *h, Slot *s, int side, hipStream_t st, hipStream_t st2 = nullptr) {
     const Dims &d = h->kp.d;
     const Job &job = *s->job;
     float *user = side ? job.d2 : job.d1;
@@ -602,7 +605,10 @@ void download_maps(sv_handle *h, Slot *s, int side, hipStream_t st) {
         }
         int e = j + 1;
         while (e < s->n && s->h_blob[(size_t)e * META_WORDS] >= 3) e++;
-        HIP_TRY(hipMemcpyAsync(dst + (size_t)j * Nm, dev + (size_t)j * Nm, (size_t)(e - j) * Nm * sizeof(float), hipMemcpyDeviceToHost, st));
+        // long runs go down as two halves on two streams: one DMA engine moves ~41 GB/s beside the uploads, two share the link better
+        const int half = (st2 && e - j >= 8) ? j + (e - j) / 2 : e;
+        HIP_TRY(hipMemcpyAsync(dst + (size_t)j * Nm, dev + (size_t)j * Nm, (size_t)(half - j) * Nm * sizeof(float), hipMemcpyDeviceToHost, st));
+        if (half < e) HIP_TRY(hipMemcpyAsync(dst + (size_t)half * Nm, dev + (size_t)half * Nm, (size_t)(e - half) * Nm * sizeof(float), hipMemcpyDeviceToHost, st2));
         j = e;
     }
 }
@@ -988,9 +994,11 @@ void download_chunk(sv_handle *h, Slot *s) {
         download_maps(h, s, 1, h->sOut);
     }
     HIP_TRY(hipStreamWaitEvent(h->sOut, s->ev_p2, 0));
-    download_maps(h, s, 0, h->sOut);
-    if (!only_left) download_maps(h, s, 1, h->sOut);
+    HIP_TRY(hipStreamWaitEvent(h->sOut2, s->ev_p2, 0));
+    download_maps(h, s, 0, h->sOut, h->sOut2);
+    if (!only_left) download_maps(h, s, 1, h->sOut, h->sOut2);
     HIP_TRY(hipEventRecord(s->ev_out, h->sOut));
+    HIP_TRY(hipStreamSynchronize(h->sOut2));
     HIP_TRY(hipEventSynchronize(s->ev_out));
 }
 
@@ -1047,8 +1055,18 @@ void drainer_main(sv_handle *h) {
         }
         if (s->out_enqueued && !h->failed) {
             try {
+                const auto t0 = std::chrono::steady_clock::now();
+                if (h->lat_trace) (void)hipEventSynchronize(s->ev_p2);  // trace only: separates "waiting for phase 2" from the copy
+                const auto t1 = std::chrono::steady_clock::now();
                 download_chunk(h, s);
+                const auto t2 = std::chrono::steady_clock::now();
                 deliver_maps(h, s, 3);
+                if (h->lat_trace) {
+                    h->drain_ns[0] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+                    h->drain_ns[1] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
+                    h->drain_ns[2] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t2).count();
+                    h->drain_chunks++;
+                }
             } catch (const std::exception &e) {
                 note_error(h, e.what());
             }
@@ -1203,6 +1221,7 @@ void free_handle_resources(sv_handle *h) {
     if (h->dbg_desc) (void)hipFree(h->dbg_desc);
     if (h->sIn) (void)hipStreamDestroy(h->sIn);
     if (h->sOut) (void)hipStreamDestroy(h->sOut);
+    if (h->sOut2) (void)hipStreamDestroy(h->sOut2);
 }
 
 // host-memory jobs: classify the caller's memory and make sure the staging buffers exist
@@ -1268,7 +1287,7 @@ int wait_jobs(sv_handle *h) {
     bool ok = hipStreamSynchronize(h->sP1) == hipSuccess;
     ok = (hipStreamSynchronize(h->sPF) == hipSuccess) && ok;
     for (hipStream_t st : h->sP2) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
-    for (hipStream_t st : {h->sIn, h->sOut})
+    for (hipStream_t st : {h->sIn, h->sOut, h->sOut2})
         if (st) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
     if (!ok) note_error(h, "stream synchronisation failed");
     if (h->timing) {
@@ -1526,6 +1545,9 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
 int sv_destroy(sv_handle *h) {
     if (!h) return SV_ERR_ARG;
     (void)wait_jobs(h);
+    if (h->lat_trace && h->drain_chunks > 0)
+        fprintf(stderr, "host-memory path, %ld chunks, ms per chunk: wait for phase 2 %.3f, download %.3f, deliver %.3f\n", h->drain_chunks,
+                1e-6 * h->drain_ns[0] / (double)h->drain_chunks, 1e-6 * h->drain_ns[1] / (double)h->drain_chunks, 1e-6 * h->drain_ns[2] / (double)h->drain_chunks);
     if (h->lat_trace && h->lat_calls > 0) {
         static const char *names[6] = {"enqueue phase 1", "wait phase 1", "filter + left triangulation", "wait right triangulation", "enqueue phase 2", "wait phase 2 (+ downloads)"};
         fprintf(stderr, "latency path, %ld calls, us per call:", h->lat_calls);
