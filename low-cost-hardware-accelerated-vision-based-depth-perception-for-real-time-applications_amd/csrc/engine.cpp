@@ -102,6 +102,7 @@ struct Slot {
     size_t in_pair = 0;
     int in_stride = 0;
     bool grid_issued = false;   // latency mode: the candidate grid of this chunk was launched while the host still triangulated
+    bool delivered_ok = false;  // host-memory jobs: the download succeeded (drainer -> deliverer)
     bool out_enqueued = false;  // host-memory jobs: phase 2 was enqueued (ev_lr / ev_p2 are pending), the maps can be downloaded
     int state = SLOT_FREE;
     // chunk in flight
@@ -143,7 +144,7 @@ struct sv_handle {
     bool host_dev_ready = false, host_pin_in_ready = false, host_pin_out_ready = false;  // lazily allocated staging (guarded by host_mu)
     std::mutex host_mu;
     // control threads + queues
-    std::thread t_issue, t_dispatch, t_finish, t_drain;
+    std::thread t_issue, t_dispatch, t_finish, t_drain, t_deliver;
     std::mutex mu;  // guards: job queue + counters, quit, slot states, q1, q2, error
     std::condition_variable cv;
     std::deque<Job *> jobs;       // submitted, not yet picked up by the issuer
@@ -154,6 +155,7 @@ struct sv_handle {
     std::deque<Slot *> q1;  // phase 1 issued, waiting for the dispatcher
     std::deque<Slot *> q2;  // host stage complete, waiting for phase 2
     std::deque<Slot *> q3;  // host-memory jobs: phase 2 enqueued, waiting for the drainer (downloads the maps)
+    std::deque<Slot *> q4;  // host-memory jobs: maps downloaded, waiting for the deliverer (pageable callers' copy, slot release)
     std::string error;
     std::atomic<bool> failed{false};
     // host pool
@@ -1053,23 +1055,48 @@ void drainer_main(sv_handle *h) {
             s = h->q3.front();
             h->q3.pop_front();
         }
+        s->delivered_ok = false;
         if (s->out_enqueued && !h->failed) {
             try {
                 const auto t0 = std::chrono::steady_clock::now();
                 if (h->lat_trace) (void)hipEventSynchronize(s->ev_p2);  // trace only: separates "waiting for phase 2" from the copy
                 const auto t1 = std::chrono::steady_clock::now();
                 download_chunk(h, s);
-                const auto t2 = std::chrono::steady_clock::now();
-                deliver_maps(h, s, 3);
+                s->delivered_ok = true;
                 if (h->lat_trace) {
                     h->drain_ns[0] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
-                    h->drain_ns[1] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
-                    h->drain_ns[2] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t2).count();
+                    h->drain_ns[1] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t1).count();
                     h->drain_chunks++;
                 }
             } catch (const std::exception &e) {
                 note_error(h, e.what());
             }
+        }
+        {  // the maps are in host memory (the caller's, or the page-locked mirror): the deliverer takes it from here, so that the next
+           // chunk's download runs while a pageable caller's maps are being copied over
+            std::lock_guard<std::mutex> lk(h->mu);
+            h->q4.push_back(s);
+        }
+        h->cv.notify_all();
+    }
+}
+
+// ---- stage 5 (host-memory jobs only): deliverer ---------------------------------------------------------------------------
+// Pageable callers: page-locked mirror -> the caller's arrays.  Frees the slot and counts the job's chunks.
+void deliverer_main(sv_handle *h) {
+    for (;;) {
+        Slot *s = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(h->mu);
+            h->cv.wait(lk, [&] { return h->quit || !h->q4.empty(); });
+            if (h->quit) return;
+            s = h->q4.front();
+            h->q4.pop_front();
+        }
+        if (s->delivered_ok && !h->failed) {
+            const auto t0 = std::chrono::steady_clock::now();
+            deliver_maps(h, s, 3);
+            if (h->lat_trace) h->drain_ns[2] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
         }
         {
             std::lock_guard<std::mutex> lk(h->mu);
@@ -1538,6 +1565,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     h->t_dispatch = std::thread(dispatcher_main, h);
     h->t_finish = std::thread(finisher_main, h);
     h->t_drain = std::thread(drainer_main, h);
+    h->t_deliver = std::thread(deliverer_main, h);
     *out = h;
     return SV_OK;
 }
@@ -1559,7 +1587,7 @@ int sv_destroy(sv_handle *h) {
         h->quit = true;
     }
     h->cv.notify_all();
-    for (std::thread *t : {&h->t_issue, &h->t_dispatch, &h->t_finish, &h->t_drain})
+    for (std::thread *t : {&h->t_issue, &h->t_dispatch, &h->t_finish, &h->t_drain, &h->t_deliver})
         if (t->joinable()) t->join();
     {
         std::lock_guard<std::mutex> lk(h->qmu);
