@@ -2254,36 +2254,57 @@ __global__ __launch_bounds__(256) void k_amean(KParams k, int nproc, const int32
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (PF_TH + 7) * PF_TW; i += 256) {  // horizontal pass (:1402-1441)
-        const int r = i / PF_TW, cx = i - r * PF_TW;
-        const int y = y0 - 4 + r, x = x0 + cx;
-        const float self = sD[r][cx + 4];
-        float out = self < 0 ? -10.0f : 0.0f;  // D_tmp: -10 where invalid (:1313-1318), canonical 0 elsewhere (:1308)
-        if (y >= 3 && y < d.H - 3 && x >= 4 && x <= d.W - 4) {
-            const int first = x - 4;  // window x-4..x+3 = tile columns cx..cx+7; ring slot of pixel p is p & 7
-            float xs[8];
+    // A thread keeps its column and walks rows wave, wave+4, ...: the ring rotation ((j - first) & 7) is then the same for all of
+    // its items, so the eight tap addresses are computed once and every later load is base + constant.
+    const int cx = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float *sDf = &sD[0][0], *sTf = &sT[0][0];
+    {  // horizontal pass (:1402-1441); first = x - 4 with x0 a multiple of 8: slot j holds tile column cx + ((j - cx + 4) & 7)
+        const float *hp[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) xs[j] = sD[r][cx + ((j - first) & 7)];
-            float res;
-            if (amean8(xs, self, res)) out = res;
+        for (int j = 0; j < 8; j++) hp[j] = sDf + wv * (PF_TW + 8) + cx + ((j - cx + 4) & 7);
+        const int x = x0 + cx;
+        const bool xin = x >= 4 && x <= d.W - 4;
+#pragma unroll
+        for (int t = 0; t < (PF_TH + 7 + 3) / 4; t++) {
+            const int r = wv + 4 * t;
+            if (r >= PF_TH + 7) break;
+            const int y = y0 - 4 + r;
+            const float self = sDf[wv * (PF_TW + 8) + cx + 4 + t * 4 * (PF_TW + 8)];
+            float out = self < 0 ? -10.0f : 0.0f;  // D_tmp: -10 where invalid (:1313-1318), canonical 0 elsewhere (:1308)
+            if (xin && y >= 3 && y < d.H - 3) {
+                float xs[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) xs[j] = hp[j][t * 4 * (PF_TW + 8)];
+                float res;
+                if (amean8(xs, self, res)) out = res;
+            }
+            sTf[wv * PF_TW + cx + t * 4 * PF_TW] = out;
         }
-        sT[r][cx] = out;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < PF_TH * PF_TW; i += 256) {  // vertical pass (:1445-1484)
-        const int ry = i / PF_TW, cx = i - ry * PF_TW;
-        const int y = y0 + ry, x = x0 + cx;
-        if (y >= d.H || x >= d.W) continue;
-        float val = S[(size_t)y * d.W + x];  // untouched unless the filter produces a value
-        if (x >= 3 && x < d.W - 3 && y >= 4 && y <= d.H - 4) {
-            const int first = y - 4;  // window rows y-4..y+3 = tile rows ry..ry+7
-            float xs[8];
+    {  // vertical pass (:1445-1484); first = y - 4 with y0 a multiple of 8: slot j holds tile row ry + ((j - ry + 4) & 7).  ry = wv + 4t:
+       // for odd t that rotation differs by 4 from the one of t = 0, i.e. slots j and j+4 trade places - and amean8 adds exactly those
+       // pairs first, so the sums are the same bits.
+        const float *vp[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) xs[j] = sT[ry + ((j - first) & 7)][cx];
-            float res;
-            if (amean8(xs, sT[ry + 4][cx], res)) val = res;
+        for (int j = 0; j < 8; j++) vp[j] = sTf + (wv + ((j - wv + 4) & 7)) * PF_TW + cx;
+        const int x = x0 + cx;
+        const bool xin = x >= 3 && x < d.W - 3;
+#pragma unroll
+        for (int t = 0; t < PF_TH / 4; t++) {
+            const int ry = wv + 4 * t;
+            const int y = y0 + ry;
+            if (y >= d.H || x >= d.W) continue;
+            float val = S[(size_t)y * d.W + x];  // untouched unless the filter produces a value
+            if (xin && y >= 4 && y <= d.H - 4) {
+                float xs[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) xs[j] = vp[j][t * 4 * PF_TW];
+                float res;
+                if (amean8(xs, sTf[(wv + 4) * PF_TW + cx + t * 4 * PF_TW], res)) val = res;
+            }
+            dst[off + (size_t)y * d.W + x] = val;
         }
-        dst[off + (size_t)y * d.W + x] = val;
     }
 }
 
