@@ -974,7 +974,7 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
     }
     if (active) dbg_maps_nproc(h, st, "amean", cur, s->dev.disp, n - 1);
     if (h->p.filter_median) {  // the last stage writes the caller's maps itself
-        launch_median(km, s->dev, n, h->nproc, st, cur, alt, u1, only_left ? nullptr : u2);
+        launch_median(km, s->dev, n, h->nproc, st, cur, dbg ? alt : nullptr, u1, only_left ? nullptr : u2);
         std::swap(cur, alt);
     } else {
         launch_output(km, s->dev, n, cur, u1, only_left ? nullptr : u2, st);

@@ -2394,21 +2394,19 @@ void launch_amean(const KParams &k, const SlotDev &s, int n, int nproc, hipStrea
 // ------------------------------------------------------------------------------------------------------------
 // K10 separable 7-tap median      reference: elas.cpp:1496-1560
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void cswap(float &a, float &b) {
-    const float lo = b < a ? b : a, hi = b < a ? a : b;
-    a = lo;
-    b = hi;
-}
-
-__device__ __forceinline__ float median7(float v0, float v1, float v2, float v3, float v4, float v5, float v6) {
-    // 7-input sorting network (16 compare-exchanges); the median of a multiset does not depend on the sort used
-    cswap(v0, v6); cswap(v2, v3); cswap(v4, v5);
-    cswap(v0, v2); cswap(v1, v4); cswap(v3, v6);
-    cswap(v0, v1); cswap(v2, v5); cswap(v3, v4);
-    cswap(v1, v2); cswap(v4, v6);
-    cswap(v2, v3); cswap(v4, v5);
-    cswap(v1, v2); cswap(v3, v4); cswap(v5, v6);
-    return v3;
+// Two neighbouring windows a0..a6 and a1..a7 share six values.  With s3 <= s4 the two middle values of those six, the median of
+// seven is med3(seventh, s3, s4) (the 4th smallest of the seven is s3 if the seventh is below it, s4 if above, else the seventh
+// itself).  The six are sorted as two triples (min3/med3/max3), and the k-th smallest of two sorted runs is
+// min over i+j=k of max(A_i, B_j).  The median of a multiset does not depend on how it is found (no NaNs in a disparity map).
+__device__ __forceinline__ void median7_pair(const float a[8], float &m0, float &m1) {
+    const float a1 = __builtin_fminf(__builtin_fminf(a[1], a[2]), a[3]), a3 = __builtin_fmaxf(__builtin_fmaxf(a[1], a[2]), a[3]);
+    const float a2 = __builtin_amdgcn_fmed3f(a[1], a[2], a[3]);
+    const float b1 = __builtin_fminf(__builtin_fminf(a[4], a[5]), a[6]), b3 = __builtin_fmaxf(__builtin_fmaxf(a[4], a[5]), a[6]);
+    const float b2 = __builtin_amdgcn_fmed3f(a[4], a[5], a[6]);
+    const float s3 = __builtin_fminf(__builtin_fminf(__builtin_fminf(a3, b3), __builtin_fmaxf(a2, b1)), __builtin_fmaxf(a1, b2));
+    const float s4 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a3, b1), __builtin_fmaxf(a2, b2)), __builtin_fmaxf(a1, b3));
+    m0 = __builtin_amdgcn_fmed3f(a[0], s3, s4);
+    m1 = __builtin_amdgcn_fmed3f(a[7], s3, s4);
 }
 
 // Horizontal then vertical 7-tap median through LDS tiles, out of place (src -> dst, and straight into the caller's map).
@@ -2418,6 +2416,8 @@ __global__ __launch_bounds__(256) void k_median(KParams k, int nproc, const int3
     const int m = blockIdx.z;
     const int pair = m / nproc, side = m - pair * nproc;
     if (blob[pair * META_WORDS] < 3) return;
+    float *user = side == 0 ? user_d1 : user_d2;  // the last stage writes the caller's map directly; dst (the engine's own copy) only for debug dumps
+    if (!user && !dst) return;
     const size_t off = map_offset(d, m, nproc);
     const float *S = src + off;
     const int x0 = blockIdx.x * PF_TW, y0 = blockIdx.y * PF_TH;
@@ -2441,28 +2441,58 @@ __global__ __launch_bounds__(256) void k_median(KParams k, int nproc, const int3
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < (PF_TH + 6) * PF_TW; i += 256) {
-        const int r = i / PF_TW, cx = i - r * PF_TW;
-        const int y = y0 - 3 + r, x = x0 + cx;
-        float out = 0.0f;  // calloc'd D_temp (:1506)
-        if (x >= 3 && x < d.W - 3 && y >= 3 && y < d.H - 3) {
-            const float c = sD[r][cx + 3];
-            out = c >= 0 ? median7(sD[r][cx], sD[r][cx + 1], sD[r][cx + 2], c, sD[r][cx + 4], sD[r][cx + 5], sD[r][cx + 6]) : c;
+    static_assert((PF_TW & 1) == 0 && (PF_TH & 1) == 0, "two outputs per thread");
+    {  // horizontal pass (:1515-1534): a thread makes columns 2c and 2c+1 of rows w, w+8, ...
+        const int c2 = (threadIdx.x & 31) * 2, w = threadIdx.x >> 5;
+        const int x = x0 + c2;
+        const bool in0 = x >= 3 && x < d.W - 3, in1 = x + 1 >= 3 && x + 1 < d.W - 3;
+#pragma unroll
+        for (int t = 0; t < (PF_TH + 6 + 7) / 8; t++) {
+            const int r = w + 8 * t;
+            if (r >= PF_TH + 6) break;
+            const int y = y0 - 3 + r;
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float2 v = *reinterpret_cast<const float2 *>(&sD[r][c2 + 2 * j]);
+                a[2 * j] = v.x;
+                a[2 * j + 1] = v.y;
+            }
+            float m0, m1;
+            median7_pair(a, m0, m1);
+            const bool yin = y >= 3 && y < d.H - 3;
+            float2 out;  // calloc'd D_temp (:1506) outside the filtered area; invalid centres keep their value
+            out.x = (yin && in0) ? (a[3] >= 0 ? m0 : a[3]) : 0.0f;
+            out.y = (yin && in1) ? (a[4] >= 0 ? m1 : a[4]) : 0.0f;
+            *reinterpret_cast<float2 *>(&sT[r][c2]) = out;
         }
-        sT[r][cx] = out;
     }
     __syncthreads();
-    float *user = side == 0 ? user_d1 : user_d2;  // the last stage writes the caller's map directly
-    for (int i = threadIdx.x; i < PF_TH * PF_TW; i += 256) {  // vertical pass (:1537-1556)
-        const int ry = i / PF_TW, cx = i - ry * PF_TW;
-        const int y = y0 + ry, x = x0 + cx;
-        if (y >= d.H || x >= d.W) continue;
-        float val = sD[ry + 3][cx + 3];
-        if (x >= 3 && x < d.W - 3 && y >= 3 && y < d.H - 3 && val >= 0)
-            val = median7(sT[ry][cx], sT[ry + 1][cx], sT[ry + 2][cx], sT[ry + 3][cx], sT[ry + 4][cx], sT[ry + 5][cx], sT[ry + 6][cx]);
-        const size_t q = (size_t)y * d.W + x;
-        dst[off + q] = val;
-        if (user) user[(size_t)pair * d.N + q] = val;
+    {  // vertical pass (:1537-1556): a thread makes rows 2p and 2p+1 of one column, p = w, w+4, ...
+        const int cx = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int x = x0 + cx;
+        const bool xin = x >= 3 && x < d.W - 3;
+#pragma unroll
+        for (int t = 0; t < PF_TH / 8; t++) {
+            const int ry = 2 * (w + 4 * t);
+            const int y = y0 + ry;
+            if (y >= d.H || x >= d.W) continue;
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] = sT[ry + j][cx];
+            float m0, m1;
+            median7_pair(a, m0, m1);
+            float v0 = sD[ry + 3][cx + 3], v1 = sD[ry + 4][cx + 3];
+            if (xin && y >= 3 && y < d.H - 3 && v0 >= 0) v0 = m0;
+            if (xin && y + 1 >= 3 && y + 1 < d.H - 3 && v1 >= 0) v1 = m1;
+            const size_t q = (size_t)y * d.W + x;
+            if (dst) dst[off + q] = v0;
+            if (user) user[(size_t)pair * d.N + q] = v0;
+            if (y + 1 < d.H) {
+                if (dst) dst[off + q + d.W] = v1;
+                if (user) user[(size_t)pair * d.N + q + d.W] = v1;
+            }
+        }
     }
 }
 
