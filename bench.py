@@ -417,6 +417,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ktimes = engine.kernel_times() if not args.no_kernel_timing else {}
     engine.timing(False)
+    engine_info["gpu_triangulation_share"] = engine.gpu_triangulation_share()  # host mode: what the dispatcher's load balancing handed to the GPU kernel
     elapsed = par.max_over_ranks(elapsed, device=coll_dev)
     gather_ms = None
     if args.gather and world > 1:  # the optional "trivial gather" of finished maps on rank 0 over RCCL/xGMI, outside the timed region

@@ -102,7 +102,9 @@ enum sv_query_key {
     SV_Q_CHUNK = 1,              /* pairs per GPU launch */
     SV_Q_SLOTS = 2,              /* chunks in flight */
     SV_Q_GPU_LATTICE_FILTER = 3, /* 1: support-lattice filters on the GPU, 0: on the host pool */
-    SV_Q_GPU_TRIANGULATION = 4   /* 1: Delaunay divide-and-conquer on the GPU (few host threads), 0: on the host pool */
+    SV_Q_GPU_TRIANGULATION = 4,  /* 1: Delaunay divide-and-conquer on the GPU (few host threads), 0: on the host pool */
+    SV_Q_GPU_TRIANGULATION_SHARE = 5 /* per mille of the pairs so far whose triangulations the GPU kernel built (in the host mode the
+                                        dispatcher hands it a share of a chunk while the pool is behind; results are identical) */
 };
 int sv_query(const sv_handle *h, int what);
 const char *sv_last_error(const sv_handle *h); /* h may be NULL: error of the last failed sv_create */

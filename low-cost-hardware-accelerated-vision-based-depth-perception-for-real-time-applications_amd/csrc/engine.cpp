@@ -101,6 +101,7 @@ struct Slot {
     const uint8_t *in_left = nullptr, *in_right = nullptr;
     size_t in_pair = 0;
     int in_stride = 0;
+    int gpu_pct = 0;            // share of this chunk's pairs whose triangulations go to the GPU kernel (set by the dispatcher)
     bool grid_issued = false;   // latency mode: the candidate grid of this chunk was launched while the host still triangulated
     bool delivered_ok = false;  // host-memory jobs: the download succeeded (drainer -> deliverer)
     bool out_enqueued = false;  // host-memory jobs: phase 2 was enqueued (ev_lr / ev_p2 are pending), the maps can be downloaded
@@ -136,6 +137,9 @@ struct sv_handle {
     bool block_sync = false;  // host waits on events sleep (throughput mode) instead of spinning (latency mode)
     bool gpu_delaunay = false;  // divide-and-conquer phase of the triangulations on the GPU (delaunay_gpu.hip); the host only orders the vertices
     int gpu_delaunay_pct = 0;   // ... for this share of the pairs (100 in the GPU mode; a part in the host mode relieves the pool)
+    bool gpu_share_auto = false;  // host mode: the dispatcher moves that share up while the pool falls behind the GPU, down while it idles
+    int auto_pct = 0;             // (dispatcher thread only)
+    std::atomic<int64_t> gpu_tri_pairs{0}, tri_pairs{0};  // pairs triangulated by the GPU kernel / all pairs, since creation
     bool gpu_filter = false;  // lattice filters on the GPU (k_support_filter) instead of the host pool
     std::vector<Slot *> slots;
     hipStream_t sP1 = nullptr, sPF = nullptr;  // phase 1; lattice filter + its D2H
@@ -810,8 +814,10 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
     meta[2] = meta[4] = 0;
     meta[6] = 0;
     {  // which pairs are triangulated on the GPU: every pair in the GPU mode, an evenly spread share of them otherwise
-        const long idx = (long)s->i0 + t.pair, pct = h->gpu_delaunay_pct;
+        const long idx = (long)s->i0 + t.pair, pct = s->gpu_pct;
         meta[7] = (pct >= 100 || ((idx + 1) * pct / 100 != idx * pct / 100)) && pct > 0 ? 1 : 0;
+        h->tri_pairs.fetch_add(1, std::memory_order_relaxed);
+        if (meta[7]) h->gpu_tri_pairs.fetch_add(1, std::memory_order_relaxed);
     }
     if (ns < 3) {  // elas.cpp:63-69
         pair_done(h, s);
@@ -903,6 +909,17 @@ void dispatcher_main(sv_handle *h) {
         }
         s->blob_off.store((size_t)s->dev.cap * META_WORDS);
         s->pending.store(s->n);
+        s->gpu_pct = h->gpu_delaunay_pct;
+        if (h->gpu_share_auto) {
+            // Tasks of earlier chunks that no pool thread has picked up yet when the next lattice arrives: the pool is behind the GPU,
+            // so the triangulation kernel takes a larger share of this chunk; a short queue gives the share back to the pool.  (One
+            // chunk at a time - a single slot, a profile's serial pass - never finds a backlog and stays on the host.)
+            const int backlog = h->queue_len.load(std::memory_order_acquire);
+            // (thresholds from a sweep on one MI355X + 14 pool threads: 1.5 / 0.5 chunks, steps of 5 up to 30 % settle near 15 %)
+            if (backlog * 2 > s->n * 3) h->auto_pct = std::min(h->auto_pct + 5, 30);
+            else if (backlog * 2 <= s->n) h->auto_pct = std::max(h->auto_pct - 5, 0);
+            s->gpu_pct = h->auto_pct;
+        }
         {
             std::lock_guard<std::mutex> lk(h->qmu);
             for (int j = 0; j < s->n; j++) h->queue.push_back(Task{s, j, -1});
@@ -928,7 +945,7 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
         dbg_put(h, "tri2", blob + meta[5], (size_t)meta[4] * 3);
     }
     HIP_TRY(hipMemcpyAsync(s->dev.blob, blob, off * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    if (h->gpu_delaunay_pct > 0) {  // triangle lists still missing: built on the device from the vertex orders the host left in the blob
+    if (s->gpu_pct > 0) {  // triangle lists still missing: built on the device from the vertex orders the host left in the blob
         int ns_max = 0;
         for (int j = 0; j < n; j++)
             if (blob[(size_t)j * META_WORDS + 7]) ns_max = std::max(ns_max, std::min(blob[(size_t)j * META_WORDS], delaunay_gpu_max_points()));
@@ -1370,6 +1387,7 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
         tp[2] = clk::now();
         s->blob_off.store((size_t)s->dev.cap * META_WORDS);
         s->pending.store(1);
+        s->gpu_pct = 0;
         run_task(h, h->inline_scratch, Task{s, 0, -1});
         tp[3] = clk::now();
         while (!s->inline_done.load(std::memory_order_acquire)) __builtin_ia32_pause();
@@ -1525,11 +1543,13 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     // latency chain of the triangulation kernel is hidden beside the other streams as long as few chunks wait for it.
     h->gpu_delaunay = !cfg->keep_debug && h->chunk >= 4 && npool < 12;
     if (const char *e = getenv("SV_GPU_DELAUNAY")) h->gpu_delaunay = atoi(e) != 0 && !cfg->keep_debug;
-    // (That share is 0 by default: the gain is 1 %, and one 0.8 ms latency-chain launch per chunk would be the longest kernel of
-    //  every profile of the default configuration without being its bottleneck.  SV_GPU_DELAUNAY_PCT=15 turns it on.)
+    // (SV_GPU_DELAUNAY_PCT fixes that share; without it the dispatcher balances it by the pool's backlog, see dispatcher_main.)
     h->gpu_delaunay_pct = h->gpu_delaunay ? 100 : 0;
     if (const char *e = getenv("SV_GPU_DELAUNAY_PCT")) h->gpu_delaunay_pct = (cfg->keep_debug || h->chunk < 4) ? 0 : std::max(0, std::min(100, atoi(e)));
     if (h->gpu_delaunay_pct >= 100) h->gpu_delaunay = true;
+    // host mode without a fixed share: the share follows the pool's backlog (42 600 against 40 100 pairs/s with 14 threads)
+    h->gpu_share_auto = !h->gpu_delaunay && !getenv("SV_GPU_DELAUNAY_PCT") && !cfg->keep_debug && h->chunk >= 4;
+    if (const char *e = getenv("SV_GPU_DELAUNAY_AUTO")) h->gpu_share_auto = h->gpu_share_auto && atoi(e) != 0;
     h->block_sync = h->chunk >= 4;
     if (const char *e = getenv("SV_EVENT_SYNC")) h->block_sync = strcmp(e, "block") == 0;
     try {
@@ -1623,6 +1643,10 @@ int sv_query(const sv_handle *h, int what) {
         case SV_Q_SLOTS: return (int)h->slots.size();
         case SV_Q_GPU_LATTICE_FILTER: return h->gpu_filter ? 1 : 0;
         case SV_Q_GPU_TRIANGULATION: return h->gpu_delaunay ? 1 : 0;
+        case SV_Q_GPU_TRIANGULATION_SHARE: {
+            const int64_t all = h->tri_pairs.load(), g = h->gpu_tri_pairs.load();
+            return all > 0 ? (int)((g * 1000 + all / 2) / all) : 0;
+        }
         default: return SV_ERR_ARG;
     }
 }

@@ -277,6 +277,10 @@ class StereoEngine:
         keys = ["host_threads", "chunk", "slots", "gpu_lattice_filter", "gpu_triangulation"]
         return {k: int(L.sv_query(self._h, i)) for i, k in enumerate(keys)}
 
+    def gpu_triangulation_share(self):
+        """Fraction of the pairs so far whose triangulations the GPU kernel built (host mode: the dispatcher's load balancing)."""
+        return int(lib().sv_query(self._h, 5)) / 1000.0
+
     def timing(self, on=True, only=None):
         """HIP-event timing of the kernel launches; `only` = iterable of kernel names restricts it (cheaper)."""
         if lib().sv_kernel_timing_select(self._h, ",".join(only).encode() if only else None) != 0:

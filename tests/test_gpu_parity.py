@@ -226,6 +226,33 @@ def test_pipeline_with_mixed_triangulation(eng, oracle, monkeypatch):
         assert np.array_equal(d1[i].view(np.uint8), o1.view(np.uint8)) and np.array_equal(d2[i].view(np.uint8), o2.view(np.uint8)), i
 
 
+def test_pipeline_with_balanced_triangulation(eng, oracle, monkeypatch):
+    """Host mode with a pool that cannot keep up (2 threads): the dispatcher hands a growing share of each chunk to the GPU
+    triangulation kernel (engine.cpp dispatcher_main); which pairs it takes depends on timing, the maps do not."""
+    monkeypatch.setenv("SV_GPU_DELAUNAY", "0")
+    monkeypatch.delenv("SV_GPU_DELAUNAY_PCT", raising=False)
+    synth = util.pkg("synth")
+    H, W, D, B = 375, 1242, 128, 4  # full-size pairs: two threads triangulate ~5 000 of them per second, the GPU asks for far more
+    batch = synth.make_batch(411, B, H, W, D)
+    l, r = np.concatenate([batch[:, 0]] * 32), np.concatenate([batch[:, 1]] * 32)
+    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), chunk=8, n_slots=6, n_streams=2, n_workers=2)
+    try:
+        assert e.query()["gpu_triangulation"] == 0
+        d1, d2, st = e.process_host(l, r)
+        share = e.gpu_triangulation_share()
+    finally:
+        e.close()
+    po = ElasParams.driver(D - 1)
+    for i in range(B):
+        o1, o2, _ = oracle.process(po, batch[i, 0], batch[i, 1])
+        for rep in range(32):
+            q = i + rep * B
+            assert st[q] >= 3
+            assert np.array_equal(d1[q].view(np.uint8), o1.view(np.uint8)) and np.array_equal(d2[q].view(np.uint8), o2.view(np.uint8)), q
+    if share == 0:
+        pytest.skip("the pool never fell behind on this box: no pair went to the GPU kernel")
+
+
 def test_random_parameter_sets(eng, oracle):
     """Elas::parameters far from the three presets (tools/fuzz_params.py): both maps, batch path and latency path, bit-exact."""
     import sys
