@@ -48,7 +48,7 @@ W, H, D = 1242, 375, 128  # headline workload (BASELINE.json configs[1]/[2]); --
 WORKLOADS = {  # name: (W, H, D, default pairs per GPU per step, chunk, slots, synth scale, first seed, distinct pairs generated)
     "kitti_d128": (1242, 375, 128, 256, 0, 0, 1, 1000, 256),
     "kitti_d256": (1242, 375, 256, 64, 0, 0, 1, 1000, 64),      # configs[3]: LDS-pressure configuration
-    "4k_d192": (3840, 2160, 192, 128, 4, 4, 3, 5000, 16),        # configs[4]: 128 pairs per GPU; 16 distinct pairs repeated (a 4K pair takes ~1 s to synthesise)
+    "4k_d192": (3840, 2160, 192, 128, 0, 0, 3, 5000, 16),        # configs[4]: 128 pairs per GPU; 16 distinct pairs repeated (a 4K pair takes ~1 s to synthesise)
 }
 METRIC = {
     "kitti_d128": "stereo pairs/sec, KITTI 1242x375 D=128 (ms/frame at batch 1 in latency_ms_batch1)",

@@ -91,7 +91,7 @@ typedef struct sv_config {
     int32_t chunk;      /* pairs per GPU launch = pairs per pipeline slot (0 = default 64, less for large images) */
     int32_t keep_debug; /* != 0: keep per-stage intermediates of the LAST processed pair for sv_debug_get */
     int32_t n_streams;  /* HIP streams the second GPU phase alternates over (0 = default 4); phase 1 has its own streams */
-    int32_t n_slots;    /* buffer slots (chunks in flight) of the 3-stage pipeline (0 = default 8, within a 24 GB budget) */
+    int32_t n_slots;    /* buffer slots (chunks in flight) of the 3-stage pipeline (0 = default 8, within a quarter of the free HBM / 64 GB) */
 } sv_config;
 
 int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out);
@@ -103,6 +103,8 @@ enum sv_query_key {
     SV_Q_SLOTS = 2,              /* chunks in flight */
     SV_Q_GPU_LATTICE_FILTER = 3, /* 1: support-lattice filters on the GPU, 0: on the host pool */
     SV_Q_GPU_TRIANGULATION = 4,  /* 1: Delaunay divide-and-conquer on the GPU (few host threads), 0: on the host pool */
+    SV_Q_GPU_TRIANGULATION_FALLBACKS = 6, /* vertex sets handed to the GPU kernel's share that the host triangulated after all (larger
+                                             than the kernels take: 131 072 vertices) */
     SV_Q_GPU_TRIANGULATION_SHARE = 5 /* per mille of the pairs so far whose triangulations the GPU kernel built (in the host mode the
                                         dispatcher hands it a share of a chunk while the pool is behind; results are identical) */
 };
@@ -178,7 +180,8 @@ int sv_host_delaunay_split(const int32_t *xy, int n, int32_t *tri_out, int cap, 
  * threads does). */
 int sv_host_delaunay_par(const int32_t *xy, int n, int32_t *tri_out, int cap, int depth, int helper_delay_us);
 /* Test hook: the divide-and-conquer phase of that triangulation on the GPU (csrc/delaunay_gpu.hip; sort, duplicate scan and k-d
- * ordering on the host), `reps` copies of the set in one launch, kernel time in *kernel_ms (may be NULL).  n <= 4000. */
+ * ordering on the host), `reps` copies of the set in one launch, kernel time in *kernel_ms (may be NULL).  n <= 4000: one workgroup per set, mesh in LDS;
+ * larger sets (<= 256 000): subtrees in LDS, upper merges in a global-memory mesh (SV_DG_SUBMAX lowers the 4000 for tests). */
 int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int reps, double *kernel_ms);
 
 /* ---- (A) the reference's exported symbols ------------------------------------------------------------- */

@@ -10,6 +10,11 @@
 // One workgroup triangulates one vertex set: the mesh lives in LDS (12-byte triangles with 16-bit handles), the tree is
 // processed bottom-up, one lane per node of the current depth, a barrier between depths.
 //
+// Sets too large for LDS (> DG_SUB_MAX vertices, the 4K configuration: ~30 000) are cut at the tree depth c where every node fits:
+// k_dgl_subtrees triangulates the 2^c subtrees as above, one workgroup each with local vertex numbers, and exports them into a
+// mesh in global memory (24-byte triangles with 32-bit handles, slot numbers of the whole set); k_dgl_top then runs the 2^c - 1
+// remaining merges on that mesh, depth by depth, one lane per merge (the seams are O(sqrt n) long), and compacts the list.
+//
 // Input: the vertices in the k-d order the reference's alternating cuts leave (host: radix sort, duplicate scan, kd_order).
 // Output: the triangle list in pool order without the bounding ("ghost") triangles (triangle.cpp:7449-7500).
 #ifndef DG_HOST_EMULATION  // tests/emu_delaunay_gpu.cpp compiles the device functions for the CPU
@@ -19,6 +24,7 @@
 
 #include "sv_kernels.h"
 #endif
+#include <stddef.h>
 #include <stdint.h>
 
 namespace sv {
@@ -46,9 +52,47 @@ struct DTri {
 #else
 #define DG_LDS __attribute__((address_space(3)))  // explicit LDS pointers: ds_* instructions instead of flat_* ones
 #endif
-struct Mesh {
+struct Mesh {  // a set (or a subtree of a large set) in LDS
+    typedef uint16_t idx_t;
+    static constexpr uint32_t NOVTX = 0xFFFFu;
+    static constexpr bool GUARDED = false;
+    static constexpr uint32_t step_limit = 0;
     DG_LDS DG_VOLATILE DTri *T;
     DG_LDS const int16_t *px, *py;
+    __device__ __forceinline__ int32_t vx(uint32_t v) const { return px[v]; }
+    __device__ __forceinline__ int32_t vy(uint32_t v) const { return py[v]; }
+};
+
+// A field of a global-memory mesh.  Relaxed agent-scope atomics: single 32-bit accesses that bypass the vector cache (other
+// workgroups / an earlier kernel wrote the mesh), keep their order per address, are left alone by the SLP vectoriser (see DG_VOLATILE)
+// and - unlike volatile accesses, each of which is followed by a full s_waitcnt - overlap when they are independent.
+struct GField {
+    uint32_t v;
+#ifdef DG_HOST_EMULATION
+    operator uint32_t() const { return v; }
+    void operator=(uint32_t x) { v = x; }
+#else
+    __device__ __forceinline__ operator uint32_t() const { return __hip_atomic_load(&v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ void operator=(uint32_t x) { __hip_atomic_store(&v, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#endif
+};
+struct GTri {  // the same triangle in a global-memory mesh
+    GField nbr[3];
+    GField vtx[3];
+};
+constexpr uint32_t GHOST32 = 0xFFFFFFFFu;
+
+struct MeshG {  // the upper levels of a large set: global memory, 32-bit handles, vertex ids of the set
+    typedef uint32_t idx_t;
+    static constexpr uint32_t NOVTX = GHOST32;
+    // A merge on this mesh reads what other workgroups / an earlier kernel wrote; should it ever see a torn mesh, its walks may
+    // not end.  Every loop trip of a merge counts against step_limit (far above any real merge): a wrong list, never a hung GPU.
+    static constexpr bool GUARDED = true;
+    GTri *T;
+    const int32_t *xy;  // (x, y) per vertex id
+    uint32_t step_limit;
+    __device__ __forceinline__ int32_t vx(uint32_t v) const { return xy[2 * (size_t)v]; }
+    __device__ __forceinline__ int32_t vy(uint32_t v) const { return xy[2 * (size_t)v + 1]; }
 };
 
 __device__ __forceinline__ uint32_t next3(uint32_t o) { return (9u >> (2 * o)) & 3u; }
@@ -63,17 +107,19 @@ __device__ __forceinline__ uint32_t hprev(uint32_t h) { return (h & ~3u) | prev3
 #define D_BOND(a, b)                                  \
     do {                                              \
         const uint32_t a_ = (a), b_ = (b);            \
-        M.T[a_ >> 2].nbr[a_ & 3u] = (uint16_t)b_;     \
-        M.T[b_ >> 2].nbr[b_ & 3u] = (uint16_t)a_;     \
+        M.T[a_ >> 2].nbr[a_ & 3u] = (IDX)b_;          \
+        M.T[b_ >> 2].nbr[b_ & 3u] = (IDX)a_;          \
     } while (0)
-#define D_PX(v) ((int64_t)M.px[(v)])
-#define D_PY(v) ((int64_t)M.py[(v)])
+#define D_PX(v) ((int64_t)M.vx(v))
+#define D_PY(v) ((int64_t)M.vy(v))
 
-__device__ __forceinline__ int64_t d_orient(const Mesh &M, uint32_t a, uint32_t b, uint32_t c) {
+template <class MT>
+__device__ __forceinline__ int64_t d_orient(const MT &M, uint32_t a, uint32_t b, uint32_t c) {
     return (D_PX(a) - D_PX(c)) * (D_PY(b) - D_PY(c)) - (D_PY(a) - D_PY(c)) * (D_PX(b) - D_PX(c));
 }
 
-__device__ __forceinline__ int64_t d_incirc(const Mesh &M, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+template <class MT>
+__device__ __forceinline__ int64_t d_incirc(const MT &M, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     const int64_t adx = D_PX(a) - D_PX(d), ady = D_PY(a) - D_PY(d);
     const int64_t bdx = D_PX(b) - D_PX(d), bdy = D_PY(b) - D_PY(d);
     const int64_t cdx = D_PX(c) - D_PX(d), cdy = D_PY(c) - D_PY(d);
@@ -86,12 +132,13 @@ struct DV {
     int32_t x, y;
 };
 
-__device__ __forceinline__ DV d_vertex(const Mesh &M, uint32_t id) {
+template <class MT>
+__device__ __forceinline__ DV d_vertex(const MT &M, uint32_t id) {
     DV v;
     v.id = id;
-    const uint32_t safe = id == GHOST ? 0u : id;
-    v.x = M.px[safe];
-    v.y = M.py[safe];
+    const uint32_t safe = id == MT::NOVTX ? 0u : id;
+    v.x = M.vx(safe);
+    v.y = M.vy(safe);
     return v;
 }
 
@@ -106,15 +153,17 @@ __device__ __forceinline__ int64_t dv_incirc(const DV &a, const DV &b, const DV 
     return (adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) + (bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy) + (cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
 }
 
-__device__ __forceinline__ uint32_t d_make(const Mesh &M, uint32_t slot) {  // triangle.cpp:2068-2101
-    DG_LDS DG_VOLATILE DTri &t = M.T[slot];
-    t.nbr[0] = 0, t.nbr[1] = 0, t.nbr[2] = 0;
-    t.vtx[0] = (uint16_t)GHOST, t.vtx[1] = (uint16_t)GHOST, t.vtx[2] = (uint16_t)GHOST;
+template <class MT>
+__device__ __forceinline__ uint32_t d_make(const MT &M, uint32_t slot) {  // triangle.cpp:2068-2101
+    typedef typename MT::idx_t IDX;
+    M.T[slot].nbr[0] = 0, M.T[slot].nbr[1] = 0, M.T[slot].nbr[2] = 0;
+    M.T[slot].vtx[0] = (IDX)MT::NOVTX, M.T[slot].vtx[1] = (IDX)MT::NOVTX, M.T[slot].vtx[2] = (IDX)MT::NOVTX;
     return slot << 2;
 }
 
 // triangle.cpp:5670-5815, the two- and three-vertex cases; a[] = vertex ids, slots [slot, slot + 2) resp. [slot, slot + 4)
 __device__ __forceinline__ void d_leaf(const Mesh &M, DG_LDS const uint16_t *a, int n, uint32_t slot, uint32_t &farleft, uint32_t &farright) {
+    typedef uint16_t IDX;
     if (n == 2) {
         uint32_t l = d_make(M, slot), r = d_make(M, slot + 1);
         D_ORG(l) = a[0];
@@ -190,13 +239,22 @@ __device__ __forceinline__ void d_leaf(const Mesh &M, DG_LDS const uint16_t *a, 
 }
 
 // triangle.cpp:5362-5651; the two new triangles take slots `slot` and `slot + 1`
-__device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32_t innerleft, uint32_t innerright, uint32_t &farright, int axis, uint32_t slot) {
+template <class MT>
+__device__ __forceinline__ void d_merge(const MT &M, uint32_t &farleft, uint32_t innerleft, uint32_t innerright, uint32_t &farright, int axis, uint32_t slot) {
+    typedef typename MT::idx_t IDX;
+    constexpr uint32_t GHOST = MT::NOVTX;  // (shadows the 16-bit constant of the namespace)
+    uint32_t steps = 0;
+#define D_STEP()                                                  \
+    do {                                                          \
+        if (MT::GUARDED && ++steps > M.step_limit) return;        \
+    } while (0)
     uint32_t ild = D_DEST(innerleft), ila = D_APEX(innerleft);
     uint32_t iro = D_ORG(innerright), ira = D_APEX(innerright);
     if (axis == 1) {  // horizontal cut: walk the four extreme handles to the bottom-/top-most hull vertices
         uint32_t flp = D_ORG(farleft), fla = D_APEX(farleft);
         uint32_t frp = D_DEST(farright);
         while (D_PY(fla) < D_PY(flp)) {
+            D_STEP();
             farleft = D_SYM(hnext(farleft));
             flp = fla;
             fla = D_APEX(farleft);
@@ -204,6 +262,7 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
         uint32_t chk = D_SYM(innerleft);
         uint32_t cv = D_APEX(chk);
         while (D_PY(cv) > D_PY(ild)) {
+            D_STEP();
             innerleft = hnext(chk);
             ila = ild;
             ild = cv;
@@ -211,6 +270,7 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
             cv = D_APEX(chk);
         }
         while (D_PY(ira) < D_PY(iro)) {
+            D_STEP();
             innerright = D_SYM(hnext(innerright));
             iro = ira;
             ira = D_APEX(innerright);
@@ -218,6 +278,7 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
         chk = D_SYM(farright);
         cv = D_APEX(chk);
         while (D_PY(cv) > D_PY(frp)) {
+            D_STEP();
             farright = hnext(chk);
             frp = cv;
             chk = D_SYM(farright);
@@ -225,6 +286,7 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
         }
     }
     for (bool changed = true; changed;) {  // lower common tangent
+        D_STEP();
         changed = false;
         if (d_orient(M, ild, ila, iro) > 0) {
             innerleft = D_SYM(hprev(innerleft));
@@ -245,8 +307,8 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
     base = hnext(base);
     D_BOND(base, innerright);
     base = hnext(base);
-    D_ORG(base) = (uint16_t)iro;
-    D_DEST(base) = (uint16_t)ild;
+    D_ORG(base) = (IDX)iro;
+    D_DEST(base) = (IDX)ild;
     if (ild == D_ORG(farleft)) farleft = hnext(base);
     if (iro == D_DEST(farright)) farright = hprev(base);
     // The seam loop keeps the coordinates of its four moving vertices in registers (a vertex is read from LDS once, when it
@@ -254,11 +316,12 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
     DV ll = d_vertex(M, ild), lr = d_vertex(M, iro);
     DV ul = d_vertex(M, D_APEX(leftcand)), ur = d_vertex(M, D_APEX(rightcand));
     for (;;) {
+        D_STEP();
         const bool leftdone = dv_orient(ul, ll, lr) <= 0, rightdone = dv_orient(ur, ll, lr) <= 0;
         if (leftdone && rightdone) {
             uint32_t top = d_make(M, slot + 1);
-            D_ORG(top) = (uint16_t)ll.id;
-            D_DEST(top) = (uint16_t)lr.id;
+            D_ORG(top) = (IDX)ll.id;
+            D_DEST(top) = (IDX)lr.id;
             D_BOND(top, base);
             top = hnext(top);
             D_BOND(top, rightcand);
@@ -270,12 +333,14 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
                 uint32_t chk = D_SYM(farleft);
                 uint32_t cv = D_APEX(chk);
                 while (D_PX(cv) < D_PX(flp)) {
+                    D_STEP();
                     farleft = hprev(chk);
                     flp = cv;
                     chk = D_SYM(farleft);
                     cv = D_APEX(chk);
                 }
                 while (D_PX(fra) > D_PX(frp)) {
+                    D_STEP();
                     farright = D_SYM(hprev(farright));
                     frp = fra;
                     fra = D_APEX(farright);
@@ -289,6 +354,7 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
             if (na.id != GHOST) {
                 bool bad = dv_incirc(ll, lr, ul, na) > 0;
                 while (bad) {
+                    D_STEP();
                     nx = hnext(nx);
                     const uint32_t topc = D_SYM(nx);
                     nx = hnext(nx);
@@ -299,12 +365,12 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
                     const uint32_t outerc = D_SYM(leftcand);
                     nx = hprev(nx);
                     D_BOND(nx, outerc);
-                    D_ORG(leftcand) = (uint16_t)ll.id;
-                    D_DEST(leftcand) = (uint16_t)GHOST;
-                    D_APEX(leftcand) = (uint16_t)na.id;
-                    D_ORG(nx) = (uint16_t)GHOST;
-                    D_DEST(nx) = (uint16_t)ul.id;
-                    D_APEX(nx) = (uint16_t)na.id;
+                    D_ORG(leftcand) = (IDX)ll.id;
+                    D_DEST(leftcand) = (IDX)GHOST;
+                    D_APEX(leftcand) = (IDX)na.id;
+                    D_ORG(nx) = (IDX)GHOST;
+                    D_DEST(nx) = (IDX)ul.id;
+                    D_APEX(nx) = (IDX)na.id;
                     ul = na;
                     nx = sidec;
                     na = d_vertex(M, D_APEX(nx));
@@ -318,6 +384,7 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
             if (na.id != GHOST) {
                 bool bad = dv_incirc(ll, lr, ur, na) > 0;
                 while (bad) {
+                    D_STEP();
                     nx = hprev(nx);
                     const uint32_t topc = D_SYM(nx);
                     nx = hprev(nx);
@@ -328,12 +395,12 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
                     const uint32_t outerc = D_SYM(rightcand);
                     nx = hnext(nx);
                     D_BOND(nx, outerc);
-                    D_ORG(rightcand) = (uint16_t)GHOST;
-                    D_DEST(rightcand) = (uint16_t)lr.id;
-                    D_APEX(rightcand) = (uint16_t)na.id;
-                    D_ORG(nx) = (uint16_t)ur.id;
-                    D_DEST(nx) = (uint16_t)GHOST;
-                    D_APEX(nx) = (uint16_t)na.id;
+                    D_ORG(rightcand) = (IDX)GHOST;
+                    D_DEST(rightcand) = (IDX)lr.id;
+                    D_APEX(rightcand) = (IDX)na.id;
+                    D_ORG(nx) = (IDX)ur.id;
+                    D_DEST(nx) = (IDX)GHOST;
+                    D_APEX(nx) = (IDX)na.id;
                     ur = na;
                     nx = sidec;
                     na = d_vertex(M, D_APEX(nx));
@@ -344,28 +411,29 @@ __device__ __forceinline__ void d_merge(const Mesh &M, uint32_t &farleft, uint32
         if (leftdone || (!rightdone && dv_incirc(ul, ll, lr, ur) > 0)) {
             D_BOND(base, rightcand);
             base = hprev(rightcand);
-            D_DEST(base) = (uint16_t)ll.id;
+            D_DEST(base) = (IDX)ll.id;
             lr = ur;
             rightcand = D_SYM(base);
             ur = d_vertex(M, D_APEX(rightcand));
         } else {
             D_BOND(base, leftcand);
             base = hnext(leftcand);
-            D_ORG(base) = (uint16_t)lr.id;
+            D_ORG(base) = (IDX)lr.id;
             ll = ul;
             leftcand = D_SYM(base);
             ul = d_vertex(M, D_APEX(leftcand));
         }
     }
 }
+#undef D_STEP
 
 // Node j of depth d of the recursion over m vertices: its vertex range [lo, lo + n), the first slot of its subtree and its
-// cut axis.  False if the tree has no such node (an ancestor already is a leaf).
-__device__ __forceinline__ bool d_node(int m, int d, int j, int &lo, int &n, uint32_t &slot, int &axis) {
+// cut axis (axis0 = the axis of the tree's root: 0 for a whole set).  False if the tree has no such node (an ancestor already is a leaf).
+__device__ __forceinline__ bool d_node(int m, int d, int j, int &lo, int &n, uint32_t &slot, int &axis, int axis0 = 0) {
     lo = 0;
     n = m;
     slot = 1;
-    axis = 0;
+    axis = axis0;
     for (int b = d - 1; b >= 0; b--) {
         if (n <= 3) return false;
         const int nl = n >> 1;
@@ -382,10 +450,10 @@ __device__ __forceinline__ bool d_node(int m, int d, int j, int &lo, int &n, uin
 }
 
 // Leaf construction or merge of node j of depth d; res[] holds (farleft | farright << 16) per node in heap order.
-__device__ __forceinline__ void d_process_node(const Mesh &M, DG_LDS uint32_t *res, DG_LDS const uint16_t *ord, int m, int d, int j) {
+__device__ __forceinline__ void d_process_node(const Mesh &M, DG_LDS uint32_t *res, DG_LDS const uint16_t *ord, int m, int d, int j, int axis0 = 0) {
     int lo, n, axis;
     uint32_t slot;
-    if (!d_node(m, d, j, lo, n, slot, axis)) return;
+    if (!d_node(m, d, j, lo, n, slot, axis, axis0)) return;
     uint32_t fl, fr;
     if (n <= 3) {
         d_leaf(M, ord + lo, n, slot, fl, fr);
@@ -398,11 +466,6 @@ __device__ __forceinline__ void d_process_node(const Mesh &M, DG_LDS uint32_t *r
     res[(1 << d) + j] = fl | (fr << 16);
 }
 
-#ifndef DG_HOST_EMULATION
-// The body of both kernels: one workgroup triangulates one vertex set.
-//   order[0..m)            vertex ids in k-d order (global memory)
-//   vertex i               x = xb[i*stride] - (db ? db[i*stride] : 0), y = yb[i*stride], i < npts
-//   out / count            triangle list (3 ids per triangle, pool order, no bounding triangles) and its length
 // Depth of the deepest leaves: the smallest D with ceil(m / 2^D) <= 3.
 __host__ __device__ inline int dg_depth(int m) {
     int D = 0;
@@ -410,44 +473,78 @@ __host__ __device__ inline int dg_depth(int m) {
     return D;
 }
 
-__device__ __forceinline__ void dg_triangulate(int m, int npts, const int32_t *__restrict__ order, const int32_t *__restrict__ xb, const int32_t *__restrict__ yb,
-                                               const int32_t *__restrict__ db, int stride, int32_t *__restrict__ out, int32_t *__restrict__ count) {
-    extern __shared__ uint32_t dg_lds[];
-    const int tid = threadIdx.x;
-    if (m < 3) {
-        if (tid == 0) *count = 0;
-        return;
-    }
-    const int nslots = 2 * m - 1;  // slot 0 + 2m - 2
-    const int depth = dg_depth(m);
-    // LDS: results of the tree nodes (heap order), triangles, coordinates, k-d ordered ids
-    DG_LDS uint32_t *res = (DG_LDS uint32_t *)dg_lds;                       // [2 << depth]: farleft | farright << 16
-    DG_LDS DG_VOLATILE DTri *T = (DG_LDS DG_VOLATILE DTri *)(res + (2 << depth));   // [nslots]
-    DG_LDS int16_t *px = (DG_LDS int16_t *)(T + nslots + (nslots & 1));
-    DG_LDS int16_t *py = px + npts + (npts & 1);
-    DG_LDS uint16_t *ord = (DG_LDS uint16_t *)(py + npts + (npts & 1));
-    for (int i = tid; i < npts; i += DG_THREADS) {
-        px[i] = (int16_t)(xb[(size_t)i * stride] - (db ? db[(size_t)i * stride] : 0));
-        py[i] = (int16_t)yb[(size_t)i * stride];
-    }
-    for (int i = tid; i < m; i += DG_THREADS) ord[i] = (uint16_t)order[i];
-    if (tid == 0) {
-        T[0].nbr[0] = T[0].nbr[1] = T[0].nbr[2] = 0;
-        T[0].vtx[0] = T[0].vtx[1] = T[0].vtx[2] = (uint16_t)GHOST;
-    }
-    __syncthreads();
-    const Mesh M{T, px, py};
-    for (int d = depth; d >= 0; d--) {
-        for (int j = tid; j < (1 << d); j += DG_THREADS) d_process_node(M, res, ord, m, d, j);
-        __syncthreads();
-    }
-    // output in pool order without the bounding triangles: corners org / dest / apex at orientation 0
+// ---- sets that do not fit LDS ---------------------------------------------------------------------------------------------
+constexpr int DG_SUB_MAX = 4000;  // vertices of a subtree (and of a whole set) triangulated in LDS
+constexpr int DG_CUT_MAX = 6;     // at most 2^6 subtrees: sets of up to 256 000 vertices
+
+// Depth at which a set of m vertices is cut: the smallest c whose largest node, ceil(m / 2^c) vertices, fits.
+__host__ __device__ inline int dg_cut_depth(int m, int sub_max) {
+    int c = 0;
+    while (((m + (1 << c) - 1) >> c) > sub_max) c++;
+    return c;
+}
+
+// A subtree's handle (local slot numbers from 1) in the numbering of the whole set (the subtree's slots start at slot0)
+__device__ __forceinline__ uint32_t dg_global_handle(uint32_t h, uint32_t slot0) { return (h >> 2) == 0 ? 0u : (((h >> 2) + slot0 - 1u) << 2) | (h & 3u); }
+
+// One of the remaining merges: node j of depth d (< cut depth) of a set of m vertices; gres[2h], gres[2h + 1] = farleft / farright of heap node h
+__device__ __forceinline__ void dg_top_node(const MeshG &M, DG_VOLATILE uint32_t *gres, int m, int d, int j) {
+    int lo, n, axis;
+    uint32_t slot;
+    if (!d_node(m, d, j, lo, n, slot, axis)) return;
+    const int hl = (2 << d) + 2 * j, hr = hl + 1;  // children of heap node (1 << d) + j
+    uint32_t fl = gres[2 * hl], fr = gres[2 * hr + 1];
+    d_merge(M, fl, gres[2 * hl + 1], gres[2 * hr], fr, axis, slot + 2 * n - 4);
+    gres[2 * ((1 << d) + j)] = fl;
+    gres[2 * ((1 << d) + j) + 1] = fr;
+}
+
+#ifndef DG_HOST_EMULATION
+// The body of both kernels: one workgroup triangulates one vertex set.
+//   order[0..m)            vertex ids in k-d order (global memory)
+//   vertex i               x = xb[i*stride] - (db ? db[i*stride] : 0), y = yb[i*stride], i < npts
+//   out / count            triangle list (3 ids per triangle, pool order, no bounding triangles) and its length
+
+// One vertex set as the kernels see it
+struct DgSet {
+    int m, npts;                   // vertices after the duplicate scan / entries of the coordinate arrays
+    const int32_t *order;          // [m] vertex ids in k-d order
+    const int32_t *xb, *yb, *db;   // vertex i: x = xb[i * stride] - (db ? db[i * stride] : 0), y = yb[i * stride]
+    int stride;
+    int32_t *out, *count;          // triangle list (3 ids per triangle, pool order, no bounding triangles) and its length
+    __device__ __forceinline__ int x(int i) const { return xb[(size_t)i * stride] - (db ? db[(size_t)i * stride] : 0); }
+    __device__ __forceinline__ int y(int i) const { return yb[(size_t)i * stride]; }
+};
+
+// LDS carve-up for a tree of n vertices with np coordinate entries: node results (heap order), triangles, coordinates, k-d ordered ids
+struct DgLds {
+    DG_LDS uint32_t *res;  // [2 << depth]: farleft | farright << 16
+    DG_LDS DG_VOLATILE DTri *T;
+    DG_LDS int16_t *px, *py;
+    DG_LDS uint16_t *ord;
+};
+__device__ __forceinline__ DgLds dg_carve(DG_LDS uint32_t *base, int n, int np) {
+    const int nslots = 2 * n - 1, depth = dg_depth(n);
+    DgLds L;
+    L.res = base;
+    L.T = (DG_LDS DG_VOLATILE DTri *)(base + (2 << depth));
+    L.px = (DG_LDS int16_t *)(L.T + nslots + (nslots & 1));
+    L.py = L.px + np + (np & 1);
+    L.ord = (DG_LDS uint16_t *)(L.py + np + (np & 1));
+    return L;
+}
+
+// Triangle list of a finished mesh, in pool order without the bounding triangles: corners org / dest / apex at orientation 0.
+// vtx(t, k) reads corner k of slot t.  All DG_THREADS threads of the workgroup call it.
+template <class F>
+__device__ __forceinline__ void dg_emit(int nslots, F vtx, uint32_t ghost, int32_t *__restrict__ out, int32_t *__restrict__ count) {
     __shared__ int s_total;
     __shared__ int s_part[DG_THREADS];
+    const int tid = threadIdx.x;
     const int per = (nslots + DG_THREADS - 1) / DG_THREADS;
     const int t0 = min(1 + tid * per, nslots), t1 = min(t0 + per, nslots);
     int mine = 0;
-    for (int t = t0; t < t1; t++) mine += (T[t].vtx[0] != GHOST && T[t].vtx[1] != GHOST && T[t].vtx[2] != GHOST) ? 1 : 0;
+    for (int t = t0; t < t1; t++) mine += (vtx(t, 0) != ghost && vtx(t, 1) != ghost && vtx(t, 2) != ghost) ? 1 : 0;
     s_part[tid] = mine;
     __syncthreads();
     if (tid == 0) {
@@ -462,36 +559,184 @@ __device__ __forceinline__ void dg_triangulate(int m, int npts, const int32_t *_
     __syncthreads();
     int pos = s_part[tid];
     for (int t = t0; t < t1; t++) {
-        if (T[t].vtx[0] == GHOST || T[t].vtx[1] == GHOST || T[t].vtx[2] == GHOST) continue;
-        out[3 * pos] = T[t].vtx[1];
-        out[3 * pos + 1] = T[t].vtx[2];
-        out[3 * pos + 2] = T[t].vtx[0];
+        const uint32_t v0 = vtx(t, 0), v1 = vtx(t, 1), v2 = vtx(t, 2);
+        if (v0 == ghost || v1 == ghost || v2 == ghost) continue;
+        out[3 * pos] = (int32_t)v1;
+        out[3 * pos + 1] = (int32_t)v2;
+        out[3 * pos + 2] = (int32_t)v0;
         pos++;
     }
     if (tid == 0) *count = s_total;
 }
 
-// Test-hook form: sets[s] = {offset of the set's first entry in `order` / `xy`, m (vertices after the duplicate scan), n_points
-// (entries of xy), offset of its triangle list in tri_out}.  order: vertex ids in k-d order; xy: (x, y) per id.
-__global__ __launch_bounds__(DG_THREADS) void k_delaunay(const int4 *__restrict__ sets, const int32_t *__restrict__ order, const int32_t *__restrict__ xy,
-                                                        int32_t *__restrict__ tri_out, int32_t *__restrict__ tri_count) {
-    const int4 st = sets[blockIdx.x];
-    dg_triangulate(st.y, st.z, order + st.x, xy + 2 * (size_t)st.x, xy + 2 * (size_t)st.x + 1, nullptr, 2, tri_out + st.w, tri_count + blockIdx.x);
+// A whole set in LDS (m <= DG_SUB_MAX).
+__device__ __forceinline__ void dg_triangulate(const DgSet &S) {
+    extern __shared__ uint32_t dg_lds[];
+    const int tid = threadIdx.x, m = S.m, npts = S.npts;
+    if (m < 3) {
+        if (tid == 0) *S.count = 0;
+        return;
+    }
+    const DgLds L = dg_carve((DG_LDS uint32_t *)dg_lds, m, npts);
+    for (int i = tid; i < npts; i += DG_THREADS) {
+        L.px[i] = (int16_t)S.x(i);
+        L.py[i] = (int16_t)S.y(i);
+    }
+    for (int i = tid; i < m; i += DG_THREADS) L.ord[i] = (uint16_t)S.order[i];
+    if (tid == 0) {
+        L.T[0].nbr[0] = L.T[0].nbr[1] = L.T[0].nbr[2] = 0;
+        L.T[0].vtx[0] = L.T[0].vtx[1] = L.T[0].vtx[2] = (uint16_t)GHOST;
+    }
+    __syncthreads();
+    const Mesh M{L.T, L.px, L.py};
+    for (int d = dg_depth(m); d >= 0; d--) {
+        for (int j = tid; j < (1 << d); j += DG_THREADS) d_process_node(M, L.res, L.ord, m, d, j);
+        __syncthreads();
+    }
+    DG_LDS DG_VOLATILE DTri *T = L.T;
+    dg_emit(2 * m - 1, [T](int t, int k) { return (uint32_t)T[t].vtx[k]; }, GHOST, S.out, S.count);
 }
 
-// Pipeline form: blockIdx.x = pair * 2 + side.  The chunk's blob (engine.cpp) holds per pair the meta words, the support points
+// Subtree j of the cut depth of a large set: triangulated in LDS with local vertex numbers (position in the k-d order), then
+// written to the set's global mesh gT in the slot numbers and vertex ids of the whole set; gxy gets the vertices' coordinates,
+// gres[2h], gres[2h + 1] the far-left / far-right handles of heap node h = 2^c + j.
+__device__ __forceinline__ void dg_subtree(const DgSet &S, int sub_max, int j, GTri *__restrict__ gT, int32_t *__restrict__ gxy, uint32_t *__restrict__ gres) {
+    extern __shared__ uint32_t dg_lds[];
+    const int tid = threadIdx.x;
+    const int c = dg_cut_depth(S.m, sub_max);
+    if (j >= (1 << c)) return;
+    int lo, n, axis0;
+    uint32_t slot0;
+    if (!d_node(S.m, c, j, lo, n, slot0, axis0) || n < 2) return;  // (every node above the cut has more than sub_max >= 6 vertices)
+    const DgLds L = dg_carve((DG_LDS uint32_t *)dg_lds, n, n);
+    for (int i = tid; i < n; i += DG_THREADS) {
+        const int id = S.order[lo + i];
+        const int x = S.x(id), y = S.y(id);
+        L.px[i] = (int16_t)x;
+        L.py[i] = (int16_t)y;
+        L.ord[i] = (uint16_t)i;
+        gxy[2 * (size_t)id] = x;
+        gxy[2 * (size_t)id + 1] = y;
+    }
+    if (tid == 0) {
+        L.T[0].nbr[0] = L.T[0].nbr[1] = L.T[0].nbr[2] = 0;
+        L.T[0].vtx[0] = L.T[0].vtx[1] = L.T[0].vtx[2] = (uint16_t)GHOST;
+    }
+    __syncthreads();
+    const Mesh M{L.T, L.px, L.py};
+    for (int d = dg_depth(n); d >= 0; d--) {
+        for (int q = tid; q < (1 << d); q += DG_THREADS) d_process_node(M, L.res, L.ord, n, d, q, axis0);
+        __syncthreads();
+    }
+    for (int t = 1 + tid; t < 2 * n - 1; t += DG_THREADS) {
+        uint32_t *g = reinterpret_cast<uint32_t *>(gT + (slot0 + t - 1));  // plain stores: the merges run in the next kernel
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            g[k] = dg_global_handle(L.T[t].nbr[k], slot0);
+            const uint32_t v = L.T[t].vtx[k];
+            g[3 + k] = v == GHOST ? GHOST32 : (uint32_t)S.order[lo + v];
+        }
+    }
+    if (tid == 0) {
+        const uint32_t r = L.res[1];
+        gres[2 * ((1 << c) + j)] = dg_global_handle(r & 0xFFFFu, slot0);
+        gres[2 * ((1 << c) + j) + 1] = dg_global_handle(r >> 16, slot0);
+        if (j == 0) {
+            uint32_t *g = reinterpret_cast<uint32_t *>(gT);
+            g[0] = g[1] = g[2] = 0;
+            g[3] = g[4] = g[5] = GHOST32;
+        }
+    }
+}
+
+// The merges above the cut, depth by depth, one lane of the first wavefront per merge (a fence between depths: a lane sees what
+// the lanes of the depth below wrote), then the triangle list by the whole workgroup.
+__device__ __forceinline__ void dg_top(const DgSet &S, int sub_max, GTri *gT, const int32_t *gxy, uint32_t *gres) {
+    const int tid = threadIdx.x, m = S.m;
+    const int c = dg_cut_depth(m, sub_max);
+    const MeshG M{gT, gxy, 16u * (uint32_t)m + 4096u};
+    if (tid < 64)
+        for (int d = c - 1; d >= 0; d--) {
+            if (tid < (1 << d)) dg_top_node(M, (DG_VOLATILE uint32_t *)gres, m, d, tid);
+            __threadfence();
+        }
+    __syncthreads();
+    dg_emit(2 * m - 1, [gT](int t, int k) { return (uint32_t)gT[t].vtx[k]; }, GHOST32, S.out, S.count);
+}
+
+// Test-hook form: sets[s] = {offset of the set's first entry in `order` / `xy`, m (vertices after the duplicate scan), n_points
+// (entries of xy), offset of its triangle list in tri_out}.  order: vertex ids in k-d order; xy: (x, y) per id.
+__device__ __forceinline__ DgSet dg_set_from_list(const int4 st, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count) {
+    DgSet S;
+    S.m = st.y, S.npts = st.z;
+    S.order = order + st.x;
+    S.xb = xy + 2 * (size_t)st.x, S.yb = S.xb + 1, S.db = nullptr, S.stride = 2;
+    S.out = tri_out + st.w, S.count = tri_count;
+    return S;
+}
+
+// Pipeline form: set = pair * 2 + side.  The chunk's blob (engine.cpp) holds per pair the meta words, the support points
 // (u, v, d) and room for the two triangle lists; behind the second list the host stage has left, per side, [m, id_0 .. id_{m-1}]:
 // the k-d ordered vertex ids (m = -1: the host triangulated this side itself, nothing to do).  Left image: (u, v); right: (u - d, v).
-__global__ __launch_bounds__(DG_THREADS) void k_delaunay_blob(int32_t *__restrict__ blob) {
-    const int pair = blockIdx.x >> 1, side = blockIdx.x & 1;
+// False: nothing to do for this set here (sets of more than sub_max points belong to the k_dgl_* kernels: `large`).
+__device__ __forceinline__ bool dg_set_from_blob(int32_t *blob, int set, int sub_max, bool large, DgSet &S) {
+    const int pair = set >> 1, side = set & 1;
     int32_t *meta = blob + (size_t)pair * META_WORDS;
     const int ns = meta[0];
-    if (ns < 3 || meta[7] == 0) return;  // meta[7]: this pair is triangulated here (the host pool did the others)
+    if (ns < 3 || meta[7] == 0 || (ns > sub_max) != large) return false;  // meta[7]: this pair is triangulated here (the host pool did the others)
     const int32_t *sup = blob + meta[1];
     const int32_t *ord = blob + meta[5] + (size_t)2 * ns * 3 + (size_t)side * (ns + 1);
-    const int m = ord[0];
-    if (m < 0) return;
-    dg_triangulate(m, ns, ord + 1, sup, sup + 1, side ? sup + 2 : nullptr, 3, blob + meta[3 + 2 * side], meta + 2 + 2 * side);
+    if (ord[0] < 0) return false;
+    S.m = ord[0], S.npts = ns;
+    S.order = ord + 1;
+    S.xb = sup, S.yb = sup + 1, S.db = side ? sup + 2 : nullptr, S.stride = 3;
+    S.out = blob + meta[3 + 2 * side], S.count = meta + 2 + 2 * side;
+    return true;
+}
+
+__global__ __launch_bounds__(DG_THREADS) void k_delaunay(const int4 *__restrict__ sets, const int32_t *__restrict__ order, const int32_t *__restrict__ xy,
+                                                        int32_t *__restrict__ tri_out, int32_t *__restrict__ tri_count) {
+    dg_triangulate(dg_set_from_list(sets[blockIdx.x], order, xy, tri_out, tri_count + blockIdx.x));
+}
+
+__global__ __launch_bounds__(DG_THREADS) void k_delaunay_blob(int32_t *__restrict__ blob) {
+    DgSet S;
+    if (dg_set_from_blob(blob, blockIdx.x, DG_SUB_MAX, false, S)) dg_triangulate(S);
+}
+
+// Large sets: scratch per set = GTri[2 * cap], (x, y)[cap], node results [4 << DG_CUT_MAX] (cap: the largest set the scratch holds)
+struct DgScratch {
+    GTri *tri;
+    int32_t *xy;
+    uint32_t *res;
+    int cap;
+    __device__ __forceinline__ GTri *T(int set) const { return tri + (size_t)set * 2 * cap; }
+    __device__ __forceinline__ int32_t *XY(int set) const { return xy + (size_t)set * 2 * cap; }
+    __device__ __forceinline__ uint32_t *R(int set) const { return res + (size_t)set * (4 << DG_CUT_MAX); }
+};
+
+__global__ __launch_bounds__(DG_THREADS) void k_dgl_subtrees(const int4 *__restrict__ sets, const int32_t *__restrict__ order, const int32_t *__restrict__ xy,
+                                                            int32_t *__restrict__ tri_out, int32_t *__restrict__ tri_count, int sub_max, DgScratch sc) {
+    const int set = blockIdx.y;
+    dg_subtree(dg_set_from_list(sets[set], order, xy, tri_out, tri_count + set), sub_max, blockIdx.x, sc.T(set), sc.XY(set), sc.R(set));
+}
+
+__global__ __launch_bounds__(DG_THREADS) void k_dgl_top(const int4 *__restrict__ sets, const int32_t *__restrict__ order, const int32_t *__restrict__ xy,
+                                                       int32_t *__restrict__ tri_out, int32_t *__restrict__ tri_count, int sub_max, DgScratch sc) {
+    const int set = blockIdx.x;
+    dg_top(dg_set_from_list(sets[set], order, xy, tri_out, tri_count + set), sub_max, sc.T(set), sc.XY(set), sc.R(set));
+}
+
+__global__ __launch_bounds__(DG_THREADS) void k_dgl_subtrees_blob(int32_t *__restrict__ blob, DgScratch sc) {
+    const int set = blockIdx.y;
+    DgSet S;
+    if (dg_set_from_blob(blob, set, DG_SUB_MAX, true, S) && S.npts <= sc.cap) dg_subtree(S, DG_SUB_MAX, blockIdx.x, sc.T(set), sc.XY(set), sc.R(set));
+}
+
+__global__ __launch_bounds__(DG_THREADS) void k_dgl_top_blob(int32_t *__restrict__ blob, DgScratch sc) {
+    const int set = blockIdx.x;
+    DgSet S;
+    if (dg_set_from_blob(blob, set, DG_SUB_MAX, true, S) && S.npts <= sc.cap) dg_top(S, DG_SUB_MAX, sc.T(set), sc.XY(set), sc.R(set));
 }
 
 #endif  // DG_HOST_EMULATION
@@ -506,7 +751,18 @@ size_t delaunay_gpu_lds_bytes(int m, int npts) {
     return sizeof(uint32_t) * (2 << dg_depth(m)) + sizeof(DTri) * (nslots + (nslots & 1)) + sizeof(int16_t) * 2 * ((size_t)npts + (npts & 1)) + sizeof(uint16_t) * (size_t)m + 16;
 }
 
-int delaunay_gpu_max_points() { return 4000; }
+int delaunay_gpu_max_points() { return DG_SUB_MAX; }
+int delaunay_gpu_large_max_points() { return DG_SUB_MAX << DG_CUT_MAX; }
+
+size_t delaunay_scratch_bytes(int cap, int nsets, size_t *tri_bytes, size_t *xy_bytes, size_t *res_bytes) {
+    const size_t t = sizeof(GTri) * 2 * (size_t)cap * nsets, x = sizeof(int32_t) * 2 * (size_t)cap * nsets, r = sizeof(uint32_t) * (4 << DG_CUT_MAX) * (size_t)nsets;
+    if (tri_bytes) *tri_bytes = t;
+    if (xy_bytes) *xy_bytes = x;
+    if (res_bytes) *res_bytes = r;
+    return t + x + r;
+}
+
+static DgScratch dg_scratch(const DelaunayScratch &h) { return DgScratch{(GTri *)h.tri, h.xy, h.res, h.cap}; }
 
 // Launches one workgroup per set; lds = the largest delaunay_gpu_lds_bytes among them (<= 160 KB).
 int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, size_t lds, hipStream_t st) {
@@ -529,6 +785,31 @@ void launch_delaunay_blob(int32_t *blob, int n_pairs, size_t lds, hipStream_t st
     static std::atomic<size_t> granted[64];
     ensure_dynamic_lds(k_delaunay_blob, lds, granted, "delaunay_gpu");
     SV_LAUNCH(K_DELAUNAY, k_delaunay_blob, dim3(2 * n_pairs), dim3(DG_THREADS), lds, st, blob);
+}
+
+// Sets of more than sub_max vertices: 2^c subtrees per set in LDS, then the upper merges in the scratch mesh (one launch each for all
+// sets; workgroups of sets that are not large, or of subtrees a set does not have, return at once).  m_max: the largest set.
+int launch_delaunay_gpu_large(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, int m_max, int sub_max,
+                              const DelaunayScratch &scratch, hipStream_t st) {
+    if (sub_max < 6 || sub_max > DG_SUB_MAX || m_max > scratch.cap || dg_cut_depth(m_max, sub_max) > DG_CUT_MAX) return -1;
+    const size_t lds = delaunay_gpu_lds_bytes(sub_max, sub_max);
+    static std::atomic<size_t> granted[64];
+    try {
+        ensure_dynamic_lds(k_dgl_subtrees, lds, granted, "delaunay_gpu");
+    } catch (const std::exception &) {
+        return -1;
+    }
+    hipLaunchKernelGGL(k_dgl_subtrees, dim3(1 << dg_cut_depth(m_max, sub_max), nsets), dim3(DG_THREADS), lds, st, sets, order, xy, tri_out, tri_count, sub_max, dg_scratch(scratch));
+    hipLaunchKernelGGL(k_dgl_top, dim3(nsets), dim3(DG_THREADS), 0, st, sets, order, xy, tri_out, tri_count, sub_max, dg_scratch(scratch));
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+void launch_delaunay_blob_large(int32_t *blob, int n_pairs, int ns_max, const DelaunayScratch &scratch, hipStream_t st) {
+    const size_t lds = delaunay_gpu_lds_bytes(DG_SUB_MAX, DG_SUB_MAX);
+    static std::atomic<size_t> granted[64];
+    ensure_dynamic_lds(k_dgl_subtrees_blob, lds, granted, "delaunay_gpu");
+    SV_LAUNCH(K_DELAUNAY, k_dgl_subtrees_blob, dim3(1 << dg_cut_depth(ns_max, DG_SUB_MAX), 2 * n_pairs), dim3(DG_THREADS), lds, st, blob, dg_scratch(scratch));
+    SV_LAUNCH(K_DELAUNAY, k_dgl_top_blob, dim3(2 * n_pairs), dim3(DG_THREADS), 0, st, blob, dg_scratch(scratch));
 }
 #endif  // DG_HOST_EMULATION
 

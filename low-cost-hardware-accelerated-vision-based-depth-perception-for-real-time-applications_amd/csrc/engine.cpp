@@ -137,8 +137,10 @@ struct sv_handle {
     bool block_sync = false;  // host waits on events sleep (throughput mode) instead of spinning (latency mode)
     bool gpu_delaunay = false;  // divide-and-conquer phase of the triangulations on the GPU (delaunay_gpu.hip); the host only orders the vertices
     int gpu_delaunay_pct = 0;   // ... for this share of the pairs (100 in the GPU mode; a part in the host mode relieves the pool)
+    int dg_limit = 0;             // largest vertex set the GPU kernels take (LDS kernel: 4 000; with the slots' global-memory scratch: more)
     bool gpu_share_auto = false;  // host mode: the dispatcher moves that share up while the pool falls behind the GPU, down while it idles
     int auto_pct = 0;             // (dispatcher thread only)
+    std::atomic<int64_t> gpu_tri_fallbacks{0};  // vertex sets of flagged pairs that the host triangulated after all (too large, or degenerate)
     std::atomic<int64_t> gpu_tri_pairs{0}, tri_pairs{0};  // pairs triangulated by the GPU kernel / all pairs, since creation
     bool gpu_filter = false;  // lattice filters on the GPU (k_support_filter) instead of the host pool
     std::vector<Slot *> slots;
@@ -742,7 +744,7 @@ void triangulate_side(sv_handle *h, HostScratch *sc, Slot *s, int j, int side) {
         // only the preparation stays here: [m, ids in k-d order] behind the two triangle lists; k_delaunay_blob does the rest.
         // Sets the kernel cannot hold (LDS) are triangulated here as usual and marked with m = -1.
         int32_t *ord = blob + meta[5] + (size_t)2 * ns * 3 + (size_t)side * (ns + 1);
-        if (ns <= delaunay_gpu_max_points()) {
+        if (ns <= h->dg_limit) {
             const int m = sc->dl.kd_ordered_ids(sc->xy.data(), ns, ord + 1);
             if (h->timing) h->host_delaunay_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
             if (m >= 0) {
@@ -752,6 +754,7 @@ void triangulate_side(sv_handle *h, HostScratch *sc, Slot *s, int j, int side) {
             }
         }
         ord[0] = -1;
+        h->gpu_tri_fallbacks.fetch_add(1, std::memory_order_relaxed);
     }
     // latency mode: the halves of the top-level cut go to two threads (throughput mode keeps every core busy with whole pairs)
     // (two triangulations at a time: halves need 4 threads, quarters 8, counting the calling thread)
@@ -946,10 +949,15 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
     }
     HIP_TRY(hipMemcpyAsync(s->dev.blob, blob, off * sizeof(int32_t), hipMemcpyHostToDevice, st));
     if (s->gpu_pct > 0) {  // triangle lists still missing: built on the device from the vertex orders the host left in the blob
-        int ns_max = 0;
-        for (int j = 0; j < n; j++)
-            if (blob[(size_t)j * META_WORDS + 7]) ns_max = std::max(ns_max, std::min(blob[(size_t)j * META_WORDS], delaunay_gpu_max_points()));
+        int ns_max = 0, ns_large = 0;  // largest flagged set the LDS kernel takes / the cut path takes (larger ones: the host did them)
+        for (int j = 0; j < n; j++) {
+            const int ns = blob[(size_t)j * META_WORDS];
+            if (!blob[(size_t)j * META_WORDS + 7]) continue;
+            if (ns <= delaunay_gpu_max_points()) ns_max = std::max(ns_max, ns);
+            else if (ns <= h->dg_limit) ns_large = std::max(ns_large, ns);
+        }
         if (ns_max >= 3) launch_delaunay_blob(s->dev.blob, n, delaunay_gpu_lds_bytes(ns_max, ns_max), st);
+        if (ns_large > 0) launch_delaunay_blob_large(s->dev.blob, n, ns_large, s->dev.dg, st);
     }
     int max_points = 0;  // the chunk's largest support-point count: sizes the grids of the per-point / per-triangle kernels
     for (int j = 0; j < n; j++) max_points = std::max(max_points, blob[(size_t)j * META_WORDS]);
@@ -1186,6 +1194,16 @@ void alloc_slot(sv_handle *h, Slot *sl) {
     dev_alloc(s.blob, sl->blob_words);
     dev_alloc(s.fsup, cap * (size_t)d.max_pts * 3);
     dev_alloc(s.fnsup, cap);
+    if (h->dg_limit > delaunay_gpu_max_points()) {  // 4K-sized lattices: sets beyond the LDS kernel go through a mesh in global memory
+        size_t tb, xb, rb;
+        delaunay_scratch_bytes(h->dg_limit, (int)cap * 2, &tb, &xb, &rb);
+        uint8_t *t = nullptr;
+        dev_alloc(t, tb);
+        s.dg.tri = t;
+        dev_alloc(s.dg.xy, xb / sizeof(int32_t));
+        dev_alloc(s.dg.res, rb / sizeof(uint32_t));
+        s.dg.cap = h->dg_limit;
+    }
     {
         uint8_t *w = nullptr;
         dev_alloc(w, support_filter_ws_bytes(h->kp, (int)cap));
@@ -1231,7 +1249,7 @@ void alloc_slot(sv_handle *h, Slot *sl) {
 
 void free_slot(Slot *sl) {
     SlotDev &s = sl->dev;
-    void *dptrs[] = {s.grad, s.dcan, s.fsup, s.fnsup, s.flt_ws, s.blob, s.rrec, s.tile_list, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize, s.ccl_ws};
+    void *dptrs[] = {s.dg.tri, s.dg.xy, s.dg.res, s.grad, s.dcan, s.fsup, s.fnsup, s.flt_ws, s.blob, s.rrec, s.tile_list, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize, s.ccl_ws};
     for (void *p : dptrs)
         if (p) (void)hipFree(p);
     if (sl->h_dcan) (void)hipHostFree(sl->h_dcan);
@@ -1518,12 +1536,18 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         size_t free_b = 0, total_b = 0;
         (void)hipSetDevice(cfg->device);
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
-        const double budget = std::min(24.0 * (1 << 30), 0.25 * (double)free_b);
+        // (4K, one MI355X, round 2: chunk x slots 4 x 4 -> 1 500 pairs/s, 8 x 6 -> 2 020, 16 x 6 -> 2 440, 32 x 4 -> 2 550: the per-launch
+        //  latency chains - lattice filter, speckle merges, GPU triangulation - want many pairs per launch more than many slots)
+        const double budget = std::min(64.0 * (1 << 30), 0.25 * (double)free_b);
         const double per_pair = 66.0 * (double)h->kp.d.N + 4.0e6;
         while ((double)h->chunk * nslots * per_pair > budget) {
-            if (cfg->chunk <= 0 && h->chunk > 1 && (h->chunk >= 2 * nslots || cfg->n_slots > 0 || nslots <= 3))
+            if (cfg->chunk <= 0 && h->chunk > 16)
                 h->chunk = (h->chunk + 1) / 2;
-            else if (cfg->n_slots <= 0 && nslots > 3)
+            else if (cfg->n_slots <= 0 && nslots > 4)
+                nslots--;
+            else if (cfg->chunk <= 0 && h->chunk > 1)
+                h->chunk = (h->chunk + 1) / 2;
+            else if (cfg->n_slots <= 0 && nslots > 2)
                 nslots--;
             else
                 break;
@@ -1550,6 +1574,9 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     // host mode without a fixed share: the share follows the pool's backlog (42 600 against 40 100 pairs/s with 14 threads)
     h->gpu_share_auto = !h->gpu_delaunay && !getenv("SV_GPU_DELAUNAY_PCT") && !cfg->keep_debug && h->chunk >= 4;
     if (const char *e = getenv("SV_GPU_DELAUNAY_AUTO")) h->gpu_share_auto = h->gpu_share_auto && atoi(e) != 0;
+    h->dg_limit = delaunay_gpu_max_points();
+    if ((h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0) && h->kp.d.max_pts > h->dg_limit && !getenv("SV_GPU_DELAUNAY_SMALL"))
+        h->dg_limit = std::min({h->kp.d.max_pts, delaunay_gpu_large_max_points(), 131072});  // 7.3 MB of scratch per set
     h->block_sync = h->chunk >= 4;
     if (const char *e = getenv("SV_EVENT_SYNC")) h->block_sync = strcmp(e, "block") == 0;
     try {
@@ -1643,6 +1670,7 @@ int sv_query(const sv_handle *h, int what) {
         case SV_Q_SLOTS: return (int)h->slots.size();
         case SV_Q_GPU_LATTICE_FILTER: return h->gpu_filter ? 1 : 0;
         case SV_Q_GPU_TRIANGULATION: return h->gpu_delaunay ? 1 : 0;
+        case SV_Q_GPU_TRIANGULATION_FALLBACKS: return (int)std::min<int64_t>(h->gpu_tri_fallbacks.load(), 0x7FFFFFFF);
         case SV_Q_GPU_TRIANGULATION_SHARE: {
             const int64_t all = h->tri_pairs.load(), g = h->gpu_tri_pairs.load();
             return all > 0 ? (int)((g * 1000 + all / 2) / all) : 0;
@@ -1798,7 +1826,12 @@ int sv_host_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap) {
 // result is returned.  Returns the triangle count, or < 0.
 int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int reps, double *kernel_ms) {
     if (!xy || !tri_out || n < 3 || reps < 1) return SV_ERR_ARG;
-    if (n > delaunay_gpu_max_points()) return SV_ERR_UNSUPPORTED;
+    // sets of more than sub_max points take the cut path (subtrees in LDS, upper merges in a global-memory mesh);
+    // SV_DG_SUBMAX lowers the limit so that tests reach deep cuts with small sets
+    int sub_max = delaunay_gpu_max_points();
+    if (const char *e = getenv("SV_DG_SUBMAX")) sub_max = std::max(6, std::min(sub_max, atoi(e)));
+    const bool large = n > sub_max;
+    if (large && (n > delaunay_gpu_large_max_points() || (size_t)n * reps > ((size_t)1 << 24))) return SV_ERR_UNSUPPORTED;
     Delaunay dl;
     std::vector<int32_t> ids(n);
     const int m = dl.kd_ordered_ids(xy, n, ids.data());
@@ -1806,6 +1839,7 @@ int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int rep
     if (m < 3) return 0;
     int32_t *d_order = nullptr, *d_xy = nullptr, *d_tri = nullptr, *d_cnt = nullptr;
     int4 *d_sets = nullptr;
+    DelaunayScratch scr;
     int rc = SV_OK, nt = 0;
     const size_t tri_words = (size_t)3 * 2 * n;
     try {
@@ -1823,7 +1857,18 @@ int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int rep
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, nullptr));
-        if (launch_delaunay_gpu(d_sets, reps, d_order, d_xy, d_tri, d_cnt, delaunay_gpu_lds_bytes(m, n), nullptr) != 0) throw std::runtime_error("k_delaunay launch failed");
+        if (large) {
+            size_t tb, xb, rb;
+            delaunay_scratch_bytes(n, reps, &tb, &xb, &rb);
+            HIP_TRY(hipMalloc(&scr.tri, tb));
+            HIP_TRY(hipMalloc((void **)&scr.xy, xb));
+            HIP_TRY(hipMalloc((void **)&scr.res, rb));
+            scr.cap = n;
+            HIP_TRY(hipEventRecord(e0, nullptr));  // (after the allocations)
+            if (launch_delaunay_gpu_large(d_sets, reps, d_order, d_xy, d_tri, d_cnt, m, sub_max, scr, nullptr) != 0) throw std::runtime_error("k_dgl launch failed");
+        } else if (launch_delaunay_gpu(d_sets, reps, d_order, d_xy, d_tri, d_cnt, delaunay_gpu_lds_bytes(m, n), nullptr) != 0) {
+            throw std::runtime_error("k_delaunay launch failed");
+        }
         HIP_TRY(hipEventRecord(e1, nullptr));
         HIP_TRY(hipEventSynchronize(e1));
         float ms = 0.f;
@@ -1841,7 +1886,7 @@ int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int rep
         g_create_error = e.what();
         rc = SV_ERR_HIP;
     }
-    for (void *p : {(void *)d_order, (void *)d_xy, (void *)d_tri, (void *)d_cnt, (void *)d_sets})
+    for (void *p : {(void *)d_order, (void *)d_xy, (void *)d_tri, (void *)d_cnt, (void *)d_sets, scr.tri, (void *)scr.xy, (void *)scr.res})
         if (p) (void)hipFree(p);
     return rc == SV_OK ? nt : rc;
 }

@@ -41,6 +41,15 @@ struct KParams {
     int rt_cap;              // triangles a raster tile list may hold before its map falls back to global atomics (<= 512)
 };
 
+// Scratch of the GPU triangulation for sets that do not fit LDS (delaunay_gpu.hip, launch_delaunay_gpu_large): per set 2 * cap
+// triangles of 24 bytes, cap (x, y) pairs, node results (delaunay_scratch_bytes).
+struct DelaunayScratch {
+    void *tri = nullptr;
+    int32_t *xy = nullptr;
+    uint32_t *res = nullptr;
+    int cap = 0;  // vertices per set the scratch holds
+};
+
 // Device buffers of one worker slot, each holding `cap` pairs back to back.
 constexpr int META_WORDS = 8;
 
@@ -50,6 +59,7 @@ struct SlotDev {
                         //                   the 16-byte descriptors are assembled from them in LDS, never stored
     int16_t *dcan;      // [cap][Wc][Hc]     raw support lattice, TRANSPOSED (u major) for the host filters
     int32_t *fsup;      // [cap][max_pts][3] support points from the on-GPU lattice filter (when it is used)
+    DelaunayScratch dg; // [cap][2] sets, when the handle may triangulate large sets on the GPU (cap 0: it may not)
     int32_t *fnsup;     // [cap]
     void *flt_ws;       // workspace of the on-GPU lattice filter (support_filter_ws_bytes)
     int32_t *blob;      // host-stage results of the chunk, one H2D copy: [cap][8] meta words, then tightly packed data.
@@ -103,6 +113,13 @@ size_t delaunay_gpu_lds_bytes(int m, int npts);
 int delaunay_gpu_max_points();
 void launch_delaunay_blob(int32_t *blob, int n_pairs, size_t lds, hipStream_t st);
 int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, size_t lds, hipStream_t st);
+// ... sets that do not fit LDS (more than delaunay_gpu_max_points() vertices): subtrees in LDS, the upper merges in a global-memory
+// mesh.  Scratch per set: 2 * cap triangles of 24 bytes, cap (x, y) pairs, node results (delaunay_scratch_bytes).
+int delaunay_gpu_large_max_points();
+size_t delaunay_scratch_bytes(int cap, int nsets, size_t *tri_bytes, size_t *xy_bytes, size_t *res_bytes);
+int launch_delaunay_gpu_large(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, int m_max, int sub_max,
+                              const DelaunayScratch &scratch, hipStream_t st);
+void launch_delaunay_blob_large(int32_t *blob, int n_pairs, int ns_max, const DelaunayScratch &scratch, hipStream_t st);
 
 // names of the kernels behind each wrapper, in launch order, for timing reports
 enum KernelId {

@@ -281,6 +281,10 @@ class StereoEngine:
         """Fraction of the pairs so far whose triangulations the GPU kernel built (host mode: the dispatcher's load balancing)."""
         return int(lib().sv_query(self._h, 5)) / 1000.0
 
+    def gpu_triangulation_fallbacks(self):
+        """Vertex sets of that share which the host triangulated after all (too large for the kernels)."""
+        return int(lib().sv_query(self._h, 6))
+
     def timing(self, on=True, only=None):
         """HIP-event timing of the kernel launches; `only` = iterable of kernel names restricts it (cheaper)."""
         if lib().sv_kernel_timing_select(self._h, ",".join(only).encode() if only else None) != 0:

@@ -185,6 +185,36 @@ def test_gpu_delaunay_matches_host(eng):
         assert np.array_equal(got.ravel(), want.ravel())
 
 
+def test_gpu_delaunay_large_sets_match_host(eng, monkeypatch):
+    """Sets beyond the LDS limit (k_dgl_subtrees / k_dgl_top: subtrees of the recursion in LDS, the upper merges in a global-memory
+    mesh): 4K-sized lattices of 5 000 - 60 000 points, several sets per launch; and, with the subtree limit lowered, cuts down to
+    depth 6 on small sets (duplicates, co-circular lattices, scattered points)."""
+    rng = np.random.default_rng(43)
+    for it, n in enumerate([4001, 5000, 9000, 17000, 31000, 60000]):
+        if it % 2 == 0:
+            pts = np.stack([rng.integers(0, 768, n) * 5, rng.integers(0, 432, n) * 5], 1)
+        else:
+            pts = np.stack([rng.integers(-190, 3840, n), rng.integers(0, 432, n) * 5], 1)
+        a, (b, ms) = eng.host_delaunay(pts), eng.gpu_delaunay(pts, reps=1 if n > 20000 else 3)
+        assert a.shape == b.shape and np.array_equal(a, b), n
+    for sub in (6, 7, 50, 333):
+        monkeypatch.setenv("SV_DG_SUBMAX", str(sub))
+        for it in range(12):
+            n = int(rng.integers(sub + 1, sub * 64 + 1))
+            k = it % 3
+            if k == 0:
+                pts = rng.integers(0, 60, (n, 2)) * 5
+            elif k == 1:
+                pts = np.stack([rng.integers(-50, 1300, n), rng.integers(0, 75, n) * 5], 1)
+            else:
+                pts = rng.integers(0, 3000, (n, 2))
+            m = len(np.unique(pts, axis=0))
+            if m < 3 or (m + 63) // 64 > sub:
+                continue
+            a, (b, _) = eng.host_delaunay(pts), eng.gpu_delaunay(pts, reps=2)
+            assert a.shape == b.shape and np.array_equal(a, b), (sub, it, n)
+
+
 @pytest.mark.parametrize("name", ["kitti0_d128", "kitti20_d128", "kitti0_d128_sub", "cones_crop_middlebury", "synth5000_4kstrip_d192"])
 def test_pipeline_with_gpu_triangulation(eng, oracle, monkeypatch, name):
     """SV_GPU_DELAUNAY=1 (what a handle with few host threads chooses by itself): the host pool only orders the vertices, the
@@ -318,6 +348,29 @@ def test_full_4k_pair(eng, oracle, gpu_filter, monkeypatch):
     assert status[0] >= 3
     assert np.array_equal(d1[0].view(np.uint8), o1.view(np.uint8))
     assert np.array_equal(d2[0].view(np.uint8), o2.view(np.uint8))
+
+
+def test_full_4k_batch_without_host_triangulation(eng, oracle, monkeypatch):
+    """Config 5 with everything between the two kernel phases on the GPU: lattice filters (SV_GPU_FILTER) and the 30 000-point
+    triangulations (SV_GPU_DELAUNAY: subtrees in LDS + upper merges in a global-memory mesh); the two host threads only sort
+    and order the vertices.  No set falls back to the host; maps bit-exact."""
+    monkeypatch.setenv("SV_GPU_FILTER", "1")
+    monkeypatch.setenv("SV_GPU_DELAUNAY", "1")
+    synth = util.pkg("synth")
+    L, R = synth.make_pair(5001, 2160, 3840, 192, scale=3)
+    e = eng.StereoEngine(3840, 2160, eng.SvParams.driver(191), chunk=4, n_slots=2, n_streams=2, n_workers=2)
+    try:
+        q = e.query()
+        assert q["gpu_lattice_filter"] == 1 and q["gpu_triangulation"] == 1
+        d1, d2, status = e.process_host(np.stack([L] * 5), np.stack([R] * 5))
+        assert e.gpu_triangulation_share() == 1.0 and e.gpu_triangulation_fallbacks() == 0
+    finally:
+        e.close()
+    o1, o2, _ = _oracle_4k(oracle, L, R)
+    assert (status > 4000).all()  # beyond the LDS kernel
+    for i in range(5):
+        assert np.array_equal(d1[i].view(np.uint8), o1.view(np.uint8)), i
+        assert np.array_equal(d2[i].view(np.uint8), o2.view(np.uint8)), i
 
 
 _ORACLE_4K = {}
