@@ -1320,6 +1320,29 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
             }
             best = min(best, bb + (0x8000 + d_plane - r));
         }
+    } else if (DENSE_BAND_FAST && (RT == 3 || RT == 2)) {
+        // Lanes clip the band differently (planes near disparity 0 or disp_max, the image's left / right border): all 2r+1 slots
+        // are evaluated as in the fast path, and a slot outside the lane's own range starts its key at energy 16384 - above
+        // the 10000 a result must beat.  (Such a slot's LDS read may fall a few entries outside the staged row: the buffer is
+        // padded, the value is never used.)
+        if (COUNT) npath[2]++;
+        if (COUNT) ncand += max(hi_o - lo_o + 1, 0);
+        const uint4 *pb = side ? pu + (d_plane - r) : pu - (d_plane + r);
+        const uint32_t vmask = valid ? 0xFFFFFFFFu : 0x0000FFFFu;
+        const int nb = hi_o - lo_o + 1;
+        const uint32_t okm = nb > 0 ? ((1u << nb) - 1u) << lo_o : 0u;  // bit o' set: the lane has that candidate
+        uint4 c[2 * RT + 1];
+#pragma unroll
+        for (int q = 0; q <= 2 * RT; q++) c[q] = pb[q];
+        int bb = KEY_NONE;
+#pragma unroll
+        for (int q = 0; q <= 2 * RT; q++) {
+            const int o = side ? q : 2 * RT - q, ao = q < RT ? RT - q : q - RT;
+            // (added, not or-ed: a prior is negative)
+            const uint32_t start = (vmask & (((uint32_t)k.prior[ao] << 16) | (uint32_t)o)) + ((__builtin_amdgcn_ubfe(~okm, (uint32_t)o, 1u)) << 30);
+            bb = min(bb, sad16_key(own, c[q], (int)start));
+        }
+        best = min(best, bb + (0x8000 + d_plane - r));  // (a lane without any candidate keeps an energy >= 16375: no result)
     } else {
         // the offset o is uniform over the wavefront, so the prior is a scalar operand and the LDS reads do not depend on earlier iterations
         if (COUNT) npath[2]++;
@@ -1431,7 +1454,7 @@ __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const
     }
 }
 
-static size_t dense_lds_bytes(const KParams &k) { return sizeof(uint4) * 2 * (size_t)dense_seg(k.d); }
+static size_t dense_lds_bytes(const KParams &k) { return sizeof(uint4) * (2 * (size_t)dense_seg(k.d) + 8); }  // + 8 entries: see the band's masked path
 
 template <int MWT, int RT>
 static void launch_dense_as(const KParams &k, const SlotDev &s, const dim3 &grid, size_t shmem, hipStream_t st) {
