@@ -17,8 +17,8 @@ def short(name):
     name = name.replace("sv::", "")
     if name.startswith("void "):  # template instantiations: "void k_dense<false>" -> "k_dense" (the <true> variants are the counting builds)
         name = name[5:]
-    if name.endswith("<false>"):
-        name = name[:-7]
+    if "<false" in name:  # "k_dense<false, 4, 3>" (not counting, 4 mask words, plane radius 3) -> "k_dense"
+        name = name[:name.index("<false")]
     return name
 
 
