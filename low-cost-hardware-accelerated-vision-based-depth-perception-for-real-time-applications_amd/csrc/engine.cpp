@@ -1575,7 +1575,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     h->gpu_share_auto = !h->gpu_delaunay && !getenv("SV_GPU_DELAUNAY_PCT") && !cfg->keep_debug && h->chunk >= 4;
     if (const char *e = getenv("SV_GPU_DELAUNAY_AUTO")) h->gpu_share_auto = h->gpu_share_auto && atoi(e) != 0;
     h->dg_limit = delaunay_gpu_max_points();
-    if ((h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0) && h->kp.d.max_pts > h->dg_limit && !getenv("SV_GPU_DELAUNAY_SMALL"))
+    if ((h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0) && h->kp.d.max_pts > h->dg_limit)
         h->dg_limit = std::min({h->kp.d.max_pts, delaunay_gpu_large_max_points(), 131072});  // 7.3 MB of scratch per set
     h->block_sync = h->chunk >= 4;
     if (const char *e = getenv("SV_EVENT_SYNC")) h->block_sync = strcmp(e, "block") == 0;
