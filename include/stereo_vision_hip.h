@@ -173,6 +173,11 @@ int sv_kernel_timing_select(sv_handle *h, const char *names);
  * triangulation (elas.cpp:442-501 -> Triangle "zQB"). */
 int sv_host_support_filter(const sv_params *p, int16_t *dcan, int width, int height, int32_t *support, int cap);
 int sv_host_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap);
+/* Test hook: exhaustive comparison, on the current device, of the adaptive-mean kernel's division shortcut (v_rcp_f32 + one FMA
+ * correction; kernels.hip: amean_div) with the IEEE division: every float mantissa, both signs, 31 exponents, the sixteen divisors
+ * a weight sum can be.  Returns the number of differing quotients (0 = the shortcut is exact), < 0 on a HIP error;
+ * *control = the same count for a * rcp(d) without the correction (non-zero: the comparison can fail). */
+long long sv_debug_check_amean_div(unsigned int *first_a_bits, unsigned int *first_d_bits, long long *control);
 /* Same triangulation with the two halves of the top-level cut built by two threads, as the engine does in latency mode
  * (chunk = 1); helper_delay_us > 0 delays the helper thread so that the caller ends up doing both halves itself. */
 int sv_host_delaunay_split(const int32_t *xy, int n, int32_t *tri_out, int cap, int helper_delay_us);

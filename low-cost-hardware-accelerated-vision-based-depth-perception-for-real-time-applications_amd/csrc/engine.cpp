@@ -1891,6 +1891,25 @@ int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int rep
     return rc == SV_OK ? nt : rc;
 }
 
+// Test hook: the adaptive mean divides by v_rcp_f32 + one FMA correction instead of the IEEE sequence; this compares the two for all
+// 2^23 mantissas x both signs x 31 exponents x the sixteen possible divisors on the current device.  Returns the number of
+// differing quotients (0 expected; *first_a / *first_d = bits of the first one), or < 0.  *control: the same count for a * rcp(d)
+// without the correction (> 0: the comparison does discriminate).
+long long sv_debug_check_amean_div(unsigned int *first_a, unsigned int *first_d, long long *control) {
+    unsigned long long *d = nullptr, hres[4] = {0, 0, 0, 0};
+    if (hipMalloc((void **)&d, sizeof(hres)) != hipSuccess) return SV_ERR_HIP;
+    long long rc = SV_ERR_HIP;
+    if (hipMemset(d, 0, sizeof(hres)) == hipSuccess && launch_check_amean_div(d, nullptr) == 0 && hipDeviceSynchronize() == hipSuccess &&
+        hipMemcpy(hres, d, sizeof(hres), hipMemcpyDeviceToHost) == hipSuccess) {
+        rc = (long long)hres[0];
+        if (first_a) *first_a = (unsigned int)hres[1];
+        if (first_d) *first_d = (unsigned int)hres[2];
+        if (control) *control = (long long)hres[3];
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
 int sv_host_delaunay_split(const int32_t *xy, int n, int32_t *tri_out, int cap, int helper_delay_us) {
     return sv_host_delaunay_par(xy, n, tri_out, cap, 1, helper_delay_us);
 }

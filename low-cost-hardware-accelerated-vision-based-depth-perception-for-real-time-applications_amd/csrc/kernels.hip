@@ -2221,6 +2221,51 @@ void launch_gap_cols(const KParams &k, const SlotDev &s, int n, int nproc, hipSt
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float absq(float x) { return __uint_as_float(__float_as_uint(x) & 0x4F000000u); }
 
+// factor_sum / weight_sum.  A weight is 4, 2 or 0 (absq() leaves 2^odd or something below 2^-96), so weight_sum is an even
+// integer in [2, 32]; for those sixteen divisors  y = v_rcp_f32(d), q = a*y, q + fma(-q, d, a)*y  is the correctly rounded
+// quotient for EVERY float a - k_check_amean_div compares it with the IEEE division (the 10-instruction v_div_scale /
+// v_div_fmas / v_div_fixup sequence) over all 2^23 mantissas, both signs, 26 exponents and the sixteen divisors on the GPU the
+// engine runs on (tests/test_gpu_parity.py::test_adaptive_mean_division_is_exact).
+__device__ __forceinline__ float amean_div(float a, float d) {
+    const float y = __builtin_amdgcn_rcpf(d);
+    const float q = a * y;
+    return __builtin_fmaf(__builtin_fmaf(-q, d, a), y, q);
+}
+
+// mism[0]: number of (a, d) pairs where amean_div differs from a / d; mism[1..2]: bits of the first such a and d;
+// mism[3]: the same count for the uncorrected a * rcp(d) - the control that shows the comparison can fail
+__global__ __launch_bounds__(256) void k_check_amean_div(unsigned long long *mism) {
+    const uint32_t mant = blockIdx.x * 256u + threadIdx.x;  // 2^23 mantissas
+    unsigned long long bad = 0, bad_plain = 0;
+    uint32_t first_a = 0, first_d = 0;
+    for (int e = 112; e <= 142; e++)                         // a in [2^-15, 2^16)
+        for (int sgn = 0; sgn < 2; sgn++) {
+            const float a = __uint_as_float(((uint32_t)sgn << 31) | ((uint32_t)e << 23) | mant);
+            for (int di = 1; di <= 16; di++) {
+                const float d = (float)(2 * di);
+                const uint32_t want = __float_as_uint(a / d);
+                if (want != __float_as_uint(amean_div(a, d))) {
+                    if (bad == 0) first_a = __float_as_uint(a), first_d = __float_as_uint(d);
+                    bad++;
+                }
+                bad_plain += want != __float_as_uint(a * __builtin_amdgcn_rcpf(d)) ? 1 : 0;
+            }
+        }
+    if (mant == 0)  // a = 0
+        for (int di = 1; di <= 16; di++)
+            if (__float_as_uint(amean_div(0.0f, (float)(2 * di))) != 0u) bad++;
+    if (bad && atomicAdd(mism, bad) == 0) {
+        mism[1] = first_a;
+        mism[2] = first_d;
+    }
+    if (bad_plain) atomicAdd(mism + 3, bad_plain);
+}
+
+int launch_check_amean_div(unsigned long long *d_mism, hipStream_t st) {
+    hipLaunchKernelGGL(k_check_amean_div, dim3((1u << 23) / 256), dim3(256), 0, st, d_mism);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // xs[j] = window value held in ring slot j (the pixel of the window whose index is congruent to j mod 8), xc = centre value.
 // Returns true and the filtered value when the reference would store it.  Everything is statically indexed: the
 // slot <-> pixel rotation is done on the load addresses, not on registers.
@@ -2235,7 +2280,7 @@ __device__ __forceinline__ bool amean8(const float xs[8], float xc, float &out) 
     const float weight_sum = (w[0] + w[4]) + (w[1] + w[5]) + (w[2] + w[6]) + (w[3] + w[7]);  // elas.cpp:1427-1434
     const float factor_sum = (f[0] + f[4]) + (f[1] + f[5]) + (f[2] + f[6]) + (f[3] + f[7]);
     if (weight_sum > 0) {
-        const float dd = factor_sum / weight_sum;
+        const float dd = amean_div(factor_sum, weight_sum);
         if (dd >= 0) {
             out = dd;
             return true;
@@ -2344,7 +2389,7 @@ __device__ __forceinline__ bool amean4(const float xs[4], float xc, float &out) 
     const float weight_sum = w[0] + w[1] + w[2] + w[3];  // elas.cpp:1352-1353
     const float factor_sum = f[0] + f[1] + f[2] + f[3];
     if (weight_sum > 0) {
-        const float dd = factor_sum / weight_sum;
+        const float dd = amean_div(factor_sum, weight_sum);
         if (dd >= 0) {
             out = dd;
             return true;

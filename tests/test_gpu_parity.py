@@ -157,6 +157,20 @@ def test_raster_fallback_path(eng, oracle, monkeypatch):
     assert util.sha(d1) == entry["stages"]["final1"] and util.sha(d2) == entry["stages"]["final2"]
 
 
+def test_adaptive_mean_division_is_exact(eng):
+    """k_amean divides by v_rcp_f32 + one FMA correction instead of the 10-instruction IEEE sequence.  The divisor (a sum of eight
+    weights 0 / 2 / 4) is an even integer in [2, 32]; for those sixteen values the shortcut must give the correctly rounded
+    quotient of EVERY float: compared here on the device for all 2^23 mantissas, both signs, 31 exponents (2^-15 .. 2^16)."""
+    import ctypes
+    L = eng.lib()
+    L.sv_debug_check_amean_div.restype = ctypes.c_longlong
+    L.sv_debug_check_amean_div.argtypes = [ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_longlong)]
+    a, d, control = ctypes.c_uint(0), ctypes.c_uint(0), ctypes.c_longlong(0)
+    bad = L.sv_debug_check_amean_div(ctypes.byref(a), ctypes.byref(d), ctypes.byref(control))
+    assert bad == 0, (bad, hex(a.value), hex(d.value))
+    assert control.value > 0  # a * rcp(d) alone is NOT always the rounded quotient: the comparison does discriminate
+
+
 def test_gpu_delaunay_matches_host(eng):
     """csrc/delaunay_gpu.hip (the divide-and-conquer phase as one workgroup per vertex set, mesh in LDS) against the host
     triangulation: random lattice / scattered / heavily co-circular sets up to the kernel's limit, and the support points of the
