@@ -144,7 +144,9 @@ struct sv_handle {
     std::atomic<int64_t> gpu_tri_pairs{0}, tri_pairs{0};  // pairs triangulated by the GPU kernel / all pairs, since creation
     bool gpu_filter = false;  // lattice filters on the GPU (k_support_filter) instead of the host pool
     std::vector<Slot *> slots;
-    hipStream_t sP1 = nullptr, sPF = nullptr;  // phase 1; lattice filter + its D2H
+    hipStream_t sP1 = nullptr, sPF[2] = {nullptr, nullptr};  // phase 1; lattice filter + its D2H (two streams, taken in turns:
+                                                                // a 4K lattice keeps its one workgroup per pair busy for milliseconds)
+    int pf_turn = 0;                                             // (issuer thread only)
     std::vector<hipStream_t> sP2;
     hipStream_t sIn = nullptr, sOut = nullptr, sOut2 = nullptr;  // host-memory jobs: image uploads / map downloads (two streams: two DMA engines), overlapping the kernels
     bool host_dev_ready = false, host_pin_in_ready = false, host_pin_out_ready = false;  // lazily allocated staging (guarded by host_mu)
@@ -431,8 +433,9 @@ void issue_phase1(sv_handle *h, Slot *s) {
     if (h->gpu_filter) {
         // the filter is one long-running workgroup per pair: on its own stream it does not hold up the next chunk's phase 1
         HIP_TRY(hipEventRecord(s->ev_sup, h->sP1));
-        HIP_TRY(hipStreamWaitEvent(h->sPF, s->ev_sup, 0));
-        tail = h->sPF;
+        tail = h->sPF[h->pf_turn];
+        h->pf_turn ^= 1;
+        HIP_TRY(hipStreamWaitEvent(tail, s->ev_sup, 0));
         launch_support_filter(k, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s->dev, s->n, tail);
         HIP_TRY(hipMemcpyAsync(s->h_fnsup, s->dev.fnsup, sizeof(int32_t) * (size_t)s->n, hipMemcpyDeviceToHost, tail));
         const size_t w = sizeof(int32_t) * 3 * (size_t)fsup_copy_pts(d);
@@ -1277,7 +1280,8 @@ void free_handle_resources(sv_handle *h) {
     for (TimingCtx *t : {&h->tc_issue, &h->tc_finish})
         for (hipEvent_t e : t->pool) (void)hipEventDestroy(e);
     if (h->sP1) (void)hipStreamDestroy(h->sP1);
-    if (h->sPF) (void)hipStreamDestroy(h->sPF);
+    for (hipStream_t st : h->sPF)
+        if (st) (void)hipStreamDestroy(st);
     for (hipStream_t st : h->sP2) (void)hipStreamDestroy(st);
     if (h->d_counters) (void)hipFree(h->d_counters);
     if (h->dbg_desc) (void)hipFree(h->dbg_desc);
@@ -1347,7 +1351,7 @@ int wait_jobs(sv_handle *h) {
     }
     (void)hipSetDevice(h->cfg.device);
     bool ok = hipStreamSynchronize(h->sP1) == hipSuccess;
-    ok = (hipStreamSynchronize(h->sPF) == hipSuccess) && ok;
+    for (hipStream_t st : h->sPF) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
     for (hipStream_t st : h->sP2) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
     for (hipStream_t st : {h->sIn, h->sOut, h->sOut2})
         if (st) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
@@ -1582,7 +1586,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     try {
         HIP_TRY(hipSetDevice(cfg->device));
         HIP_TRY(hipStreamCreateWithFlags(&h->sP1, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&h->sPF, hipStreamNonBlocking));
+        for (hipStream_t &st : h->sPF) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
         for (int i = 0; i < np2; i++) {
             hipStream_t st;
             HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
