@@ -1581,6 +1581,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     h->dg_limit = delaunay_gpu_max_points();
     if ((h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0) && h->kp.d.max_pts > h->dg_limit)
         h->dg_limit = std::min({h->kp.d.max_pts, delaunay_gpu_large_max_points(), 131072});  // 7.3 MB of scratch per set
+    if (const char *e = getenv("SV_GPU_DELAUNAY_MAX")) h->dg_limit = std::min(h->dg_limit, std::max(atoi(e), 16));  // tests: larger sets fall back to the pool
     h->block_sync = h->chunk >= 4;
     if (const char *e = getenv("SV_EVENT_SYNC")) h->block_sync = strcmp(e, "block") == 0;
     try {

@@ -233,7 +233,7 @@ def test_gpu_delaunay_large_sets_match_host(eng, monkeypatch):
 def test_pipeline_with_gpu_triangulation(eng, oracle, monkeypatch, name):
     """SV_GPU_DELAUNAY=1 (what a handle with few host threads chooses by itself): the host pool only orders the vertices, the
     triangle lists are built on the device straight into the chunk's blob.  Same maps, bit for bit; the 4K strip's 7 500-point
-    sets exceed the kernel's LDS and take the per-set host fallback inside the same chunk."""
+    sets exceed the kernel's LDS and take the cut path (subtrees in LDS, upper merges in a global-memory mesh)."""
     monkeypatch.setenv("SV_GPU_DELAUNAY", "1")
     entry = DIG[name]
     L, R = util.case_images(entry)
@@ -247,6 +247,24 @@ def test_pipeline_with_gpu_triangulation(eng, oracle, monkeypatch, name):
     for i in range(5):
         assert util.sha(d1[i]) == entry["stages"]["final1"]
         assert util.sha(d2[i]) == entry["stages"]["final2"]
+
+
+def test_gpu_triangulation_falls_back_per_set(eng, oracle, monkeypatch):
+    """Vertex sets beyond what the GPU kernels take (here capped at 5 000 points: the 4K strip has ~7 500) are triangulated by the
+    pool inside a chunk whose other work stays on the GPU; the handle counts them (SV_Q_GPU_TRIANGULATION_FALLBACKS)."""
+    monkeypatch.setenv("SV_GPU_DELAUNAY", "1")
+    monkeypatch.setenv("SV_GPU_DELAUNAY_MAX", "5000")
+    entry = DIG["synth5000_4kstrip_d192"]
+    L, R = util.case_images(entry)
+    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=2, n_streams=2, n_workers=3)
+    try:
+        d1, d2, st = e.process_host(np.stack([L] * 5), np.stack([R] * 5))
+        assert e.gpu_triangulation_fallbacks() == 10  # both sides of the five pairs
+    finally:
+        e.close()
+    assert (st == entry["n_support"]).all() and entry["n_support"] > 5000
+    for i in range(5):
+        assert util.sha(d1[i]) == entry["stages"]["final1"] and util.sha(d2[i]) == entry["stages"]["final2"]
 
 
 def test_pipeline_with_mixed_triangulation(eng, oracle, monkeypatch):
