@@ -699,9 +699,9 @@ __global__ __launch_bounds__(DG_THREADS) void k_delaunay(const int4 *__restrict_
     dg_triangulate(dg_set_from_list(sets[blockIdx.x], order, xy, tri_out, tri_count + blockIdx.x));
 }
 
-__global__ __launch_bounds__(DG_THREADS) void k_delaunay_blob(int32_t *__restrict__ blob) {
+__global__ __launch_bounds__(DG_THREADS) void k_delaunay_blob(int32_t *__restrict__ blob, int sub_max) {
     DgSet S;
-    if (dg_set_from_blob(blob, blockIdx.x, DG_SUB_MAX, false, S)) dg_triangulate(S);
+    if (dg_set_from_blob(blob, blockIdx.x, sub_max, false, S)) dg_triangulate(S);
 }
 
 // Large sets: scratch per set = GTri[2 * cap], (x, y)[cap], node results [4 << DG_CUT_MAX] (cap: the largest set the scratch holds)
@@ -727,16 +727,16 @@ __global__ __launch_bounds__(DG_THREADS) void k_dgl_top(const int4 *__restrict__
     dg_top(dg_set_from_list(sets[set], order, xy, tri_out, tri_count + set), sub_max, sc.T(set), sc.XY(set), sc.R(set));
 }
 
-__global__ __launch_bounds__(DG_THREADS) void k_dgl_subtrees_blob(int32_t *__restrict__ blob, DgScratch sc) {
+__global__ __launch_bounds__(DG_THREADS) void k_dgl_subtrees_blob(int32_t *__restrict__ blob, int sub_max, DgScratch sc) {
     const int set = blockIdx.y;
     DgSet S;
-    if (dg_set_from_blob(blob, set, DG_SUB_MAX, true, S) && S.npts <= sc.cap) dg_subtree(S, DG_SUB_MAX, blockIdx.x, sc.T(set), sc.XY(set), sc.R(set));
+    if (dg_set_from_blob(blob, set, sub_max, true, S) && S.npts <= sc.cap) dg_subtree(S, sub_max, blockIdx.x, sc.T(set), sc.XY(set), sc.R(set));
 }
 
-__global__ __launch_bounds__(DG_THREADS) void k_dgl_top_blob(int32_t *__restrict__ blob, DgScratch sc) {
+__global__ __launch_bounds__(DG_THREADS) void k_dgl_top_blob(int32_t *__restrict__ blob, int sub_max, DgScratch sc) {
     const int set = blockIdx.x;
     DgSet S;
-    if (dg_set_from_blob(blob, set, DG_SUB_MAX, true, S) && S.npts <= sc.cap) dg_top(S, DG_SUB_MAX, sc.T(set), sc.XY(set), sc.R(set));
+    if (dg_set_from_blob(blob, set, sub_max, true, S) && S.npts <= sc.cap) dg_top(S, sub_max, sc.T(set), sc.XY(set), sc.R(set));
 }
 
 #endif  // DG_HOST_EMULATION
@@ -781,10 +781,10 @@ int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const
 }
 
 // Both triangulations of every pair of a chunk, straight into the chunk's device blob.
-void launch_delaunay_blob(int32_t *blob, int n_pairs, size_t lds, hipStream_t st) {
+void launch_delaunay_blob(int32_t *blob, int n_pairs, size_t lds, int sub_max, hipStream_t st) {
     static std::atomic<size_t> granted[64];
     ensure_dynamic_lds(k_delaunay_blob, lds, granted, "delaunay_gpu");
-    SV_LAUNCH(K_DELAUNAY, k_delaunay_blob, dim3(2 * n_pairs), dim3(DG_THREADS), lds, st, blob);
+    SV_LAUNCH(K_DELAUNAY, k_delaunay_blob, dim3(2 * n_pairs), dim3(DG_THREADS), lds, st, blob, sub_max);
 }
 
 // Sets of more than sub_max vertices: 2^c subtrees per set in LDS, then the upper merges in the scratch mesh (one launch each for all
@@ -804,12 +804,12 @@ int launch_delaunay_gpu_large(const int4 *sets, int nsets, const int32_t *order,
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-void launch_delaunay_blob_large(int32_t *blob, int n_pairs, int ns_max, const DelaunayScratch &scratch, hipStream_t st) {
-    const size_t lds = delaunay_gpu_lds_bytes(DG_SUB_MAX, DG_SUB_MAX);
+void launch_delaunay_blob_large(int32_t *blob, int n_pairs, int ns_max, int sub_max, const DelaunayScratch &scratch, hipStream_t st) {
+    const size_t lds = delaunay_gpu_lds_bytes(sub_max, sub_max);
     static std::atomic<size_t> granted[64];
     ensure_dynamic_lds(k_dgl_subtrees_blob, lds, granted, "delaunay_gpu");
-    SV_LAUNCH(K_DELAUNAY, k_dgl_subtrees_blob, dim3(1 << dg_cut_depth(ns_max, DG_SUB_MAX), 2 * n_pairs), dim3(DG_THREADS), lds, st, blob, dg_scratch(scratch));
-    SV_LAUNCH(K_DELAUNAY, k_dgl_top_blob, dim3(2 * n_pairs), dim3(DG_THREADS), 0, st, blob, dg_scratch(scratch));
+    SV_LAUNCH(K_DELAUNAY, k_dgl_subtrees_blob, dim3(1 << dg_cut_depth(ns_max, sub_max), 2 * n_pairs), dim3(DG_THREADS), lds, st, blob, sub_max, dg_scratch(scratch));
+    SV_LAUNCH(K_DELAUNAY, k_dgl_top_blob, dim3(2 * n_pairs), dim3(DG_THREADS), 0, st, blob, sub_max, dg_scratch(scratch));
 }
 #endif  // DG_HOST_EMULATION
 

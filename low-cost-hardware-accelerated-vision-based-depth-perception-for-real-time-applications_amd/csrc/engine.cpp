@@ -137,6 +137,7 @@ struct sv_handle {
     bool block_sync = false;  // host waits on events sleep (throughput mode) instead of spinning (latency mode)
     bool gpu_delaunay = false;  // divide-and-conquer phase of the triangulations on the GPU (delaunay_gpu.hip); the host only orders the vertices
     int gpu_delaunay_pct = 0;   // ... for this share of the pairs (100 in the GPU mode; a part in the host mode relieves the pool)
+    int dg_sub_max = 0;           // vertex sets up to this size are triangulated whole in LDS, larger ones as subtrees of at most this size
     int dg_limit = 0;             // largest vertex set the GPU kernels take (LDS kernel: 4 000; with the slots' global-memory scratch: more)
     bool gpu_share_auto = false;  // host mode: the dispatcher moves that share up while the pool falls behind the GPU, down while it idles
     int auto_pct = 0;             // (dispatcher thread only)
@@ -956,11 +957,11 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
         for (int j = 0; j < n; j++) {
             const int ns = blob[(size_t)j * META_WORDS];
             if (!blob[(size_t)j * META_WORDS + 7]) continue;
-            if (ns <= delaunay_gpu_max_points()) ns_max = std::max(ns_max, ns);
+            if (ns <= h->dg_sub_max) ns_max = std::max(ns_max, ns);
             else if (ns <= h->dg_limit) ns_large = std::max(ns_large, ns);
         }
-        if (ns_max >= 3) launch_delaunay_blob(s->dev.blob, n, delaunay_gpu_lds_bytes(ns_max, ns_max), st);
-        if (ns_large > 0) launch_delaunay_blob_large(s->dev.blob, n, ns_large, s->dev.dg, st);
+        if (ns_max >= 3) launch_delaunay_blob(s->dev.blob, n, delaunay_gpu_lds_bytes(ns_max, ns_max), h->dg_sub_max, st);
+        if (ns_large > 0) launch_delaunay_blob_large(s->dev.blob, n, ns_large, h->dg_sub_max, s->dev.dg, st);
     }
     int max_points = 0;  // the chunk's largest support-point count: sizes the grids of the per-point / per-triangle kernels
     for (int j = 0; j < n; j++) max_points = std::max(max_points, blob[(size_t)j * META_WORDS]);
@@ -1197,7 +1198,7 @@ void alloc_slot(sv_handle *h, Slot *sl) {
     dev_alloc(s.blob, sl->blob_words);
     dev_alloc(s.fsup, cap * (size_t)d.max_pts * 3);
     dev_alloc(s.fnsup, cap);
-    if (h->dg_limit > delaunay_gpu_max_points()) {  // 4K-sized lattices: sets beyond the LDS kernel go through a mesh in global memory
+    if (h->dg_limit > h->dg_sub_max) {  // 4K-sized lattices: sets beyond the LDS kernel go through a mesh in global memory
         size_t tb, xb, rb;
         delaunay_scratch_bytes(h->dg_limit, (int)cap * 2, &tb, &xb, &rb);
         uint8_t *t = nullptr;
@@ -1578,8 +1579,9 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     // host mode without a fixed share: the share follows the pool's backlog (42 600 against 40 100 pairs/s with 14 threads)
     h->gpu_share_auto = !h->gpu_delaunay && !getenv("SV_GPU_DELAUNAY_PCT") && !cfg->keep_debug && h->chunk >= 4;
     if (const char *e = getenv("SV_GPU_DELAUNAY_AUTO")) h->gpu_share_auto = h->gpu_share_auto && atoi(e) != 0;
-    h->dg_limit = delaunay_gpu_max_points();
-    if ((h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0) && h->kp.d.max_pts > h->dg_limit)
+    h->dg_limit = h->dg_sub_max = delaunay_gpu_max_points();
+    if (const char *e = getenv("SV_DG_SUBMAX")) h->dg_sub_max = std::max(6, std::min(h->dg_sub_max, atoi(e)));  // experiments / tests
+    if ((h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0) && h->kp.d.max_pts > h->dg_sub_max)
         h->dg_limit = std::min({h->kp.d.max_pts, delaunay_gpu_large_max_points(), 131072});  // 7.3 MB of scratch per set
     if (const char *e = getenv("SV_GPU_DELAUNAY_MAX")) h->dg_limit = std::min(h->dg_limit, std::max(atoi(e), 16));  // tests: larger sets fall back to the pool
     h->block_sync = h->chunk >= 4;

@@ -112,7 +112,7 @@ void launch_output(const KParams &k, const SlotDev &s, int n, const float *src, 
 // duplicate scan, entries of xy, offset of the set's triangle list in tri_out (in int32 units)}
 size_t delaunay_gpu_lds_bytes(int m, int npts);
 int delaunay_gpu_max_points();
-void launch_delaunay_blob(int32_t *blob, int n_pairs, size_t lds, hipStream_t st);
+void launch_delaunay_blob(int32_t *blob, int n_pairs, size_t lds, int sub_max, hipStream_t st);  // sets of more than sub_max points are left to ..._large
 int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, size_t lds, hipStream_t st);
 // ... sets that do not fit LDS (more than delaunay_gpu_max_points() vertices): subtrees in LDS, the upper merges in a global-memory
 // mesh.  Scratch per set: 2 * cap triangles of 24 bytes, cap (x, y) pairs, node results (delaunay_scratch_bytes).
@@ -120,7 +120,7 @@ int delaunay_gpu_large_max_points();
 size_t delaunay_scratch_bytes(int cap, int nsets, size_t *tri_bytes, size_t *xy_bytes, size_t *res_bytes);
 int launch_delaunay_gpu_large(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, int m_max, int sub_max,
                               const DelaunayScratch &scratch, hipStream_t st);
-void launch_delaunay_blob_large(int32_t *blob, int n_pairs, int ns_max, const DelaunayScratch &scratch, hipStream_t st);
+void launch_delaunay_blob_large(int32_t *blob, int n_pairs, int ns_max, int sub_max, const DelaunayScratch &scratch, hipStream_t st);
 
 // names of the kernels behind each wrapper, in launch order, for timing reports
 enum KernelId {

@@ -249,6 +249,25 @@ def test_pipeline_with_gpu_triangulation(eng, oracle, monkeypatch, name):
         assert util.sha(d2[i]) == entry["stages"]["final2"]
 
 
+@pytest.mark.parametrize("sub_max", ["700", "40"])
+def test_pipeline_with_cut_triangulation(eng, oracle, monkeypatch, sub_max):
+    """The cut path of the GPU triangulation inside the pipeline on ordinary images: with the LDS limit lowered to 700 (40)
+    vertices the 2 100-point sets of a KITTI pair are built as 4 (64) subtrees plus the upper merges in global memory."""
+    monkeypatch.setenv("SV_GPU_DELAUNAY", "1")
+    monkeypatch.setenv("SV_DG_SUBMAX", sub_max)
+    entry = DIG["kitti0_d128"]
+    L, R = util.case_images(entry)
+    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=2, n_streams=2, n_workers=3)
+    try:
+        d1, d2, st = e.process_host(np.stack([L] * 6), np.stack([R] * 6))
+        assert e.gpu_triangulation_fallbacks() == 0
+    finally:
+        e.close()
+    assert (st == entry["n_support"]).all()
+    for i in range(6):
+        assert util.sha(d1[i]) == entry["stages"]["final1"] and util.sha(d2[i]) == entry["stages"]["final2"]
+
+
 def test_gpu_triangulation_falls_back_per_set(eng, oracle, monkeypatch):
     """Vertex sets beyond what the GPU kernels take (here capped at 5 000 points: the 4K strip has ~7 500) are triangulated by the
     pool inside a chunk whose other work stays on the GPU; the handle counts them (SV_Q_GPU_TRIANGULATION_FALLBACKS)."""
