@@ -86,8 +86,8 @@ typedef struct sv_config {
     int32_t height;     /* image height (>= 32) */
     int32_t device;     /* HIP device ordinal */
     int32_t n_workers;  /* host pool threads for the CPU stage between the two GPU phases (0 = default: the cgroup CPU quota / the
-                         * affinity mask, shared between the ranks of a node, at most 16 without a quota).  With fewer than 12 threads all
-                         * triangulations run on the GPU and the pool only orders the vertices (sv_query) */
+                         * affinity mask, shared between the ranks of a node, at most 16 without a quota).  The triangulations are split between
+                         * this pool and the GPU kernel by the pool's backlog (all of them on the GPU with one or two threads): sv_query */
     int32_t chunk;      /* pairs per GPU launch = pairs per pipeline slot (0 = default 64, less for large images) */
     int32_t keep_debug; /* != 0: keep per-stage intermediates of the LAST processed pair for sv_debug_get */
     int32_t n_streams;  /* HIP streams the second GPU phase alternates over (0 = default 4); phase 1 has its own streams */

@@ -922,8 +922,9 @@ void dispatcher_main(sv_handle *h) {
             // so the triangulation kernel takes a larger share of this chunk; a short queue gives the share back to the pool.  (One
             // chunk at a time - a single slot, a profile's serial pass - never finds a backlog and stays on the host.)
             const int backlog = h->queue_len.load(std::memory_order_acquire);
-            // (thresholds from a sweep on one MI355X + 14 pool threads: 1.5 / 0.5 chunks, steps of 5 up to 30 % settle near 15 %)
-            if (backlog * 2 > s->n * 3) h->auto_pct = std::min(h->auto_pct + 5, 30);
+            // (thresholds from a sweep on one MI355X + 14 pool threads: 1.5 / 0.5 chunks, steps of 5: settles near 15 %; 26 % with 12
+            //  threads, 47 % with 10, 60 % with 8, 74 % with 6, 86 % with 4 - each 1-2 % above what the all-GPU mode reaches)
+            if (backlog * 2 > s->n * 3) h->auto_pct = std::min(h->auto_pct + 5, 95);
             else if (backlog * 2 <= s->n) h->auto_pct = std::max(h->auto_pct - 5, 0);
             s->gpu_pct = h->auto_pct;
         }
@@ -1564,13 +1565,13 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         h->chunk = 1;
     }
     if (h->chunk < 4 && !getenv("SV_GPU_FILTER")) h->gpu_filter = false;
-    // triangulation on the GPU: on request, or by itself when few host threads are available (it costs GPU time and LDS, and a
-    // single pair is faster on the host); never with keep_debug (the parity tests read the host's triangle lists)
-    // Measured in round 2, sustained over 20 000 pairs: 38 100 - 38 500 pairs/s in the GPU mode with 4, 8 or 15 host threads; the host
-    // mode needs >= 14 threads for more (40 100 - 40 400 with 14, 33 000 with 13), and it is best with a small share of the pairs
-    // still going to the GPU kernel (10 - 20 %: 40 600 - 40 950, and steadier; 30 %: 40 100): the pool gets slack, and the 0.8 ms
-    // latency chain of the triangulation kernel is hidden beside the other streams as long as few chunks wait for it.
-    h->gpu_delaunay = !cfg->keep_debug && h->chunk >= 4 && npool < 12;
+    // Who triangulates: the pool, the GPU kernel (delaunay_gpu.hip), or both.  All on the GPU (the pool then only sorts and orders the
+    // vertices) on request or with one or two pool threads; never with keep_debug (the parity tests read the host's triangle lists)
+    // and not for single pairs (faster on the host).  Otherwise the dispatcher splits every chunk by the pool's backlog.  Measured
+    // at the end of round 2, sustained over 20 000 pairs on one MI355X: all-GPU 39 600 - 40 200 pairs/s with any pool; pool only
+    // 40 100 - 40 400 with 14 threads (33 000 with 13); balanced 43 100 / 42 200 / 41 800 / 41 200 / 40 800 / 40 400 with
+    // 14 / 12 / 10 / 8 / 6 / 4 threads.
+    h->gpu_delaunay = !cfg->keep_debug && h->chunk >= 4 && npool < 3;
     if (const char *e = getenv("SV_GPU_DELAUNAY")) h->gpu_delaunay = atoi(e) != 0 && !cfg->keep_debug;
     // (SV_GPU_DELAUNAY_PCT fixes that share; without it the dispatcher balances it by the pool's backlog, see dispatcher_main.)
     h->gpu_delaunay_pct = h->gpu_delaunay ? 100 : 0;
@@ -1579,6 +1580,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     // host mode without a fixed share: the share follows the pool's backlog (42 600 against 40 100 pairs/s with 14 threads)
     h->gpu_share_auto = !h->gpu_delaunay && !getenv("SV_GPU_DELAUNAY_PCT") && !cfg->keep_debug && h->chunk >= 4;
     if (const char *e = getenv("SV_GPU_DELAUNAY_AUTO")) h->gpu_share_auto = h->gpu_share_auto && atoi(e) != 0;
+    if (h->gpu_share_auto) h->auto_pct = std::max(0, std::min(95, (100 - 7 * npool) / 5 * 5));  // where the balance was measured to settle, roughly
     h->dg_limit = h->dg_sub_max = delaunay_gpu_max_points();
     if (const char *e = getenv("SV_DG_SUBMAX")) h->dg_sub_max = std::max(6, std::min(h->dg_sub_max, atoi(e)));  // experiments / tests
     if ((h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0) && h->kp.d.max_pts > h->dg_sub_max)
