@@ -1148,9 +1148,10 @@ __global__ __launch_bounds__(256) void k_raster_tiles(KParams k, const int32_t *
                     hi = -0x7FFFFFFF;
                 }
             }
-            const int glo = group8_min(lo), ghi = group8_max(hi);
-            for (int v = glo; v < ghi; v++)
-                if (v >= lo && v < hi) atomicMax(&tile[v - ty0][u - tx0], t);
+            // every lane walks its own column piece [lo, hi) (nothing is shared between the lanes of a group here: a loop over the
+            // group's common row range with a per-lane test cost two cross-lane reductions and two compares per row more)
+            int32_t *p = lo < hi ? &tile[lo - ty0][u - tx0] : nullptr;
+            for (int v = lo; v < hi; v++, p += RT_W) atomicMax(p, t);
         }
     }
     __syncthreads();
