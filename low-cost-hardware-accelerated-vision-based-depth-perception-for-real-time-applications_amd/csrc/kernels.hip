@@ -1076,28 +1076,8 @@ __global__ __launch_bounds__(256) void k_planes(KParams k, const int32_t *__rest
         }
 }
 
-// Scan conversion (elas.cpp:912-940): 16 lanes per triangle (lattice triangles are only a few columns wide), each lane
-// walks one column; atomicMax(triangle index) reproduces "the last triangle in list order that covers a pixel decides it".
-__device__ __forceinline__ int group16_min(int v) {
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 16));
-    return v;
-}
-__device__ __forceinline__ int group8_min(int v) {
-#pragma unroll
-    for (int off = 4; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off, 8));
-    return v;
-}
-__device__ __forceinline__ int group8_max(int v) {
-#pragma unroll
-    for (int off = 4; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 8));
-    return v;
-}
-__device__ __forceinline__ int group16_max(int v) {
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off, 16));
-    return v;
-}
+// Scan conversion (elas.cpp:912-940): atomicMax(triangle index) on the tile reproduces "the last triangle in list order that
+// covers a pixel decides it".
 
 // elas.cpp:912-940 for the part of every binned triangle that falls into this workgroup's tile
 __global__ __launch_bounds__(256) void k_raster_tiles(KParams k, const int32_t *__restrict__ blob, const RasterRec *__restrict__ rrec, const int32_t *__restrict__ tile_cnt,
