@@ -2265,7 +2265,7 @@ __device__ __forceinline__ bool amean8(const float xs[8], float xc, float &out) 
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const float t = 4.0f - absq(xs[j] - xc);
-        w[j] = 0.0f > t ? 0.0f : t;  // _mm_max_ps(xconst0, t)
+        w[j] = __builtin_fmaxf(t, 0.0f);  // _mm_max_ps(xconst0, t); t is never NaN (nor -0: absq() is a power of two), so one v_max_f32 does it
         f[j] = xs[j] * w[j];
     }
     const float weight_sum = (w[0] + w[4]) + (w[1] + w[5]) + (w[2] + w[6]) + (w[3] + w[7]);  // elas.cpp:1427-1434
@@ -2374,7 +2374,7 @@ __device__ __forceinline__ bool amean4(const float xs[4], float xc, float &out) 
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const float t = 4.0f - absq(xs[j] - xc);
-        w[j] = 0.0f > t ? 0.0f : t;
+        w[j] = __builtin_fmaxf(t, 0.0f);
         f[j] = xs[j] * w[j];
     }
     const float weight_sum = w[0] + w[1] + w[2] + w[3];  // elas.cpp:1352-1353
