@@ -1199,7 +1199,7 @@ __device__ __forceinline__ int dense_band_full(const KParams &k, int side, const
 // ~60 scalar conditions alive per workgroup, spills them to VGPR lanes and reloads them in the pixel loops.
 template <bool COUNT, int MWT, int RT>
 __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, int v, const uint4 own, const uint4 *pu, const float4 rec, const uint32_t *mw,
-                                             const uint32_t *cell, int &ncand, int (&npath)[5]) {
+                                             const uint32_t *cell, int &ncand, int (&npath)[5], const uint4 *lds_first, const uint4 *lds_last) {
     const Dims &d = k.d;
     const int MW = MWT ? MWT : d.MW, plane_radius = RT ? RT : k.plane_radius;
     if ((int)texture16(own) < k.match_texture) return -10.0f;                   // elas.cpp:732-736 (the map keeps its -10)
@@ -1314,8 +1314,8 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
     } else if (DENSE_BAND_FAST && (RT == 3 || RT == 2)) {
         // Lanes clip the band differently (planes near disparity 0 or disp_max, the image's left / right border): all 2r+1 slots
         // are evaluated as in the fast path, and a slot outside the lane's own range starts its key at energy 16384 - above
-        // the 10000 a result must beat.  (Such a slot's LDS read may fall a few entries outside the staged row: the buffer is
-        // padded, the value is never used.)
+        // the 10000 a result must beat.  (Such a slot may lie a few entries outside the staged rows: its address is clamped into
+        // the buffer, the value is never used.)
         if (COUNT) npath[2]++;
         if (COUNT) ncand += max(hi_o - lo_o + 1, 0);
         const uint4 *pb = side ? pu + (d_plane - r) : pu - (d_plane + r);
@@ -1324,7 +1324,7 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
         const uint32_t okm = nb > 0 ? ((1u << nb) - 1u) << lo_o : 0u;  // bit o' set: the lane has that candidate
         uint4 c[2 * RT + 1];
 #pragma unroll
-        for (int q = 0; q <= 2 * RT; q++) c[q] = pb[q];
+        for (int q = 0; q <= 2 * RT; q++) c[q] = *min(max(pb + q, lds_first), lds_last);  // (a slot the lane does not have may lie outside the staged rows)
         int bb = KEY_NONE;
 #pragma unroll
         for (int q = 0; q <= 2 * RT; q++) {
@@ -1424,7 +1424,7 @@ __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const
                 }
                 const uint4 own = side ? sR[u - r0] : sL[u - l0];
                 const uint4 *pu = side ? sL + (u - l0) : sR + (u - r0);  // the other image at the pixel's own column
-                out = dense_pixel<COUNT, MWT, RT>(k, side, u, v, own, pu, rec, mw, cell, ncand, npath);
+                out = dense_pixel<COUNT, MWT, RT>(k, side, u, v, own, pu, rec, mw, cell, ncand, npath, dense_lds, dense_lds + 2 * dense_seg(d) - 1);
                 if (COUNT) npix++;
             }
             // integer-valued: a disparity, -1 or -10.  Half resolution (elas.cpp:707-711): only even (u, v) are matched, result at (u/2, v/2)
@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const
     }
 }
 
-static size_t dense_lds_bytes(const KParams &k) { return sizeof(uint4) * (2 * (size_t)dense_seg(k.d) + 8); }  // + 8 entries: see the band's masked path
+static size_t dense_lds_bytes(const KParams &k) { return sizeof(uint4) * 2 * (size_t)dense_seg(k.d); }
 
 template <int MWT, int RT>
 static void launch_dense_as(const KParams &k, const SlotDev &s, const dim3 &grid, size_t shmem, hipStream_t st) {
