@@ -1198,11 +1198,11 @@ __device__ __forceinline__ int dense_band_full(const KParams &k, int side, const
 // has many wave-uniform decisions on them (which mask words exist, which band slots exist); as runtime values the compiler keeps
 // ~60 scalar conditions alive per workgroup, spills them to VGPR lanes and reloads them in the pixel loops.
 template <bool COUNT, int MWT, int RT>
-__device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, int v, const uint4 own, const uint4 *pu, const float4 rec, const uint32_t *mw,
+__device__ __forceinline__ int dense_pixel(const KParams &k, int side, int u, int v, const uint4 own, const uint4 *pu, const float4 rec, const uint32_t *mw,
                                              const uint32_t *cell, int &ncand, int (&npath)[5], const uint4 *lds_first, const uint4 *lds_last) {
     const Dims &d = k.d;
     const int MW = MWT ? MWT : d.MW, plane_radius = RT ? RT : k.plane_radius;
-    if ((int)texture16(own) < k.match_texture) return -10.0f;                   // elas.cpp:732-736 (the map keeps its -10)
+    if ((int)texture16(own) < k.match_texture) return -10;                      // elas.cpp:732-736 (the map keeps its -10)
     const int d_plane = (int)(rec.x * (float)u + rec.y * (float)v + rec.z);      // :739, ((a*u)+(b*v))+c without contraction
     const int d_plane_min = max(d_plane - plane_radius, 0);
     const int d_plane_max = min(d_plane + plane_radius, d.D - 1);
@@ -1345,7 +1345,7 @@ __device__ __forceinline__ float dense_pixel(const KParams &k, int side, int u, 
             best = min(best, sad16_key(own, pu[sgn * dc], prior * 65536 + (0x8000 | dc)));
         }
     }
-    return best < (10000 << 16) ? (float)(best & 0x7FFF) : -1.0f;  // :797-800 (min_val starts at 10000, :752)
+    return best < (10000 << 16) ? (best & 0x7FFF) : -1;  // :797-800 (min_val starts at 10000, :752); the maps hold these integers as int16
 }
 
 // descriptors staged per image: DENSE_TW own columns + disp_max candidates beyond them, rounded so that the right image's
@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const
             const int u = x0 + j * 256 + threadIdx.x;
             if (u >= x1) continue;
             const int t = tt[side][j];
-            float out = -10.0f;  // elas.cpp:823-824
+            int out = -10;  // elas.cpp:823-824
             if (t >= 0 && u >= 2 && u < d.W - 2 && !(d.sub && (u & 1))) {
                 const float4 rec = trirec[(size_t)ps * d.max_tri + t];
                 const uint32_t *cell = gB + (size_t)ps * d.ncell * MW + cell_off[j];
