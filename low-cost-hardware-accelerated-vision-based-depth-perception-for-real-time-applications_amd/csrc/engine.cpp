@@ -922,10 +922,11 @@ void dispatcher_main(sv_handle *h) {
             // so the triangulation kernel takes a larger share of this chunk; a short queue gives the share back to the pool.  (One
             // chunk at a time - a single slot, a profile's serial pass - never finds a backlog and stays on the host.)
             const int backlog = h->queue_len.load(std::memory_order_acquire);
-            // (thresholds from a sweep on one MI355X + 14 pool threads: 1.5 / 0.5 chunks, steps of 5: settles near 15 %; 26 % with 12
-            //  threads, 47 % with 10, 60 % with 8, 74 % with 6, 86 % with 4 - each 1-2 % above what the all-GPU mode reaches)
-            if (backlog * 2 > s->n * 3) h->auto_pct = std::min(h->auto_pct + 5, 95);
-            else if (backlog * 2 <= s->n) h->auto_pct = std::max(h->auto_pct - 5, 0);
+            // (thresholds from sweeps on one MI355X: more than one chunk of unstarted tasks: up 2 points, less than a quarter: down 2 -
+            //  steps of 5 at 1.5 / 0.5 chunks gave the same mean rate with more scatter; settles at 13-30 % with 14 threads, 26 % with 12,
+            //  47 % with 10, 60 % with 8, 74 % with 6, 86 % with 4 - each 1-2 % above what the all-GPU mode reaches)
+            if (backlog > s->n) h->auto_pct = std::min(h->auto_pct + 2, 95);
+            else if (backlog * 4 <= s->n) h->auto_pct = std::max(h->auto_pct - 2, 0);
             s->gpu_pct = h->auto_pct;
         }
         {
@@ -1580,7 +1581,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     // host mode without a fixed share: the share follows the pool's backlog (42 600 against 40 100 pairs/s with 14 threads)
     h->gpu_share_auto = !h->gpu_delaunay && !getenv("SV_GPU_DELAUNAY_PCT") && !cfg->keep_debug && h->chunk >= 4;
     if (const char *e = getenv("SV_GPU_DELAUNAY_AUTO")) h->gpu_share_auto = h->gpu_share_auto && atoi(e) != 0;
-    if (h->gpu_share_auto) h->auto_pct = std::max(0, std::min(95, (100 - 7 * npool) / 5 * 5));  // where the balance was measured to settle, roughly
+    if (h->gpu_share_auto) h->auto_pct = std::max(0, std::min(95, 117 - 7 * npool));  // where the balance was measured to settle (4 ... 14 threads)
     h->dg_limit = h->dg_sub_max = delaunay_gpu_max_points();
     if (const char *e = getenv("SV_DG_SUBMAX")) h->dg_sub_max = std::max(6, std::min(h->dg_sub_max, atoi(e)));  // experiments / tests
     if ((h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0) && h->kp.d.max_pts > h->dg_sub_max)
