@@ -1581,7 +1581,8 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     // host mode without a fixed share: the share follows the pool's backlog (42 600 against 40 100 pairs/s with 14 threads)
     h->gpu_share_auto = !h->gpu_delaunay && !getenv("SV_GPU_DELAUNAY_PCT") && !cfg->keep_debug && h->chunk >= 4;
     if (const char *e = getenv("SV_GPU_DELAUNAY_AUTO")) h->gpu_share_auto = h->gpu_share_auto && atoi(e) != 0;
-    if (h->gpu_share_auto) h->auto_pct = std::max(0, std::min(95, 117 - 7 * npool));  // where the balance was measured to settle (4 ... 14 threads)
+    // start where the balance was measured to settle (4 ... 14 threads); a handle with fewer than four slots cannot build up a backlog
+    if (h->gpu_share_auto && nslots >= 4) h->auto_pct = std::max(0, std::min(95, 117 - 7 * npool));
     h->dg_limit = h->dg_sub_max = delaunay_gpu_max_points();
     if (const char *e = getenv("SV_DG_SUBMAX")) h->dg_sub_max = std::max(6, std::min(h->dg_sub_max, atoi(e)));  // experiments / tests
     if ((h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0) && h->kp.d.max_pts > h->dg_sub_max)
