@@ -6,21 +6,28 @@
 A "step" is one pass of the whole hot path (gray pair -> final left disparity map + L/R-checked right map) over one
 batch of KITTI-shaped stereo pairs that is already resident in HBM.  Metric = BASELINE.json's "stereo pairs/sec" at
 1242x375, D=128 (throughput configuration, batch 256 per GPU = kitti_mini pair 0 + 255 synthetic pairs, SURVEY.md
-section 8d config 3); the batch-1 latency ("ms/frame") is reported beside it.  One process per GPU (torch.distributed /
-RCCL for the barrier and the max-over-ranks time only: pairs are independent, there is no data-path collective), weak
-scaling.
+section 8d config 3); the batch-1 latency ("ms/frame") is reported beside it.  One process per GPU, weak scaling, no
+data-path collective (pairs are independent); torch.distributed / RCCL carries the barrier, the max-over-ranks time and
+the optional chunked gather of finished maps on rank 0.  With --gpus N > 1 and no launcher around it (WORLD_SIZE unset)
+this process only starts N fresh ranks (launcher.py) and relays rank 0's line; under torch.distributed.run it is a rank.
+
+Before anything is timed the engine must reproduce the reference's maps for the workload's gate pair bit for bit
+(`parity_gate`: sha256 against tests/golden/digests.json; exit code 3 otherwise).  The timed region lasts at least
+--min-seconds (5 s): `steps` on the line is the number of steps actually timed, `ms_per_step` x `steps` the timed wall.
 
 Also on the JSON line:
-  roofline        the dominant kernel (largest total time over ALL kernels in a pass without kernel overlap), its
-                  algorithmic bytes as SURVEY.md section 8(d) counts them (dense matching = 2N read + 8N write) over its average
-                  launch duration by HIP events inside the timed region, against the 8 TB/s HBM3E peak; the same
-                  with the no-overlap duration (`serial`), with the interface bytes (`frac_interface`), and the
-                  committed rocprofv3 summaries the durations can be checked against (`profile`)
+  configs         BASELINE.json's other configurations, each on its own engine behind its own parity gate: kitti_d256
+                  (configs[3]) and 4k_d192 (configs[4]; with N > 1 its maps are gathered on rank 0 inside the timed region)
+  roofline        the kernel with the largest total time over ALL kernels of the pipelined configuration (the one that is
+                  timed; the pick of a no-overlap pass beside it): its algorithmic bytes as SURVEY.md section 8(d) counts
+                  them over its average launch duration by HIP events inside the timed region, against the 8 TB/s HBM3E
+                  peak; the same with the no-overlap duration (`serial`), with the interface bytes (`frac_interface`),
+                  and the committed rocprofv3 summaries the durations can be checked against (`profile`)
   roofline_valu   what actually binds the matching kernels: VALU issue.  Wave instructions per pair (committed
                   SQ_INSTS_VALU pass), the issue floor they imply, and the SAD byte rate against the chip's
                   157 T byte-absdiff/s (live candidate counters of the no-overlap pass)
   host_to_host    SURVEY.md section 8(d)'s pair: gray L+R in host memory -> maps back in host memory, streamed
-                  (sv_submit_batch_host), page-locked and pageable caller memory; never `value`
+                  (sv_submit_batch_host), page-locked and pageable caller memory, three repetitions each; never `value`
   cpu_baseline    the reference's own serial LIBELAS (oracle/_ref, compiled from /root/reference in the build
                   container) or, if that artefact is absent, our CPU restatement, timed on this host, 1 thread;
                   cpu_baseline_all_cores: one pair per process on every core this process may use
@@ -50,6 +57,9 @@ WORKLOADS = {  # name: (W, H, D, default pairs per GPU per step, chunk, slots, s
     "kitti_d256": (1242, 375, 256, 64, 0, 0, 1, 1000, 64),      # configs[3]: LDS-pressure configuration
     "4k_d192": (3840, 2160, 192, 128, 0, 0, 3, 5000, 16),        # configs[4]: 128 pairs per GPU; 16 distinct pairs repeated (a 4K pair takes ~1 s to synthesise)
 }
+GATES = {"kitti_d128": "kitti0_d128", "kitti_d256": "kitti0_d256", "4k_d192": "synth5000_4k_d192"}  # parity-gate pair: entry of tests/golden/digests.json
+GATHER_CHUNK = {"kitti_d128": 64, "kitti_d256": 64, "4k_d192": 16}  # pairs per gather collective ("chunked (e.g. 16 pairs)")
+SUBCONFIG_DISTINCT = {"4k_d192": 4}  # sub-measurements synthesise fewer distinct pairs (a 4K pair takes ~1 s)
 METRIC = {
     "kitti_d128": "stereo pairs/sec, KITTI 1242x375 D=128 (ms/frame at batch 1 in latency_ms_batch1)",
     "kitti_d256": "stereo pairs/sec, KITTI 1242x375 D=256 (LDS-pressure configuration; ms/frame at batch 1 in latency_ms_batch1)",
@@ -61,7 +71,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 SAD_PEAK_BYTE_OPS = 1024 * 64 * 4 / 4 * 2.4e9
 KERNEL_TRACE_NAMES = {"descriptor": ["k_descriptor", "k_sobel"], "support_match": ["k_support"], "support_filter": ["k_filter_classify", "k_filter_resolve", "k_filter_vertical", "k_filter_collect"], "grid_mark": ["k_grid_mark"],
                       "grid_dilate": ["k_grid_dilate"], "plane_fit": ["k_planes"], "triangles_raster": ["k_raster_tiles"], "triangles_raster_fallback": ["k_raster"],
-                      "dense_match": ["k_dense"], "lr_check": ["k_lr", "k_lr2"], "delaunay_gpu": ["dg::k_delaunay_blob"], "ccl_band": ["k_ccl_band"],
+                      "dense_match": ["k_dense"], "lr_check": ["k_lr", "k_lr2"], "delaunay_gpu": ["dg::k_delaunay_blob", "dg::k_dgl_subtrees_blob", "dg::k_dgl_top_blob"], "ccl_band": ["k_ccl_band"],
                       "ccl_finish": ["k_ccl_border", "k_ccl_total", "k_ccl_apply", "k_ccl_slow", "k_ccl_merge"], "gap_rows": ["k_gap_rows"], "gap_cols": ["k_gap_cols"],
                       "adaptive_mean": ["k_amean", "k_amean_sub"], "median": ["k_median"], "output": ["k_output"]}
 
@@ -179,8 +189,9 @@ def cpu_baseline(sample_pairs, synth, subsampling=False, scale=1, all_cores_pair
     return one, many
 
 
-def host_throughput(eng, e, batch, Hm, Wm, steps, pinned, want_d2):
-    """`steps` host-memory batches submitted back to back (sv_submit_batch_host) and waited for: pairs/s, PCIe inclusive."""
+def host_throughput(eng, e, batch, Hm, Wm, steps, pinned, want_d2, reps=1):
+    """`steps` host-memory batches submitted back to back (sv_submit_batch_host) and waited for: pairs/s, PCIe inclusive; `reps`
+    repetitions on the same buffers (sorted)."""
     B = batch.shape[0]
     alloc = eng.pinned_array if pinned else (lambda shape, dt: np.zeros(shape, dt))
     L, R = alloc((B, H, W), np.uint8), alloc((B, H, W), np.uint8)
@@ -188,11 +199,14 @@ def host_throughput(eng, e, batch, Hm, Wm, steps, pinned, want_d2):
     d1 = alloc((B, Hm, Wm), np.float32)
     d2 = alloc((B, Hm, Wm), np.float32) if want_d2 else None
     e.process_host(L, R, want_d2=want_d2, d1=d1, d2=d2)  # warm-up (allocates the staging buffers at the first call)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        e.submit_host(L, R, d1, d2)
-    e.wait()
-    return B * steps / (time.perf_counter() - t0)
+    rates = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e.submit_host(L, R, d1, d2)
+        e.wait()
+        rates.append(B * steps / (time.perf_counter() - t0))
+    return sorted(rates)
 
 
 def host_latency(eng, params, l1, r1, pinned, calls=200):
@@ -245,15 +259,16 @@ def pcie_ceiling(mb=256, reps=5):
             "how": "%d MB page-locked <-> HBM copies, %d per direction" % (mb, reps)}
 
 
-def host_to_host(eng, e, params, batch, steps, lat_pair):
+def host_to_host(eng, e, params, batch, steps, lat_pair, reps=3):
     Hm, Wm = (H // 2, W // 2) if params.subsampling else (H, W)
     in_b, map_b = 2 * W * H, 4 * Wm * Hm
-    out = {"definition": "gray L+R u8 in host memory -> f32 maps back in host memory, %d pairs per batch, %d batches streamed (sv_submit_batch_host)" % (batch.shape[0], steps),
+    out = {"definition": "gray L+R u8 in host memory -> f32 maps back in host memory, %d pairs per batch, %d batches streamed (sv_submit_batch_host), median of %d repetitions" % (batch.shape[0], steps, reps),
            "bytes_per_pair": {"in": in_b, "d1": map_b}, "pcie_ceiling_GBps": pcie_ceiling()}
     for kind in ("pinned", "pageable"):
-        r1 = host_throughput(eng, e, batch, Hm, Wm, steps, kind == "pinned", False)
-        r2 = host_throughput(eng, e, batch, Hm, Wm, steps, kind == "pinned", True)
-        out[kind] = {"pairs_per_s_d1": round(r1, 1), "pairs_per_s_d1_d2": round(r2, 1),
+        runs1 = host_throughput(eng, e, batch, Hm, Wm, steps, kind == "pinned", False, reps)
+        runs2 = host_throughput(eng, e, batch, Hm, Wm, steps, kind == "pinned", True, reps)
+        r1, r2 = runs1[len(runs1) // 2], runs2[len(runs2) // 2]
+        out[kind] = {"pairs_per_s_d1": round(r1, 1), "pairs_per_s_d1_runs": [round(x, 1) for x in runs1], "pairs_per_s_d1_d2": round(r2, 1), "pairs_per_s_d1_d2_runs": [round(x, 1) for x in runs2],
                      "pcie_GBps_d1": {"h2d": round(r1 * in_b / 1e9, 2), "d2h": round(r1 * map_b / 1e9, 2)},
                      "pcie_GBps_d1_d2": {"h2d": round(r2 * in_b / 1e9, 2), "d2h": round(r2 * 2 * map_b / 1e9, 2)}}
     out["latency_ms_batch1_host"] = {k: host_latency(eng, params, lat_pair[0], lat_pair[1], k == "pinned") for k in ("pinned", "pageable")}
@@ -282,16 +297,316 @@ def profile_durations(kernel, pattern):
     return {"file": os.path.relpath(f, ROOT), "avg_launch_us": round(tot_us / calls, 2), "pairs_per_launch": ppl}
 
 
-def load_real_pair():
+def load_real_pair_for(Wx, Hx):
+    if (Wx, Hx) != (1242, 375):
+        return None
     try:
         from PIL import Image
         gl = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "kitti0_left.png")))
         gr = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "kitti0_right.png")))
-        if gl.shape == (H, W):
+        if gl.shape == (Hx, Wx):
             return np.ascontiguousarray(gl), np.ascontiguousarray(gr)
     except (OSError, ImportError):
         pass
     return None
+
+
+def golden_digests():
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def parity_gate(engine, torch, synth, name, subsampling):
+    """before any timing is reported, the engine that is about to be timed processes the workload's
+    gate pair and its caller-visible maps must hash to what the REFERENCE produced for that pair (tests/golden/digests.json,
+    written by tests/golden/make_golden.py from oracle/_ref; sha256 over the raw float32 bytes, i.e. tolerance 0).  The oracle
+    itself is not involved and nothing under /root/reference is read.  Raises SystemExit(3) on a mismatch."""
+    Wx, Hx, Dx = WORKLOADS[name][:3]
+    key = GATES[name] + ("_sub" if subsampling else "")
+    entry = golden_digests().get(key)
+    if entry is None:
+        return {"status": "unavailable", "case": key, "why": "no golden digest for this configuration"}
+    if "synth" in entry:
+        L, R = synth.make_pair(**entry["synth"])
+    else:
+        pair = load_real_pair_for(Wx, Hx)
+        if pair is None:
+            return {"status": "unavailable", "case": key, "why": "gray fixture missing"}
+        L, R = pair
+    import hashlib
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    if [sha(L), sha(R)] != entry["input_sha256"]:
+        print("parity gate %s: the gate pair's bytes differ from the fixture the reference was run on" % key, file=sys.stderr)
+        raise SystemExit(3)
+    dev = "cuda:%d" % engine.device
+    l1, r1 = torch.from_numpy(L[None].copy()).to(dev), torch.from_numpy(R[None].copy()).to(dev)
+    g1, g2 = engine.process_device(l1, r1)
+    torch.cuda.synchronize()
+    got = {"final1": sha(g1[0].cpu().numpy()), "final2": sha(g2[0].cpu().numpy())}
+    bad = [k for k in got if got[k] != entry["stages"][k]]
+    if bad:
+        print("parity gate %s FAILED: %s differ from the reference's maps (sha256 %s, expected %s)" %
+              (key, bad, [got[k][:16] for k in bad], [entry["stages"][k][:16] for k in bad]), file=sys.stderr)
+        raise SystemExit(3)
+    return {"status": "pass", "case": key, "checked": "sha256 of d1[0] and d2[0] (raw float32 bytes) == tests/golden/digests.json:%s.stages.final1/final2 (the reference's own output, tolerance 0)" % key}
+
+
+class GatherRun:
+    """Chunked gather of every step's left maps on rank 0 while the engine computes the following chunks (parallel.ChunkedGather,
+    SURVEY.md section 8e).  The rank's batch is submitted as B/g batches of g pairs; a helper thread takes each one as soon as the
+    engine reports it complete (sv_wait_batches) and starts its collective on a side stream.  The maps of consecutive steps
+    alternate between two buffers; chunk k of step s+2 is only submitted once the gather of chunk k of step s has completed."""
+
+    def __init__(self, torch, par, engine, B, Hm, Wm, g, device, backend):
+        import threading
+        self.torch, self.engine, self.B, self.g = torch, engine, B, g
+        self.G = -(-B // g)
+        self.cg = par.ChunkedGather(B, Hm, Wm, torch.float32, g, torch.device("cuda", device), dst=0, stage_on_cpu=(backend != "nccl"))
+        self.device, self.nccl = device, backend == "nccl"
+        self.bufs, self.steps, self.done, self.thread, self.error = None, 0, [], None, None
+        self._threading = threading
+
+    def start(self, bufs, steps):
+        self.bufs, self.steps = bufs, steps
+        self.done = [self._threading.Event() for _ in range(steps * self.G)]
+        self.thread = self._threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        torch = self.torch
+        try:
+            torch.cuda.set_device(self.device)
+            side = torch.cuda.Stream(device=self.device) if self.nccl else None
+            prev = None
+            for i in range(self.steps * self.G):
+                s, k = divmod(i, self.G)
+                self.engine.wait_batches(i + 1)
+                if side is not None:
+                    with torch.cuda.stream(side):
+                        hnd = self.cg.submit(self.bufs[s % 2][0], k)
+                        self.cg.wait(hnd)  # (the side stream waits, not the host)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                    cur = (hnd, ev)
+                else:
+                    cur = (self.cg.submit(self.bufs[s % 2][0], k), None)
+                if prev is not None:  # the previous chunk's collective has had a whole chunk of compute to finish
+                    self._finish(prev)
+                    self.done[i - 1].set()
+                prev = cur
+            self._finish(prev)
+            self.done[-1].set()
+        except BaseException as e:  # noqa: BLE001 - re-raised by join()
+            self.error = e
+            for ev in self.done:
+                ev.set()
+
+    def _finish(self, item):
+        hnd, ev = item
+        if ev is not None:
+            ev.synchronize()
+        else:
+            self.cg.wait(hnd)
+
+    def before_chunk(self, s, k):
+        if s >= 2:
+            self.done[(s - 2) * self.G + k].wait()
+
+    def join(self):
+        self.thread.join()
+        if self.error is not None:
+            raise self.error
+
+
+def timed_region(torch, engine, left, right, bufs, steps, barrier, sync_steps=False, gather=None):
+    """`steps` passes over the batch, bracketed by barrier + synchronize on both sides; returns the wall seconds of this rank."""
+    B = left.shape[0]
+    barrier()
+    t0 = time.perf_counter()
+    if gather is not None:
+        gather.start(bufs, steps)
+        g = gather.g
+        for s in range(steps):
+            d1, d2 = bufs[s % 2]
+            for k, lo in enumerate(range(0, B, g)):
+                gather.before_chunk(s, k)
+                engine.submit_device(left[lo:lo + g], right[lo:lo + g], d1[lo:lo + g], d2[lo:lo + g])
+        gather.join()
+        engine.wait()
+    elif sync_steps:
+        for _ in range(steps):
+            engine.process_device(left, right, bufs[0][0], bufs[0][1])
+    else:  # "streamed": the batches are handed to the engine back to back, the next one fills the pipeline while the last drains
+        for _ in range(steps):
+            engine.submit_device(left, right, bufs[0][0], bufs[0][1])
+        engine.wait()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def run_config(ctx, name, steps_req, warmup, min_seconds, headline, gather):
+    """One BASELINE configuration on this rank's GPU: inputs, engine, parity gate, warm-up, timed region (>= min_seconds), latency.
+    Returns a dict (every rank; rank 0's is printed).  headline=True adds the per-kernel passes and keeps the engine for the
+    host-to-host measurements (returned under '_engine')."""
+    torch, dist, eng, synth, par, args = ctx["torch"], ctx["dist"], ctx["eng"], ctx["synth"], ctx["par"], ctx["args"]
+    rank, world, local_rank, backend, coll_dev = ctx["rank"], ctx["world"], ctx["local_rank"], ctx["backend"], ctx["coll_dev"]
+    Wx, Hx, Dx, wb, wchunk, wslots, wscale, wseed, wdistinct = WORKLOADS[name]
+    B = (args.batch or wb) if headline else wb
+    chunk = (args.chunk or wchunk) if headline else wchunk
+    slots = (args.slots or wslots) if headline else wslots
+    sub = bool(args.subsampling) and headline
+    # weak scaling: every rank owns B pairs of its own (seeds wseed + rank*B + i); no data-path collective
+    seeds = par.pair_seeds(rank, B, seed0=wseed)
+    distinct = min(B, wdistinct if headline else min(wdistinct, SUBCONFIG_DISTINCT.get(name, wdistinct)))
+    batch = synth.make_batch(seeds[0], distinct, Hx, Wx, Dx, scale=wscale)
+    if distinct < B:
+        batch = np.concatenate([batch] * (-(-B // distinct)))[:B]
+    real = load_real_pair_for(Wx, Hx)
+    data_desc = "synthetic (%d distinct pairs%s, seeds %d..%d)" % (distinct, ", repeated to %d" % B if distinct < B else "", seeds[0], seeds[0] + distinct - 1)
+    if headline and args.real_pair:
+        assert real is not None, "the committed pair is 1242x375"
+        batch[:, 0], batch[:, 1] = real
+        data_desc = "kitti_mini pair 0 replicated"
+    elif real is not None and not (headline and args.synthetic_only):
+        batch[0, 0], batch[0, 1] = real  # SURVEY.md 8d config 3: "pair 0 plus 255 synthetic"
+        data_desc = "kitti_mini pair 0 (committed gray fixture) + %d synthetic pairs (seeds %d..%d%s)" % (B - 1, seeds[1], seeds[min(distinct, B) - 1], ", repeated" if distinct < B else "")
+    left = torch.from_numpy(np.ascontiguousarray(batch[:, 0])).cuda()
+    right = torch.from_numpy(np.ascontiguousarray(batch[:, 1])).cuda()
+    params = eng.SvParams.driver(Dx - 1)
+    params.subsampling = 1 if sub else 0  # the reference's "s1" rows (results_log.txt): half-resolution maps
+    Hm, Wm = (Hx // 2, Wx // 2) if sub else (Hx, Wx)
+    nbuf = 2 if gather else 1
+    bufs = [(torch.empty((B, Hm, Wm), dtype=torch.float32, device="cuda"), torch.empty((B, Hm, Wm), dtype=torch.float32, device="cuda")) for _ in range(nbuf)]
+    d1, d2 = bufs[0]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = {"_params": params, "_batch": batch, "_real": real, "_B": B, "_dims": (Wx, Hx, Dx, Wm, Hm), "data": data_desc}
+    # ---- pass without kernel overlap (one slot, one stream; every kernel timed): clean per-kernel durations and the live
+    # candidate counters of the matching kernels
+    serial_k, counters = None, None
+    if headline and not args.no_kernel_timing:
+        schunk = chunk or (32 if Wx < 2000 else 4)
+        es = eng.StereoEngine(Wx, Hx, params, device=local_rank, n_workers=args.workers, chunk=schunk, n_streams=1, n_slots=1)
+        nb = min(B, 2 * schunk)
+        es.process_device(left[:nb], right[:nb], d1[:nb], d2[:nb])
+        es.timing(True)
+        es.process_device(left[:nb], right[:nb], d1[:nb], d2[:nb])
+        kt = es.kernel_times()
+        es.timing(False)
+        nc = min(nb, 8)  # candidate counters: separate (slower) instantiations of the matching kernels, a few pairs suffice
+        es.counters(True)
+        es.process_device(left[:nc], right[:nc], d1[:nc], d2[:nc])
+        counters = {k: v / nc for k, v in es.counters().items()}
+        es.close()
+        serial_k = {k: (v[0], v[1], nb * 1.0 / max(v[1], 1)) for k, v in kt.items() if v[1] > 0 and not k.startswith("host:")}  # (total ms, launches, pairs per launch)
+    res["_serial_k"], res["_counters"] = serial_k, counters
+
+    engine = eng.StereoEngine(Wx, Hx, params, device=local_rank, n_workers=args.workers if headline else 0, chunk=chunk, n_streams=args.streams if headline else 0, n_slots=slots)
+    engine_info = engine.query()
+    gate = parity_gate(engine, torch, synth, name, sub) if not args.no_gate else {"status": "skipped"}
+    est = None
+    for _ in range(max(1, warmup)):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        engine.process_device(left, right, d1, d2)
+        torch.cuda.synchronize()
+        est = time.perf_counter() - a
+    # ---- which kernel owns the most time in the configuration that is actually timed: a short pipelined pass with events around
+    # every launch (costs 1-2 % of the rate, so it is not the timed region itself)
+    pipe_k = None
+    if headline and not args.no_kernel_timing:
+        engine.timing(True)
+        for _ in range(2):
+            engine.submit_device(left, right, d1, d2)
+        engine.wait()
+        pipe_k = {k: v for k, v in engine.kernel_times().items() if v[1] > 0 and not k.startswith("host:")}
+        engine.timing(False)
+        dom = max(pipe_k, key=lambda k: pipe_k[k][0])
+        res["_dom"] = dom
+        # HIP events on the engine's own streams inside the timed region: the dominant kernel only (or all: --time-all-kernels)
+        engine.timing(True, only=None if args.time_all_kernels else tuple({dom, max(serial_k, key=lambda k: serial_k[k][0])}))
+    res["_pipe_k"] = pipe_k
+    # the timed region lasts at least min_seconds whatever --steps says (bursts hide CPU-quota throttling): every rank runs the
+    # same number of steps
+    steps = max(1, steps_req)
+    if min_seconds > 0 and est:
+        steps = max(steps, int(np.ceil(min_seconds / est)))
+    if world > 1:
+        t = torch.tensor([steps], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        steps = int(t.item())
+    my_elapsed = timed_region(torch, engine, left, right, bufs[:1], steps, barrier, sync_steps=args.sync_steps and headline)
+    res["_ktimes"] = engine.kernel_times() if headline and not args.no_kernel_timing else {}
+    engine.timing(False)
+    engine_info["gpu_triangulation_share"] = engine.gpu_triangulation_share()  # host mode: what the dispatcher's load balancing handed to the GPU kernel
+    elapsed = par.max_over_ranks(my_elapsed, device=coll_dev)
+    per_rank = [B * steps / my_elapsed]
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.float64, device=coll_dev)
+        t[rank] = my_elapsed
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank = [B * steps / float(x) for x in t.tolist()]
+    res.update({"pairs_per_s": round(B * world * steps / elapsed, 2), "ms_per_step": round(1e3 * elapsed / steps, 3), "steps": steps, "steps_requested": steps_req, "warmup": max(1, warmup),
+                "timed_seconds": round(elapsed, 3), "pairs_per_gpu_per_step": B, "per_rank_pairs_per_s": [round(x, 1) for x in per_rank],
+                "parity_gate": gate, "engine": engine_info, "valid_fraction": round(float((d1 >= 0).float().mean().item()), 4),
+                "checksum_rank0": float(d1.double().sum().item())})
+    # ---- the same run with the finished left maps gathered on rank 0 (RCCL), chunk by chunk, overlapping the kernels
+    if gather and world > 1:
+        g = min(B, GATHER_CHUNK.get(name, 64))
+        gr = GatherRun(torch, par, engine, B, Hm, Wm, g, local_rank, backend)
+        gsteps = max(2, min(steps, int(np.ceil(max(1.0, min_seconds / 2) / max(est, 1e-6)))))
+        g_el = par.max_over_ranks(timed_region(torch, engine, left, right, bufs, gsteps, barrier, gather=gr), device=coll_dev)
+        ok = True
+        if rank == 0:  # rank order == pair order; rank 0's own block must be its own maps of the last step
+            ok = bool(torch.equal(gr.cg.root[0].to(bufs[(gsteps - 1) % 2][0].device), bufs[(gsteps - 1) % 2][0]))
+        into_root = (world - 1) * B * Hm * Wm * 4 * gsteps
+        res["with_gather"] = {"pairs_per_s": round(B * world * gsteps / g_el, 2), "ms_per_step": round(1e3 * g_el / gsteps, 3), "steps": gsteps,
+                              "collective": "dist.gather of %d-pair chunks into one preallocated [world,B,H,W] f32 buffer on rank 0, issued per finished chunk (sv_wait_batches), overlapping later chunks' kernels" % g,
+                              "chunk_pairs": g, "bytes_into_root_per_step": into_root // gsteps, "root_ingest_GBps": round(into_root / g_el / 1e9, 2),
+                              "backend": backend, "root_block0_equals_own_maps": ok}
+        del gr
+    # ---- batch-1 latency on rank 0 (ms/frame), SURVEY.md 8d config 2: the gate pair's size, one pair per call, device memory in and out
+    lat_ms = None
+    if rank == 0 and not args.no_latency:
+        lat_pair = real if real is not None else (batch[0, 0], batch[0, 1])
+        e1 = eng.StereoEngine(Wx, Hx, params, device=local_rank, n_workers=LATENCY_WORKERS, chunk=1, n_streams=1, n_slots=2)
+        l1 = torch.from_numpy(np.array(lat_pair[0][None])).cuda()
+        r1 = torch.from_numpy(np.array(lat_pair[1][None])).cuda()
+        o1, o2 = d1[:1].clone(), d2[:1].clone()
+        ncalls = 200 if headline else 50
+        for _ in range(20 if headline else 5):
+            e1.process_device(l1, r1, o1, o2)
+        ts = []
+        for _ in range(ncalls):
+            torch.cuda.synchronize()
+            a = time.perf_counter()
+            e1.process_device(l1, r1, o1, o2)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - a)
+        e1.close()
+        lat_ms = {"median": round(1e3 * float(np.median(ts)), 3), "p99": round(1e3 * float(np.percentile(ts, 99)), 3),
+                  "pair": "kitti_mini pair 0" if real is not None else "first pair of the batch", "calls": ncalls,
+                  "memory": "device in / device out" + (" (host memory: host_to_host.latency_ms_batch1_host)" if headline else "")}
+    res["latency_ms_batch1"] = lat_ms
+    if headline:
+        res["_engine"], res["_bufs"], res["_left"], res["_right"] = engine, bufs, left, right
+    else:
+        engine.close()
+        del left, right, bufs, d1, d2
+        torch.cuda.empty_cache()
+    return res
+
+
+def public(d):
+    return {k: v for k, v in d.items() if not k.startswith("_")}
 
 
 def main():
@@ -299,6 +614,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--min-seconds", type=float, default=5.0, help="the headline's timed region lasts at least this long: more steps than --steps are run when needed "
+                    "(`steps` on the line = steps actually timed; 0 = exactly --steps)")
     ap.add_argument("--batch", type=int, default=0, help="pairs per GPU per step (0 = the workload's default: 256 for the headline)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="kitti_d128", help="kitti_d128 is BASELINE.json's metric configuration")
     ap.add_argument("--workers", type=int, default=0, help="host pool threads (0 = library default)")
@@ -312,17 +629,23 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 latency measurements (profiling runs: keeps the per-kernel averages to the timed region's launches)")
     ap.add_argument("--no-host", action="store_true", help="skip the host-to-host measurements")
     ap.add_argument("--no-real", action="store_true", help="skip the extra throughput measurement on copies of kitti_mini pair 0")
+    ap.add_argument("--no-configs", action="store_true", help="skip the sub-measurements of BASELINE.json's other configurations (kitti_d256, 4k_d192)")
+    ap.add_argument("--no-gate", action="store_true", help="skip the parity gate (profiling runs only: a line without `parity_gate: pass` is not a result)")
     ap.add_argument("--sync-steps", action="store_true", help="wait for each step before submitting the next (default: streamed submission)")
     ap.add_argument("--synthetic-only", action="store_true", help="all pairs synthetic (default: kitti_mini pair 0 + synthetic pairs, SURVEY.md 8d config 3)")
     ap.add_argument("--real-pair", action="store_true", help="fill the whole batch with copies of the committed kitti_mini pair 0")
     ap.add_argument("--subsampling", action="store_true", help="Elas::parameters::subsampling (the reference's s1 benchmark rows): half-resolution maps")
-    ap.add_argument("--gather", action="store_true", help="after the timed region, also gather all left maps on rank 0 (RCCL) and report the time")
+    ap.add_argument("--gather", action="store_true", help="N > 1: also time the headline with the finished left maps gathered on rank 0 (chunked, overlapped; always on for 4k_d192)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` without a launcher around it: this process becomes the launcher.  It has not touched the GPU
+    # (no torch import so far) and never will; N fresh children do the work, rank 0's JSON line is relayed.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launcher = importlib.import_module(PKG + ".launcher")
+        sys.exit(launcher.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+
     global W, H, D
-    W, H, D, wb, wchunk, wslots, wscale, wseed, wdistinct = WORKLOADS[args.workload]
-    args.batch = args.batch or wb
-    args.chunk = args.chunk or wchunk
-    args.slots = args.slots or wslots
+    W, H, D = WORKLOADS[args.workload][:3]
 
     import torch
     import torch.distributed as dist
@@ -331,11 +654,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the product has no CPU path"
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     # BENCH_BACKEND=gloo rehearses the multi-process path on a box with fewer GPUs than ranks (ranks then share devices and
-    # the control-plane collectives run on CPU tensors); the real runs use nccl (= RCCL) with one GPU per rank
+    # the collectives run on CPU tensors); the real runs use nccl (= RCCL) with one GPU per rank
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
+    elif world > torch.cuda.device_count():
+        raise SystemExit("--gpus %d but only %d GPU(s) visible (BENCH_BACKEND=gloo rehearses the multi-process path on fewer)" % (world, torch.cuda.device_count()))
     coll_dev = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     if world > 1:
@@ -343,92 +669,18 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     eng = importlib.import_module(PKG + ".engine")
     synth = importlib.import_module(PKG + ".synth")
     par = importlib.import_module(PKG + ".parallel")
-    B = args.batch
-    # weak scaling: every rank owns B pairs of its own (seeds wseed + rank*B + i); no data-path collective
-    seeds = par.pair_seeds(rank, B, seed0=wseed)
-    distinct = min(B, wdistinct)
-    batch = synth.make_batch(seeds[0], distinct, H, W, D, scale=wscale)
-    if distinct < B:
-        batch = np.concatenate([batch] * (-(-B // distinct)))[:B]
-    real = load_real_pair()
-    data_desc = "synthetic (%d distinct pairs%s)" % (distinct, ", repeated to %d" % B if distinct < B else "")
-    if args.real_pair:
-        assert real is not None, "the committed pair is 1242x375"
-        batch[:, 0], batch[:, 1] = real
-        data_desc = "kitti_mini pair 0 replicated"
-    elif real is not None and not args.synthetic_only:
-        batch[0, 0], batch[0, 1] = real  # "pair 0 plus 255 synthetic"
-        data_desc = "kitti_mini pair 0 (committed gray fixture) + %d synthetic pairs (seeds %d..%d)" % (B - 1, seeds[1], seeds[-1])
-    left = torch.from_numpy(np.ascontiguousarray(batch[:, 0])).cuda()
-    right = torch.from_numpy(np.ascontiguousarray(batch[:, 1])).cuda()
-    params = eng.SvParams.driver(D - 1)
-    params.subsampling = 1 if args.subsampling else 0  # the reference's "s1" rows (results_log.txt): half-resolution maps
-    Hm, Wm = (H // 2, W // 2) if args.subsampling else (H, W)
-    d1 = torch.empty((B, Hm, Wm), dtype=torch.float32, device="cuda")
-    d2 = torch.empty((B, Hm, Wm), dtype=torch.float32, device="cuda")
+    ctx = {"torch": torch, "dist": dist, "eng": eng, "synth": synth, "par": par, "args": args, "rank": rank, "world": world,
+           "local_rank": local_rank, "backend": backend, "coll_dev": coll_dev}
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- pass without kernel overlap (one slot, one stream; every kernel timed): clean per-kernel durations, the dominant
-    # kernel by total time over ALL kernels, and the live candidate counters of the matching kernels
-    serial_k, counters, dom = None, None, None
-    if not args.no_kernel_timing:
-        schunk = args.chunk or (32 if W < 2000 else 4)
-        es = eng.StereoEngine(W, H, params, device=local_rank, n_workers=args.workers, chunk=schunk, n_streams=1, n_slots=1)
-        nb = min(B, 2 * schunk)
-        es.process_device(left[:nb], right[:nb], d1[:nb], d2[:nb])
-        es.timing(True)
-        es.process_device(left[:nb], right[:nb], d1[:nb], d2[:nb])
-        kt = es.kernel_times()
-        es.timing(False)
-        nc = min(nb, 8)  # candidate counters: separate (slower) instantiations of the matching kernels, a few pairs suffice
-        es.counters(True)
-        es.process_device(left[:nc], right[:nc], d1[:nc], d2[:nc])
-        counters = {k: v / nc for k, v in es.counters().items()}
-        es.close()
-        serial_k = {k: (v[0], v[1], nb * 1.0 / max(v[1], 1)) for k, v in kt.items() if v[1] > 0 and not k.startswith("host:")}  # (total ms, launches, pairs per launch)
-        dom = max(serial_k, key=lambda k: serial_k[k][0])
-
-    engine = eng.StereoEngine(W, H, params, device=local_rank, n_workers=args.workers, chunk=args.chunk, n_streams=args.streams, n_slots=args.slots)
-    engine_info = engine.query()
-    for _ in range(args.warmup):
-        engine.process_device(left, right, d1, d2)
-    if not args.no_kernel_timing:  # HIP events on the engine's own streams, inside the timed region
-        engine.timing(True, only=None if args.time_all_kernels else (dom,))
-    barrier()
-    t0 = time.perf_counter()
-    if args.sync_steps:
-        for _ in range(args.steps):
-            engine.process_device(left, right, d1, d2)
-    else:  # "streamed": the K batches are handed to the engine back to back, the next one fills the pipeline while the last drains
-        for _ in range(args.steps):
-            engine.submit_device(left, right, d1, d2)
-        engine.wait()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ktimes = engine.kernel_times() if not args.no_kernel_timing else {}
-    engine.timing(False)
-    engine_info["gpu_triangulation_share"] = engine.gpu_triangulation_share()  # host mode: what the dispatcher's load balancing handed to the GPU kernel
-    elapsed = par.max_over_ranks(elapsed, device=coll_dev)
-    gather_ms = None
-    if args.gather and world > 1:  # the optional "trivial gather" of finished maps on rank 0 over RCCL/xGMI, outside the timed region
-        barrier()
-        g0 = time.perf_counter()
-        allmaps = par.gather_maps(d1 if backend == "nccl" else d1.cpu(), dst=0)
-        barrier()
-        gather_ms = round(1e3 * (time.perf_counter() - g0), 3)
-        del allmaps
-    valid_frac = float((d1 >= 0).float().mean().item())
-    checksum = float(d1.double().sum().item())
+    hl = run_config(ctx, args.workload, args.steps, args.warmup, args.min_seconds, True, gather=(args.gather or args.workload == "4k_d192"))
+    engine, params, batch, real, B = hl["_engine"], hl["_params"], hl["_batch"], hl["_real"], hl["_B"]
+    Wm, Hm = hl["_dims"][3], hl["_dims"][4]
+    d1, d2 = hl["_bufs"][0]
+    steps = hl["steps"]
 
     # ---- the same engine on a batch of copies of the real pair (real maps are far more fragmented than synthetic ones)
     real_rate = None
@@ -436,7 +688,7 @@ def main():
         rl = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(real[0], (B, H, W)))).cuda()
         rr = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(real[1], (B, H, W)))).cuda()
         engine.process_device(rl, rr, d1, d2)
-        rsteps = max(3, args.steps // 2)
+        rsteps = max(3, steps // 4)
         torch.cuda.synchronize()
         r0 = time.perf_counter()
         for _ in range(rsteps):
@@ -450,52 +702,48 @@ def main():
     h2h = None
     lat_pair = real if real is not None else (batch[0, 0], batch[0, 1])
     if rank == 0 and world == 1 and not args.no_host:
-        h2h = host_to_host(eng, engine, params, batch, max(3, args.steps // 2), lat_pair)
+        h2h = host_to_host(eng, engine, params, batch, max(3, min(20, steps // 4)), lat_pair)
         if args.no_latency:
             h2h.pop("latency_ms_batch1_host", None)
-
-    # batch-1 latency on rank 0 (ms/frame), SURVEY.md §8d config 2: pair 0 of kitti_mini (the committed gray fixture; the first
-    # pair of the batch if the fixture is absent), one pair per call, 200 timed calls after 20 warm-ups, device memory in and out
-    lat_ms = None
-    if rank == 0 and not args.no_latency:
-        e1 = eng.StereoEngine(W, H, params, device=local_rank, n_workers=LATENCY_WORKERS, chunk=1, n_streams=1, n_slots=2)
-        l1 = torch.from_numpy(np.array(lat_pair[0][None])).cuda()
-        r1 = torch.from_numpy(np.array(lat_pair[1][None])).cuda()
-        which = "kitti_mini pair 0" if real is not None else "first pair of the batch"
-        o1, o2 = d1[:1].clone(), d2[:1].clone()
-        for _ in range(20):
-            e1.process_device(l1, r1, o1, o2)
-        ts = []
-        for _ in range(200):
-            torch.cuda.synchronize()
-            a = time.perf_counter()
-            e1.process_device(l1, r1, o1, o2)
-            torch.cuda.synchronize()
-            ts.append(time.perf_counter() - a)
-        e1.close()
-        lat_ms = {"median": round(1e3 * float(np.median(ts)), 3), "p99": round(1e3 * float(np.percentile(ts, 99)), 3), "pair": which, "calls": 200,
-                  "memory": "device in / device out (host memory: host_to_host.latency_ms_batch1_host)"}
     engine.close()
+    del hl["_engine"], hl["_bufs"], hl["_left"], hl["_right"], d1, d2
+    torch.cuda.empty_cache()
+
+    # ---- BASELINE.json's other configurations, each on its own engine with its own parity gate (>= 2 s of steps each):
+    # configs[3] KITTI D=256 (one GPU) and configs[4] 4K D=192, 128 pairs per GPU, gathered on rank 0 when N > 1
+    configs = {}
+    if args.workload == "kitti_d128" and not args.no_configs and not args.subsampling:
+        for cname in (("kitti_d256", "4k_d192") if world == 1 else ("4k_d192",)):
+            r = public(run_config(ctx, cname, 3, 2, 2.0, False, gather=(cname == "4k_d192")))
+            r["config"] = "%dx%d D=%d, %d pairs per GPU per step, %d GPU(s)" % (WORKLOADS[cname][0], WORKLOADS[cname][1], WORKLOADS[cname][2], r["pairs_per_gpu_per_step"], world)
+            configs[cname] = r
 
     if rank == 0:
-        total_pairs = B * world * args.steps
-        rate = total_pairs / elapsed
+        serial_k, pipe_k, ktimes, counters = hl["_serial_k"], hl["_pipe_k"], hl["_ktimes"], hl["_counters"]
+        rate = hl["pairs_per_s"]
         out = {
             "metric": METRIC[args.workload] + (" subsampling=1" if args.subsampling else ""),
-            "value": round(rate, 2),
+            "value": rate,
             "unit": "pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "n_gpus": world, "steps": steps, "steps_requested": args.steps, "warmup": hl["warmup"],
+            "ms_per_step": hl["ms_per_step"], "timed_seconds": hl["timed_seconds"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": data_desc,
+            "dtype": "u8", "data": hl["data"],
+            "parity_gate": hl["parity_gate"]["status"], "parity_gate_detail": hl["parity_gate"],
             "config": {"workload": "%s_%dx%d_D%d_batch%d_per_gpu_streamed" % (args.workload.split("_")[0], W, H, D, B), "width": W, "height": H, "disp_max": D - 1,
                        "preset": "driver(MIDDLEBURY+only_left+adaptive_mean+median)" + ("+subsampling" if args.subsampling else ""), "pairs_per_gpu_per_step": B,
-                       "parallelism": "batch-sharded x%d, no data-path collective" % world, "engine": engine_info},
-            "latency_ms_batch1": lat_ms, "value_real_pair": real_rate, "host_to_host": h2h, "gather_ms": gather_ms,
-            "valid_fraction": round(valid_frac, 4), "checksum_rank0": checksum,
+                       "parallelism": "batch-sharded x%d, no data-path collective" % world, "engine": hl["engine"]},
+            "launcher": os.environ.get("SV_LAUNCHER", "external (torch.distributed.run)" if world > 1 else "none"),
+            "collective_backend": backend if world > 1 else None, "rccl_ranks": (dist.get_world_size() if world > 1 and backend == "nccl" else None),
+            "per_rank_pairs_per_s": hl["per_rank_pairs_per_s"],
+            "with_gather": hl.get("with_gather"),
+            "configs": configs,
+            "latency_ms_batch1": hl["latency_ms_batch1"], "value_real_pair": real_rate, "host_to_host": h2h,
+            "valid_fraction": hl["valid_fraction"], "checksum_rank0": hl["checksum_rank0"],
         }
         if h2h:
             out["value_host_to_host"] = h2h["pinned"]["pairs_per_s_d1"]
+            out["value_host_to_host_spread"] = h2h["pinned"]["pairs_per_s_d1_runs"]
         if ktimes and serial_k:
             N = W * H
             step = params.candidate_stepsize
@@ -507,35 +755,53 @@ def main():
             host = {k: v for k, v in ktimes.items() if k.startswith("host:")}
             ktimes = {k: v for k, v in ktimes.items() if not k.startswith("host:") and v[1] > 0}
             out["host_stage_cpu_ms_per_pair"] = {k: round(v[0] / max(v[1], 1), 4) for k, v in host.items()}
-            # dominant kernel: argmax of total time over ALL kernels of the no-overlap pass
-            s_ms, s_calls, s_ppl = serial_k[dom]
-            ms, calls = ktimes[dom]
-            ppl = B * args.steps / calls  # rank 0's launches of this kernel each cover one chunk
-            avg_s, s_avg_s = 1e-3 * ms / calls, 1e-3 * s_ms / s_calls
-            a8 = alg.get(dom, 0)
-            achieved = a8 * ppl / avg_s / 1e9
-            s_achieved = a8 * s_ppl / s_avg_s / 1e9
-            traffic, traffic_src, pmc = None, None, {}
+            pmc = {}
             try:  # HBM bytes from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as the microarch guide prescribes)
                 with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                     pmc = json.load(f)
-                if dom in pmc["bytes_per_pair"]:
-                    traffic = int(pmc["bytes_per_pair"][dom] * ppl)
-                    traffic_src = pmc["_source"]
-            except (OSError, ValueError, KeyError):
+            except (OSError, ValueError):
                 pass
+            pmc_b = pmc.get("bytes_per_pair", {})
+            # dominant kernel: argmax of total time over ALL kernels of the pipelined configuration (the one that is timed); the
+            # pick of the no-overlap pass beside it
+            dom = hl["_dom"]
+            dom_serial = max(serial_k, key=lambda k: serial_k[k][0])
+
+            def roof(kname):
+                s_ms, s_calls, s_ppl = serial_k.get(kname, (0.0, 0, 0.0))
+                ms, calls = ktimes.get(kname, (0.0, 0))
+                ent = {"kernel": kname, "algorithmic_bytes_per_pair": alg.get(kname, 0), "interface_bytes_per_pair": itf.get(kname, 0)}
+                a8 = alg.get(kname, 0)
+                if calls:
+                    ppl = B * steps / calls  # rank 0's launches of this kernel each cover one chunk
+                    avg_s = 1e-3 * ms / calls
+                    ent.update({"achieved": round(a8 * ppl / avg_s / 1e9, 2), "frac": round(a8 * ppl / avg_s / 1e9 / HBM_PEAK_GBS, 5), "avg_launch_us": round(1e6 * avg_s, 2), "pairs_per_launch": ppl,
+                                "algorithmic_bytes_per_launch": int(a8 * ppl), "frac_interface": round(itf.get(kname, 0) * ppl / avg_s / 1e9 / HBM_PEAK_GBS, 5),
+                                "traffic": int(pmc_b[kname] * ppl) if kname in pmc_b else None})
+                if s_calls:
+                    s_avg = 1e-3 * s_ms / s_calls
+                    ent["serial"] = {"avg_launch_us": round(1e6 * s_avg, 2), "pairs_per_launch": s_ppl, "achieved": round(a8 * s_ppl / s_avg / 1e9, 2),
+                                     "frac": round(a8 * s_ppl / s_avg / 1e9 / HBM_PEAK_GBS, 5), "duration_source": "HIP events, one slot / one stream pass of this run (no kernel overlap)"}
+                ent["profile"] = {"pipelined": profile_durations(kname, "r*_bench_pipelined_kernel_stats.csv"), "serial": profile_durations(kname, "r*_serial_kernel_stats_pmc.csv")}
+                return ent
+
+            r = roof(dom)
+            tot_pipe = sum(v[0] for v in pipe_k.values())
             out["roofline"] = {
                 "bound": "hbm", "kernel": dom, "dominant_by_time": dom,
-                "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                "traffic": traffic, "traffic_source": traffic_src,
-                "algorithmic_bytes_per_pair": a8, "algorithmic_bytes_per_launch": int(a8 * ppl), "bytes_definition": "SURVEY.md 8(d) stage minimum (dense = 2N read + 8N write); no credit for intermediates (gradient planes, triangle ids)",
-                "avg_launch_us": round(1e6 * avg_s, 2), "pairs_per_launch": ppl, "duration_source": "HIP events on the launching stream, timed region (kernels of other streams overlap)",
-                "serial": {"avg_launch_us": round(1e6 * s_avg_s, 2), "pairs_per_launch": s_ppl, "achieved": round(s_achieved, 2), "frac": round(s_achieved / HBM_PEAK_GBS, 5),
-                           "duration_source": "HIP events, one slot / one stream pass of this run (no kernel overlap)"},
-                "frac_interface": round(itf.get(dom, 0) * ppl / avg_s / 1e9 / HBM_PEAK_GBS, 5), "interface_bytes_per_pair": itf.get(dom, 0),
-                "profile": {"pipelined": profile_durations(dom, "r*_bench_pipelined_kernel_stats.csv"), "serial": profile_durations(dom, "r*_serial_kernel_stats_pmc.csv")},
+                "dominant_by_time_source": "largest total of HIP-event durations over ALL kernels in a 2-step pass of the pipelined configuration (the one `value` is measured in); kernels of other streams overlap, so a latency-chain kernel counts with its wall time",
+                "dominant_share_of_pipelined_kernel_time": round(pipe_k[dom][0] / tot_pipe, 4), "dominant_serial": dom_serial,
+                "achieved": r.get("achieved"), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r.get("frac"),
+                "traffic": r.get("traffic"), "traffic_source": pmc.get("_source"),
+                "algorithmic_bytes_per_pair": r["algorithmic_bytes_per_pair"], "algorithmic_bytes_per_launch": r.get("algorithmic_bytes_per_launch"),
+                "bytes_definition": "SURVEY.md 8(d) stage minimum (dense = 2N read + 8N write); no credit for intermediates (gradient planes, triangle ids); kernels 8(d) does not list (triangulation, plane fit, grid) have 0",
+                "avg_launch_us": r.get("avg_launch_us"), "pairs_per_launch": r.get("pairs_per_launch"), "duration_source": "HIP events on the launching stream, timed region (kernels of other streams overlap)",
+                "serial": r.get("serial"), "frac_interface": r.get("frac_interface"), "interface_bytes_per_pair": r["interface_bytes_per_pair"], "profile": r["profile"],
                 "whole_pipeline": {"bytes_per_pair_8d": 88 * N, "achieved": round(88 * N * (rate / world) / 1e9, 2), "frac": round(88 * N * (rate / world) / 1e9 / HBM_PEAK_GBS, 5)},
             }
+            if dom_serial != dom:
+                out["roofline"]["serial_pick"] = roof(dom_serial)
+            out["pipelined_kernel_time_share"] = {k: round(v[0] / tot_pipe, 4) for k, v in sorted(pipe_k.items(), key=lambda kv: -kv[1][0])}
             # VALU issue: what binds the matching kernels
             vi = pmc.get("valu_wave_insts_per_pair", {})
             valu = {"note": "integer VALU issue, not HBM, binds the matching kernels: 1024 SIMDs, 2.4 GHz, 4 cycles per wave64 v_sad_u8 / min / max / med3 (tools/valu_rate.hip)",
@@ -559,19 +825,30 @@ def main():
             if counters:
                 valu["counters_per_pair"] = {k: round(v, 1) for k, v in counters.items()}
             out["roofline_valu"] = valu
-            out["roofline_by_kernel"] = {kk: {"serial_us_per_pair": round(1e3 * v[0] / (v[1] * v[2]), 3),
-                                               "frac_8d_serial": round(alg.get(kk, 0) / (1e-3 * v[0] / (v[1] * v[2])) / 1e9 / HBM_PEAK_GBS, 5),
-                                               "frac_interface_serial": round(itf.get(kk, 0) / (1e-3 * v[0] / (v[1] * v[2])) / 1e9 / HBM_PEAK_GBS, 5)}
-                                         for kk, v in sorted(serial_k.items(), key=lambda kv: -kv[1][0])}
+            # per kernel, no-overlap pass.  frac_8d_serial credits SURVEY 8(d)'s bytes; an in-place kernel moves fewer (it only writes
+            # the pixels it changes), so its credited fraction can exceed what the memory system saw: frac_traffic_serial prices the
+            # bytes of the committed PMC passes instead, and `credited_over_traffic` flags the rows where the credit is the larger one
+            rbk = {}
+            for kk, v in sorted(serial_k.items(), key=lambda kv: -kv[1][0]):
+                sec = 1e-3 * v[0] / (v[1] * v[2])
+                ent = {"serial_us_per_pair": round(1e6 * sec, 3), "frac_8d_serial": round(alg.get(kk, 0) / sec / 1e9 / HBM_PEAK_GBS, 5),
+                       "frac_interface_serial": round(itf.get(kk, 0) / sec / 1e9 / HBM_PEAK_GBS, 5)}
+                if kk in pmc_b:
+                    ent["frac_traffic_serial"] = round(pmc_b[kk] / sec / 1e9 / HBM_PEAK_GBS, 5)
+                    if alg.get(kk, 0) > pmc_b[kk]:
+                        ent["credited_over_traffic"] = round(alg[kk] / pmc_b[kk], 2)
+                        ent["note"] = "8(d) credits %d B per pair, the PMC passes count %d B: works in place / on bit masks, not a utilisation figure" % (alg[kk], pmc_b[kk])
+                rbk[kk] = ent
+            out["roofline_by_kernel"] = rbk
             out["serial_kernel_us_per_pair_sum"] = round(sum(1e3 * v[0] / (v[1] * v[2]) for v in serial_k.values()), 3)
-            out["kernel_ms_per_pair_timed_region"] = {k: round(v[0] / (B * args.steps), 5) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])}
+            out["kernel_ms_per_pair_timed_region"] = {k: round(v[0] / (B * steps), 5) for k, v in sorted(ktimes.items(), key=lambda kv: -kv[1][0])}
         if world == 1 and args.cpu_sample > 0:
-            one, many = cpu_baseline(args.cpu_sample if W < 2000 else min(args.cpu_sample, 4), synth, args.subsampling, scale=wscale,
+            one, many = cpu_baseline(args.cpu_sample if W < 2000 else min(args.cpu_sample, 4), synth, args.subsampling, scale=WORKLOADS[args.workload][6],
                                      all_cores_pairs=(4 * usable_cpus() if W < 2000 else 0))
             out["cpu_baseline"] = one
             if many:
                 out["cpu_baseline_all_cores"] = many
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -127,6 +127,10 @@ int sv_process_batch_device(sv_handle *h, const uint8_t *left, const uint8_t *ri
  * returns when every submitted batch is complete.  Buffers must stay valid until then.  sv_process_batch_device == submit + wait. */
 int sv_submit_batch_device(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status);
 int sv_wait(sv_handle *h);
+/* Returns when the n oldest batches submitted since the last sv_wait are complete; later ones keep running (batches complete in
+ * submission order).  For consumers that take finished batches while the engine computes the next - e.g. a chunked gather of the
+ * maps on one rank that overlaps the other chunks' kernels.  Not to be called concurrently with sv_wait. */
+int sv_wait_batches(sv_handle *h, int n);
 
 /* Same call with HOST memory in and out - the form of the reference's seam, which takes host pointers (elas.h:162, call site
  * stereo_vision.cpp:313).  The batch streams through the pipeline chunk by chunk: the images of chunk k+1 go up and the maps of

@@ -1369,6 +1369,33 @@ int wait_jobs(sv_handle *h) {
     return h->failed ? SV_ERR_HIP : SV_OK;
 }
 
+// Waits until the `n` oldest batches submitted since the last sv_wait are complete (their maps visible to every stream of the
+// device / in the caller's host memory).  Later batches keep flowing through the pipeline meanwhile: a consumer - e.g. the
+// chunked gather of bench.py - takes finished batches while the engine computes the next ones.  Batches complete in
+// submission order.  Must not run concurrently with sv_wait (which releases the batch records).
+int wait_first_jobs(sv_handle *h, int n) {
+    if (!h) return SV_ERR_ARG;
+    if (n <= 0) return SV_OK;
+    bool device_job = false;
+    {
+        std::unique_lock<std::mutex> lk(h->mu);
+        if ((size_t)n > h->live.size()) {
+            h->error = "sv_wait_batches: fewer batches have been submitted since the last sv_wait";
+            return SV_ERR_ARG;
+        }
+        Job *j = h->live[(size_t)n - 1];
+        h->cv.wait(lk, [&] { return (j->host ? j->drained : j->issued2) == j->nchunks; });
+        device_job = !j->host;
+    }
+    if (device_job) {  // every chunk's second phase is enqueued: what is left is the streams' work up to here
+        (void)hipSetDevice(h->cfg.device);
+        bool ok = true;
+        for (hipStream_t st : h->sP2) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
+        if (!ok) note_error(h, "stream synchronisation failed");
+    }
+    return h->failed ? SV_ERR_HIP : SV_OK;
+}
+
 // Latency mode: one pair, chunk 1, nothing in flight.  The calling thread issues phase 1, spins on its event, runs the lattice
 // filter and the left triangulation itself (the right one goes to a pool thread meanwhile), issues phase 2 and waits for it:
 // no hand-over between the three control threads, which costs more than the kernels of a single pair.
@@ -1672,6 +1699,8 @@ int sv_submit_batch_device(sv_handle *h, const uint8_t *left, const uint8_t *rig
 }
 
 int sv_wait(sv_handle *h) { return wait_jobs(h); }
+
+int sv_wait_batches(sv_handle *h, int n) { return wait_first_jobs(h, n); }
 
 int sv_query(const sv_handle *h, int what) {
     if (!h) return SV_ERR_ARG;

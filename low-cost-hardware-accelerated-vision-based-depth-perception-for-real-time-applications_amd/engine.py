@@ -93,6 +93,8 @@ def lib():
     L.sv_last_error.restype = ctypes.c_char_p
     L.sv_wait.argtypes = [ctypes.c_void_p]
     L.sv_wait.restype = ctypes.c_int
+    L.sv_wait_batches.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sv_wait_batches.restype = ctypes.c_int
     L.sv_host_alloc.argtypes = [ctypes.c_size_t]
     L.sv_host_alloc.restype = ctypes.c_void_p
     L.sv_host_free.argtypes = [ctypes.c_void_p]
@@ -213,6 +215,10 @@ class StereoEngine:
 
     def wait(self):
         self._check(lib().sv_wait(self._h))
+
+    def wait_batches(self, n):
+        """Returns when the n oldest batches submitted since the last wait() are complete; later ones keep running."""
+        self._check(lib().sv_wait_batches(self._h, int(n)))
 
     # ---- host path (numpy in / out, PCIe inclusive): streamed through the pipeline, no allocation per call
     def _host_args(self, left, right, d1, d2, want_d2):

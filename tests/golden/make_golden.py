@@ -100,6 +100,8 @@ def main():
         dict(name="cones_crop_robotics_sub", image="cones_crop", preset="robotics", disp_max=63, subsampling=1, keep=["support", "wta1", "final1", "final2"]),
         dict(name="synth8_d32_sub", synth=dict(seed=8, H=97, W=203, D=32), preset="driver", disp_max=31, subsampling=1, keep=["support", "wta1", "final1"]),
         dict(name="synth5000_4kstrip_d192", synth=dict(seed=5000, H=512, W=3840, D=192, scale=3), preset="driver", disp_max=191, keep=[]),
+        # BASELINE.json configs[4] at full size (digest only): the pair bench.py's parity gate of the 4K configuration runs
+        dict(name="synth5000_4k_d192", synth=dict(seed=5000, H=2160, W=3840, D=192, scale=3), preset="driver", disp_max=191, keep=[]),
     ]
     digests = {}
     for case in cases:

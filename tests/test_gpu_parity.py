@@ -499,6 +499,41 @@ def test_streamed_submission_equals_synchronous(eng):
         e.close()
 
 
+def test_wait_batches_hands_over_finished_batches_in_order(eng):
+    """sv_wait_batches(n): the n oldest submitted batches are complete (their maps final) while later ones may still run; the
+    consumer of bench.py's chunked gather relies on it.  Device and host-memory batches."""
+    import torch
+    synth = util.pkg("synth")
+    H, W, D, B = 120, 320, 64, 6
+    batches = [synth.make_batch(700 + 20 * i, B, H, W, D) for i in range(4)]
+    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), chunk=4, n_slots=3, n_workers=4)
+    try:
+        ins = [(torch.from_numpy(b[:, 0].copy()).cuda(), torch.from_numpy(b[:, 1].copy()).cuda()) for b in batches]
+        ref = [e.process_device(l, r) for l, r in ins]
+        outs = [(torch.full_like(ref[0][0], -77.0), torch.full_like(ref[0][1], -77.0)) for _ in ins]
+        torch.cuda.synchronize()
+        for (l, r), (o1, o2) in zip(ins, outs):
+            e.submit_device(l, r, o1, o2)
+        for i in range(len(ins)):
+            e.wait_batches(i + 1)
+            torch.cuda.synchronize()
+            assert torch.equal(ref[i][0], outs[i][0]) and torch.equal(ref[i][1], outs[i][1]), i
+        with pytest.raises(eng.StereoError):
+            e.wait_batches(len(ins) + 1)  # more than were submitted since the last wait()
+        e.wait()
+        # host-memory batches: complete = the maps are in the caller's arrays
+        h_out = [(np.full((B, H, W), -77.0, np.float32), np.full((B, H, W), -77.0, np.float32)) for _ in batches]
+        keep = [(np.ascontiguousarray(b[:, 0]), np.ascontiguousarray(b[:, 1])) for b in batches]
+        for (l, r), (o1, o2) in zip(keep, h_out):
+            e.submit_host(l, r, o1, o2)
+        for i in range(len(batches)):
+            e.wait_batches(i + 1)
+            assert np.array_equal(h_out[i][0], ref[i][0].cpu().numpy()) and np.array_equal(h_out[i][1], ref[i][1].cpu().numpy()), i
+        e.wait()
+    finally:
+        e.close()
+
+
 def test_kernel_timing_selection(eng):
     """sv_kernel_timing_select: only the named kernels get HIP events; unknown names are refused."""
     import torch

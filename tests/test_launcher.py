@@ -1,0 +1,55 @@
+"""CPU: `python bench.py --gpus N` without an outside launcher - the parent starts N fresh ranks itself (launcher.py, standard
+library only, never touches the GPU), relays rank 0's line and propagates failures; and the chunked gather the ranks run
+(parallel.ChunkedGather) fills one preallocated [world, B, H, W] buffer on rank 0 in rank order.  gloo, world size 2 and 3."""
+import io
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+import util
+
+WORKER = os.path.join(util.HERE, "mp_gather_worker.py")
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_launcher_runs_ranks_and_relays_rank0(nranks):
+    launcher = util.pkg("launcher")
+    out = io.StringIO()
+    rc = launcher.spawn_ranks([sys.executable, WORKER, "gather"], nranks, out=out, timeout=240)
+    assert rc == 0
+    lines = [ln for ln in out.getvalue().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines  # rank 0's line only
+    r = json.loads(lines[0])
+    assert r == {"ok": True, "world": nranks, "nchunks": 3, "root_shape": [nranks, 7, 5, 9], "tmax": float(nranks), "launcher": "self", "local_world_size": str(nranks)}
+
+
+def test_launcher_propagates_a_failing_rank_and_stops_the_others():
+    launcher = util.pkg("launcher")
+    t0 = time.time()
+    rc = launcher.spawn_ranks([sys.executable, WORKER, "fail"], 2, out=io.StringIO(), timeout=240)
+    assert rc == 7
+    assert time.time() - t0 < 120  # rank 0 was stopped, not waited for until the rendezvous timed out
+
+
+def test_launcher_module_is_stdlib_only():
+    """The parent of a multi-GPU run must not initialise HIP: the launcher imports neither torch nor the engine."""
+    code = "import sys, importlib; importlib.import_module(%r + '.launcher'); print(int('torch' in sys.modules), int('numpy' in sys.modules))" % util.PKG
+    out = subprocess.check_output([sys.executable, "-c", code], cwd=util.ROOT, text=True)
+    assert out.split() == ["0", "0"]
+
+
+def test_bench_without_launcher_starts_its_own_ranks():
+    """No GPU here: both children stop at bench.py's 'needs a GPU' assertion - the point is that `--gpus 2` with WORLD_SIZE
+    unset spawns ranks (each reports its own failure) and the parent returns non-zero instead of asserting on WORLD_SIZE."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: covered by tests/test_multiprocess_gpu.py::test_bench_launches_its_own_ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert p.stderr.count("bench.py needs a GPU") >= 1 and "WORLD_SIZE=" not in p.stderr
+    assert p.stdout.strip() == ""

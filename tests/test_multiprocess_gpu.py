@@ -68,3 +68,24 @@ def test_two_ranks_drive_the_engine(oracle, tmp_path):
 
     assert alone == expected(usable)
     assert int(r0["host_threads"]) == int(r1["host_threads"]) == expected(usable // 2)
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset): the parent spawns two fresh ranks, which share this
+    box's GPU (BENCH_BACKEND=gloo: collectives on CPU tensors), pass the parity gate, run the timed region and the chunked,
+    overlapped gather; rank 0's JSON line is the parent's only stdout."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT")}
+    env["BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--min-seconds", "0.5", "--batch", "128", "--no-host",
+           "--no-latency", "--no-real", "--cpu-sample", "0", "--no-configs", "--gather"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["launcher"] == "self" and r["collective_backend"] == "gloo" and r["parity_gate"] == "pass"
+    assert len(r["per_rank_pairs_per_s"]) == 2 and r["value"] > 0 and r["steps"] >= 3
+    g = r["with_gather"]
+    assert g["root_block0_equals_own_maps"] is True and g["chunk_pairs"] == 64 and g["pairs_per_s"] > 0
+    assert r["roofline"]["kernel"] and "cpu_baseline" not in r  # the CPU baseline is a rank-0, N=1 measurement
