@@ -484,15 +484,21 @@ void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
 //     when a lattice point is visited, the neighbours LATER in scan order are still unmodified, so
 //        c_late  = consistent neighbours later-or-equal in scan order (exact at visit time)
 //        c_all   = consistent neighbours in the original lattice (upper bound at visit time)
-//     c_late >= min_support -> certainly kept; c_all < min_support -> certainly dropped; only the rest ("uncertain") depend
-//     on the fate of earlier points: a few parallel refinement rounds settle most of them, what remains is resolved one after
-//     the other, in scan order, by one wavefront that counts the <= 60 earlier neighbours with a ballot.  The redundancy
-//     passes only couple points of one column / one row: one lane walks one line.
-//     Four launches, all state in global memory (L2-resident: 11 bytes per lattice point), no size limit:
-//       k_filter_classify   grid-wide, one thread per lattice point (the 121-neighbour counts: 60 % of the old one-workgroup kernel)
-//       k_filter_resolve    one workgroup per pair: refinement rounds + sequential rest; writes the lattice without the dropped points
-//       k_filter_vertical   grid-wide, one lane per lattice column
-//       k_filter_collect    one workgroup per pair: horizontal pass (one lane per lattice row), ordered compaction, corner points
+//     c_late >= min_support -> certainly kept; c_all < min_support -> certainly dropped; only the rest ("uncertain": 1-5 % of
+//     the valid points of a real pair, a few hundred of a 4K lattice's 330 000) depend on the fate of earlier points: a few
+//     parallel refinement rounds settle most of them, what remains is resolved one after the other, in scan order, by one
+//     wavefront that counts the <= 60 earlier neighbours with a ballot.
+//     The redundancy passes only couple points of one column / one row, and along a line the scan is a recurrence over the
+//     kept-flags of the previous five points: everything that does not depend on the walk (is the point valid, does it have a
+//     match among the five ORIGINAL later neighbours, which of the five earlier neighbours match) is computed for all points
+//     in parallel into one byte per point; the walk itself is five dependent instructions per point on LDS bytes.
+//     Five launches, every one of them grid-wide except the (tiny) resolve step; state in global memory, no size limit:
+//       k_filter_classify    one thread per lattice point: the 121-neighbour counts; ordered list of each block's uncertain points
+//       k_filter_resolve     one workgroup per pair, work ~ number of uncertain points: refinement rounds + sequential rest
+//       k_filter_vertical    one workgroup per strip of lattice columns: flag bytes in parallel, one lane per column walks them
+//       k_filter_horizontal  one workgroup per strip of lattice rows: the same along the rows
+//       k_filter_collect     one workgroup per 1024 lattice points: ordered compaction with a decoupled look-back over the
+//                            blocks of a pair, corner points by 64-bit atomic minima, finished by the pair's last block
 //     Lattice layout: transposed, T[u*Hc + v] (scan order == index order).
 // ------------------------------------------------------------------------------------------------------------
 #define FST_NONE 0
@@ -519,42 +525,19 @@ __device__ __forceinline__ int block_exclusive_scan(int val, int *s_scan, int *t
     return excl;
 }
 
-// order-preserving compaction of the lattice indices that satisfy `pred` (each thread owns a contiguous index range)
-template <class Pred>
-__device__ __forceinline__ int compact_indices(int lat, uint32_t *list, int *s_scan, Pred pred) {
-    const int tid = threadIdx.x;
-    const int per = (lat + FLT_THREADS - 1) / FLT_THREADS;
-    const int i_lo = min(tid * per, lat), i_hi = min(i_lo + per, lat);
-    int mine = 0;
-    for (int i = i_lo; i < i_hi; i++) mine += pred(i) ? 1 : 0;
-    int total;
-    int pos = block_exclusive_scan(mine, s_scan, &total);
-    for (int i = i_lo; i < i_hi; i++)
-        if (pred(i)) list[pos++] = (uint32_t)i;
-    __threadfence_block();
-    __syncthreads();
-    return total;
-}
-
-// one step of a redundancy walk: `w[0..10]` = values at positions p-5..p+5 of the line (out-of-line slots hold -1)
-__device__ __forceinline__ bool redundant_here(const int w[11]) {
-    const int dd = w[5];
-    if (dd < 0) return false;
-    int lo = 0, hi = 0;
-#pragma unroll
-    for (int j = 1; j <= 5; j++) {
-        lo |= (w[5 - j] >= 0) & (abs(dd - w[5 - j]) <= 1);
-        hi |= (w[5 + j] >= 0) & (abs(dd - w[5 + j]) <= 1);
-    }
-    return (lo & hi) != 0;
-}
+// look-back / completion words of k_filter_collect, per pair: [0, nb2) block status, then done counter, point count, 4 corner keys
+__host__ __device__ inline int filter_collect_blocks(int lat) { return (lat + FLT_THREADS - 1) / FLT_THREADS; }
+__host__ __device__ inline int filter_stat_words(int lat) { return ((filter_collect_blocks(lat) + 2 + 1) & ~1) + 8; }  // the keys are 8-byte aligned
 
 // ---- (1) classification (elas.cpp:152-176), one thread per lattice point.  A block of 256 consecutive indices needs the
 // contiguous index span [first - 5*Hc - 5, last + 5*Hc + 5] of the transposed lattice: staged in LDS once, then the 11x11 window
-// (win <= 5, fully unrolled: independent reads, all in flight together) comes from there.
+// (win <= 5, fully unrolled: independent reads, all in flight together) comes from there.  The block's uncertain points go,
+// in index order, to its own segment useg[first ...] (count in ucnt): the resolve step never has to look at the lattice.
 #define FCL_THREADS 256
-__global__ __launch_bounds__(FCL_THREADS) void k_filter_classify(Dims d, int win, int thr, int need, const int16_t *__restrict__ dcan, uint8_t *__restrict__ fst) {
+__global__ __launch_bounds__(FCL_THREADS) void k_filter_classify(Dims d, int win, int thr, int need, const int16_t *__restrict__ dcan, uint8_t *__restrict__ fst,
+                                                                 uint32_t *__restrict__ useg, int32_t *__restrict__ ucnt) {
     extern __shared__ int16_t fcl_lds[];
+    __shared__ int s_wcnt[FCL_THREADS / 64];
     const int pair = blockIdx.y, Hc = d.Hc, Wc = d.Wc, lat = Wc * Hc;
     const int16_t *G = dcan + (size_t)pair * lat;
     const int first = blockIdx.x * FCL_THREADS, margin = 5 * Hc + 5;
@@ -565,9 +548,8 @@ __global__ __launch_bounds__(FCL_THREADS) void k_filter_classify(Dims d, int win
     }
     __syncthreads();
     const int idx = first + threadIdx.x;
-    if (idx >= lat) return;
     const int16_t *T = fcl_lds - s0;  // T[g] for g inside the span
-    const int dd = T[idx];
+    const int dd = idx < lat ? (int)T[idx] : -1;
     uint8_t state = FST_NONE;
     if (dd >= 0) {
         const int u = idx / Hc, v = idx - u * Hc;
@@ -591,26 +573,56 @@ __global__ __launch_bounds__(FCL_THREADS) void k_filter_classify(Dims d, int win
         }
         state = (uint8_t)(c_late >= need ? FST_KEEP : (c_late + c_early < need) ? FST_DROP : (FST_UNC | (c_late << 2)));
     }
-    fst[(size_t)pair * lat + idx] = state;
+    if (idx < lat) fst[(size_t)pair * lat + idx] = state;
+    const bool unc = (state & 3) == FST_UNC;
+    const unsigned long long m = __ballot(unc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_wcnt[wave] = (int)__popcll(m);
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < FCL_THREADS / 64; w++) {
+        base += w < wave ? s_wcnt[w] : 0;
+        total += s_wcnt[w];
+    }
+    if (unc) useg[(size_t)pair * lat + first + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+    if (threadIdx.x == 0) ucnt[(size_t)pair * gridDim.x + blockIdx.x] = total;
 }
 
-// ---- (2) the uncertain points: parallel refinement rounds, then the rest in scan order by one wavefront; output = the lattice
-// with the inconsistent points removed.  One workgroup per pair; T / st / list live in global memory (L2).
-__global__ __launch_bounds__(FLT_THREADS) void k_filter_resolve(Dims d, int win, int thr, int need, const int16_t *__restrict__ dcan, uint8_t *fst, uint32_t *flist,
-                                                                int16_t *__restrict__ latA) {
+// ---- (2) the uncertain points: parallel refinement rounds, then the rest in scan order by one wavefront; the states it
+// leaves behind are final (KEEP / DROP).  One workgroup per pair; its work is proportional to the number of classify blocks
+// and of uncertain points, not to the lattice.  Also clears the pair's look-back words for k_filter_collect.
+__global__ __launch_bounds__(FLT_THREADS) void k_filter_resolve(Dims d, int win, int thr, int need, const int16_t *__restrict__ dcan, uint8_t *fst, uint32_t *useg,
+                                                                const int32_t *__restrict__ ucnt, int nb, uint32_t *ulist, uint32_t *stat, int nstat) {
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int Wc = d.Wc, Hc = d.Hc, lat = Wc * Hc;
+    const int Hc = d.Hc, lat = d.Wc * Hc;
     const int16_t *T = dcan + (size_t)pair * lat;
     uint8_t *st = fst + (size_t)pair * lat;
-    uint32_t *list = flist + (size_t)pair * lat;
-    int16_t *A = latA + (size_t)pair * lat;
+    uint32_t *seg = useg + (size_t)pair * lat;
+    uint32_t *list = ulist + (size_t)pair * lat;
     __shared__ int s_scan[FLT_THREADS];
-    (void)Wc;
-    // refinement rounds over the compacted uncertain points, fully parallel: earlier neighbours that are certainly kept count
+    {  // look-back state of the collect step: block status words, done counter, point count = 0; corner keys = "none"
+        uint32_t *sw = stat + (size_t)pair * nstat;
+        for (int i = tid; i < nstat; i += FLT_THREADS) sw[i] = i < nstat - 8 ? 0u : 0xFFFFFFFFu;
+    }
+    // ordered list of the uncertain points from the classify blocks' segments
+    const int per = (nb + FLT_THREADS - 1) / FLT_THREADS;
+    const int b_lo = min(tid * per, nb), b_hi = min(b_lo + per, nb);
+    const int32_t *cnt = ucnt + (size_t)pair * nb;
+    int mine = 0;
+    for (int b = b_lo; b < b_hi; b++) mine += cnt[b];
+    int n_unc;
+    int pos = block_exclusive_scan(mine, s_scan, &n_unc);
+    for (int b = b_lo; b < b_hi; b++) {
+        const int c = cnt[b];
+        for (int r = 0; r < c; r++) list[pos++] = seg[(size_t)b * FCL_THREADS + r];
+    }
+    __threadfence_block();
+    __syncthreads();
+    // refinement rounds over the uncertain points, fully parallel: earlier neighbours that are certainly kept count
     // for sure, earlier neighbours that are certainly dropped never count.  (A round only reads states of EARLIER points and
     // only turns UNC into KEEP/DROP; both decisions stay valid whatever the remaining UNC points become, so concurrent
     // updates are benign.)
-    int n_unc = compact_indices(lat, list, s_scan, [&](int i) { return (st[i] & 3) == FST_UNC; });
     for (int round = 0; round < 3 && n_unc > 0; round++) {
         for (int q = tid; q < n_unc; q += FLT_THREADS) {
             const int idx = (int)list[q];
@@ -643,13 +655,25 @@ __global__ __launch_bounds__(FLT_THREADS) void k_filter_resolve(Dims d, int win,
         __threadfence_block();
         __syncthreads();
     }
-    // what is still uncertain is resolved in scan order by one wavefront: lanes = the earlier neighbours
-    // (win*(2win+1) + win <= 60 for win <= 5)
-    if (n_unc > 0) n_unc = compact_indices(lat, list, s_scan, [&](int i) { return (st[i] & 3) == FST_UNC; });
+    // what is still uncertain, in order, into the (now free) segment buffer
+    uint32_t *rest = seg;
+    int n_rest = 0;
+    if (n_unc > 0) {
+        const int per_q = (n_unc + FLT_THREADS - 1) / FLT_THREADS;
+        const int q_lo = min(tid * per_q, n_unc), q_hi = min(q_lo + per_q, n_unc);
+        int left = 0;
+        for (int q = q_lo; q < q_hi; q++) left += (st[list[q]] & 3) == FST_UNC ? 1 : 0;
+        int p2 = block_exclusive_scan(left, s_scan, &n_rest);
+        for (int q = q_lo; q < q_hi; q++)
+            if ((st[list[q]] & 3) == FST_UNC) rest[p2++] = list[q];
+        __threadfence_block();
+        __syncthreads();
+    }
+    // ... resolved in scan order by one wavefront: lanes = the earlier neighbours (win*(2win+1) + win <= 60 for win <= 5)
     if (tid < 64) {
         const int rowlen = 2 * win + 1, n_early = win * rowlen + win;
-        for (int i = 0; i < n_unc; i++) {
-            const int idx = (int)list[i];
+        for (int i = 0; i < n_rest; i++) {
+            const int idx = (int)rest[i];
             const int u = idx / Hc, v = idx - u * Hc;
             const int dd = T[idx], c_late = st[idx] >> 2;  // (its own entry is only written below)
             bool ok = false;
@@ -668,149 +692,250 @@ __global__ __launch_bounds__(FLT_THREADS) void k_filter_resolve(Dims d, int win,
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
     }
-    __threadfence_block();
-    __syncthreads();
-    for (int i = tid; i < lat; i += FLT_THREADS) A[i] = (st[i] & 3) == FST_DROP ? (int16_t)-1 : T[i];
 }
 
-// ---- (3) redundancy pass along the columns (elas.cpp:178-233 with vertical = true; max_dist 5, threshold 1).  Only points of
-// one line interact, so one lane walks one line; it keeps the 11 values around the current position in registers (positions
-// behind reflect its own earlier invalidations) and reads one new value per step.  Out of place: the loads never depend on the
-// walk, so the compiler can issue them ahead.
-__global__ __launch_bounds__(64) void k_filter_vertical(Dims d, const int16_t *__restrict__ latA, int16_t *__restrict__ latB) {
-    const int pair = blockIdx.y, u = blockIdx.x * 64 + threadIdx.x;
-    const int Wc = d.Wc, Hc = d.Hc;
-    if (u >= Wc) return;
-    const int16_t *col = latA + (size_t)pair * Wc * Hc + (size_t)u * Hc;
-    int16_t *out = latB + (size_t)pair * Wc * Hc + (size_t)u * Hc;
-    int w[11];
+// ---- (3) / (4) redundancy passes (elas.cpp:178-233; max_dist 5, threshold 1).  Only points of one line interact, and the scan
+// along a line is a recurrence over the kept-flags of the previous five points:
+//     kept(p) = valid(p) && !( hi(p) && (S & m(p)) != 0 ),   S = kept-flags of p-1..p-5 (bit j-1 = point p-j)
+// with hi(p) = "one of the five LATER points (still unmodified when p is visited) matches" and m(p) bit j-1 = "point p-j matches"
+// (a match: valid and |difference| <= 1) - both from the pass's input, i.e. computable for every point independently.
+// flag byte: bit 0 valid, bit 1 hi, bits 2-6 m.  `a` = the eleven values p-5 .. p+5 (out-of-line slots hold -1).
+__device__ __forceinline__ uint32_t redundancy_flags(const int a[11]) {
+    const int dd = a[5];
+    if (dd < 0) return 0u;
+    uint32_t hi = 0u, m = 0u;
 #pragma unroll
-    for (int j = 0; j < 11; j++) w[j] = (j >= 5 && j - 5 < Hc) ? (int)col[j - 5] : -1;
-#pragma unroll 8
-    for (int v = 0; v < Hc; v++) {
-        const int nxt = v + 6 < Hc ? (int)col[v + 6] : -1;
-        if (redundant_here(w)) w[5] = -1;
-        out[v] = (int16_t)w[5];
-#pragma unroll
-        for (int j = 0; j < 10; j++) w[j] = w[j + 1];
-        w[10] = nxt;
+    for (int j = 1; j <= 5; j++) {
+        m |= (uint32_t)((a[5 - j] >= 0) & (abs(dd - a[5 - j]) <= 1)) << (j - 1);
+        hi |= (uint32_t)((a[5 + j] >= 0) & (abs(dd - a[5 + j]) <= 1));
+    }
+    return 1u | (hi << 1) | (m << 2);
+}
+
+// walks `n` flag bytes `stride` apart; leaves 1 / 0 (kept / not) in them
+__device__ __forceinline__ void redundancy_walk(uint8_t *f, int n, int stride) {
+    uint32_t S = 0u;
+    for (int p = 0; p < n; p++) {
+        const uint32_t x = f[(size_t)p * stride];
+        const uint32_t kept = (x & 1u) & ~(((x >> 1) & 1u) & (uint32_t)((S & (x >> 2)) != 0u));
+        f[(size_t)p * stride] = (uint8_t)kept;
+        S = ((S << 1) | kept) & 31u;
     }
 }
 
-// ---- (4) redundancy pass along the rows, collection in scan order (elas.cpp:424-428; lattice row / column 0 excluded), corner
-// points (elas.cpp:235-264).  One workgroup per pair.
-__global__ __launch_bounds__(FLT_THREADS) void k_filter_collect(KParams k, const int16_t *__restrict__ latB, int16_t *latC, uint32_t *flist, int32_t *__restrict__ fsup,
+#define FRD_THREADS 256
+// vertical: a strip of `SW` lattice columns (a contiguous index range).  LDS: values [SW][Hc + 10] int16, flags [Hc][SW].
+// Input = the raw lattice minus the points the inconsistency pass dropped.
+__global__ __launch_bounds__(FRD_THREADS) void k_filter_vertical(Dims d, int SW, const int16_t *__restrict__ dcan, const uint8_t *__restrict__ fst, int16_t *__restrict__ latB) {
+    extern __shared__ int16_t frd_lds[];
+    const int pair = blockIdx.y, Wc = d.Wc, Hc = d.Hc, P = Hc + 10;
+    const int u0 = blockIdx.x * SW, nu = min(SW, Wc - u0);
+    int16_t *val = frd_lds;
+    uint8_t *fl = reinterpret_cast<uint8_t *>(val + (size_t)SW * P);
+    const size_t g0 = (size_t)pair * Wc * Hc + (size_t)u0 * Hc;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < nu; c += FRD_THREADS / 64) {
+        for (int v = lane; v < Hc; v += 64) {
+            const size_t g = g0 + (size_t)c * Hc + v;
+            val[c * P + 5 + v] = (fst[g] & 3) == FST_DROP ? (int16_t)-1 : dcan[g];
+        }
+        if (lane < 10) val[c * P + (lane < 5 ? lane : Hc + lane)] = (int16_t)-1;
+    }
+    __syncthreads();
+    for (int c = wave; c < nu; c += FRD_THREADS / 64)
+        for (int v = lane; v < Hc; v += 64) {
+            int a[11];
+#pragma unroll
+            for (int j = 0; j < 11; j++) a[j] = val[c * P + v + j];
+            fl[v * SW + c] = (uint8_t)redundancy_flags(a);
+        }
+    __syncthreads();
+    if ((int)threadIdx.x < nu) redundancy_walk(fl + threadIdx.x, Hc, SW);
+    __syncthreads();
+    for (int c = wave; c < nu; c += FRD_THREADS / 64)
+        for (int v = lane; v < Hc; v += 64) latB[g0 + (size_t)c * Hc + v] = fl[v * SW + c] ? val[c * P + 5 + v] : (int16_t)-1;
+}
+
+// horizontal: a strip of `SH` lattice rows (SH a power of two <= 64).  LDS: values [Wc + 10][SH] int16, flags [Wc][SH].
+__global__ __launch_bounds__(FRD_THREADS) void k_filter_horizontal(Dims d, int SH, const int16_t *__restrict__ latB, int16_t *__restrict__ latC) {
+    extern __shared__ int16_t frd_lds[];
+    const int pair = blockIdx.y, Wc = d.Wc, Hc = d.Hc;
+    const int v0 = blockIdx.x * SH, nv = min(SH, Hc - v0);
+    int16_t *val = frd_lds;
+    uint8_t *fl = reinterpret_cast<uint8_t *>(val + (size_t)(Wc + 10) * SH);
+    const size_t g0 = (size_t)pair * Wc * Hc + v0;
+    const int r = threadIdx.x & (SH - 1), ug = threadIdx.x / SH, ustep = FRD_THREADS / SH;
+    for (int u = ug - 5; u < Wc + 5; u += ustep) val[(u + 5) * SH + r] = (u >= 0 && u < Wc && r < nv) ? latB[g0 + (size_t)u * Hc + r] : (int16_t)-1;
+    __syncthreads();
+    for (int u = ug; u < Wc; u += ustep) {
+        int a[11];
+#pragma unroll
+        for (int j = 0; j < 11; j++) a[j] = val[(u + j) * SH + r];
+        fl[u * SH + r] = (uint8_t)redundancy_flags(a);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nv) redundancy_walk(fl + threadIdx.x, Wc, SH);
+    __syncthreads();
+    if (r < nv)
+        for (int u = ug; u < Wc; u += ustep) latC[g0 + (size_t)u * Hc + r] = fl[u * SH + r] ? val[(u + 5) * SH + r] : (int16_t)-1;
+}
+
+// ---- (5) collection in scan order (elas.cpp:424-428; lattice row / column 0 excluded) and corner points (elas.cpp:235-264).
+// One workgroup per FLT_THREADS consecutive lattice indices; the blocks of a pair are chained by a decoupled look-back (status
+// word = flag << 30 | count: 1 = this block's count, 2 = inclusive prefix; lower-numbered workgroups are dispatched first, so
+// the predecessors a block waits for are running or done).  Corner points: every block offers its nearest point per corner as
+// a 64-bit key (distance^2, list position, disparity) to an atomic minimum - "first minimum in list order" is the minimum of
+// (distance, position) - and the pair's last block to finish appends the six corner points and publishes the count.
+#define FST_AGG 1u
+#define FST_INC 2u
+__global__ __launch_bounds__(FLT_THREADS) void k_filter_collect(KParams k, const int16_t *__restrict__ latC, uint32_t *stat, int nstat, int32_t *__restrict__ fsup,
                                                                 int32_t *__restrict__ fnsup) {
     const Dims &d = k.d;
-    const int pair = blockIdx.x, tid = threadIdx.x;
-    const int Wc = d.Wc, Hc = d.Hc, lat = Wc * Hc;
-    const int16_t *B = latB + (size_t)pair * lat;
-    int16_t *T = latC + (size_t)pair * lat;
-    uint32_t *list = flist + (size_t)pair * lat;
-    __shared__ int s_scan[FLT_THREADS];
-    __shared__ int s_dist[FLT_THREADS], s_idx[FLT_THREADS];
-    for (int v = tid; v < Hc; v += FLT_THREADS) {  // consecutive lanes = consecutive rows: every step is one coalesced access
-        int w[11];
+    const int pair = blockIdx.y, b = blockIdx.x, nb2 = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Hc = d.Hc, lat = d.Wc * Hc;
+    uint32_t *sw = stat + (size_t)pair * nstat;
+    uint32_t *done = sw + nb2, *npts = sw + nb2 + 1;
+    unsigned long long *ckey = reinterpret_cast<unsigned long long *>(sw + nstat - 8);
+    __shared__ int s_wcnt[FLT_THREADS / 64];
+    __shared__ int s_excl;
+    const int i = b * FLT_THREADS + tid;
+    int dv = -1, u = 0, v = 0;
+    if (i < lat) {
+        u = i / Hc;
+        v = i - u * Hc;
+        dv = latC[(size_t)pair * lat + i];
+    }
+    const bool pred = dv >= 0 && u >= 1 && v >= 1;
+    const unsigned long long m = __ballot(pred);
+    if (lane == 0) s_wcnt[wave] = (int)__popcll(m);
+    __syncthreads();
+    int base = 0, cnt = 0;
 #pragma unroll
-        for (int j = 0; j < 11; j++) w[j] = (j >= 5 && j - 5 < Wc) ? (int)B[(j - 5) * Hc + v] : -1;
-#pragma unroll 8
-        for (int u = 0; u < Wc; u++) {
-            const int nxt = u + 6 < Wc ? (int)B[(u + 6) * Hc + v] : -1;
-            if (redundant_here(w)) w[5] = -1;
-            T[u * Hc + v] = (int16_t)w[5];
+    for (int w = 0; w < FLT_THREADS / 64; w++) {
+        base += w < wave ? s_wcnt[w] : 0;
+        cnt += s_wcnt[w];
+    }
+    if (wave == 0) {  // look-back over the predecessors' status words, 64 at a time
+        if (lane == 0) __hip_atomic_store(&sw[b], ((b == 0 ? FST_INC : FST_AGG) << 30) | (uint32_t)cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int excl = 0;
+        for (int top = b - 1; top >= 0; top -= 64) {
+            const int j = top - lane;
+            uint32_t s = FST_INC << 30;  // (lanes before block 0: an inclusive prefix of zero)
+            if (j >= 0) {
+                do {
+                    s = __hip_atomic_load(&sw[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((s >> 30) == 0u);
+            }
+            const unsigned long long inc = __ballot((s >> 30) == FST_INC);
+            const int stop = inc ? (int)__builtin_ctzll(inc) : 63;  // nearest predecessor that already holds an inclusive prefix
+            int add = lane <= stop ? (int)(s & 0x3FFFFFFFu) : 0;
 #pragma unroll
-            for (int j = 0; j < 10; j++) w[j] = w[j + 1];
-            w[10] = nxt;
+            for (int off = 32; off >= 1; off >>= 1) add += __shfl_xor(add, off, 64);
+            excl += add;
+            if (inc) break;
+        }
+        if (lane == 0) {
+            if (b > 0) __hip_atomic_store(&sw[b], (FST_INC << 30) | (uint32_t)(excl + cnt), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
         }
     }
-    __threadfence_block();
     __syncthreads();
-
+    const int q = s_excl + base + (int)__popcll(m & ((1ull << lane) - 1ull));
     int32_t *out = fsup + (size_t)pair * d.max_pts * 3;
-    const int n_main = compact_indices(lat, list, s_scan, [&](int i) { return T[i] >= 0 && i >= Hc && (i % Hc) != 0; });
-    for (int q = tid; q < n_main; q += FLT_THREADS) {
-        const int i = (int)list[q];
-        const int u = i / Hc, v = i - u * Hc;
+    if (pred) {
         out[3 * q] = u * d.step;
         out[3 * q + 1] = v * d.step;
-        out[3 * q + 2] = T[i];
+        out[3 * q + 2] = dv;
     }
-    int n_total = n_main;
-    if (k.add_corners) {  // elas.cpp:235-264: the four image corners take the disparity of the nearest point (first minimum)
+    if (k.add_corners && m) {  // elas.cpp:235-264: the four image corners take the disparity of the nearest point (first minimum)
         const int bu[4] = {0, 0, d.W - 1, d.W - 1}, bv[4] = {0, d.H - 1, 0, d.H - 1};
-        int best[4], bidx[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) best[c] = 10000000, bidx[c] = 0x7FFFFFFF;
-        for (int q = tid; q < n_main; q += FLT_THREADS) {  // ascending q within a thread: strict < keeps the first minimum
-            const int i = (int)list[q];
-            const int pu = (i / Hc) * d.step, pv = (i % Hc) * d.step;
-#pragma unroll
-            for (int c = 0; c < 4; c++) {
-                const int du = bu[c] - pu, dv = bv[c] - pv;
-                const int dist = du * du + dv * dv;
-                if (dist < best[c]) {
-                    best[c] = dist;
-                    bidx[c] = q;
-                }
-            }
-        }
-        int cd[4];
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            s_dist[tid] = best[c];
-            s_idx[tid] = bidx[c];
-            __syncthreads();
-            for (int off = FLT_THREADS / 2; off >= 1; off >>= 1) {
-                if (tid < off) {
-                    const int od = s_dist[tid + off], oi = s_idx[tid + off];
-                    if (od < s_dist[tid] || (od == s_dist[tid] && oi < s_idx[tid])) {
-                        s_dist[tid] = od;
-                        s_idx[tid] = oi;
-                    }
-                }
-                __syncthreads();
+            unsigned long long key = ~0ull;
+            if (pred) {
+                const int du = bu[c] - u * d.step, dw = bv[c] - v * d.step;
+                const int dist = du * du + dw * dw;
+                // (the reference's search starts from best_dist = 10000000, :245: points that far away are never taken)
+                if (dist < 10000000) key = ((unsigned long long)dist << 34) | ((unsigned long long)q << 11) | (unsigned long long)dv;
             }
-            cd[c] = s_dist[0] < 10000000 ? (int)T[list[s_idx[0]]] : 0;
-            __syncthreads();
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const unsigned long long o = __shfl_xor(key, off, 64);
+                key = o < key ? o : key;
+            }
+            if (lane == 0) atomicMin(&ckey[c], key);
         }
-        if (tid == 0) {
-            int q = n_main;
-            for (int c = 0; c < 4; c++) {
-                out[3 * q] = bu[c];
-                out[3 * q + 1] = bv[c];
-                out[3 * q + 2] = cd[c];
-                q++;
-            }
-            for (int c = 2; c < 4; c++) {  // the two right-image corners (:258-259)
-                out[3 * q] = bu[c] + cd[c];
-                out[3 * q + 1] = bv[c];
-                out[3 * q + 2] = cd[c];
-                q++;
-            }
-        }
-        n_total = n_main + 6;
     }
-    if (tid == 0) fnsup[pair] = n_total;
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        if (b == nb2 - 1) __hip_atomic_store(npts, (uint32_t)(s_excl + cnt), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const uint32_t prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)prev == nb2 - 1) {  // every block of the pair has written its points and offered its corner candidates
+            __threadfence();
+            const int n_main = (int)__hip_atomic_load(npts, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            int n_total = n_main;
+            if (k.add_corners) {
+                const int bu[4] = {0, 0, d.W - 1, d.W - 1}, bv[4] = {0, d.H - 1, 0, d.H - 1};
+                int cd[4];
+                for (int c = 0; c < 4; c++) {
+                    const unsigned long long key = __hip_atomic_load(&ckey[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cd[c] = key == ~0ull ? 0 : (int)(key & 0x7FFull);
+                }
+                int qq = n_main;
+                for (int c = 0; c < 4; c++) {
+                    out[3 * qq] = bu[c];
+                    out[3 * qq + 1] = bv[c];
+                    out[3 * qq + 2] = cd[c];
+                    qq++;
+                }
+                for (int c = 2; c < 4; c++) {  // the two right-image corners (:258-259)
+                    out[3 * qq] = bu[c] + cd[c];
+                    out[3 * qq + 1] = bv[c];
+                    out[3 * qq + 2] = cd[c];
+                    qq++;
+                }
+                n_total = n_main + 6;
+            }
+            fnsup[pair] = n_total;
+        }
+    }
 }
 
-size_t support_filter_ws_bytes(const KParams &k, int cap) {  // per slot: state bytes, index list, three lattice copies
-    const size_t lat = (size_t)k.d.Wc * k.d.Hc;
-    return (size_t)cap * lat * (1 + 4 + 3 * 2) + 256;
+// strip widths of the redundancy kernels: the widest power of two (<= 64 lines) whose LDS tile stays within 96 KB
+static int filter_strip(int line_len) {
+    int s = 64;
+    while (s > 1 && (size_t)s * (3 * (size_t)line_len + 20) > 96 * 1024) s >>= 1;
+    return s;
+}
+
+size_t support_filter_ws_bytes(const KParams &k, int cap) {  // per slot: segment + ordered list of uncertain points, two lattice copies, state bytes, block counts, look-back words
+    const size_t lat = (size_t)k.d.Wc * k.d.Hc, nb = (lat + FCL_THREADS - 1) / FCL_THREADS;
+    return (size_t)cap * (lat * (4 + 4 + 2 + 2 + 1) + 8 + nb * 4 + (size_t)filter_stat_words((int)lat) * 4) + 256;
 }
 
 void launch_support_filter(const KParams &k, int win, int thr, int need, const SlotDev &s, int n, hipStream_t st) {
     const size_t lat = (size_t)k.d.Wc * k.d.Hc, cap = (size_t)s.cap;
+    const int nb = (int)((lat + FCL_THREADS - 1) / FCL_THREADS), nb2 = filter_collect_blocks((int)lat), nstat = filter_stat_words((int)lat);
     uint8_t *base = static_cast<uint8_t *>(s.flt_ws);
-    uint32_t *flist = reinterpret_cast<uint32_t *>(base);
-    int16_t *latA = reinterpret_cast<int16_t *>(base + cap * lat * 4), *latB = latA + cap * lat, *latC = latB + cap * lat;
+    uint32_t *useg = reinterpret_cast<uint32_t *>(base), *ulist = useg + cap * lat;
+    uint32_t *stat = ulist + cap * lat;                                   // (8-byte aligned: cap * lat * 8 bytes in)
+    int32_t *ucnt = reinterpret_cast<int32_t *>(stat + cap * (size_t)nstat);
+    int16_t *latB = reinterpret_cast<int16_t *>(ucnt + cap * (size_t)nb), *latC = latB + cap * lat;
     uint8_t *fst = reinterpret_cast<uint8_t *>(latC + cap * lat);
     const size_t cl_lds = sizeof(int16_t) * (FCL_THREADS + 2 * (size_t)(5 * k.d.Hc + 5));
-    static std::atomic<size_t> granted[64];
+    const int SW = filter_strip(k.d.Hc), SH = filter_strip(k.d.Wc);
+    const size_t v_lds = (size_t)SW * (3 * (size_t)k.d.Hc + 20), h_lds = (size_t)SH * (3 * (size_t)k.d.Wc + 20);
+    static std::atomic<size_t> granted[64], granted_v[64], granted_h[64];
     ensure_dynamic_lds(k_filter_classify, cl_lds, granted, "support_filter");
-    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_classify, dim3((unsigned)((lat + FCL_THREADS - 1) / FCL_THREADS), n), dim3(FCL_THREADS), cl_lds, st, k.d, win, thr, need, s.dcan, fst);
-    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_resolve, dim3(n), dim3(FLT_THREADS), 0, st, k.d, win, thr, need, s.dcan, fst, flist, latA);
-    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_vertical, dim3((k.d.Wc + 63) / 64, n), dim3(64), 0, st, k.d, latA, latB);
-    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_collect, dim3(n), dim3(FLT_THREADS), 0, st, k, latB, latC, flist, s.fsup, s.fnsup);
+    ensure_dynamic_lds(k_filter_vertical, v_lds, granted_v, "support_filter (vertical)");
+    ensure_dynamic_lds(k_filter_horizontal, h_lds, granted_h, "support_filter (horizontal)");
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_classify, dim3((unsigned)nb, n), dim3(FCL_THREADS), cl_lds, st, k.d, win, thr, need, s.dcan, fst, useg, ucnt);
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_resolve, dim3(n), dim3(FLT_THREADS), 0, st, k.d, win, thr, need, s.dcan, fst, useg, ucnt, nb, ulist, stat, nstat);
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_vertical, dim3((k.d.Wc + SW - 1) / SW, n), dim3(FRD_THREADS), v_lds, st, k.d, SW, s.dcan, fst, latB);
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_horizontal, dim3((k.d.Hc + SH - 1) / SH, n), dim3(FRD_THREADS), h_lds, st, k.d, SH, latB, latC);
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_collect, dim3(nb2, n), dim3(FLT_THREADS), 0, st, k, latC, stat, nstat, s.fsup, s.fnsup);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -79,7 +79,7 @@ def test_bench_launches_its_own_ranks(tmp_path):
     env["BENCH_BACKEND"] = "gloo"
     cmd = [sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--min-seconds", "0.5", "--batch", "128", "--no-host",
            "--no-latency", "--no-real", "--cpu-sample", "0", "--no-configs", "--gather"]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=360)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, p.stdout[-2000:]
