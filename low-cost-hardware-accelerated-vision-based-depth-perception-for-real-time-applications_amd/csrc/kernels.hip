@@ -492,13 +492,15 @@ void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
 //     kept-flags of the previous five points: everything that does not depend on the walk (is the point valid, does it have a
 //     match among the five ORIGINAL later neighbours, which of the five earlier neighbours match) is computed for all points
 //     in parallel into one byte per point; the walk itself is five dependent instructions per point on LDS bytes.
-//     Five launches, every one of them grid-wide except the (tiny) resolve step; state in global memory, no size limit:
+//     Seven small launches, grid-wide except the resolve step (whose work is the few uncertain points); state in global
+//     memory (13 bytes per lattice point), no size limit:
 //       k_filter_classify    one thread per lattice point: the 121-neighbour counts; ordered list of each block's uncertain points
-//       k_filter_resolve     one workgroup per pair, work ~ number of uncertain points: refinement rounds + sequential rest
-//       k_filter_vertical    one workgroup per strip of lattice columns: flag bytes in parallel, one lane per column walks them
-//       k_filter_horizontal  one workgroup per strip of lattice rows: the same along the rows
-//       k_filter_collect     one workgroup per 1024 lattice points: ordered compaction with a decoupled look-back over the
-//                            blocks of a pair, corner points by 64-bit atomic minima, finished by the pair's last block
+//       k_filter_resolve     one workgroup per pair: refinement rounds + sequential rest over the uncertain points only
+//       k_filter_vertical    one workgroup per strip of 16 lattice columns: flag bytes in parallel, one lane per column walks them
+//       k_filter_horizontal  one workgroup per strip of 16 lattice rows: the same along the rows
+//       k_filter_count / k_filter_collect / k_filter_corners
+//                            ordered compaction over blocks of 1024 lattice points (counts, then positions = sum of the
+//                            predecessors' counts), nearest point per image corner as a 64-bit key minimum, corner points
 //     Lattice layout: transposed, T[u*Hc + v] (scan order == index order).
 // ------------------------------------------------------------------------------------------------------------
 #define FST_NONE 0
@@ -506,28 +508,34 @@ void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
 #define FST_DROP 2
 #define FST_UNC 3
 
-#define FLT_THREADS 1024
+#define FLT_THREADS 1024  // lattice points per collect block
+#define RSV_THREADS 256   // threads of the resolve workgroup
 
-__device__ __forceinline__ int block_exclusive_scan(int val, int *s_scan, int *total) {  // FLT_THREADS threads
-    const int tid = threadIdx.x;
-    s_scan[tid] = val;
-    __syncthreads();
+// exclusive prefix sum over the workgroup (NT threads): wavefront scans by shuffles, one barrier pair for the wavefront totals
+template <int NT>
+__device__ __forceinline__ int block_exclusive_scan(int val, int *s_wave, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = val;
 #pragma unroll
-    for (int off = 1; off < FLT_THREADS; off <<= 1) {
-        const int add = tid >= off ? s_scan[tid - off] : 0;
-        __syncthreads();
-        s_scan[tid] += add;
-        __syncthreads();
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        incl += lane >= off ? o : 0;
     }
-    *total = s_scan[FLT_THREADS - 1];
-    const int excl = s_scan[tid] - val;
+    if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    return excl;
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; w++) {
+        const int c = s_wave[w];
+        base += w < wave ? c : 0;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - val;
 }
 
-// look-back / completion words of k_filter_collect, per pair: [0, nb2) block status, then done counter, point count, 4 corner keys
 __host__ __device__ inline int filter_collect_blocks(int lat) { return (lat + FLT_THREADS - 1) / FLT_THREADS; }
-__host__ __device__ inline int filter_stat_words(int lat) { return ((filter_collect_blocks(lat) + 2 + 1) & ~1) + 8; }  // the keys are 8-byte aligned
 
 // ---- (1) classification (elas.cpp:152-176), one thread per lattice point.  A block of 256 consecutive indices needs the
 // contiguous index span [first - 5*Hc - 5, last + 5*Hc + 5] of the transposed lattice: staged in LDS once, then the 11x11 window
@@ -591,28 +599,25 @@ __global__ __launch_bounds__(FCL_THREADS) void k_filter_classify(Dims d, int win
 
 // ---- (2) the uncertain points: parallel refinement rounds, then the rest in scan order by one wavefront; the states it
 // leaves behind are final (KEEP / DROP).  One workgroup per pair; its work is proportional to the number of classify blocks
-// and of uncertain points, not to the lattice.  Also clears the pair's look-back words for k_filter_collect.
-__global__ __launch_bounds__(FLT_THREADS) void k_filter_resolve(Dims d, int win, int thr, int need, const int16_t *__restrict__ dcan, uint8_t *fst, uint32_t *useg,
-                                                                const int32_t *__restrict__ ucnt, int nb, uint32_t *ulist, uint32_t *stat, int nstat) {
+// and of uncertain points, not to the lattice.
+__global__ __launch_bounds__(RSV_THREADS) void k_filter_resolve(Dims d, int win, int thr, int need, const int16_t *__restrict__ dcan, uint8_t *fst, uint32_t *useg,
+                                                                const int32_t *__restrict__ ucnt, int nb, uint32_t *ulist) {
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int Hc = d.Hc, lat = d.Wc * Hc;
     const int16_t *T = dcan + (size_t)pair * lat;
     uint8_t *st = fst + (size_t)pair * lat;
     uint32_t *seg = useg + (size_t)pair * lat;
     uint32_t *list = ulist + (size_t)pair * lat;
-    __shared__ int s_scan[FLT_THREADS];
-    {  // look-back state of the collect step: block status words, done counter, point count = 0; corner keys = "none"
-        uint32_t *sw = stat + (size_t)pair * nstat;
-        for (int i = tid; i < nstat; i += FLT_THREADS) sw[i] = i < nstat - 8 ? 0u : 0xFFFFFFFFu;
-    }
+    __shared__ int s_wave[RSV_THREADS / 64];
     // ordered list of the uncertain points from the classify blocks' segments
-    const int per = (nb + FLT_THREADS - 1) / FLT_THREADS;
+    const int per = (nb + RSV_THREADS - 1) / RSV_THREADS;
     const int b_lo = min(tid * per, nb), b_hi = min(b_lo + per, nb);
     const int32_t *cnt = ucnt + (size_t)pair * nb;
     int mine = 0;
     for (int b = b_lo; b < b_hi; b++) mine += cnt[b];
     int n_unc;
-    int pos = block_exclusive_scan(mine, s_scan, &n_unc);
+    int pos = block_exclusive_scan<RSV_THREADS>(mine, s_wave, &n_unc);
+    if (n_unc == 0) return;
     for (int b = b_lo; b < b_hi; b++) {
         const int c = cnt[b];
         for (int r = 0; r < c; r++) list[pos++] = seg[(size_t)b * FCL_THREADS + r];
@@ -623,8 +628,8 @@ __global__ __launch_bounds__(FLT_THREADS) void k_filter_resolve(Dims d, int win,
     // for sure, earlier neighbours that are certainly dropped never count.  (A round only reads states of EARLIER points and
     // only turns UNC into KEEP/DROP; both decisions stay valid whatever the remaining UNC points become, so concurrent
     // updates are benign.)
-    for (int round = 0; round < 3 && n_unc > 0; round++) {
-        for (int q = tid; q < n_unc; q += FLT_THREADS) {
+    for (int round = 0; round < 3; round++) {
+        for (int q = tid; q < n_unc; q += RSV_THREADS) {
             const int idx = (int)list[q];
             const int s0 = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((s0 & 3) != FST_UNC) continue;
@@ -658,12 +663,12 @@ __global__ __launch_bounds__(FLT_THREADS) void k_filter_resolve(Dims d, int win,
     // what is still uncertain, in order, into the (now free) segment buffer
     uint32_t *rest = seg;
     int n_rest = 0;
-    if (n_unc > 0) {
-        const int per_q = (n_unc + FLT_THREADS - 1) / FLT_THREADS;
+    {
+        const int per_q = (n_unc + RSV_THREADS - 1) / RSV_THREADS;
         const int q_lo = min(tid * per_q, n_unc), q_hi = min(q_lo + per_q, n_unc);
         int left = 0;
         for (int q = q_lo; q < q_hi; q++) left += (st[list[q]] & 3) == FST_UNC ? 1 : 0;
-        int p2 = block_exclusive_scan(left, s_scan, &n_rest);
+        int p2 = block_exclusive_scan<RSV_THREADS>(left, s_wave, &n_rest);
         for (int q = q_lo; q < q_hi; q++)
             if ((st[list[q]] & 3) == FST_UNC) rest[p2++] = list[q];
         __threadfence_block();
@@ -712,26 +717,39 @@ __device__ __forceinline__ uint32_t redundancy_flags(const int a[11]) {
     return 1u | (hi << 1) | (m << 2);
 }
 
-// walks `n` flag bytes `stride` apart; leaves 1 / 0 (kept / not) in them
-__device__ __forceinline__ void redundancy_walk(uint8_t *f, int n, int stride) {
+// Flag bytes of one line are contiguous ([line][LS] with LS = 4 (mod 16): lanes that walk neighbouring lines read different
+// banks).  The walk reads 16 flags at a time - four independent dword reads, nothing in the loop is stored to the flags - and
+// leaves the kept-flags as one 16-bit word per 16 positions in kb[line * KS + p / 16].
+__host__ __device__ inline int filter_line_stride(int n) { return ((n + 15) & ~15) + 4; }
+__host__ __device__ inline int filter_kept_stride(int n) { return ((n + 15) >> 4) | 1; }
+__device__ __forceinline__ void redundancy_walk(const uint8_t *f, int n, uint16_t *kb) {
+    const uint32_t *fw = reinterpret_cast<const uint32_t *>(f);
     uint32_t S = 0u;
-    for (int p = 0; p < n; p++) {
-        const uint32_t x = f[(size_t)p * stride];
-        const uint32_t kept = (x & 1u) & ~(((x >> 1) & 1u) & (uint32_t)((S & (x >> 2)) != 0u));
-        f[(size_t)p * stride] = (uint8_t)kept;
-        S = ((S << 1) | kept) & 31u;
+    for (int p0 = 0; p0 < n; p0 += 16) {  // (positions beyond n: the line's padding holds zero flags)
+        const uint32_t w0 = fw[(p0 >> 2)], w1 = fw[(p0 >> 2) + 1], w2 = fw[(p0 >> 2) + 2], w3 = fw[(p0 >> 2) + 3];
+        uint32_t bits = 0u;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const uint32_t w = j < 4 ? w0 : j < 8 ? w1 : j < 12 ? w2 : w3;
+            const uint32_t x = (w >> (8 * (j & 3))) & 0xFFu;
+            const uint32_t kept = (x & 1u) & ~(((x >> 1) & 1u) & (uint32_t)((S & (x >> 2)) != 0u));
+            bits |= kept << j;
+            S = ((S << 1) | kept) & 31u;
+        }
+        kb[p0 >> 4] = (uint16_t)bits;
     }
 }
 
 #define FRD_THREADS 256
-// vertical: a strip of `SW` lattice columns (a contiguous index range).  LDS: values [SW][Hc + 10] int16, flags [Hc][SW].
-// Input = the raw lattice minus the points the inconsistency pass dropped.
+// vertical: a strip of `SW` lattice columns (a contiguous index range).  LDS: values [SW][Hc + 10] int16, flags [SW][LS], kept
+// words [SW][KS].  Input = the raw lattice minus the points the inconsistency pass dropped.
 __global__ __launch_bounds__(FRD_THREADS) void k_filter_vertical(Dims d, int SW, const int16_t *__restrict__ dcan, const uint8_t *__restrict__ fst, int16_t *__restrict__ latB) {
     extern __shared__ int16_t frd_lds[];
-    const int pair = blockIdx.y, Wc = d.Wc, Hc = d.Hc, P = Hc + 10;
+    const int pair = blockIdx.y, Wc = d.Wc, Hc = d.Hc, P = Hc + 10, LS = filter_line_stride(Hc), KS = filter_kept_stride(Hc);
     const int u0 = blockIdx.x * SW, nu = min(SW, Wc - u0);
     int16_t *val = frd_lds;
-    uint8_t *fl = reinterpret_cast<uint8_t *>(val + (size_t)SW * P);
+    uint16_t *kb = reinterpret_cast<uint16_t *>(val + (size_t)SW * P + ((SW * P) & 1));
+    uint8_t *fl = reinterpret_cast<uint8_t *>(kb + (size_t)SW * KS + ((SW * KS) & 1));
     const size_t g0 = (size_t)pair * Wc * Hc + (size_t)u0 * Hc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = wave; c < nu; c += FRD_THREADS / 64) {
@@ -743,103 +761,110 @@ __global__ __launch_bounds__(FRD_THREADS) void k_filter_vertical(Dims d, int SW,
     }
     __syncthreads();
     for (int c = wave; c < nu; c += FRD_THREADS / 64)
-        for (int v = lane; v < Hc; v += 64) {
-            int a[11];
+        for (int v = lane; v < LS; v += 64) {  // (up to the end of the padded line: zero flags behind the last point)
+            uint32_t f = 0u;
+            if (v < Hc) {
+                int a[11];
 #pragma unroll
-            for (int j = 0; j < 11; j++) a[j] = val[c * P + v + j];
-            fl[v * SW + c] = (uint8_t)redundancy_flags(a);
+                for (int j = 0; j < 11; j++) a[j] = val[c * P + v + j];
+                f = redundancy_flags(a);
+            }
+            fl[c * LS + v] = (uint8_t)f;
         }
     __syncthreads();
-    if ((int)threadIdx.x < nu) redundancy_walk(fl + threadIdx.x, Hc, SW);
+    if ((int)threadIdx.x < nu) redundancy_walk(fl + threadIdx.x * LS, Hc, kb + threadIdx.x * KS);
     __syncthreads();
     for (int c = wave; c < nu; c += FRD_THREADS / 64)
-        for (int v = lane; v < Hc; v += 64) latB[g0 + (size_t)c * Hc + v] = fl[v * SW + c] ? val[c * P + 5 + v] : (int16_t)-1;
+        for (int v = lane; v < Hc; v += 64) latB[g0 + (size_t)c * Hc + v] = ((kb[c * KS + (v >> 4)] >> (v & 15)) & 1) ? val[c * P + 5 + v] : (int16_t)-1;
 }
 
-// horizontal: a strip of `SH` lattice rows (SH a power of two <= 64).  LDS: values [Wc + 10][SH] int16, flags [Wc][SH].
+// horizontal: a strip of `SH` lattice rows (SH a power of two <= 64).  LDS: values [Wc + 10][SH] int16, flags [SH][LS], kept
+// words [SH][KS].
 __global__ __launch_bounds__(FRD_THREADS) void k_filter_horizontal(Dims d, int SH, const int16_t *__restrict__ latB, int16_t *__restrict__ latC) {
     extern __shared__ int16_t frd_lds[];
-    const int pair = blockIdx.y, Wc = d.Wc, Hc = d.Hc;
+    const int pair = blockIdx.y, Wc = d.Wc, Hc = d.Hc, LS = filter_line_stride(Wc), KS = filter_kept_stride(Wc);
     const int v0 = blockIdx.x * SH, nv = min(SH, Hc - v0);
     int16_t *val = frd_lds;
-    uint8_t *fl = reinterpret_cast<uint8_t *>(val + (size_t)(Wc + 10) * SH);
+    uint16_t *kb = reinterpret_cast<uint16_t *>(val + (size_t)(Wc + 10) * SH + (((Wc + 10) * SH) & 1));
+    uint8_t *fl = reinterpret_cast<uint8_t *>(kb + (size_t)SH * KS + ((SH * KS) & 1));
     const size_t g0 = (size_t)pair * Wc * Hc + v0;
     const int r = threadIdx.x & (SH - 1), ug = threadIdx.x / SH, ustep = FRD_THREADS / SH;
     for (int u = ug - 5; u < Wc + 5; u += ustep) val[(u + 5) * SH + r] = (u >= 0 && u < Wc && r < nv) ? latB[g0 + (size_t)u * Hc + r] : (int16_t)-1;
     __syncthreads();
-    for (int u = ug; u < Wc; u += ustep) {
-        int a[11];
+    for (int u = ug; u < LS; u += ustep) {
+        uint32_t f = 0u;
+        if (u < Wc) {
+            int a[11];
 #pragma unroll
-        for (int j = 0; j < 11; j++) a[j] = val[(u + j) * SH + r];
-        fl[u * SH + r] = (uint8_t)redundancy_flags(a);
+            for (int j = 0; j < 11; j++) a[j] = val[(u + j) * SH + r];
+            f = redundancy_flags(a);
+        }
+        fl[r * LS + u] = (uint8_t)f;
     }
     __syncthreads();
-    if ((int)threadIdx.x < nv) redundancy_walk(fl + threadIdx.x, Wc, SH);
+    if ((int)threadIdx.x < nv) redundancy_walk(fl + threadIdx.x * LS, Wc, kb + threadIdx.x * KS);
     __syncthreads();
     if (r < nv)
-        for (int u = ug; u < Wc; u += ustep) latC[g0 + (size_t)u * Hc + r] = fl[u * SH + r] ? val[(u + 5) * SH + r] : (int16_t)-1;
+        for (int u = ug; u < Wc; u += ustep) latC[g0 + (size_t)u * Hc + r] = ((kb[r * KS + (u >> 4)] >> (u & 15)) & 1) ? val[(u + 5) * SH + r] : (int16_t)-1;
 }
 
-// ---- (5) collection in scan order (elas.cpp:424-428; lattice row / column 0 excluded) and corner points (elas.cpp:235-264).
-// One workgroup per FLT_THREADS consecutive lattice indices; the blocks of a pair are chained by a decoupled look-back (status
-// word = flag << 30 | count: 1 = this block's count, 2 = inclusive prefix; lower-numbered workgroups are dispatched first, so
-// the predecessors a block waits for are running or done).  Corner points: every block offers its nearest point per corner as
-// a 64-bit key (distance^2, list position, disparity) to an atomic minimum - "first minimum in list order" is the minimum of
-// (distance, position) - and the pair's last block to finish appends the six corner points and publishes the count.
-#define FST_AGG 1u
-#define FST_INC 2u
-__global__ __launch_bounds__(FLT_THREADS) void k_filter_collect(KParams k, const int16_t *__restrict__ latC, uint32_t *stat, int nstat, int32_t *__restrict__ fsup,
-                                                                int32_t *__restrict__ fnsup) {
+// ---- (5) collection in scan order (elas.cpp:424-428; lattice row / column 0 excluded) and corner points (elas.cpp:235-264), as
+// two grid-wide launches over blocks of FLT_THREADS consecutive lattice indices - the kernel boundary is the only
+// synchronisation.  k_filter_count: points each block will emit.  k_filter_collect: a block's first list position is the sum
+// of its predecessors' counts (<= 1 300 values even for the largest lattice); it writes its points and offers the nearest
+// one per image corner as a key (distance^2, list position, disparity) - "first minimum in list order" (:246-253) is the
+// minimum of (distance, position); the pair's block 0 of a third, tiny launch (k_filter_corners) reduces the keys and appends
+// the six corner points.
+__device__ __forceinline__ bool collect_pred(const Dims &d, const int16_t *__restrict__ C, int i, int lat, int &u, int &v, int &dv) {
+    dv = -1;
+    u = v = 0;
+    if (i < lat) {
+        u = i / d.Hc;
+        v = i - u * d.Hc;
+        dv = C[i];
+    }
+    return dv >= 0 && u >= 1 && v >= 1;
+}
+
+__global__ __launch_bounds__(FLT_THREADS) void k_filter_count(Dims d, const int16_t *__restrict__ latC, int32_t *__restrict__ bcnt) {
+    const int pair = blockIdx.y, lat = d.Wc * d.Hc;
+    __shared__ int s_wave[FLT_THREADS / 64];
+    int u, v, dv;
+    const bool pred = collect_pred(d, latC + (size_t)pair * lat, blockIdx.x * FLT_THREADS + threadIdx.x, lat, u, v, dv);
+    const unsigned long long m = __ballot(pred);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = (int)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+#pragma unroll
+        for (int w = 0; w < FLT_THREADS / 64; w++) tot += s_wave[w];
+        bcnt[(size_t)pair * gridDim.x + blockIdx.x] = tot;
+    }
+}
+
+__global__ __launch_bounds__(FLT_THREADS) void k_filter_collect(KParams k, const int16_t *__restrict__ latC, const int32_t *__restrict__ bcnt, unsigned long long *__restrict__ bkey,
+                                                                int32_t *__restrict__ fsup) {
     const Dims &d = k.d;
     const int pair = blockIdx.y, b = blockIdx.x, nb2 = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Hc = d.Hc, lat = d.Wc * Hc;
-    uint32_t *sw = stat + (size_t)pair * nstat;
-    uint32_t *done = sw + nb2, *npts = sw + nb2 + 1;
-    unsigned long long *ckey = reinterpret_cast<unsigned long long *>(sw + nstat - 8);
-    __shared__ int s_wcnt[FLT_THREADS / 64];
+    const int lat = d.Wc * d.Hc;
+    __shared__ int s_wave[FLT_THREADS / 64];
     __shared__ int s_excl;
-    const int i = b * FLT_THREADS + tid;
-    int dv = -1, u = 0, v = 0;
-    if (i < lat) {
-        u = i / Hc;
-        v = i - u * Hc;
-        dv = latC[(size_t)pair * lat + i];
-    }
-    const bool pred = dv >= 0 && u >= 1 && v >= 1;
+    __shared__ unsigned long long s_key[4][FLT_THREADS / 64];
+    int u, v, dv;
+    const bool pred = collect_pred(d, latC + (size_t)pair * lat, b * FLT_THREADS + tid, lat, u, v, dv);
     const unsigned long long m = __ballot(pred);
-    if (lane == 0) s_wcnt[wave] = (int)__popcll(m);
-    __syncthreads();
-    int base = 0, cnt = 0;
+    if (lane == 0) s_wave[wave] = (int)__popcll(m);
+    if (wave == 0) {  // this block's first list position: the sum of its predecessors' counts
+        int acc = 0;
+        for (int j = lane; j < b; j += 64) acc += bcnt[(size_t)pair * nb2 + j];
 #pragma unroll
-    for (int w = 0; w < FLT_THREADS / 64; w++) {
-        base += w < wave ? s_wcnt[w] : 0;
-        cnt += s_wcnt[w];
-    }
-    if (wave == 0) {  // look-back over the predecessors' status words, 64 at a time
-        if (lane == 0) __hip_atomic_store(&sw[b], ((b == 0 ? FST_INC : FST_AGG) << 30) | (uint32_t)cnt, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        int excl = 0;
-        for (int top = b - 1; top >= 0; top -= 64) {
-            const int j = top - lane;
-            uint32_t s = FST_INC << 30;  // (lanes before block 0: an inclusive prefix of zero)
-            if (j >= 0) {
-                do {
-                    s = __hip_atomic_load(&sw[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                } while ((s >> 30) == 0u);
-            }
-            const unsigned long long inc = __ballot((s >> 30) == FST_INC);
-            const int stop = inc ? (int)__builtin_ctzll(inc) : 63;  // nearest predecessor that already holds an inclusive prefix
-            int add = lane <= stop ? (int)(s & 0x3FFFFFFFu) : 0;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) add += __shfl_xor(add, off, 64);
-            excl += add;
-            if (inc) break;
-        }
-        if (lane == 0) {
-            if (b > 0) __hip_atomic_store(&sw[b], (FST_INC << 30) | (uint32_t)(excl + cnt), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            s_excl = excl;
-        }
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+        if (lane == 0) s_excl = acc;
     }
     __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < FLT_THREADS / 64; w++) base += w < wave ? s_wave[w] : 0;
     const int q = s_excl + base + (int)__popcll(m & ((1ull << lane) - 1ull));
     int32_t *out = fsup + (size_t)pair * d.max_pts * 3;
     if (pred) {
@@ -847,95 +872,122 @@ __global__ __launch_bounds__(FLT_THREADS) void k_filter_collect(KParams k, const
         out[3 * q + 1] = v * d.step;
         out[3 * q + 2] = dv;
     }
-    if (k.add_corners && m) {  // elas.cpp:235-264: the four image corners take the disparity of the nearest point (first minimum)
-        const int bu[4] = {0, 0, d.W - 1, d.W - 1}, bv[4] = {0, d.H - 1, 0, d.H - 1};
+    if (!k.add_corners) return;
+    const int bu[4] = {0, 0, d.W - 1, d.W - 1}, bv[4] = {0, d.H - 1, 0, d.H - 1};
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            unsigned long long key = ~0ull;
-            if (pred) {
-                const int du = bu[c] - u * d.step, dw = bv[c] - v * d.step;
-                const int dist = du * du + dw * dw;
-                // (the reference's search starts from best_dist = 10000000, :245: points that far away are never taken)
-                if (dist < 10000000) key = ((unsigned long long)dist << 34) | ((unsigned long long)q << 11) | (unsigned long long)dv;
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const unsigned long long o = __shfl_xor(key, off, 64);
-                key = o < key ? o : key;
-            }
-            if (lane == 0) atomicMin(&ckey[c], key);
+    for (int c = 0; c < 4; c++) {
+        unsigned long long key = ~0ull;
+        if (pred) {
+            const int du = bu[c] - u * d.step, dw = bv[c] - v * d.step;
+            const int dist = du * du + dw * dw;
+            // (the reference's search starts from best_dist = 10000000, :245: points that far away are never taken)
+            if (dist < 10000000) key = ((unsigned long long)dist << 34) | ((unsigned long long)q << 11) | (unsigned long long)dv;
         }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long o = __shfl_xor(key, off, 64);
+            key = o < key ? o : key;
+        }
+        if (lane == 0) s_key[c][wave] = key;
     }
-    __threadfence();
     __syncthreads();
-    if (tid == 0) {
-        if (b == nb2 - 1) __hip_atomic_store(npts, (uint32_t)(s_excl + cnt), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        const uint32_t prev = __hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int)prev == nb2 - 1) {  // every block of the pair has written its points and offered its corner candidates
-            __threadfence();
-            const int n_main = (int)__hip_atomic_load(npts, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            int n_total = n_main;
-            if (k.add_corners) {
-                const int bu[4] = {0, 0, d.W - 1, d.W - 1}, bv[4] = {0, d.H - 1, 0, d.H - 1};
-                int cd[4];
-                for (int c = 0; c < 4; c++) {
-                    const unsigned long long key = __hip_atomic_load(&ckey[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    cd[c] = key == ~0ull ? 0 : (int)(key & 0x7FFull);
-                }
-                int qq = n_main;
-                for (int c = 0; c < 4; c++) {
-                    out[3 * qq] = bu[c];
-                    out[3 * qq + 1] = bv[c];
-                    out[3 * qq + 2] = cd[c];
-                    qq++;
-                }
-                for (int c = 2; c < 4; c++) {  // the two right-image corners (:258-259)
-                    out[3 * qq] = bu[c] + cd[c];
-                    out[3 * qq + 1] = bv[c];
-                    out[3 * qq + 2] = cd[c];
-                    qq++;
-                }
-                n_total = n_main + 6;
-            }
-            fnsup[pair] = n_total;
-        }
+    if (tid < 4) {
+        unsigned long long key = ~0ull;
+#pragma unroll
+        for (int w = 0; w < FLT_THREADS / 64; w++) key = s_key[tid][w] < key ? s_key[tid][w] : key;
+        bkey[((size_t)pair * nb2 + b) * 4 + tid] = key;
     }
 }
 
-// strip widths of the redundancy kernels: the widest power of two (<= 64 lines) whose LDS tile stays within 96 KB
+// one wavefront per pair: point count, corner points (elas.cpp:235-264), fnsup
+__global__ __launch_bounds__(64) void k_filter_corners(KParams k, const int32_t *__restrict__ bcnt, const unsigned long long *__restrict__ bkey, int nb2, int32_t *__restrict__ fsup,
+                                                       int32_t *__restrict__ fnsup) {
+    const Dims &d = k.d;
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    int n_main = 0;
+    unsigned long long key[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    for (int j = lane; j < nb2; j += 64) {
+        n_main += bcnt[(size_t)pair * nb2 + j];
+        if (k.add_corners)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const unsigned long long o = bkey[((size_t)pair * nb2 + j) * 4 + c];
+                key[c] = o < key[c] ? o : key[c];
+            }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        n_main += __shfl_xor(n_main, off, 64);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const unsigned long long o = __shfl_xor(key[c], off, 64);
+            key[c] = o < key[c] ? o : key[c];
+        }
+    }
+    if (lane != 0) return;
+    int n_total = n_main;
+    if (k.add_corners) {
+        int32_t *out = fsup + (size_t)pair * d.max_pts * 3;
+        const int bu[4] = {0, 0, d.W - 1, d.W - 1}, bv[4] = {0, d.H - 1, 0, d.H - 1};
+        int cd[4];
+        for (int c = 0; c < 4; c++) cd[c] = key[c] == ~0ull ? 0 : (int)(key[c] & 0x7FFull);
+        int qq = n_main;
+        for (int c = 0; c < 4; c++) {
+            out[3 * qq] = bu[c];
+            out[3 * qq + 1] = bv[c];
+            out[3 * qq + 2] = cd[c];
+            qq++;
+        }
+        for (int c = 2; c < 4; c++) {  // the two right-image corners (:258-259)
+            out[3 * qq] = bu[c] + cd[c];
+            out[3 * qq + 1] = bv[c];
+            out[3 * qq + 2] = cd[c];
+            qq++;
+        }
+        n_total = n_main + 6;
+    }
+    fnsup[pair] = n_total;
+}
+
+// LDS bytes of the redundancy kernels for strips of `s` lines of `n` points
+static size_t filter_strip_lds(int s, int n) {
+    return (size_t)s * (n + 10) * 2 + 2 + ((size_t)s * filter_kept_stride(n) + 1) * 2 + (size_t)s * filter_line_stride(n);
+}
+// strip width: 16 lines (many workgroups, short flag phases), fewer when a line is so long that the tile would exceed 96 KB
 static int filter_strip(int line_len) {
-    int s = 64;
-    while (s > 1 && (size_t)s * (3 * (size_t)line_len + 20) > 96 * 1024) s >>= 1;
+    int s = 16;
+    while (s > 1 && filter_strip_lds(s, line_len) > 96 * 1024) s >>= 1;
     return s;
 }
 
-size_t support_filter_ws_bytes(const KParams &k, int cap) {  // per slot: segment + ordered list of uncertain points, two lattice copies, state bytes, block counts, look-back words
-    const size_t lat = (size_t)k.d.Wc * k.d.Hc, nb = (lat + FCL_THREADS - 1) / FCL_THREADS;
-    return (size_t)cap * (lat * (4 + 4 + 2 + 2 + 1) + 8 + nb * 4 + (size_t)filter_stat_words((int)lat) * 4) + 256;
+size_t support_filter_ws_bytes(const KParams &k, int cap) {  // per slot: segment + ordered list of uncertain points, two lattice copies, state bytes, block counts and keys
+    const size_t lat = (size_t)k.d.Wc * k.d.Hc, nb = (lat + FCL_THREADS - 1) / FCL_THREADS, nb2 = (size_t)filter_collect_blocks((int)lat);
+    return (size_t)cap * (lat * (4 + 4 + 2 + 2 + 1) + nb * 4 + nb2 * (4 * 8 + 4) + 16) + 256;
 }
 
 void launch_support_filter(const KParams &k, int win, int thr, int need, const SlotDev &s, int n, hipStream_t st) {
     const size_t lat = (size_t)k.d.Wc * k.d.Hc, cap = (size_t)s.cap;
-    const int nb = (int)((lat + FCL_THREADS - 1) / FCL_THREADS), nb2 = filter_collect_blocks((int)lat), nstat = filter_stat_words((int)lat);
+    const int nb = (int)((lat + FCL_THREADS - 1) / FCL_THREADS), nb2 = filter_collect_blocks((int)lat);
     uint8_t *base = static_cast<uint8_t *>(s.flt_ws);
-    uint32_t *useg = reinterpret_cast<uint32_t *>(base), *ulist = useg + cap * lat;
-    uint32_t *stat = ulist + cap * lat;                                   // (8-byte aligned: cap * lat * 8 bytes in)
-    int32_t *ucnt = reinterpret_cast<int32_t *>(stat + cap * (size_t)nstat);
-    int16_t *latB = reinterpret_cast<int16_t *>(ucnt + cap * (size_t)nb), *latC = latB + cap * lat;
+    unsigned long long *bkey = reinterpret_cast<unsigned long long *>(base);
+    uint32_t *useg = reinterpret_cast<uint32_t *>(bkey + cap * (size_t)nb2 * 4), *ulist = useg + cap * lat;
+    int32_t *ucnt = reinterpret_cast<int32_t *>(ulist + cap * lat), *bcnt = ucnt + cap * (size_t)nb;
+    int16_t *latB = reinterpret_cast<int16_t *>(bcnt + cap * (size_t)nb2), *latC = latB + cap * lat;
     uint8_t *fst = reinterpret_cast<uint8_t *>(latC + cap * lat);
     const size_t cl_lds = sizeof(int16_t) * (FCL_THREADS + 2 * (size_t)(5 * k.d.Hc + 5));
     const int SW = filter_strip(k.d.Hc), SH = filter_strip(k.d.Wc);
-    const size_t v_lds = (size_t)SW * (3 * (size_t)k.d.Hc + 20), h_lds = (size_t)SH * (3 * (size_t)k.d.Wc + 20);
+    const size_t v_lds = filter_strip_lds(SW, k.d.Hc), h_lds = filter_strip_lds(SH, k.d.Wc);
     static std::atomic<size_t> granted[64], granted_v[64], granted_h[64];
     ensure_dynamic_lds(k_filter_classify, cl_lds, granted, "support_filter");
     ensure_dynamic_lds(k_filter_vertical, v_lds, granted_v, "support_filter (vertical)");
     ensure_dynamic_lds(k_filter_horizontal, h_lds, granted_h, "support_filter (horizontal)");
     SV_LAUNCH(K_SUPPORT_FILTER, k_filter_classify, dim3((unsigned)nb, n), dim3(FCL_THREADS), cl_lds, st, k.d, win, thr, need, s.dcan, fst, useg, ucnt);
-    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_resolve, dim3(n), dim3(FLT_THREADS), 0, st, k.d, win, thr, need, s.dcan, fst, useg, ucnt, nb, ulist, stat, nstat);
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_resolve, dim3(n), dim3(RSV_THREADS), 0, st, k.d, win, thr, need, s.dcan, fst, useg, ucnt, nb, ulist);
     SV_LAUNCH(K_SUPPORT_FILTER, k_filter_vertical, dim3((k.d.Wc + SW - 1) / SW, n), dim3(FRD_THREADS), v_lds, st, k.d, SW, s.dcan, fst, latB);
     SV_LAUNCH(K_SUPPORT_FILTER, k_filter_horizontal, dim3((k.d.Hc + SH - 1) / SH, n), dim3(FRD_THREADS), h_lds, st, k.d, SH, latB, latC);
-    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_collect, dim3(nb2, n), dim3(FLT_THREADS), 0, st, k, latC, stat, nstat, s.fsup, s.fnsup);
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_count, dim3(nb2, n), dim3(FLT_THREADS), 0, st, k.d, latC, bcnt);
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_collect, dim3(nb2, n), dim3(FLT_THREADS), 0, st, k, latC, bcnt, bkey, s.fsup);
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_corners, dim3(n), dim3(64), 0, st, k, bcnt, bkey, nb2, s.fsup, s.fnsup);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ import csv
 import json
 import os
 
-NAMES = {"k_filter_classify": "support_filter", "k_filter_resolve": "support_filter", "k_filter_vertical": "support_filter", "k_filter_horizontal": "support_filter", "k_filter_collect": "support_filter", "k_dense": "dense_match", "k_support": "support_match", "k_descriptor": "descriptor", "k_sobel": "descriptor", "k_amean": "adaptive_mean",
+NAMES = {"k_filter_classify": "support_filter", "k_filter_resolve": "support_filter", "k_filter_vertical": "support_filter", "k_filter_horizontal": "support_filter", "k_filter_collect": "support_filter", "k_filter_count": "support_filter", "k_filter_corners": "support_filter", "k_dense": "dense_match", "k_support": "support_match", "k_descriptor": "descriptor", "k_sobel": "descriptor", "k_amean": "adaptive_mean",
          "k_amean_sub": "adaptive_mean", "k_raster_tiles": "triangles_raster", "k_lr": "lr_check", "k_lr2": "lr_check", "k_median": "median", "k_planes": "plane_fit",
          "k_ccl_band": "ccl_band", "k_gap_cols": "gap_cols", "k_gap_rows": "gap_rows", "k_grid_mark": "grid_mark", "k_grid_dilate": "grid_dilate",
          "k_raster": "triangles_raster_fallback", "k_ccl_border": "ccl_finish", "k_ccl_total": "ccl_finish", "k_ccl_apply": "ccl_finish", "k_ccl_slow": "ccl_finish",
