@@ -204,8 +204,9 @@ typedef struct {
 } Uchar4; /* reference: src/common_includes/structs.h:18-20 */
 
 /* reference: stereo_vision.cpp:565-623.  left/right: BGRA uint8 [height][width][4].  Returns the library-owned
- * point array [width*height] (valid until the next call / clean()).  State is frozen at the first call, like the
- * reference's function-static init (stereo_vision.cpp:582). */
+ * point array [W*H] of the FIRST call's width x height (valid until the next call / clean()).  State is frozen at the
+ * first call, like the reference's function-static init (stereo_vision.cpp:582); later frames of another size are resized
+ * to it (cv::resize INTER_LINEAR restated, :590-591).  removeSky / subsampling are not read (see sv_legacy_set_subsampling). */
 Double3 *generatePointCloud(unsigned char *left, unsigned char *right, char *CAMERA_CALIBRATION_YAML, int width, int height, bool kittiCalibration,
                             bool objectTracking, bool graphics, bool display, int scale, int pc_extrapolation, const char *YOLO_CFG,
                             const char *YOLO_WEIGHTS, const char *YOLO_CLASSES, bool removeSky, bool subsampling);
@@ -221,6 +222,12 @@ const double *sv_legacy_Q(void);
  * by default here as well.  Call before the first generatePointCloud (the state is frozen there, :582).  OpenCV arithmetic
  * restated (parity unpinned, like the gray conversion). */
 void sv_legacy_set_rectify(int on);
+/* Half-resolution mode of the legacy path (Elas::parameters::subsampling, set from the driver's `subsample`, stereo_vision.cpp:309).
+ * generatePointCloud does NOT read its arguments 15 and 16 (removeSky, subsampling): the reference's own binding passes only 14
+ * (stereo_vision/sv.py:180,189), so those slots are undefined under "sv.py drives it unchanged".  Call before the first frame. */
+void sv_legacy_set_subsampling(int on);
+/* HIP device of the legacy path (default 0).  Call before the first frame. */
+void sv_legacy_set_device(int device);
 /* The four maps lmapx, lmapy, rmapx, rmapy as [4][height][width] floats (host), NULL unless rectification is on. */
 const float *sv_legacy_rectify_maps(void);
 /* Test hook: the gray images of the last frame as the matcher received them (after the remap if it is on); [height][width] each. */

@@ -1200,7 +1200,7 @@ void alloc_slot(sv_handle *h, Slot *sl) {
     dev_alloc(s.blob, sl->blob_words);
     dev_alloc(s.fsup, cap * (size_t)d.max_pts * 3);
     dev_alloc(s.fnsup, cap);
-    if (h->dg_limit > h->dg_sub_max) {  // 4K-sized lattices: sets beyond the LDS kernel go through a mesh in global memory
+    if (h->dg_limit > h->dg_sub_max) {  // support lists beyond the LDS kernel (4K-sized lattices) go through a mesh in global memory
         size_t tb, xb, rb;
         delaunay_scratch_bytes(h->dg_limit, (int)cap * 2, &tb, &xb, &rb);
         uint8_t *t = nullptr;
@@ -1488,6 +1488,18 @@ int run_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, 
 
 }  // namespace
 
+// Internal entry for the legacy path (legacy.cpp; not in the public header): like sv_process_batch_device for one pair, but the
+// first GPU phase waits for `ready` on the device, so the caller does not have to synchronise the stream that produced the inputs.
+int sv_internal_process_after(sv_handle *h, hipEvent_t ready, const uint8_t *left, const uint8_t *right, int stride, float *d1, float *d2) {
+    if (!h) return SV_ERR_ARG;
+    (void)hipSetDevice(h->cfg.device);
+    if (ready && hipStreamWaitEvent(h->sP1, ready, 0) != hipSuccess) {
+        h->error = "hipStreamWaitEvent failed";
+        return SV_ERR_HIP;
+    }
+    return run_job(h, left, right, 1, stride, d1, d2, nullptr);
+}
+
 extern "C" {
 
 void sv_params_init(sv_params *p, int setting) {
@@ -1566,6 +1578,17 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     int np2 = cfg->n_streams > 0 ? cfg->n_streams : 4;
     int nslots = cfg->n_slots > 0 ? cfg->n_slots : 8;
     h->chunk = cfg->chunk > 0 ? cfg->chunk : 64;
+    // Vertex sets the GPU triangulation takes: up to dg_sub_max whole in LDS; larger ones (4K lattices) through a mesh in the slots'
+    // global-memory scratch, sized for the support lists a handle really sees (the bulk-copied head of a list, fsup_copy_pts: a
+    // sixth of the lattice - a 4K pair has 21 000 of 330 000 lattice points) - not for the lattice.  A KITTI lattice's lists
+    // (~2 000 points, 4 096 copied) fit the LDS kernel: no scratch there.  Sets beyond the limit are triangulated by the pool.
+    h->dg_limit = h->dg_sub_max = delaunay_gpu_max_points();
+    if (const char *e = getenv("SV_DG_SUBMAX")) h->dg_sub_max = std::max(6, std::min(h->dg_sub_max, atoi(e)));  // experiments / tests
+    if (!cfg->keep_debug) {
+        const int want = std::min({h->kp.d.max_pts, delaunay_gpu_large_max_points(), 131072, fsup_copy_pts(h->kp.d)});
+        if (want > h->dg_sub_max + h->dg_sub_max / 4 || (getenv("SV_DG_SUBMAX") && want > h->dg_sub_max)) h->dg_limit = want;
+    }
+    if (const char *e = getenv("SV_GPU_DELAUNAY_MAX")) h->dg_limit = std::min(h->dg_limit, std::max(atoi(e), 16));  // tests: larger sets fall back to the pool
     if (cfg->chunk <= 0 || cfg->n_slots <= 0) {
         size_t free_b = 0, total_b = 0;
         (void)hipSetDevice(cfg->device);
@@ -1573,7 +1596,8 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         // (4K, one MI355X, round 2: chunk x slots 4 x 4 -> 1 500 pairs/s, 8 x 6 -> 2 020, 16 x 6 -> 2 440, 32 x 4 -> 2 550: the per-launch
         //  latency chains - lattice filter, speckle merges, GPU triangulation - want many pairs per launch more than many slots)
         const double budget = std::min(64.0 * (1 << 30), 0.25 * (double)free_b);
-        const double per_pair = 66.0 * (double)h->kp.d.N + 4.0e6;
+        double per_pair = 66.0 * (double)h->kp.d.N + 4.0e6;
+        if (h->dg_limit > h->dg_sub_max) per_pair += (double)delaunay_scratch_bytes(h->dg_limit, 2, nullptr, nullptr, nullptr);  // two vertex sets per pair
         while ((double)h->chunk * nslots * per_pair > budget) {
             if (cfg->chunk <= 0 && h->chunk > 16)
                 h->chunk = (h->chunk + 1) / 2;
@@ -1610,11 +1634,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     if (const char *e = getenv("SV_GPU_DELAUNAY_AUTO")) h->gpu_share_auto = h->gpu_share_auto && atoi(e) != 0;
     // start where the balance was measured to settle (4 ... 14 threads); a handle with fewer than four slots cannot build up a backlog
     if (h->gpu_share_auto && nslots >= 4) h->auto_pct = std::max(0, std::min(95, 117 - 7 * npool));
-    h->dg_limit = h->dg_sub_max = delaunay_gpu_max_points();
-    if (const char *e = getenv("SV_DG_SUBMAX")) h->dg_sub_max = std::max(6, std::min(h->dg_sub_max, atoi(e)));  // experiments / tests
-    if ((h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0) && h->kp.d.max_pts > h->dg_sub_max)
-        h->dg_limit = std::min({h->kp.d.max_pts, delaunay_gpu_large_max_points(), 131072});  // 7.3 MB of scratch per set
-    if (const char *e = getenv("SV_GPU_DELAUNAY_MAX")) h->dg_limit = std::min(h->dg_limit, std::max(atoi(e), 16));  // tests: larger sets fall back to the pool
+    if (!(h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0)) h->dg_limit = h->dg_sub_max;  // the pool triangulates everything: no scratch
     h->block_sync = h->chunk >= 4;
     if (const char *e = getenv("SV_EVENT_SYNC")) h->block_sync = strcmp(e, "block") == 0;
     try {

@@ -3,7 +3,7 @@
 //
 //   generatePointCloud   reference: src/serial_includes/main/stereo_vision.cpp:565-623
 //     first call  -> externalInit (:498-562): freeze width/height/scale/calibration, stereoRectify -> Q, allocate `points`
-//     every call  -> wrap BGRA buffers, resize (identity: out size == input size, :587-591), cvtColor BGRA2GRAY (:338-339),
+//     every call  -> wrap BGRA buffers, resize to the frozen size (:587-591; a copy when the sizes agree), cvtColor BGRA2GRAY (:338-339),
 //                    generateDisparityMap (:296-318: Elas MIDDLEBURY + postprocess_only_left + adaptive mean, then
 //                    convertTo(CV_8UC1, 4.0)), publishPointCloud (:222-259: (X,Y,Z) = Q*[x y d 1] / w)
 //   clean / getColor     :105-114 / :625-627
@@ -14,7 +14,9 @@
 // Documented deviations from the reference: clean() does not exit(0); `points` is filled on every call
 // (the reference only fills it when graphics==true and otherwise returns uninitialised memory); YOLO object tracking,
 // the GLUT viewer and imshow windows are not part of this library (objectTracking/graphics/display are accepted and
-// ignored).
+// ignored).  Arguments 15 and 16 (removeSky, subsampling) are NOT read: the reference's own binding passes 14 arguments
+// (stereo_vision/sv.py:180,189), so a callee that read them would read whatever the caller's registers / stack hold.  Half-
+// resolution mode is selected with sv_legacy_set_subsampling(1) before the first frame instead (our sv.py does that).
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,7 +31,12 @@
 #include "../../include/stereo_vision_hip.h"
 #include "calib.h"
 
+// engine.cpp (not part of the public header): one device-resident pair on a latency handle whose first GPU phase waits for `ready`
+// on the device instead of the caller synchronising its stream on the host
+int sv_internal_process_after(sv_handle *h, hipEvent_t ready, const uint8_t *left, const uint8_t *right, int stride, float *d1, float *d2);
+
 namespace sv {
+void launch_resize_bgra(const unsigned char *src, int sw, int sh, unsigned char *dst, int dw, int dh, hipStream_t st);
 void launch_bgra_to_gray(const unsigned char *bgra_l, const unsigned char *bgra_r, unsigned char *gray_l, unsigned char *gray_r, int n, hipStream_t st);
 void launch_dmap_and_cloud(const float *disp, unsigned char *dmap, double *points, const double *Q16, int W, int H, hipStream_t st);
 void launch_remap_gray(const unsigned char *src, unsigned char *dst, const float *mapx, const float *mapy, int W, int H, hipStream_t st);
@@ -58,11 +65,21 @@ struct Legacy {
     std::vector<Uchar4> colors;         // last left image
     unsigned char *h_dmap = nullptr;    // last u8 disparity image (host, page-locked)
     hipStream_t stream = nullptr;
+    int device = 0;
+    hipEvent_t ev_in = nullptr;         // inputs of the matcher are ready (the engine's first stream waits for it: no host sync)
+    // upload staging: the caller's buffers are pageable and only valid during the call - they are copied into page-locked
+    // memory piece by piece, each piece's DMA running while the next is being copied
+    unsigned char *h_stage = nullptr;
+    size_t stage_bytes = 0;
+    unsigned char *d_src_l = nullptr, *d_src_r = nullptr;  // frames of another size than the frozen one, before the resize
+    size_t src_bytes = 0;
 };
 
 Legacy g;
 std::mutex g_mu;
 bool g_want_rectify = false;  // sv_legacy_set_rectify: read by the first generatePointCloud call
+bool g_want_subsampling = false;  // sv_legacy_set_subsampling: likewise
+int g_want_device = 0;            // sv_legacy_set_device: likewise
 
 #define L_TRY(expr)                                                                              \
     do {                                                                                         \
@@ -99,7 +116,7 @@ bool legacy_init(int width, int height, float scale, const char *yaml, bool subs
     memset(&cfg, 0, sizeof(cfg));
     cfg.width = width;
     cfg.height = height;
-    cfg.device = 0;
+    cfg.device = g.device = g_want_device;
     cfg.n_workers = 4;  // latency mode: two triangulations, each split over two threads
     cfg.n_streams = 1;
     cfg.n_slots = 2;
@@ -109,8 +126,11 @@ bool legacy_init(int width, int height, float scale, const char *yaml, bool subs
         return false;
     }
     const size_t N = (size_t)width * height;
-    L_TRY(hipSetDevice(0));
-    L_TRY(hipStreamCreate(&g.stream));
+    L_TRY(hipSetDevice(g.device));
+    L_TRY(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    L_TRY(hipEventCreateWithFlags(&g.ev_in, hipEventDisableTiming));
+    g.stage_bytes = 2 * N * 4;
+    L_TRY(hipHostMalloc((void **)&g.h_stage, g.stage_bytes, hipHostMallocDefault));
     L_TRY(hipMalloc((void **)&g.d_bgra_l, N * 4));
     L_TRY(hipMalloc((void **)&g.d_bgra_r, N * 4));
     L_TRY(hipMalloc((void **)&g.d_gray_l, N));
@@ -144,31 +164,66 @@ bool legacy_init(int width, int height, float scale, const char *yaml, bool subs
     return g.points != nullptr;
 }
 
-bool legacy_frame(const unsigned char *left, const unsigned char *right) {
-    const size_t N = (size_t)g.W * g.H;
-    L_TRY(hipMemcpyAsync(g.d_bgra_l, left, N * 4, hipMemcpyHostToDevice, g.stream));
-    L_TRY(hipMemcpyAsync(g.d_bgra_r, right, N * 4, hipMemcpyHostToDevice, g.stream));
-    sv::launch_bgra_to_gray(g.d_bgra_l, g.d_bgra_r, g.d_gray_l, g.d_gray_r, (int)N, g.stream);
+// host -> device through the page-locked staging buffer, in pieces: piece k+1 is copied while piece k's DMA runs
+bool upload_staged(unsigned char *dev, const unsigned char *src, size_t bytes, unsigned char *stage) {
+    const size_t piece = (size_t)512 << 10;
+    for (size_t o = 0; o < bytes; o += piece) {
+        const size_t n = bytes - o < piece ? bytes - o : piece;
+        memcpy(stage + o, src + o, n);
+        L_TRY(hipMemcpyAsync(dev + o, stage + o, n, hipMemcpyHostToDevice, g.stream));
+    }
+    return true;
+}
+
+bool legacy_frame(const unsigned char *left, const unsigned char *right, int width, int height) {
+    const size_t N = (size_t)g.W * g.H, Nin = (size_t)width * height;
+    const bool resize = width != g.W || height != g.H;
+    L_TRY(hipSetDevice(g.device));
+    if (2 * Nin * 4 > g.stage_bytes) {  // a frame larger than the frozen size: grow the staging (rare: once per new size)
+        L_TRY(hipStreamSynchronize(g.stream));
+        if (g.h_stage) (void)hipHostFree(g.h_stage);
+        g.h_stage = nullptr;
+        g.stage_bytes = 2 * Nin * 4;
+        L_TRY(hipHostMalloc((void **)&g.h_stage, g.stage_bytes, hipHostMallocDefault));
+    }
+    if (resize && Nin * 4 > g.src_bytes) {
+        L_TRY(hipStreamSynchronize(g.stream));
+        if (g.d_src_l) (void)hipFree(g.d_src_l);
+        if (g.d_src_r) (void)hipFree(g.d_src_r);
+        g.d_src_l = g.d_src_r = nullptr;
+        g.src_bytes = Nin * 4;
+        L_TRY(hipMalloc((void **)&g.d_src_l, g.src_bytes));
+        L_TRY(hipMalloc((void **)&g.d_src_r, g.src_bytes));
+    }
     // leftdpf / rightdpf start as zeros every frame (stereo_vision.cpp:304-305)
     L_TRY(hipMemsetAsync(g.d_disp, 0, N * sizeof(float), g.stream));
     L_TRY(hipMemsetAsync(g.d_disp2, 0, N * sizeof(float), g.stream));
-    L_TRY(hipStreamSynchronize(g.stream));
+    if (!upload_staged(resize ? g.d_src_l : g.d_bgra_l, left, Nin * 4, g.h_stage)) return false;
+    if (!upload_staged(resize ? g.d_src_r : g.d_bgra_r, right, Nin * 4, g.h_stage + Nin * 4)) return false;
+    if (resize) {  // resize(left_img, left_img_OLD, out_img_size) (:590-591): cv::resize, INTER_LINEAR, 8UC4
+        sv::launch_resize_bgra(g.d_src_l, width, height, g.d_bgra_l, g.W, g.H, g.stream);
+        sv::launch_resize_bgra(g.d_src_r, width, height, g.d_bgra_r, g.W, g.H, g.stream);
+    }
+    sv::launch_bgra_to_gray(g.d_bgra_l, g.d_bgra_r, g.d_gray_l, g.d_gray_r, (int)N, g.stream);
     const unsigned char *in_l = g.d_gray_l, *in_r = g.d_gray_r;
     if (g.rectify) {  // remap(tmpL, img_left, lmapx, lmapy, INTER_LINEAR); remap(tmpR, img_right, rmapx, rmapy, INTER_LINEAR) (:341)
         sv::launch_remap_gray(g.d_gray_l, g.d_rect_l, g.d_maps, g.d_maps + N, g.W, g.H, g.stream);
         sv::launch_remap_gray(g.d_gray_r, g.d_rect_r, g.d_maps + 2 * N, g.d_maps + 3 * N, g.W, g.H, g.stream);
-        L_TRY(hipStreamSynchronize(g.stream));
         in_l = g.d_rect_l, in_r = g.d_rect_r;
     }
-    if (sv_process_batch_device(g.engine, in_l, in_r, 1, g.W, g.d_disp, g.d_disp2, nullptr) != SV_OK) {
+    L_TRY(hipEventRecord(g.ev_in, g.stream));
+    // the colours of the left image as the viewer gets them (left_img_OLD, :590): the staged copy when the sizes agree
+    if (!resize) memcpy(g.colors.data(), g.h_stage, N * 4);  // (while the GPU converts and matches)
+    // the engine's first stream waits for ev_in on the device; the call returns when the maps are complete
+    if (sv_internal_process_after(g.engine, g.ev_in, in_l, in_r, g.W, g.d_disp, g.d_disp2) != SV_OK) {
         fprintf(stderr, "stereo_vision_hip: %s\n", sv_last_error(g.engine));
         return false;
     }
     sv::launch_dmap_and_cloud(g.d_disp, g.d_dmap, g.d_points, g.d_Q, g.W, g.H, g.stream);
     L_TRY(hipMemcpyAsync(g.points, g.d_points, N * sizeof(Double3), hipMemcpyDeviceToHost, g.stream));
     L_TRY(hipMemcpyAsync(g.h_dmap, g.d_dmap, N, hipMemcpyDeviceToHost, g.stream));
+    if (resize) L_TRY(hipMemcpyAsync(g.colors.data(), g.d_bgra_l, N * 4, hipMemcpyDeviceToHost, g.stream));
     L_TRY(hipStreamSynchronize(g.stream));
-    memcpy(g.colors.data(), left, N * 4);
     return true;
 }
 
@@ -186,7 +241,11 @@ Double3 *generatePointCloud(unsigned char *left, unsigned char *right, char *CAM
     (void)YOLO_CFG;
     (void)YOLO_WEIGHTS;
     (void)YOLO_CLASSES;
-    (void)removeSky;  // dmapOLD.copyTo(dmapOLD, sky_mask) copies an image onto itself (stereo_vision.cpp:604-607): no effect
+    // Arguments 15 / 16 are never read: the reference's binding passes 14 (stereo_vision/sv.py:180,189), so their slots hold whatever
+    // the caller left there.  removeSky has no effect in the reference anyway (dmapOLD.copyTo(dmapOLD, sky_mask) copies an image onto
+    // itself, stereo_vision.cpp:604-607); subsampling comes from sv_legacy_set_subsampling.
+    (void)removeSky;
+    (void)subsampling;
     std::lock_guard<std::mutex> lk(g_mu);
     if (!left || !right) return nullptr;
     if (!g.ready && !g.failed) {  // function-static init of the reference (stereo_vision.cpp:582): first call freezes the state
@@ -196,27 +255,29 @@ Double3 *generatePointCloud(unsigned char *left, unsigned char *right, char *CAM
         }
         if (objectTracking) printf("\n** Object tracking requested: not provided by this library (detector weights are not part of the hot path)\n");
         else printf("\n** Object tracking disabled\n");
-        g.ready = legacy_init(width, height, (float)scale, CAMERA_CALIBRATION_YAML, subsampling);
+        g.ready = legacy_init(width, height, (float)scale, CAMERA_CALIBRATION_YAML, g_want_subsampling);
         g.failed = !g.ready;
     }
     if (!g.ready) return nullptr;
-    // The reference wraps each call's width x height buffers and resizes them to the frozen out_img_size (:587-591).  There is
-    // no resize here: a frame of another size is refused instead of reading W*H*4 bytes from buffers that may be smaller.
-    if (width != g.W || height != g.H) {
-        fprintf(stderr, "stereo_vision_hip: frame is %dx%d but the first call froze %dx%d (stereo_vision.cpp:582); call clean() first\n", width, height, g.W, g.H);
+    // The reference wraps each call's width x height buffers and resizes them to the frozen out_img_size (:587-591).
+    if (width < 1 || height < 1 || (size_t)width * height > ((size_t)1 << 26)) {
+        fprintf(stderr, "stereo_vision_hip: bad frame size %dx%d\n", width, height);
         return nullptr;
     }
-    if (!legacy_frame(left, right)) return nullptr;
+    if (!legacy_frame(left, right, width, height)) return nullptr;
     return g.points;
 }
 
 void clean(void) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (g.engine) sv_destroy(g.engine);
-    void *dptrs[] = {g.d_bgra_l, g.d_bgra_r, g.d_gray_l, g.d_gray_r, g.d_dmap, g.d_disp, g.d_disp2, g.d_points, g.d_Q, g.d_maps, g.d_rect_l, g.d_rect_r};
+    if (g.ready || g.failed) (void)hipSetDevice(g.device);
+    void *dptrs[] = {g.d_bgra_l, g.d_bgra_r, g.d_gray_l, g.d_gray_r, g.d_dmap, g.d_disp, g.d_disp2, g.d_points, g.d_Q, g.d_maps, g.d_rect_l, g.d_rect_r, g.d_src_l, g.d_src_r};
     for (void *p : dptrs)
         if (p) (void)hipFree(p);
+    if (g.ev_in) (void)hipEventDestroy(g.ev_in);
     if (g.stream) (void)hipStreamDestroy(g.stream);
+    if (g.h_stage) (void)hipHostFree(g.h_stage);
     if (g.points) (void)hipHostFree(g.points);
     if (g.h_dmap) (void)hipHostFree(g.h_dmap);
     g = Legacy();
@@ -236,6 +297,16 @@ const double *sv_legacy_Q(void) { return g.ready ? g.rect.Q : nullptr; }
 void sv_legacy_set_rectify(int on) {
     std::lock_guard<std::mutex> lk(g_mu);
     g_want_rectify = on != 0;
+}
+
+void sv_legacy_set_subsampling(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_want_subsampling = on != 0;
+}
+
+void sv_legacy_set_device(int device) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_want_device = device < 0 ? 0 : device;
 }
 
 const float *sv_legacy_rectify_maps(void) { return (g.ready && g.rectify) ? g.h_maps.data() : nullptr; }

@@ -1,6 +1,7 @@
 // Front-/back-end maps of the legacy entry point, on the GPU:
 //   BGRA -> gray        cv::cvtColor(COLOR_BGRA2GRAY) for 8-bit images, OpenCV 4.x fixed point (15-bit weights
 //                       B 3735, G 19235, R 9798, rounding 1<<14)              call site: stereo_vision.cpp:338-339
+//   resize              cv::resize(INTER_LINEAR) of a frame whose size differs from the frozen one           :590-591
 //   f32 -> u8 x4        leftdpf.convertTo(dmap, CV_8UC1, 4.0) = saturate(round-half-even(4*d))       :316
 //   reprojection        pos = Q*[i j d 1]^T, (X,Y,Z) = pos.xyz / pos.w in double                     :233-256
 // OpenCV is an un-vendored dependency of the reference: these restate its documented arithmetic (parity unpinned).
@@ -19,6 +20,50 @@ __global__ __launch_bounds__(256) void k_bgra_to_gray(const uchar4 *__restrict__
 
 void launch_bgra_to_gray(const unsigned char *bgra_l, const unsigned char *bgra_r, unsigned char *gray_l, unsigned char *gray_r, int n, hipStream_t st) {
     hipLaunchKernelGGL(k_bgra_to_gray, dim3((n + 255) / 256), dim3(256), 0, st, (const uchar4 *)bgra_l, (const uchar4 *)bgra_r, gray_l, gray_r, n);
+}
+
+// cv::resize(src, dst, dsize) with the default INTER_LINEAR for 8UC4 images (stereo_vision.cpp:590-591 - the frame a later call
+// hands over is resized to the size the first call froze), OpenCV 4.x's generic path restated: per destination column
+// fx = (float)((dx + 0.5) * scale_x - 0.5), sx = floor(fx), fx -= sx (clamped to the first / last source column with fx = 0),
+// 11-bit coefficients a = cvRound((1 - fx) * 2048), cvRound(fx * 2048); rows likewise, their indices clipped instead;
+// horizontal pass in int (S0*a0 + S1*a1), vertical pass ((b0*(H0>>4))>>16) + ((b1*(H1>>4))>>16) + 2) >> 2.  Exact 2x
+// decimation in both directions takes OpenCV's INTER_AREA shortcut ((sum of the 2x2 block + 2) >> 2).  Equal sizes are a
+// plain copy and never get here.  Parity unpinned, like the other OpenCV restatements of this file.
+__global__ __launch_bounds__(256) void k_resize_bgra(const uchar4 *__restrict__ src, int sw, int sh, uchar4 *__restrict__ dst, int dw, int dh, double scale_x, double scale_y,
+                                                     int area2) {
+    const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+    if (dx >= dw) return;
+    if (area2) {
+        const uchar4 a = src[(size_t)(2 * dy) * sw + 2 * dx], b = src[(size_t)(2 * dy) * sw + 2 * dx + 1];
+        const uchar4 c = src[(size_t)(2 * dy + 1) * sw + 2 * dx], e = src[(size_t)(2 * dy + 1) * sw + 2 * dx + 1];
+        dst[(size_t)dy * dw + dx] = make_uchar4((unsigned char)((a.x + b.x + c.x + e.x + 2) >> 2), (unsigned char)((a.y + b.y + c.y + e.y + 2) >> 2),
+                                                (unsigned char)((a.z + b.z + c.z + e.z + 2) >> 2), (unsigned char)((a.w + b.w + c.w + e.w + 2) >> 2));
+        return;
+    }
+    float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
+    int sx = (int)floorf(fx);
+    fx -= (float)sx;
+    if (sx < 0) fx = 0.f, sx = 0;
+    if (sx >= sw - 1) fx = 0.f, sx = sw - 1;
+    const int a0 = __float2int_rn((1.f - fx) * 2048.f), a1 = __float2int_rn(fx * 2048.f);
+    const int sx1 = min(sx + 1, sw - 1);
+    float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+    const int sy = (int)floorf(fy);
+    fy -= (float)sy;
+    const int b0 = __float2int_rn((1.f - fy) * 2048.f), b1 = __float2int_rn(fy * 2048.f);
+    const int y0 = min(max(sy, 0), sh - 1), y1 = min(max(sy + 1, 0), sh - 1);
+    const uchar4 p00 = src[(size_t)y0 * sw + sx], p01 = src[(size_t)y0 * sw + sx1], p10 = src[(size_t)y1 * sw + sx], p11 = src[(size_t)y1 * sw + sx1];
+    auto mix = [&](int s00, int s01, int s10, int s11) -> unsigned char {
+        const int h0 = s00 * a0 + s01 * a1, h1 = s10 * a0 + s11 * a1;
+        return (unsigned char)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    };
+    dst[(size_t)dy * dw + dx] = make_uchar4(mix(p00.x, p01.x, p10.x, p11.x), mix(p00.y, p01.y, p10.y, p11.y), mix(p00.z, p01.z, p10.z, p11.z), mix(p00.w, p01.w, p10.w, p11.w));
+}
+
+void launch_resize_bgra(const unsigned char *src, int sw, int sh, unsigned char *dst, int dw, int dh, hipStream_t st) {
+    const double scale_x = 1.0 / ((double)dw / sw), scale_y = 1.0 / ((double)dh / sh);  // resize.cpp: scale = 1 / inv_scale
+    const int area2 = (sw == 2 * dw && sh == 2 * dh) ? 1 : 0;
+    hipLaunchKernelGGL(k_resize_bgra, dim3((dw + 255) / 256, dh), dim3(256), 0, st, (const uchar4 *)src, sw, sh, (uchar4 *)dst, dw, dh, scale_x, scale_y, area2);
 }
 
 // cv::remap(src, dst, mapx, mapy, INTER_LINEAR) for 8-bit single-channel images and CV_32FC1 maps, BORDER_CONSTANT(0)

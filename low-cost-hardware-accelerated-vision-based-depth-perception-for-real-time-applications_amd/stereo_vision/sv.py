@@ -9,7 +9,8 @@ Same class, constructor arguments, ctypes signature and CLI flags as the referen
 
 Differences, all forced by the environment or by bugs of the reference:
   * no cv2: BGR->BGRA is a numpy concatenate, images are read with PIL;
-  * all 16 C arguments are passed (the reference passes 14, so the callee reads removeSky/subsampling from garbage);
+  * the C function is called with the reference's 14 arguments (sv.py:180,189); the library does not read arguments 15/16
+    (removeSky, subsampling) - half-resolution mode is selected with sv_legacy_set_subsampling() before the first frame;
   * __del__ calls clean(), which here frees the library state but does NOT exit() the interpreter;
   * the dataset download helpers of the reference's CLI are not provided (no network); --demo reads --kitti.
 """
@@ -52,10 +53,13 @@ class stereo_vision:
         self.YOLO_CLASSES = YOLO_CLASSES
         self.CAMERA_CALIBRATION_YAML = CAMERA_CALIBRATION_YAML
         self.subsampling = bool(subsampling)
-        # reference: sv.py:180 lists 14 entries; the C function takes 16 (stereo_vision.cpp:566-581)
+        # reference: sv.py:180 - 14 entries (the C function declares 16, stereo_vision.cpp:566-581; the last two are never read here)
         self.sv.generatePointCloud.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_bool,
                                                ctypes.c_bool, ctypes.c_bool, ctypes.c_bool, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
-                                               ctypes.c_char_p, ctypes.c_char_p, ctypes.c_bool, ctypes.c_bool]
+                                               ctypes.c_char_p, ctypes.c_char_p]
+        self.sv.sv_legacy_set_subsampling.argtypes = [ctypes.c_int]
+        self.sv.sv_legacy_set_subsampling.restype = None
+        self.sv.sv_legacy_set_subsampling(int(self.subsampling))  # frozen by the first frame, like the driver's static Elas (stereo_vision.cpp:307-311)
         self.sv.clean.restype = None
         self._closed = False
         self._bgra = None
@@ -80,8 +84,7 @@ class stereo_vision:
         try:
             return self.sv.generatePointCloud(self._bgra[0].ctypes.data, self._bgra[1].ctypes.data, self.CAMERA_CALIBRATION_YAML.encode("utf-8"), self.width, self.height, self.defaultCalibFile,
                                               self.objectTracking, self.graphics, self.display, self.scale, self.pc_extrapolation,
-                                              self.YOLO_CFG.encode("utf-8"), self.YOLO_WEIGHTS.encode("utf-8"), self.YOLO_CLASSES.encode("utf-8"),
-                                              False, self.subsampling)
+                                              self.YOLO_CFG.encode("utf-8"), self.YOLO_WEIGHTS.encode("utf-8"), self.YOLO_CLASSES.encode("utf-8"))
         except ValueError as e:  # NULL pointer from the library: initialisation or a HIP call failed (message on stderr)
             raise RuntimeError("generatePointCloud failed (see stderr)") from e
 

@@ -172,7 +172,7 @@ def test_colour_crop_fixture_matches_gray_fixture():
 def test_generate_point_cloud_colour_input(oracle):
     """Distinct B, G, R through k_bgra_to_gray (stereo_vision.cpp:338-339): the u8 disparity image equals the oracle's result on
     gray_cv4 of the same colour images (disp_max 255 as the driver runs it) - a B/R swap or wrong weights change the gray
-    image and with it the map.  Also: the first call freezes the size (stereo_vision.cpp:582); another size is refused."""
+    image and with it the map."""
     svmod = util.pkg("stereo_vision")
     rgb_l, rgb_r = util.load_png("kitti0_crop_color_left.png"), util.load_png("kitti0_crop_color_right.png")
     H, W = rgb_l.shape[:2]
@@ -184,9 +184,6 @@ def test_generate_point_cloud_colour_input(oracle):
         pts = s.generatePointCloud(rgb_l[..., ::-1], rgb_r[..., ::-1])  # BGR, as cv2.imread hands images to the reference's wrapper
         assert pts.shape == (W * H, 3)
         dmap = s.last_disparity_u8()
-        with pytest.raises(ValueError):  # NULL return: the frozen size is W x H, the buffers of another size are not touched
-            s.sv.generatePointCloud(s._bgra[0].ctypes.data, s._bgra[1].ctypes.data, s.CAMERA_CALIBRATION_YAML.encode(), W + 8, H, True, False, False, False, 1, 0,
-                                    b"", b"", b"", False, False)
     finally:
         s.close()
     d1, _, _ = oracle.process(ElasParams.driver(255), gl, gr)
@@ -269,5 +266,108 @@ def test_generate_point_cloud_with_rectification(oracle):
     want_l, want_r = _remap_linear_u8(_gray_cv4(rgb_l), maps[0], maps[1]), _remap_linear_u8(_gray_cv4(rgb_r), maps[2], maps[3])
     assert (want_l != _gray_cv4(rgb_l)).mean() > 0.2  # the maps of this calibration at this size are not the identity
     assert np.array_equal(gl, want_l) and np.array_equal(gr, want_r)
+    d1, _, _ = oracle.process(ElasParams.driver(255), gl, gr)
+    assert np.array_equal(dmap, np.clip(np.rint(d1 * np.float32(4.0)), 0, 255).astype(np.uint8))
+
+
+def _resize_linear_8uc4(src, dw, dh):
+    """cv::resize(INTER_LINEAR) for 8-bit images as legacy_kernels.hip restates it (OpenCV 4.x generic path; exact 2x decimation =
+    the INTER_AREA shortcut): float32 coordinate arithmetic, 11-bit coefficients, the two-step integer blend."""
+    sh, sw = src.shape[:2]
+    S = src.astype(np.int64)
+    if sw == 2 * dw and sh == 2 * dh:
+        return ((S[0::2, 0::2] + S[0::2, 1::2] + S[1::2, 0::2] + S[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    f32 = np.float32
+
+    def coeffs(n_dst, n_src, clamp):
+        scale = 1.0 / (n_dst / n_src)
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(f32)
+        i = np.floor(f).astype(np.int64)
+        f = (f - i.astype(f32)).astype(f32)
+        if clamp:
+            lo, hi = i < 0, i >= n_src - 1
+            f = np.where(lo | hi, f32(0), f)
+            i = np.where(lo, 0, np.where(hi, n_src - 1, i))
+        c0 = np.rint((f32(1) - f) * f32(2048)).astype(np.int64)
+        c1 = np.rint(f * f32(2048)).astype(np.int64)
+        return i, c0, c1
+
+    sx, a0, a1 = coeffs(dw, sw, True)
+    sy, b0, b1 = coeffs(dh, sh, False)
+    sx1 = np.minimum(sx + 1, sw - 1)
+    y0, y1 = np.clip(sy, 0, sh - 1), np.clip(sy + 1, 0, sh - 1)
+    h0 = S[y0][:, sx] * a0[None, :, None] + S[y0][:, sx1] * a1[None, :, None]
+    h1 = S[y1][:, sx] * a0[None, :, None] + S[y1][:, sx1] * a1[None, :, None]
+    return ((((b0[:, None, None] * (h0 >> 4)) >> 16) + ((b1[:, None, None] * (h1 >> 4)) >> 16) + 2) >> 2).astype(np.uint8)
+
+
+def _bgra(rgb):
+    return np.ascontiguousarray(np.concatenate([rgb[..., ::-1], np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=2))
+
+
+@pytest.mark.gpu
+def test_reference_binding_with_fourteen_arguments():
+    """The reference's own ctypes binding, entry for entry (stereo_vision/sv.py:167,180,189): 14 argtypes, the BGRA buffers passed as
+    bytes, 14 arguments.  Arguments 15/16 of the C signature are then undefined - the library must not read them: the map is
+    the full-resolution golden one (half-resolution mode can only come from sv_legacy_set_subsampling)."""
+    from numpy.ctypeslib import ndpointer
+    eng = util.pkg("engine")
+    L, R = util.load_png("kitti0_left.png"), util.load_png("kitti0_right.png")
+    H, W = L.shape
+    lib = _lib(eng)
+    lib.generatePointCloud.restype = ndpointer(dtype=ctypes.c_double, shape=(W * H, 3))
+    lib.generatePointCloud.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_bool, ctypes.c_bool, ctypes.c_bool,
+                                       ctypes.c_bool, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    lib.clean.restype = None
+    yml = os.path.join(os.path.dirname(eng.LIB_PATH), "stereo_vision", "data", "kitti_2011_09_26.yml").encode("utf-8")
+    left = _bgra(np.repeat(L[:, :, None], 3, 2)).tobytes()
+    right = _bgra(np.repeat(R[:, :, None], 3, 2)).tobytes()
+    try:
+        for _ in range(3):  # (whatever the unread slots hold, call after call)
+            pts = lib.generatePointCloud(left, right, yml, W, H, True, False, False, False, 1, 1, b"src/yolo/yolov4-tiny.cfg", b"src/yolo/yolov4-tiny.weights", b"src/yolo/classes.txt")
+            assert pts.shape == (W * H, 3)
+            w, h = ctypes.c_int(), ctypes.c_int()
+            lib.sv_legacy_last_dmap.restype = ctypes.POINTER(ctypes.c_ubyte)
+            dmap = np.ctypeslib.as_array(lib.sv_legacy_last_dmap(ctypes.byref(w), ctypes.byref(h)), shape=(H, W)).copy()
+            final = util.golden_npz("kitti0_d256")["final1"].reshape(H, W)
+            assert np.array_equal(dmap, np.clip(np.rint(final * np.float32(4.0)), 0, 255).astype(np.uint8))
+    finally:
+        lib.clean()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("factor", ["2x", "1.25x", "0.8x"])
+def test_frames_of_another_size_are_resized(oracle, factor):
+    """stereo_vision.cpp:587-591: every call's width x height buffers are resized to the size the first call froze.  The gray images
+    the matcher received equal gray_cv4(resize restatement) of the frame, and the map equals the oracle's on those images."""
+    eng = util.pkg("engine")
+    rgb_l, rgb_r = util.load_png("kitti0_crop_color_left.png"), util.load_png("kitti0_crop_color_right.png")
+    H, W = rgb_l.shape[:2]  # the frozen size: 320 x 128
+    sw, sh = {"2x": (2 * W, 2 * H), "1.25x": (W * 5 // 4, H * 5 // 4), "0.8x": (W * 4 // 5, 102)}[factor]
+    from PIL import Image
+    big_l = np.asarray(Image.fromarray(rgb_l).resize((sw, sh), Image.BICUBIC))  # any frame of the other size will do
+    big_r = np.asarray(Image.fromarray(rgb_r).resize((sw, sh), Image.BICUBIC))
+    lib = _lib(eng)
+    lib.generatePointCloud.restype = ctypes.c_void_p
+    lib.generatePointCloud.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_bool, ctypes.c_bool, ctypes.c_bool,
+                                       ctypes.c_bool, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p]
+    lib.clean.restype = None
+    lib.getColor.restype = ctypes.POINTER(ctypes.c_ubyte)
+    yml = os.path.join(os.path.dirname(eng.LIB_PATH), "stereo_vision", "data", "kitti_2011_09_26.yml").encode("utf-8")
+    a_l, a_r, b_l, b_r = _bgra(rgb_l), _bgra(rgb_r), _bgra(big_l), _bgra(big_r)
+    try:
+        assert lib.generatePointCloud(a_l.ctypes.data, a_r.ctypes.data, yml, W, H, True, False, False, False, 1, 1, b"", b"", b"")  # freezes W x H
+        assert lib.generatePointCloud(b_l.ctypes.data, b_r.ctypes.data, yml, sw, sh, True, False, False, False, 1, 1, b"", b"", b"")
+        gl, gr = np.zeros((H, W), np.uint8), np.zeros((H, W), np.uint8)
+        lib.sv_legacy_last_gray.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        assert lib.sv_legacy_last_gray(gl.ctypes.data, gr.ctypes.data) == 0
+        lib.sv_legacy_last_dmap.restype = ctypes.POINTER(ctypes.c_ubyte)
+        dmap = np.ctypeslib.as_array(lib.sv_legacy_last_dmap(None, None), shape=(H, W)).copy()
+        colors = np.ctypeslib.as_array(lib.getColor(), shape=(H, W, 4)).copy()
+    finally:
+        lib.clean()
+    want_l, want_r = _resize_linear_8uc4(b_l, W, H), _resize_linear_8uc4(b_r, W, H)
+    assert np.array_equal(colors, want_l)  # left_img_OLD, what the viewer colours the cloud with
+    assert np.array_equal(gl, _gray_cv4(want_l[..., 2::-1])) and np.array_equal(gr, _gray_cv4(want_r[..., 2::-1]))
     d1, _, _ = oracle.process(ElasParams.driver(255), gl, gr)
     assert np.array_equal(dmap, np.clip(np.rint(d1 * np.float32(4.0)), 0, 255).astype(np.uint8))
