@@ -327,7 +327,10 @@ class _PinnedBlock:
 
     def __del__(self):
         if getattr(self, "ptr", None):
-            lib().sv_host_free(self.ptr)
+            try:
+                lib().sv_host_free(self.ptr)
+            except TypeError:  # interpreter shutdown: the module globals are already gone (the process's memory goes with it)
+                pass
             self.ptr = None
 
 

@@ -35,7 +35,7 @@ for sub in (False, True):
     tc = []
     for _ in range(100):
         t0 = time.perf_counter()
-        s.sv.generatePointCloud(ctypes.cast(lb, ctypes.c_void_p), ctypes.cast(rb, ctypes.c_void_p), yml, W, H, s.defaultCalibFile, False, False, False, s.scale, 1, b"", b"", b"", False, sub)
+        s.sv.generatePointCloud(ctypes.cast(lb, ctypes.c_void_p), ctypes.cast(rb, ctypes.c_void_p), yml, W, H, s.defaultCalibFile, False, False, False, s.scale, 1, b"", b"", b"")
         tc.append(time.perf_counter() - t0)
     print("  C entry point alone: median %.3f ms  p99 %.3f ms" % (1e3 * np.median(tc), 1e3 * np.percentile(tc, 99)))
     print("generatePointCloud subsampling=%s: median %.3f ms  p99 %.3f ms (disp_max 255, incl. BGR->BGRA in numpy, H2D, D2H of 11 MB of points)"
