@@ -105,6 +105,7 @@ enum sv_query_key {
     SV_Q_GPU_TRIANGULATION = 4,  /* 1: Delaunay divide-and-conquer on the GPU (few host threads), 0: on the host pool */
     SV_Q_GPU_TRIANGULATION_FALLBACKS = 6, /* vertex sets handed to the GPU kernel's share that the host triangulated after all (larger
                                              than the kernels take: 131 072 vertices) */
+    SV_Q_NUMA_BOUND = 7,         /* 1: the handle's host threads are bound to the CPUs of the GPU's NUMA node (SV_NO_AFFINITY=1 disables) */
     SV_Q_GPU_TRIANGULATION_SHARE = 5 /* per mille of the pairs so far whose triangulations the GPU kernel built (in the host mode the
                                         dispatcher hands it a share of a chunk while the pool is behind; results are identical) */
 };

@@ -14,7 +14,9 @@
 // Stage 1 runs ahead as far as the ring allows, so the pool always has work and phase-1 kernels of later chunks overlap
 // phase-2 kernels of earlier ones on the GPU.  Every launch covers a whole chunk (batch index in blockIdx.z / .y).
 // No allocation, hipMalloc or device-wide synchronisation on the per-batch path.
+#include <ctype.h>
 #include <math.h>
+#include <pthread.h>
 #include <sched.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -143,6 +145,7 @@ struct sv_handle {
     int auto_pct = 0;             // (dispatcher thread only)
     std::atomic<int64_t> gpu_tri_fallbacks{0};  // vertex sets of flagged pairs that the host triangulated after all (too large, or degenerate)
     std::atomic<int64_t> gpu_tri_pairs{0}, tri_pairs{0};  // pairs triangulated by the GPU kernel / all pairs, since creation
+    bool node_bound = false;  // the handle's threads are bound to the CPUs of the GPU's NUMA node
     bool gpu_filter = false;  // lattice filters on the GPU (k_support_filter) instead of the host pool
     std::vector<Slot *> slots;
     hipStream_t sP1 = nullptr, sPF[2] = {nullptr, nullptr};  // phase 1; lattice filter + its D2H (two streams, taken in turns:
@@ -1182,6 +1185,57 @@ int default_pool_size() {
     return std::max(1, std::min(have_quota ? 32 : 16, have_quota && share > 4 ? share - 2 : share));
 }
 
+// CPUs of the NUMA node the GPU hangs off (its PCI device's numa_node), within this process's affinity mask.  The handle's threads
+// are bound to them: their page-locked buffers live on that node (the runtime places hipHostMalloc memory next to the device),
+// and a process with a CPU quota but the whole machine in its mask (16 of 256 CPUs on the test boxes) is otherwise moved between
+// the sockets.  Empty (no binding) when the topology cannot be read, the node has no allowed CPU, or SV_NO_AFFINITY is set.
+bool gpu_node_cpus(int device, cpu_set_t *out) {
+    CPU_ZERO(out);
+    if (getenv("SV_NO_AFFINITY")) return false;
+    char bdf[64] = {0}, path[256], buf[4096];
+    if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), device) != hipSuccess) return false;
+    for (char *c = bdf; *c; c++) *c = (char)tolower(*c);
+    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+    int node = -1;
+    if (FILE *f = fopen(path, "r")) {
+        if (fscanf(f, "%d", &node) != 1) node = -1;
+        fclose(f);
+    }
+    if (node < 0) return false;
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    const bool got = fgets(buf, sizeof(buf), f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+    int n = 0;
+    for (char *p = buf; *p;) {  // "0-63,128-191"
+        char *end;
+        const long a = strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0 && CPU_ISSET((int)c, &allowed)) {
+                CPU_SET((int)c, out);
+                n++;
+            }
+        while (*p == ',' || *p == '\n' || *p == ' ') p++;
+    }
+    return n > 0;
+}
+
+void bind_thread(std::thread &t, const cpu_set_t *set) {
+    if (set) (void)pthread_setaffinity_np(t.native_handle(), sizeof(cpu_set_t), set);
+}
+
 template <class T>
 void dev_alloc(T *&p, size_t count) {
     HIP_TRY(hipMalloc((void **)&p, count * sizeof(T)));
@@ -1658,10 +1712,14 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         delete h;
         return SV_ERR_HIP;
     }
+    cpu_set_t node_cpus;
+    const cpu_set_t *bind = gpu_node_cpus(cfg->device, &node_cpus) ? &node_cpus : nullptr;
+    h->node_bound = bind != nullptr;
     for (int i = 0; i < npool; i++) {
         HostScratch *sc = new HostScratch();
         h->scratch.push_back(sc);
         h->pool.emplace_back(pool_main, h, sc);
+        bind_thread(h->pool.back(), bind);
     }
     h->inline_scratch = new HostScratch();
     h->inline_ok = getenv("SV_NO_INLINE") == nullptr;
@@ -1671,6 +1729,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     h->t_finish = std::thread(finisher_main, h);
     h->t_drain = std::thread(drainer_main, h);
     h->t_deliver = std::thread(deliverer_main, h);
+    for (std::thread *t : {&h->t_issue, &h->t_dispatch, &h->t_finish, &h->t_drain, &h->t_deliver}) bind_thread(*t, bind);
     *out = h;
     return SV_OK;
 }
@@ -1730,6 +1789,7 @@ int sv_query(const sv_handle *h, int what) {
         case SV_Q_SLOTS: return (int)h->slots.size();
         case SV_Q_GPU_LATTICE_FILTER: return h->gpu_filter ? 1 : 0;
         case SV_Q_GPU_TRIANGULATION: return h->gpu_delaunay ? 1 : 0;
+        case SV_Q_NUMA_BOUND: return h->node_bound ? 1 : 0;
         case SV_Q_GPU_TRIANGULATION_FALLBACKS: return (int)std::min<int64_t>(h->gpu_tri_fallbacks.load(), 0x7FFFFFFF);
         case SV_Q_GPU_TRIANGULATION_SHARE: {
             const int64_t all = h->tri_pairs.load(), g = h->gpu_tri_pairs.load();

@@ -281,7 +281,9 @@ class StereoEngine:
         """What the handle decided at creation: host threads, chunk, slots, where the lattice filters and the triangulations run."""
         L = lib()
         keys = ["host_threads", "chunk", "slots", "gpu_lattice_filter", "gpu_triangulation"]
-        return {k: int(L.sv_query(self._h, i)) for i, k in enumerate(keys)}
+        out = {k: int(L.sv_query(self._h, i)) for i, k in enumerate(keys)}
+        out["numa_bound"] = int(L.sv_query(self._h, 7))
+        return out
 
     def gpu_triangulation_share(self):
         """Fraction of the pairs so far whose triangulations the GPU kernel built (host mode: the dispatcher's load balancing)."""
