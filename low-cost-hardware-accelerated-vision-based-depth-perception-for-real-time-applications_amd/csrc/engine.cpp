@@ -142,7 +142,8 @@ struct sv_handle {
     int dg_sub_max = 0;           // vertex sets up to this size are triangulated whole in LDS, larger ones as subtrees of at most this size
     int dg_limit = 0;             // largest vertex set the GPU kernels take (LDS kernel: 4 000; with the slots' global-memory scratch: more)
     bool gpu_share_auto = false;  // host mode: the dispatcher moves that share up while the pool falls behind the GPU, down while it idles
-    int auto_pct = 0;             // (dispatcher thread only)
+    int auto_pct = 0, auto_acc = 0;  // (dispatcher thread only)
+    bool share_sliced = false;    // the GPU kernel's share as a slice of every chunk instead of whole chunks
     std::atomic<int64_t> gpu_tri_fallbacks{0};  // vertex sets of flagged pairs that the host triangulated after all (too large, or degenerate)
     std::atomic<int64_t> gpu_tri_pairs{0}, tri_pairs{0};  // pairs triangulated by the GPU kernel / all pairs, since creation
     bool node_bound = false;  // the handle's threads are bound to the CPUs of the GPU's NUMA node
@@ -930,7 +931,19 @@ void dispatcher_main(sv_handle *h) {
             //  47 % with 10, 60 % with 8, 74 % with 6, 86 % with 4 - each 1-2 % above what the all-GPU mode reaches)
             if (backlog > s->n) h->auto_pct = std::min(h->auto_pct + 2, 95);
             else if (backlog * 4 <= s->n) h->auto_pct = std::max(h->auto_pct - 2, 0);
-            s->gpu_pct = h->auto_pct;
+            // The share is handed out in whole chunks (every 1 / share-th chunk goes to the GPU kernel entirely) rather than as a
+            // slice of every chunk: the kernel is a latency chain of ~0.9 ms whatever the number of sets (one workgroup each), so
+            // fewer, fuller launches cost the same GPU time per set and a quarter of the launches.  SV_GPU_DELAUNAY_SLICED=1: the old way.
+            if (h->share_sliced) {
+                s->gpu_pct = h->auto_pct;
+            } else {
+                h->auto_acc += h->auto_pct;
+                s->gpu_pct = 0;
+                if (h->auto_acc >= 100) {
+                    h->auto_acc -= 100;
+                    s->gpu_pct = 100;
+                }
+            }
         }
         {
             std::lock_guard<std::mutex> lk(h->qmu);
@@ -1686,6 +1699,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     // host mode without a fixed share: the share follows the pool's backlog (42 600 against 40 100 pairs/s with 14 threads)
     h->gpu_share_auto = !h->gpu_delaunay && !getenv("SV_GPU_DELAUNAY_PCT") && !cfg->keep_debug && h->chunk >= 4;
     if (const char *e = getenv("SV_GPU_DELAUNAY_AUTO")) h->gpu_share_auto = h->gpu_share_auto && atoi(e) != 0;
+    h->share_sliced = getenv("SV_GPU_DELAUNAY_SLICED") != nullptr;
     // start where the balance was measured to settle (4 ... 14 threads); a handle with fewer than four slots cannot build up a backlog
     if (h->gpu_share_auto && nslots >= 4) h->auto_pct = std::max(0, std::min(95, 117 - 7 * npool));
     if (!(h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0)) h->dg_limit = h->dg_sub_max;  // the pool triangulates everything: no scratch
