@@ -599,78 +599,108 @@ __global__ __launch_bounds__(FCL_THREADS) void k_filter_classify(Dims d, int win
 
 // ---- (2) the uncertain points: parallel refinement rounds, then the rest in scan order by one wavefront; the states it
 // leaves behind are final (KEEP / DROP).  One workgroup per pair; its work is proportional to the number of classify blocks
-// and of uncertain points, not to the lattice.
-__global__ __launch_bounds__(RSV_THREADS) void k_filter_resolve(Dims d, int win, int thr, int need, const int16_t *__restrict__ dcan, uint8_t *fst, uint32_t *useg,
-                                                                const int32_t *__restrict__ ucnt, int nb, uint32_t *ulist) {
+// and of uncertain points, not to the lattice.  Uncertain point q (in scan order) is entry q - pref[b] of the segment of the
+// classify block b with pref[b] <= q < pref[b + 1]: a binary search in the blocks' prefix sums (LDS) spreads the points evenly
+// over the threads however they cluster in the lattice (they do: along depth edges).
+#define RSV_MAX_BLOCKS 8192  // classify blocks per pair whose prefix sums fit the LDS table (lattices up to 2 M points)
+__global__ __launch_bounds__(RSV_THREADS) void k_filter_resolve(Dims d, int win, int thr, int need, const int16_t *__restrict__ dcan, uint8_t *fst, const uint32_t *__restrict__ useg,
+                                                                const int32_t *__restrict__ ucnt, int nb, uint32_t *__restrict__ ulist, uint32_t *__restrict__ urest) {
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int Hc = d.Hc, lat = d.Wc * Hc;
     const int16_t *T = dcan + (size_t)pair * lat;
     uint8_t *st = fst + (size_t)pair * lat;
-    uint32_t *seg = useg + (size_t)pair * lat;
-    uint32_t *list = ulist + (size_t)pair * lat;
+    const uint32_t *seg = useg + (size_t)pair * lat;
+    uint32_t *list = ulist + (size_t)pair * lat, *rest = urest + (size_t)pair * lat;
     __shared__ int s_wave[RSV_THREADS / 64];
-    // ordered list of the uncertain points from the classify blocks' segments
+    extern __shared__ int s_pref[];  // [nb + 1]
+    const int32_t *cnt = ucnt + (size_t)pair * nb;
     const int per = (nb + RSV_THREADS - 1) / RSV_THREADS;
     const int b_lo = min(tid * per, nb), b_hi = min(b_lo + per, nb);
-    const int32_t *cnt = ucnt + (size_t)pair * nb;
     int mine = 0;
     for (int b = b_lo; b < b_hi; b++) mine += cnt[b];
     int n_unc;
     int pos = block_exclusive_scan<RSV_THREADS>(mine, s_wave, &n_unc);
     if (n_unc == 0) return;
     for (int b = b_lo; b < b_hi; b++) {
-        const int c = cnt[b];
-        for (int r = 0; r < c; r++) list[pos++] = seg[(size_t)b * FCL_THREADS + r];
+        s_pref[b] = pos;
+        pos += cnt[b];
+    }
+    if (tid == 0) s_pref[nb] = n_unc;
+    __syncthreads();
+    for (int q = tid; q < n_unc; q += RSV_THREADS) {  // the ordered list: one entry per thread and trip
+        int lo = 0, hi = nb;                          // largest b with pref[b] <= q (empty blocks share a prefix: take the last)
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_pref[mid] <= q) lo = mid;
+            else hi = mid;
+        }
+        list[q] = seg[(size_t)lo * FCL_THREADS + (q - s_pref[lo])];
     }
     __threadfence_block();
     __syncthreads();
     // refinement rounds over the uncertain points, fully parallel: earlier neighbours that are certainly kept count
     // for sure, earlier neighbours that are certainly dropped never count.  (A round only reads states of EARLIER points and
     // only turns UNC into KEEP/DROP; both decisions stay valid whatever the remaining UNC points become, so concurrent
-    // updates are benign.)
-    for (int round = 0; round < 3; round++) {
+    // updates are benign.)  The rounds end as soon as one of them leaves nothing behind.
+    int left = 1;
+    for (int round = 0; round < 3 && left; round++) {
+        int open = 0;
         for (int q = tid; q < n_unc; q += RSV_THREADS) {
             const int idx = (int)list[q];
             const int s0 = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if ((s0 & 3) != FST_UNC) continue;
             const int dd = T[idx], c_late = s0 >> 2;
             const int u = idx / Hc, v = idx - u * Hc;
+            // the 60 earlier neighbours: values and states requested together (plain loads: a state byte read while another thread of
+            // this workgroup settles that point is the old or the new state, and either is valid for a round), then counted
+            int nd[60], ns[60];
+            {
+                int t = 0;
+#pragma unroll
+                for (int du = -5; du <= 0; du++) {
+                    const int u2 = u + du;
+                    const bool col_ok = du >= -win && u2 >= 0;
+#pragma unroll
+                    for (int dv = -5; dv <= 5; dv++) {
+                        if (du == 0 && dv >= 0) continue;
+                        const int v2 = v + dv;
+                        const bool ok = col_ok && dv >= -win && dv <= win && v2 >= 0 && v2 < Hc;
+                        const int j = (ok ? u2 : u) * Hc + (ok ? v2 : v);
+                        nd[t] = ok ? (int)T[j] : -1;
+                        ns[t] = st[j];
+                        t++;
+                    }
+                }
+            }
             int sure = 0, maybe = 0;
 #pragma unroll
-            for (int du = -5; du <= 0; du++) {
-                const int u2 = u + du;
-                const bool col_ok = du >= -win && u2 >= 0;
-#pragma unroll
-                for (int dv = -5; dv <= 5; dv++) {
-                    if (du == 0 && dv >= 0) continue;
-                    const int v2 = v + dv;
-                    const bool ok = col_ok && dv >= -win && dv <= win && v2 >= 0 && v2 < Hc;
-                    const int j = (ok ? u2 : u) * Hc + (ok ? v2 : v);
-                    const int d2 = T[j], s2 = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 3;
-                    const int cons = ok & (d2 >= 0) & (abs(dd - d2) <= thr);
-                    sure += cons & (s2 == FST_KEEP);
-                    maybe += cons & (s2 == FST_UNC);
-                }
+            for (int t = 0; t < 60; t++) {
+                const int cons = (nd[t] >= 0) & (abs(dd - nd[t]) <= thr);
+                sure += cons & ((ns[t] & 3) == FST_KEEP);
+                maybe += cons & ((ns[t] & 3) == FST_UNC);
             }
             if (c_late + sure >= need)
                 __hip_atomic_store(&st[idx], (uint8_t)FST_KEEP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else if (c_late + sure + maybe < need)
                 __hip_atomic_store(&st[idx], (uint8_t)FST_DROP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else
+                open++;
         }
         __threadfence_block();
-        __syncthreads();
+        left = __syncthreads_or(open);
     }
-    // what is still uncertain, in order, into the (now free) segment buffer
-    uint32_t *rest = seg;
+    if (!left) return;
+    // what is still uncertain, in order
     int n_rest = 0;
     {
         const int per_q = (n_unc + RSV_THREADS - 1) / RSV_THREADS;
         const int q_lo = min(tid * per_q, n_unc), q_hi = min(q_lo + per_q, n_unc);
-        int left = 0;
-        for (int q = q_lo; q < q_hi; q++) left += (st[list[q]] & 3) == FST_UNC ? 1 : 0;
-        int p2 = block_exclusive_scan<RSV_THREADS>(left, s_wave, &n_rest);
-        for (int q = q_lo; q < q_hi; q++)
-            if ((st[list[q]] & 3) == FST_UNC) rest[p2++] = list[q];
+        int open = 0;
+        for (int q = q_lo; q < q_hi; q++) open += (st[list[q]] & 3) == FST_UNC ? 1 : 0;
+        int p2 = block_exclusive_scan<RSV_THREADS>(open, s_wave, &n_rest);
+        if (open)
+            for (int q = q_lo; q < q_hi; q++)
+                if ((st[list[q]] & 3) == FST_UNC) rest[p2++] = list[q];
         __threadfence_block();
         __syncthreads();
     }
@@ -982,7 +1012,10 @@ void launch_support_filter(const KParams &k, int win, int thr, int need, const S
     ensure_dynamic_lds(k_filter_vertical, v_lds, granted_v, "support_filter (vertical)");
     ensure_dynamic_lds(k_filter_horizontal, h_lds, granted_h, "support_filter (horizontal)");
     SV_LAUNCH(K_SUPPORT_FILTER, k_filter_classify, dim3((unsigned)nb, n), dim3(FCL_THREADS), cl_lds, st, k.d, win, thr, need, s.dcan, fst, useg, ucnt);
-    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_resolve, dim3(n), dim3(RSV_THREADS), 0, st, k.d, win, thr, need, s.dcan, fst, useg, ucnt, nb, ulist);
+    if (nb > RSV_MAX_BLOCKS) throw std::runtime_error("support_filter: lattice too large for the resolve step's block table");
+    // (urest: the remaining points after the rounds; they overwrite nothing the rounds' list still needs - a buffer of its own: latC is free until the horizontal pass)
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_resolve, dim3(n), dim3(RSV_THREADS), sizeof(int) * ((size_t)nb + 1), st, k.d, win, thr, need, s.dcan, fst, useg, ucnt, nb, ulist,
+              reinterpret_cast<uint32_t *>(latB));
     SV_LAUNCH(K_SUPPORT_FILTER, k_filter_vertical, dim3((k.d.Wc + SW - 1) / SW, n), dim3(FRD_THREADS), v_lds, st, k.d, SW, s.dcan, fst, latB);
     SV_LAUNCH(K_SUPPORT_FILTER, k_filter_horizontal, dim3((k.d.Hc + SH - 1) / SH, n), dim3(FRD_THREADS), h_lds, st, k.d, SH, latB, latC);
     SV_LAUNCH(K_SUPPORT_FILTER, k_filter_count, dim3(nb2, n), dim3(FLT_THREADS), 0, st, k.d, latC, bcnt);
