@@ -36,6 +36,119 @@ def test_stereo_rectify_structure():
     assert abs(Qh[2, 3] / f - 0.5) < 0.01                                    # half-size images: half the focal length
 
 
+def _rodrigues(v):
+    """Rotation vector -> matrix (Rodrigues' formula), numpy."""
+    th = float(np.linalg.norm(v))
+    if th < np.finfo(float).eps:
+        return np.eye(3)
+    k = np.asarray(v, float) / th
+    K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.cos(th) * np.eye(3) + (1 - np.cos(th)) * np.outer(k, k) + np.sin(th) * K
+
+
+def _rodrigues_inv(R):
+    """Matrix -> rotation vector as cvRodrigues2 does it: nearest rotation by SVD first, then axis * angle."""
+    U, _, Vt = np.linalg.svd(R)
+    R = U @ Vt
+    r = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    s, c = np.linalg.norm(r) / 2, np.clip((np.trace(R) - 1) / 2, -1, 1)
+    return r * (np.arccos(c) / (2 * s))
+
+
+def _undistort(K, D, pts, R=None, P=None, iters=5):
+    """cv::undistortPoints, 5-coefficient model: fixed-point iteration, optional R and P[:, :3]; float32 result like its CV_32FC2 destination."""
+    x0 = (pts[:, 0].astype(np.float64) - K[0, 2]) / K[0, 0]
+    y0 = (pts[:, 1].astype(np.float64) - K[1, 2]) / K[1, 1]
+    x, y = x0.copy(), y0.copy()
+    k1, k2, p1, p2, k3 = D
+    for _ in range(iters):
+        r2 = x * x + y * y
+        ic = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2)
+        dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        x, y = (x0 - dx) * ic, (y0 - dy) * ic
+    M = np.eye(3) if R is None else np.asarray(R, float)
+    if P is not None:
+        M = np.asarray(P, float)[:, :3] @ M
+    h = M @ np.stack([x, y, np.ones_like(x)])
+    return np.stack([h[0] / h[2], h[1] / h[2]], 1).astype(np.float32)
+
+
+def _stereo_rectify_numpy(K1, D1, K2, D2, R, T, w, h):
+    """cv::stereoRectify(..., CALIB_ZERO_DISPARITY, alpha = 0, newImageSize = imageSize) for a horizontal rig, OpenCV >= 3.4.2 rules,
+    derived here independently of csrc/calib.cpp (SVD instead of its Newton polar factor, vectorised corners and rectangles)."""
+    r_r = _rodrigues(-0.5 * _rodrigues_inv(R))
+    t = r_r @ T
+    idx = 0 if abs(t[0]) > abs(t[1]) else 1
+    uu = np.zeros(3)
+    uu[idx] = 1.0 if t[idx] > 0 else -1.0
+    ww = np.cross(t, uu)
+    nw = np.linalg.norm(ww)
+    if nw > 0:
+        ww *= np.arccos(abs(t[idx]) / np.linalg.norm(t)) / nw
+    wR = _rodrigues(ww)
+    R1, R2 = wR @ r_r.T, wR @ r_r
+    t = R2 @ T
+    fc = (K1[idx ^ 1, idx ^ 1] + K2[idx ^ 1, idx ^ 1]) * 0.5  # new size == old size: ratio 1/2 of the sum
+    corners = np.array([[0, 0], [w, 0], [0, h], [w, h]], np.float32)
+    cc = []
+    for K, D, Rk in ((K1, D1, R1), (K2, D2, R2)):
+        u = _undistort(K, D, corners).astype(np.float64)
+        X = Rk @ np.stack([u[:, 0], u[:, 1], np.ones(4)])
+        proj = np.stack([(fc * X[0] / X[2]).astype(np.float32), (fc * X[1] / X[2]).astype(np.float32)], 1).astype(np.float64)
+        cc.append(np.array([w / 2.0 - proj[:, 0].sum() / 4, h / 2.0 - proj[:, 1].sum() / 4]))
+    c0 = (cc[0] + cc[1]) * 0.5  # CALIB_ZERO_DISPARITY
+    P1 = np.array([[fc, 0, c0[0], 0], [0, fc, c0[1], 0], [0, 0, 1, 0]])
+    P2 = P1.copy()
+    P2[idx, 3] = t[idx] * fc
+    g = np.arange(9, dtype=np.float32)
+    grid = np.stack([np.tile(g * np.float32(w) / np.float32(8), 9), np.repeat(g * np.float32(h) / np.float32(8), 9)], 1)
+    s0 = 0.0
+    for K, D, Rk, Pk in ((K1, D1, R1, P1), (K2, D2, R2, P2)):
+        q = _undistort(K, D, grid, Rk, Pk).reshape(9, 9, 2)  # [y][x]
+        ix0, ix1 = q[:, 0, 0].max(), q[:, 8, 0].min()
+        iy0, iy1 = q[0, :, 1].max(), q[8, :, 1].min()
+        s0 = max(s0, c0[0] / (c0[0] - ix0), c0[1] / (c0[1] - iy0), (w - c0[0]) / (ix1 - c0[0]), (h - c0[1]) / (iy1 - c0[1]))
+    f = fc * s0  # alpha = 0: zoom until only valid pixels remain
+    P1[0, 0] = P1[1, 1] = P2[0, 0] = P2[1, 1] = f
+    P2[idx, 3] *= s0
+    Q = np.array([[1, 0, 0, -c0[0]], [0, 1, 0, -c0[1]], [0, 0, 0, f], [0, 0, -1.0 / t[idx], 0.0]])
+    return Q, P1, P2, t
+
+
+def _read_calibration(path):
+    import re
+    txt = open(path).read()
+
+    def arr(name, n):
+        m = re.search(name + r":[^\[]*\[([^\]]*)\]", txt)
+        return np.array([float(x) for x in m.group(1).replace("\n", " ").split(",")], float)[:n]
+
+    return (arr("K1", 9).reshape(3, 3), arr("D1", 5), arr("K2", 9).reshape(3, 3), arr("D2", 5), arr("R", 9).reshape(3, 3), arr("T", 3))
+
+
+def test_stereo_rectify_numbers_for_the_bundled_calibration():
+    """Q, P1, P2 of csrc/calib.cpp for the KITTI calibration against the same published algorithm derived a second time in numpy,
+    and against what has a closed form: 1 / Q[3][2] = |T| exactly (the rectifying rotations put the baseline on the x axis), the focal
+    length before the alpha = 0 zoom = (fy1 + fy2) / 2 (OpenCV >= 3.4.2), P2[0][3] = -|T| f.  (OpenCV itself is not installed: the
+    arithmetic stays unpinned against the library, but a slip in the C++ restatement now shows.)"""
+    eng = util.pkg("engine")
+    util.pkg("build").build()
+    yml = os.path.join(os.path.dirname(eng.LIB_PATH), "stereo_vision", "data", "kitti_2011_09_26.yml")
+    K1, D1, K2, D2, R, T = _read_calibration(yml)
+    for (w, h, scale) in ((1242, 375, 1.0), (621, 187, 2.0)):
+        Q, P1, P2 = _q(eng, w, h, scale=scale)
+        k1, k2 = K1.copy(), K2.copy()
+        k1[:2] /= scale
+        k2[:2] /= scale
+        Qn, P1n, P2n, t = _stereo_rectify_numpy(k1, D1, k2, D2, R, T, w, h)
+        assert abs(1.0 / Q[3, 2] - np.linalg.norm(T)) < 1e-12 and abs(t[0] + np.linalg.norm(T)) < 1e-12 and abs(t[1]) < 1e-12 and abs(t[2]) < 1e-12
+        assert np.allclose(Q, Qn, rtol=1e-9, atol=1e-9), (Q, Qn)
+        assert np.allclose(P1, P1n, rtol=1e-9, atol=1e-9) and np.allclose(P2, P2n, rtol=1e-9, atol=1e-9)
+        assert abs(P2[0, 3] + np.linalg.norm(T) * Q[2, 3]) < 1e-9
+        assert Q[2, 3] >= (k1[1, 1] + k2[1, 1]) / 2  # the zoom only ever magnifies at alpha = 0
+
+
 @pytest.mark.gpu
 def test_generate_point_cloud_like_reference_smoke_test():
     eng = util.pkg("engine")
