@@ -111,6 +111,41 @@ def test_textureless_and_too_few_support_points(eng, oracle):
     assert status[0] < 3 and not d1.any() and not d2.any()
 
 
+@pytest.mark.parametrize("gpu_filter", [False, True])
+@pytest.mark.parametrize("W,H,D", [(32, 32, 16), (47, 33, 16), (65, 40, 24), (130, 36, 32), (257, 67, 48), (513, 35, 64), (96, 131, 32), (4100, 83, 64), (121, 1101, 32)])
+def test_small_and_odd_image_sizes(eng, oracle, W, H, D, gpu_filter, monkeypatch):
+    """Image sizes nothing is tuned for: the smallest the library takes (32 x 32: a 7 x 7 lattice, two grid cells a side), widths that are
+    no multiple of 4 / 64 / the tile widths, a map narrower than one tile and one a single column wider than a tile, more rows than
+    columns, a row of more than 4 096 pixels, a column of more than 1 024 - five distinct seeded pairs each through a chunk-4 pipeline (a ragged last chunk), both presets, lattice filters on
+    the GPU and on the host: every map equals the oracle's.  (The compiled reference agrees with the oracle on the 257 x 67 and
+    96 x 131 cases and segfaults on the five with at most 40 rows - two grid-cell rows leave its flat 3 x 3 dilation, elas.cpp:613-628,
+    without a valid range; there the memory-safe restatement is what defines the result.)"""
+    synth = util.pkg("synth")
+    if gpu_filter:
+        monkeypatch.setenv("SV_GPU_FILTER", "1")
+    else:
+        monkeypatch.setenv("SV_HOST_FILTER", "1")
+    batch = synth.make_batch(9000 + W, 5, H, W, D)
+    for preset in ("driver", "robotics"):
+        p = eng.SvParams.driver(D - 1) if preset == "driver" else eng.SvParams.preset("robotics")
+        po = ElasParams.driver(D - 1) if preset == "driver" else ElasParams.preset("robotics")
+        p.disp_max = po.disp_max = D - 1
+        e = eng.StereoEngine(W, H, p, chunk=4, n_slots=2, n_workers=3)
+        try:
+            d1, d2, status = e.process_host(np.ascontiguousarray(batch[:, 0]), np.ascontiguousarray(batch[:, 1]))
+        finally:
+            e.close()
+        for i in range(batch.shape[0]):
+            o1 = np.zeros((H, W), np.float32)
+            o2 = np.zeros((H, W), np.float32)
+            n = oracle.run_stages(po, batch[i, 0], batch[i, 1])
+            if n >= 3:  # (fewer: the maps stay as the caller handed them over, elas.cpp:63-69 - zeros here)
+                o1, o2 = oracle.stage("final1").reshape(H, W), oracle.stage("final2").reshape(H, W)
+            assert status[i] == n, (preset, i, status[i], n)
+            assert np.array_equal(d1[i].view(np.uint8), o1.view(np.uint8)), (preset, i, "D1")
+            assert np.array_equal(d2[i].view(np.uint8), o2.view(np.uint8)), (preset, i, "D2")
+
+
 def test_elas_process_seam(eng, oracle):
     """sv_elas_process has Elas::process's argument meaning (elas.h:153-162)."""
     entry = DIG["kitti0_crop_d64"]

@@ -1,5 +1,5 @@
 import os, sys, importlib, numpy as np, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+R = os.environ.get('GRAFT_REPO_ROOT', '/root/repo'); sys.path.insert(0, R); sys.path.insert(0, R + '/tests')
 import util
 eng = util.pkg("engine")
 import torch
@@ -7,7 +7,6 @@ torch.cuda.init()
 rng = np.random.default_rng(41)
 bad = 0
 for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 200):
-    print("case", it, flush=True)
     n = int(rng.integers(3, int(os.environ.get("GDL_MAXN", "3900")) if it % 10 == 0 else 500))
     k = it % 4
     if k == 0: pts = rng.integers(0, 250, (n, 2)) * 5
