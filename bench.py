@@ -360,11 +360,14 @@ class GatherRun:
     engine reports it complete (sv_wait_batches) and starts its collective on a side stream.  The maps of consecutive steps
     alternate between two buffers; chunk k of step s+2 is only submitted once the gather of chunk k of step s has completed."""
 
-    def __init__(self, torch, par, engine, B, Hm, Wm, g, device, backend):
+    def __init__(self, torch, par, engine, B, Hm, Wm, g, device, backend, u8=None):
         import threading
         self.torch, self.engine, self.B, self.g = torch, engine, B, g
         self.G = -(-B // g)
-        self.cg = par.ChunkedGather(B, Hm, Wm, torch.float32, g, torch.device("cuda", device), dst=0, stage_on_cpu=(backend != "nccl"))
+        # u8 = the engine module: gather the driver's 8-bit disparity image (sv_disparity_to_u8_device, a quarter of the bytes) instead of the float maps
+        self.u8 = u8
+        self.u8buf = [torch.empty((B, Hm, Wm), dtype=torch.uint8, device=torch.device("cuda", device)) for _ in range(2)] if u8 is not None else None
+        self.cg = par.ChunkedGather(B, Hm, Wm, torch.uint8 if u8 is not None else torch.float32, g, torch.device("cuda", device), dst=0, stage_on_cpu=(backend != "nccl"))
         self.device, self.nccl = device, backend == "nccl"
         self.bufs, self.steps, self.done, self.thread, self.error = None, 0, [], None, None
         self._threading = threading
@@ -386,15 +389,23 @@ class GatherRun:
                 s, k = divmod(i, self.G)
                 self.submitted.acquire()
                 self.engine.wait_batches(i + 1)
+                src = self.bufs[s % 2][0]
+                lo, hi = k * self.g, min(self.B, (k + 1) * self.g)
                 if side is not None:
                     with torch.cuda.stream(side):
-                        hnd = self.cg.submit(self.bufs[s % 2][0], k)
+                        if self.u8 is not None:
+                            self.u8.disparity_to_u8(src[lo:hi], out=self.u8buf[s % 2][lo:hi])  # on the side stream, in front of the collective
+                            src = self.u8buf[s % 2]
+                        hnd = self.cg.submit(src, k)
                         self.cg.wait(hnd)  # (the side stream waits, not the host)
                         ev = torch.cuda.Event()
                         ev.record(side)
                     cur = (hnd, ev)
                 else:
-                    cur = (self.cg.submit(self.bufs[s % 2][0], k), None)
+                    if self.u8 is not None:
+                        self.u8.disparity_to_u8(src[lo:hi], out=self.u8buf[s % 2][lo:hi])
+                        src = self.u8buf[s % 2]
+                    cur = (self.cg.submit(src, k), None)
                 if prev is not None:  # the previous chunk's collective has had a whole chunk of compute to finish
                     self._finish(prev)
                     self.done[i - 1].set()
@@ -568,21 +579,28 @@ def run_config(ctx, name, steps_req, warmup, min_seconds, headline, gather):
     # ---- the same run with the finished left maps gathered on rank 0 (RCCL), chunk by chunk, overlapping the kernels
     if gather and world > 1:
         g = min(B, GATHER_CHUNK.get(name, 64))
-        gr = GatherRun(torch, par, engine, B, Hm, Wm, g, local_rank, backend)
         gsteps = max(2, min(steps, int(np.ceil(max(1.0, min_seconds / 2) / max(est, 1e-6)))))
         t = torch.tensor([gsteps], dtype=torch.int64, device=coll_dev)  # every rank issues the same number of collectives
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         gsteps = int(t.item())
-        g_el = par.max_over_ranks(timed_region(torch, engine, left, right, bufs, gsteps, barrier, gather=gr), device=coll_dev)
-        ok = True
-        if rank == 0:  # rank order == pair order; rank 0's own block must be its own maps of the last step
-            ok = bool(torch.equal(gr.cg.root[0].to(bufs[(gsteps - 1) % 2][0].device), bufs[(gsteps - 1) % 2][0]))
-        into_root = (world - 1) * B * Hm * Wm * 4 * gsteps
-        res["with_gather"] = {"pairs_per_s": round(B * world * gsteps / g_el, 2), "ms_per_step": round(1e3 * g_el / gsteps, 3), "steps": gsteps,
-                              "collective": "dist.gather of %d-pair chunks into one preallocated [world,B,H,W] f32 buffer on rank 0, issued per finished chunk (sv_wait_batches), overlapping later chunks' kernels" % g,
-                              "chunk_pairs": g, "bytes_into_root_per_step": into_root // gsteps, "root_ingest_GBps": round(into_root / g_el / 1e9, 2),
-                              "backend": backend, "root_block0_equals_own_maps": ok}
-        del gr
+        for key, u8 in (("with_gather", None), ("with_gather_u8", eng)):  # the float maps; the driver's 8-bit disparity images (4 x d, stereo_vision.cpp:316)
+            gr = GatherRun(torch, par, engine, B, Hm, Wm, g, local_rank, backend, u8=u8)
+            g_el = par.max_over_ranks(timed_region(torch, engine, left, right, bufs, gsteps, barrier, gather=gr), device=coll_dev)
+            ok = True
+            if rank == 0:  # rank order == pair order; rank 0's own block must be its own maps of the last step
+                mine = bufs[(gsteps - 1) % 2][0]
+                if u8 is not None:
+                    mine = eng.disparity_to_u8(mine)
+                    torch.cuda.synchronize()
+                ok = bool(torch.equal(gr.cg.root[0].to(mine.device), mine))
+            esz = 1 if u8 is not None else 4
+            into_root = (world - 1) * B * Hm * Wm * esz * gsteps
+            res[key] = {"pairs_per_s": round(B * world * gsteps / g_el, 2), "ms_per_step": round(1e3 * g_el / gsteps, 3), "steps": gsteps,
+                        "collective": "dist.gather of %d-pair chunks into one preallocated [world,B,H,W] %s buffer on rank 0, issued per finished chunk (sv_wait_batches), overlapping later chunks' kernels"
+                                      % (g, "u8 (saturate(round(4 d)), converted on the gather's side stream)" if u8 is not None else "f32"),
+                        "chunk_pairs": g, "bytes_into_root_per_step": into_root // gsteps, "root_ingest_GBps": round(into_root / g_el / 1e9, 2),
+                        "backend": backend, "root_block0_equals_own_maps": ok}
+            del gr
     # ---- batch-1 latency on rank 0 (ms/frame), SURVEY.md 8d config 2: the gate pair's size, one pair per call, device memory in and out
     lat_ms = None
     if rank == 0 and not args.no_latency:
@@ -746,7 +764,7 @@ def main():
             "launcher": os.environ.get("SV_LAUNCHER", "external (torch.distributed.run)" if world > 1 else "none"),
             "collective_backend": backend if world > 1 else None, "rccl_ranks": (dist.get_world_size() if world > 1 and backend == "nccl" else None),
             "per_rank_pairs_per_s": hl["per_rank_pairs_per_s"],
-            "with_gather": hl.get("with_gather"),
+            "with_gather": hl.get("with_gather"), "with_gather_u8": hl.get("with_gather_u8"),
             "configs": configs,
             "latency_ms_batch1": hl["latency_ms_batch1"], "value_real_pair": real_rate, "host_to_host": h2h,
             "valid_fraction": hl["valid_fraction"], "checksum_rank0": hl["checksum_rank0"],

@@ -245,6 +245,10 @@ int sv_legacy_last_gray(unsigned char *left, unsigned char *right);
  * Runs on the device's default stream and returns when the points are complete. */
 int sv_reproject_batch_device(const float *disp, int batch, int width, int height, const double *Q16, const double *XR9, const double *XT3, unsigned char *dmap_out,
                               double *points_out);
+/* The driver's 8-bit disparity image alone: dmap = saturate(round_half_even(4 * d)) (leftdpf.convertTo(dmap, CV_8UC1, 4.0),
+ * stereo_vision.cpp:316) for `count` floats in device memory, enqueued on `stream` (a hipStream_t, NULL = the default stream) and NOT
+ * waited for - e.g. in front of a gather of finished maps, which then moves a quarter of the bytes. */
+int sv_disparity_to_u8_device(const float *disp, size_t count, unsigned char *dmap_out, void *stream);
 /* Mean 3-D position of the cloud inside each detector box (x, y, w, h in pixels), i.e. what publishPointCloud hands to its
  * viewer for every tracked object (stereo_vision.cpp:261-278; the boxes come from a detector the caller runs - the
  * reference's YOLO weights are not part of this library).  boxes: int32 [n][4]; out: double [n][3] = (X, Y, Z) sums over

@@ -40,6 +40,7 @@ void launch_resize_bgra(const unsigned char *src, int sw, int sh, unsigned char 
 void launch_bgra_to_gray(const unsigned char *bgra_l, const unsigned char *bgra_r, unsigned char *gray_l, unsigned char *gray_r, int n, hipStream_t st);
 void launch_dmap_and_cloud(const float *disp, unsigned char *dmap, double *points, const double *Q16, int W, int H, hipStream_t st);
 void launch_remap_gray(const unsigned char *src, unsigned char *dst, const float *mapx, const float *mapy, int W, int H, hipStream_t st);
+int launch_disp_to_u8(const float *disp, size_t n, unsigned char *out, hipStream_t st);
 int launch_reproject_batch(const float *disp, int batch, int W, int H, const double *Q16, const double *XR9, const double *XT3, unsigned char *dmap, double *points,
                            hipStream_t st);
 }  // namespace sv
@@ -326,6 +327,12 @@ int sv_reproject_batch_device(const float *disp, int batch, int width, int heigh
     if (batch == 0) return SV_OK;
     if (sv::launch_reproject_batch(disp, batch, width, height, Q16, XR9, XT3, dmap_out, points_out, nullptr) != 0) return SV_ERR_HIP;
     return hipStreamSynchronize(nullptr) == hipSuccess ? SV_OK : SV_ERR_HIP;
+}
+
+int sv_disparity_to_u8_device(const float *disp, size_t count, unsigned char *dmap_out, void *stream) {
+    if (!disp || !dmap_out) return SV_ERR_ARG;
+    if (sv::launch_disp_to_u8(disp, count, dmap_out, static_cast<hipStream_t>(stream)) != 0) return SV_ERR_HIP;
+    return SV_OK;
 }
 
 int sv_legacy_box_means(const int32_t *boxes, int n, double *out) {

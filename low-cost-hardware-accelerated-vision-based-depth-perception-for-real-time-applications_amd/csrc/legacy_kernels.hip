@@ -106,6 +106,29 @@ void launch_dmap_and_cloud(const float *disp, unsigned char *dmap, double *point
     hipLaunchKernelGGL(k_dmap_cloud, dim3((W + 255) / 256, H), dim3(256), 0, st, disp, dmap, points, Q16, W, H);
 }
 
+// leftdpf.convertTo(dmap, CV_8UC1, 4.0) alone (stereo_vision.cpp:316), four pixels per thread: what a consumer that wants the driver's
+// 8-bit disparity image - e.g. a gather of finished maps over xGMI, a quarter of the float maps' bytes - takes instead of D1.
+__global__ __launch_bounds__(256) void k_disp_to_u8(const float *__restrict__ disp, uint8_t *__restrict__ out, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    auto cv8 = [](float d) -> uint32_t {
+        int v = __float2int_rn(d * 4.0f);  // cvRound: round half to even; saturate_cast<uchar>
+        return (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    };
+    if (i + 3 < n && ((reinterpret_cast<uintptr_t>(disp + i) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out + i) & 3) == 0)) {
+        const float4 d = *reinterpret_cast<const float4 *>(disp + i);
+        *reinterpret_cast<uint32_t *>(out + i) = cv8(d.x) | (cv8(d.y) << 8) | (cv8(d.z) << 16) | (cv8(d.w) << 24);
+    } else {
+        for (size_t j = i; j < n && j < i + 4; j++) out[j] = (uint8_t)cv8(disp[j]);
+    }
+}
+
+int launch_disp_to_u8(const float *disp, size_t n, unsigned char *out, hipStream_t st) {
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_disp_to_u8, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, disp, out, n);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // Batched form with the CUDA variant's optional robot-frame transform (parallel_includes/main/stereo_vision.cu:188-212:
 // point = XR * (X, Y, Z) + XT); Q / XR / XT travel as kernel arguments.
 struct ReprojectArgs {

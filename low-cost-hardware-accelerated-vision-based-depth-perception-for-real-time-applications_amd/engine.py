@@ -371,6 +371,23 @@ def reproject(disp, Q, XR=None, XT=None, want_dmap=True):
     return dmap, pts
 
 
+def disparity_to_u8(disp, out=None):
+    """The driver's 8-bit disparity image (saturate(round_half_even(4 * d)), stereo_vision.cpp:316) of a CUDA float32 tensor, on torch's
+    current stream (not waited for)."""
+    import torch
+    assert disp.is_cuda and disp.dtype == torch.float32 and disp.is_contiguous()
+    if out is None:
+        out = torch.empty(disp.shape, dtype=torch.uint8, device=disp.device)
+    assert out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.numel() == disp.numel()
+    L = lib()
+    L.sv_disparity_to_u8_device.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p]
+    with torch.cuda.device(disp.device):
+        rc = L.sv_disparity_to_u8_device(disp.data_ptr(), disp.numel(), out.data_ptr(), torch.cuda.current_stream(disp.device).cuda_stream)
+    if rc != 0:
+        raise StereoError("sv_disparity_to_u8_device failed (%d)" % rc)
+    return out
+
+
 def host_support_filter(params, dcan, width, height):
     """Product host stage: lattice filters + corner points (CPU by design; see csrc/host_stage.h)."""
     d = np.ascontiguousarray(dcan, dtype=np.int16).copy()

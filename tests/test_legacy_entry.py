@@ -484,3 +484,21 @@ def test_frames_of_another_size_are_resized(oracle, factor):
     assert np.array_equal(gl, _gray_cv4(want_l[..., 2::-1])) and np.array_equal(gr, _gray_cv4(want_r[..., 2::-1]))
     d1, _, _ = oracle.process(ElasParams.driver(255), gl, gr)
     assert np.array_equal(dmap, np.clip(np.rint(d1 * np.float32(4.0)), 0, 255).astype(np.uint8))
+
+
+@pytest.mark.gpu
+def test_disparity_to_u8_device():
+    """sv_disparity_to_u8_device == leftdpf.convertTo(dmap, CV_8UC1, 4.0) (stereo_vision.cpp:316): round half to even, saturate;
+    every alignment of the four-pixels-per-thread kernel, ties, negatives (-10 / -1 invalid marks), values beyond 63.75."""
+    import torch
+    eng = util.pkg("engine")
+    rng = np.random.default_rng(5)
+    base = np.concatenate([rng.uniform(-12, 80, 5003).astype(np.float32), np.arange(-4, 300, dtype=np.float32) / 8, np.array([-10, -1, 0, 63.75, 63.875, 64, 1e9, -1e9], np.float32)])
+    for off in range(4):
+        for n in (1, 2, 3, 4, 5, 1023, 1024, 1025, base.size - off):
+            a = np.ascontiguousarray(base[off:off + n])
+            t = torch.from_numpy(base.copy()).cuda()[off:off + n]
+            out = eng.disparity_to_u8(t.contiguous() if off == 0 else t)  # a view at an odd offset stays contiguous: unaligned start
+            torch.cuda.synchronize()
+            want = np.clip(np.rint(a * np.float32(4.0)), 0, 255).astype(np.uint8)
+            assert np.array_equal(out.cpu().numpy(), want), (off, n)

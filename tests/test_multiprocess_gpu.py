@@ -88,4 +88,6 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert len(r["per_rank_pairs_per_s"]) == 2 and r["value"] > 0 and r["steps"] >= 3
     g = r["with_gather"]
     assert g["root_block0_equals_own_maps"] is True and g["chunk_pairs"] == 64 and g["pairs_per_s"] > 0
+    g8 = r["with_gather_u8"]  # the same gather with the driver's 8-bit disparity images: a quarter of the bytes
+    assert g8["root_block0_equals_own_maps"] is True and g8["bytes_into_root_per_step"] * 4 == g["bytes_into_root_per_step"]
     assert r["roofline"]["kernel"] and "cpu_baseline" not in r  # the CPU baseline is a rank-0, N=1 measurement
