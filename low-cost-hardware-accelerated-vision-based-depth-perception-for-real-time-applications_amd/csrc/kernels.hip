@@ -94,6 +94,10 @@ struct __attribute__((packed)) UnalignedWord {  // caller's image rows have any 
     uint32_t v;
 };
 
+struct __attribute__((aligned(4))) DwordQuad {  // four dwords at any dword-aligned address: one global_load_dwordx4
+    uint32_t x, y, z, w;
+};
+
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 typedef short s2 __attribute__((ext_vector_type(2)));
 // _mm_packus_epi16 for one pair: two int16 saturated to [0, 255], packed into bytes 0 and 1
@@ -542,7 +546,15 @@ __host__ __device__ inline int filter_collect_blocks(int lat) { return (lat + FL
 // (win <= 5, fully unrolled: independent reads, all in flight together) comes from there.  The block's uncertain points go,
 // in index order, to its own segment useg[first ...] (count in ucnt): the resolve step never has to look at the lattice.
 #define FCL_THREADS 256
-__global__ __launch_bounds__(FCL_THREADS) void k_filter_classify(Dims d, int win, int thr, int need, const int16_t *__restrict__ dcan, uint8_t *__restrict__ fst,
+// The lattice the later steps work on: one 32-bit word per point, value (int16) in the low half, state byte in bits 16-23; `FCS_PAD`
+// words of padding in front of and behind a pair's lattice, so that the resolve step may fetch the eleven neighbours of a lattice
+// column as three wide loads wherever the column lies.
+#define FCS_PAD 16
+__host__ __device__ inline size_t filter_cs_stride(int lat) { return (size_t)lat + 2 * FCS_PAD; }
+__device__ __forceinline__ int cs_value(uint32_t w) { return (int)(int16_t)(w & 0xFFFFu); }
+__device__ __forceinline__ int cs_state(uint32_t w) { return (int)((w >> 16) & 0xFFu); }
+
+__global__ __launch_bounds__(FCL_THREADS) void k_filter_classify(Dims d, int win, int thr, int need, const int16_t *__restrict__ dcan, uint32_t *__restrict__ fcs,
                                                                  uint32_t *__restrict__ useg, int32_t *__restrict__ ucnt) {
     extern __shared__ int16_t fcl_lds[];
     __shared__ int s_wcnt[FCL_THREADS / 64];
@@ -581,7 +593,7 @@ __global__ __launch_bounds__(FCL_THREADS) void k_filter_classify(Dims d, int win
         }
         state = (uint8_t)(c_late >= need ? FST_KEEP : (c_late + c_early < need) ? FST_DROP : (FST_UNC | (c_late << 2)));
     }
-    if (idx < lat) fst[(size_t)pair * lat + idx] = state;
+    if (idx < lat) fcs[(size_t)pair * filter_cs_stride(lat) + FCS_PAD + idx] = (uint32_t)(uint16_t)dd | ((uint32_t)state << 16);
     const bool unc = (state & 3) == FST_UNC;
     const unsigned long long m = __ballot(unc);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -603,12 +615,12 @@ __global__ __launch_bounds__(FCL_THREADS) void k_filter_classify(Dims d, int win
 // classify block b with pref[b] <= q < pref[b + 1]: a binary search in the blocks' prefix sums (LDS) spreads the points evenly
 // over the threads however they cluster in the lattice (they do: along depth edges).
 #define RSV_MAX_BLOCKS 8192  // classify blocks per pair whose prefix sums fit the LDS table (lattices up to 2 M points)
-__global__ __launch_bounds__(RSV_THREADS) void k_filter_resolve(Dims d, int win, int thr, int need, const int16_t *__restrict__ dcan, uint8_t *fst, const uint32_t *__restrict__ useg,
+__global__ __launch_bounds__(RSV_THREADS) void k_filter_resolve(Dims d, int win, int thr, int need, uint32_t *fcs, const uint32_t *__restrict__ useg,
                                                                 const int32_t *__restrict__ ucnt, int nb, uint32_t *__restrict__ ulist, uint32_t *__restrict__ urest) {
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int Hc = d.Hc, lat = d.Wc * Hc;
-    const int16_t *T = dcan + (size_t)pair * lat;
-    uint8_t *st = fst + (size_t)pair * lat;
+    uint32_t *cs = fcs + (size_t)pair * filter_cs_stride(lat) + FCS_PAD;  // cs[idx]: value | state << 16
+    uint8_t *stb = reinterpret_cast<uint8_t *>(cs) + 2;                   // the state byte of point idx: stb[4 * idx]
     const uint32_t *seg = useg + (size_t)pair * lat;
     uint32_t *list = ulist + (size_t)pair * lat, *rest = urest + (size_t)pair * lat;
     __shared__ int s_wave[RSV_THREADS / 64];
@@ -647,42 +659,50 @@ __global__ __launch_bounds__(RSV_THREADS) void k_filter_resolve(Dims d, int win,
         int open = 0;
         for (int q = tid; q < n_unc; q += RSV_THREADS) {
             const int idx = (int)list[q];
-            const int s0 = __hip_atomic_load(&st[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t w0 = __hip_atomic_load(&cs[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int s0 = cs_state(w0);
             if ((s0 & 3) != FST_UNC) continue;
-            const int dd = T[idx], c_late = s0 >> 2;
+            const int dd = cs_value(w0), c_late = s0 >> 2;
             const int u = idx / Hc, v = idx - u * Hc;
-            // the 60 earlier neighbours: values and states requested together (plain loads: a state byte read while another thread of
-            // this workgroup settles that point is the old or the new state, and either is valid for a round), then counted
-            int nd[60], ns[60];
-            {
-                int t = 0;
+            // the 60 earlier neighbours: rows v-5 .. v+5 of the five columns before u and rows v-5 .. v-1 of column u, each column's
+            // eleven words as three wide loads (plain loads: a word read while another thread of this workgroup settles that point
+            // carries the old or the new state, and either is valid for a round); rows beyond the column's ends are masked below
+            // (they are the neighbouring column's words, or the padding)
+            uint32_t nw[6][12];
 #pragma unroll
-                for (int du = -5; du <= 0; du++) {
-                    const int u2 = u + du;
-                    const bool col_ok = du >= -win && u2 >= 0;
-#pragma unroll
-                    for (int dv = -5; dv <= 5; dv++) {
-                        if (du == 0 && dv >= 0) continue;
-                        const int v2 = v + dv;
-                        const bool ok = col_ok && dv >= -win && dv <= win && v2 >= 0 && v2 < Hc;
-                        const int j = (ok ? u2 : u) * Hc + (ok ? v2 : v);
-                        nd[t] = ok ? (int)T[j] : -1;
-                        ns[t] = st[j];
-                        t++;
-                    }
+            for (int c = 0; c < 6; c++) {
+                const uint32_t *col = cs + (ptrdiff_t)max(u - 5 + c, 0) * Hc + (v - 5);
+                const DwordQuad a = *reinterpret_cast<const DwordQuad *>(col);
+                nw[c][0] = a.x, nw[c][1] = a.y, nw[c][2] = a.z, nw[c][3] = a.w;
+                if (c < 5) {
+                    const DwordQuad b = *reinterpret_cast<const DwordQuad *>(col + 4), e = *reinterpret_cast<const DwordQuad *>(col + 8);
+                    nw[c][4] = b.x, nw[c][5] = b.y, nw[c][6] = b.z, nw[c][7] = b.w;
+                    nw[c][8] = e.x, nw[c][9] = e.y, nw[c][10] = e.z, nw[c][11] = e.w;
+                } else {
+                    nw[c][4] = col[4];
                 }
             }
             int sure = 0, maybe = 0;
 #pragma unroll
-            for (int t = 0; t < 60; t++) {
-                const int cons = (nd[t] >= 0) & (abs(dd - nd[t]) <= thr);
-                sure += cons & ((ns[t] & 3) == FST_KEEP);
-                maybe += cons & ((ns[t] & 3) == FST_UNC);
+            for (int c = 0; c < 6; c++) {
+                const int du = c - 5, u2 = u + du;
+                const bool col_ok = du >= -win && u2 >= 0;
+#pragma unroll
+                for (int r = 0; r < 11; r++) {
+                    const int dv = r - 5;
+                    if (du == 0 && dv >= 0) continue;
+                    const int v2 = v + dv;
+                    const bool ok = col_ok && dv >= -win && dv <= win && v2 >= 0 && v2 < Hc;
+                    const int d2 = cs_value(nw[c][r]), s2 = cs_state(nw[c][r]) & 3;
+                    const int cons = ok & (d2 >= 0) & (abs(dd - d2) <= thr);
+                    sure += cons & (s2 == FST_KEEP);
+                    maybe += cons & (s2 == FST_UNC);
+                }
             }
             if (c_late + sure >= need)
-                __hip_atomic_store(&st[idx], (uint8_t)FST_KEEP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&stb[4 * (size_t)idx], (uint8_t)FST_KEEP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else if (c_late + sure + maybe < need)
-                __hip_atomic_store(&st[idx], (uint8_t)FST_DROP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&stb[4 * (size_t)idx], (uint8_t)FST_DROP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             else
                 open++;
         }
@@ -696,11 +716,11 @@ __global__ __launch_bounds__(RSV_THREADS) void k_filter_resolve(Dims d, int win,
         const int per_q = (n_unc + RSV_THREADS - 1) / RSV_THREADS;
         const int q_lo = min(tid * per_q, n_unc), q_hi = min(q_lo + per_q, n_unc);
         int open = 0;
-        for (int q = q_lo; q < q_hi; q++) open += (st[list[q]] & 3) == FST_UNC ? 1 : 0;
+        for (int q = q_lo; q < q_hi; q++) open += (stb[4 * (size_t)list[q]] & 3) == FST_UNC ? 1 : 0;
         int p2 = block_exclusive_scan<RSV_THREADS>(open, s_wave, &n_rest);
         if (open)
             for (int q = q_lo; q < q_hi; q++)
-                if ((st[list[q]] & 3) == FST_UNC) rest[p2++] = list[q];
+                if ((stb[4 * (size_t)list[q]] & 3) == FST_UNC) rest[p2++] = list[q];
         __threadfence_block();
         __syncthreads();
     }
@@ -710,18 +730,20 @@ __global__ __launch_bounds__(RSV_THREADS) void k_filter_resolve(Dims d, int win,
         for (int i = 0; i < n_rest; i++) {
             const int idx = (int)rest[i];
             const int u = idx / Hc, v = idx - u * Hc;
-            const int dd = T[idx], c_late = st[idx] >> 2;  // (its own entry is only written below)
+            const uint32_t w0 = cs[idx];  // (its own state is only written below)
+            const int dd = cs_value(w0), c_late = cs_state(w0) >> 2;
             bool ok = false;
             if (lane < n_early) {
                 const int u2 = lane < win * rowlen ? u - win + lane / rowlen : u;
                 const int v2 = lane < win * rowlen ? v - win + lane % rowlen : v - win + (lane - win * rowlen);
                 if (u2 >= 0 && v2 >= 0 && v2 < Hc) {
-                    const int d2 = T[u2 * Hc + v2];
-                    ok = d2 >= 0 && abs(dd - d2) <= thr && (__hip_atomic_load(&st[u2 * Hc + v2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 3) == FST_KEEP;
+                    const uint32_t w2 = __hip_atomic_load(&cs[u2 * Hc + v2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int d2 = cs_value(w2);
+                    ok = d2 >= 0 && abs(dd - d2) <= thr && (cs_state(w2) & 3) == FST_KEEP;
                 }
             }
             const int c = (int)__popcll(__ballot(ok));
-            if (lane == 0) __hip_atomic_store(&st[idx], (uint8_t)((c_late + c >= need) ? FST_KEEP : FST_DROP), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == 0) __hip_atomic_store(&stb[4 * (size_t)idx], (uint8_t)((c_late + c >= need) ? FST_KEEP : FST_DROP), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -773,7 +795,7 @@ __device__ __forceinline__ void redundancy_walk(const uint8_t *f, int n, uint16_
 #define FRD_THREADS 256
 // vertical: a strip of `SW` lattice columns (a contiguous index range).  LDS: values [SW][Hc + 10] int16, flags [SW][LS], kept
 // words [SW][KS].  Input = the raw lattice minus the points the inconsistency pass dropped.
-__global__ __launch_bounds__(FRD_THREADS) void k_filter_vertical(Dims d, int SW, const int16_t *__restrict__ dcan, const uint8_t *__restrict__ fst, int16_t *__restrict__ latB) {
+__global__ __launch_bounds__(FRD_THREADS) void k_filter_vertical(Dims d, int SW, const uint32_t *__restrict__ fcs, int16_t *__restrict__ latB) {
     extern __shared__ int16_t frd_lds[];
     const int pair = blockIdx.y, Wc = d.Wc, Hc = d.Hc, P = Hc + 10, LS = filter_line_stride(Hc), KS = filter_kept_stride(Hc);
     const int u0 = blockIdx.x * SW, nu = min(SW, Wc - u0);
@@ -781,11 +803,12 @@ __global__ __launch_bounds__(FRD_THREADS) void k_filter_vertical(Dims d, int SW,
     uint16_t *kb = reinterpret_cast<uint16_t *>(val + (size_t)SW * P + ((SW * P) & 1));
     uint8_t *fl = reinterpret_cast<uint8_t *>(kb + (size_t)SW * KS + ((SW * KS) & 1));
     const size_t g0 = (size_t)pair * Wc * Hc + (size_t)u0 * Hc;
+    const uint32_t *cs = fcs + (size_t)pair * filter_cs_stride(Wc * Hc) + FCS_PAD + (size_t)u0 * Hc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int c = wave; c < nu; c += FRD_THREADS / 64) {
         for (int v = lane; v < Hc; v += 64) {
-            const size_t g = g0 + (size_t)c * Hc + v;
-            val[c * P + 5 + v] = (fst[g] & 3) == FST_DROP ? (int16_t)-1 : dcan[g];
+            const uint32_t w = cs[(size_t)c * Hc + v];
+            val[c * P + 5 + v] = (cs_state(w) & 3) == FST_DROP ? (int16_t)-1 : (int16_t)cs_value(w);
         }
         if (lane < 10) val[c * P + (lane < 5 ? lane : Hc + lane)] = (int16_t)-1;
     }
@@ -992,7 +1015,7 @@ static int filter_strip(int line_len) {
 
 size_t support_filter_ws_bytes(const KParams &k, int cap) {  // per slot: segment + ordered list of uncertain points, two lattice copies, state bytes, block counts and keys
     const size_t lat = (size_t)k.d.Wc * k.d.Hc, nb = (lat + FCL_THREADS - 1) / FCL_THREADS, nb2 = (size_t)filter_collect_blocks((int)lat);
-    return (size_t)cap * (lat * (4 + 4 + 2 + 2 + 1) + nb * 4 + nb2 * (4 * 8 + 4) + 16) + 256;
+    return (size_t)cap * (lat * (4 + 4 + 2 + 2) + filter_cs_stride((int)lat) * 4 + nb * 4 + nb2 * (4 * 8 + 4) + 16) + 256;
 }
 
 void launch_support_filter(const KParams &k, int win, int thr, int need, const SlotDev &s, int n, hipStream_t st) {
@@ -1002,8 +1025,8 @@ void launch_support_filter(const KParams &k, int win, int thr, int need, const S
     unsigned long long *bkey = reinterpret_cast<unsigned long long *>(base);
     uint32_t *useg = reinterpret_cast<uint32_t *>(bkey + cap * (size_t)nb2 * 4), *ulist = useg + cap * lat;
     int32_t *ucnt = reinterpret_cast<int32_t *>(ulist + cap * lat), *bcnt = ucnt + cap * (size_t)nb;
-    int16_t *latB = reinterpret_cast<int16_t *>(bcnt + cap * (size_t)nb2), *latC = latB + cap * lat;
-    uint8_t *fst = reinterpret_cast<uint8_t *>(latC + cap * lat);
+    uint32_t *fcs = reinterpret_cast<uint32_t *>(bcnt + cap * (size_t)nb2);  // value | state << 16 per point, padded per pair
+    int16_t *latB = reinterpret_cast<int16_t *>(fcs + cap * filter_cs_stride((int)lat)), *latC = latB + cap * lat;
     const size_t cl_lds = sizeof(int16_t) * (FCL_THREADS + 2 * (size_t)(5 * k.d.Hc + 5));
     const int SW = filter_strip(k.d.Hc), SH = filter_strip(k.d.Wc);
     const size_t v_lds = filter_strip_lds(SW, k.d.Hc), h_lds = filter_strip_lds(SH, k.d.Wc);
@@ -1011,12 +1034,12 @@ void launch_support_filter(const KParams &k, int win, int thr, int need, const S
     ensure_dynamic_lds(k_filter_classify, cl_lds, granted, "support_filter");
     ensure_dynamic_lds(k_filter_vertical, v_lds, granted_v, "support_filter (vertical)");
     ensure_dynamic_lds(k_filter_horizontal, h_lds, granted_h, "support_filter (horizontal)");
-    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_classify, dim3((unsigned)nb, n), dim3(FCL_THREADS), cl_lds, st, k.d, win, thr, need, s.dcan, fst, useg, ucnt);
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_classify, dim3((unsigned)nb, n), dim3(FCL_THREADS), cl_lds, st, k.d, win, thr, need, s.dcan, fcs, useg, ucnt);
     if (nb > RSV_MAX_BLOCKS) throw std::runtime_error("support_filter: lattice too large for the resolve step's block table");
     // (urest: the remaining points after the rounds; they overwrite nothing the rounds' list still needs - a buffer of its own: latC is free until the horizontal pass)
-    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_resolve, dim3(n), dim3(RSV_THREADS), sizeof(int) * ((size_t)nb + 1), st, k.d, win, thr, need, s.dcan, fst, useg, ucnt, nb, ulist,
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_resolve, dim3(n), dim3(RSV_THREADS), sizeof(int) * ((size_t)nb + 1), st, k.d, win, thr, need, fcs, useg, ucnt, nb, ulist,
               reinterpret_cast<uint32_t *>(latB));
-    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_vertical, dim3((k.d.Wc + SW - 1) / SW, n), dim3(FRD_THREADS), v_lds, st, k.d, SW, s.dcan, fst, latB);
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_vertical, dim3((k.d.Wc + SW - 1) / SW, n), dim3(FRD_THREADS), v_lds, st, k.d, SW, fcs, latB);
     SV_LAUNCH(K_SUPPORT_FILTER, k_filter_horizontal, dim3((k.d.Hc + SH - 1) / SH, n), dim3(FRD_THREADS), h_lds, st, k.d, SH, latB, latC);
     SV_LAUNCH(K_SUPPORT_FILTER, k_filter_count, dim3(nb2, n), dim3(FLT_THREADS), 0, st, k.d, latC, bcnt);
     SV_LAUNCH(K_SUPPORT_FILTER, k_filter_collect, dim3(nb2, n), dim3(FLT_THREADS), 0, st, k, latC, bcnt, bkey, s.fsup);
