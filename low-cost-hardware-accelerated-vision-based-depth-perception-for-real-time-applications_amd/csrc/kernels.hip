@@ -1430,12 +1430,14 @@ __device__ __forceinline__ int dense_band_full(const KParams &k, int side, const
 // MWT / RT: mask words per cell and plane radius as compile-time constants (0 = read them from the parameters).  The kernel
 // has many wave-uniform decisions on them (which mask words exist, which band slots exist); as runtime values the compiler keeps
 // ~60 scalar conditions alive per workgroup, spills them to VGPR lanes and reloads them in the pixel loops.
-template <bool COUNT, int MWT, int RT>
+template <bool COUNT, int MWT, int RT, bool TEX>
 __device__ __forceinline__ int dense_pixel(const KParams &k, int side, int u, int v, const uint4 own, const uint4 *pu, const float4 rec, const uint32_t *mw,
                                              const uint32_t *cell, int &ncand, int (&npath)[5], const uint4 *lds_first, const uint4 *lds_last) {
     const Dims &d = k.d;
     const int MW = MWT ? MWT : d.MW, plane_radius = RT ? RT : k.plane_radius;
-    if ((int)texture16(own) < k.match_texture) return -10;                      // elas.cpp:732-736 (the map keeps its -10)
+    // elas.cpp:732-736 (the map keeps its -10).  TEX = false: match_texture <= 0 (MIDDLEBURY and the driver's preset), the sum of
+    // absolute values can never be below it - the test and its four SADs are not compiled in (-4 % of the kernel)
+    if (TEX && (int)texture16(own) < k.match_texture) return -10;
     const int d_plane = (int)(rec.x * (float)u + rec.y * (float)v + rec.z);      // :739, ((a*u)+(b*v))+c without contraction
     const int d_plane_min = max(d_plane - plane_radius, 0);
     const int d_plane_max = min(d_plane + plane_radius, d.D - 1);
@@ -1585,7 +1587,7 @@ __device__ __forceinline__ int dense_pixel(const KParams &k, int side, int u, in
 // segment may start up to 3 columns early
 __host__ __device__ inline int dense_seg(const Dims &d) { return DENSE_TW + ((d.disp_max + 3) & ~3); }
 
-template <bool COUNT, int MWT, int RT>
+template <bool COUNT, int MWT, int RT, bool TEX>
 __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const uint8_t *__restrict__ grad, const int32_t *__restrict__ blob, const int32_t *__restrict__ tri_id,
                                                const float4 *__restrict__ trirec, const uint32_t *__restrict__ gB, int16_t *__restrict__ wta,
                                                unsigned long long *__restrict__ counters) {
@@ -1657,7 +1659,7 @@ __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const
                 }
                 const uint4 own = side ? sR[u - r0] : sL[u - l0];
                 const uint4 *pu = side ? sL + (u - l0) : sR + (u - r0);  // the other image at the pixel's own column
-                out = dense_pixel<COUNT, MWT, RT>(k, side, u, v, own, pu, rec, mw, cell, ncand, npath, dense_lds, dense_lds + 2 * dense_seg(d) - 1);
+                out = dense_pixel<COUNT, MWT, RT, TEX>(k, side, u, v, own, pu, rec, mw, cell, ncand, npath, dense_lds, dense_lds + 2 * dense_seg(d) - 1);
                 if (COUNT) npix++;
             }
             // integer-valued: a disparity, -1 or -10.  Half resolution (elas.cpp:707-711): only even (u, v) are matched, result at (u/2, v/2)
@@ -1680,11 +1682,11 @@ __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const
 
 static size_t dense_lds_bytes(const KParams &k) { return sizeof(uint4) * 2 * (size_t)dense_seg(k.d); }
 
-template <int MWT, int RT>
+template <int MWT, int RT, bool TEX>
 static void launch_dense_as(const KParams &k, const SlotDev &s, const dim3 &grid, size_t shmem, hipStream_t st) {
     static std::atomic<size_t> granted[64];
-    ensure_dynamic_lds(k_dense<false, MWT, RT>, shmem, granted, "dense_match");
-    SV_LAUNCH(K_DENSE, (k_dense<false, MWT, RT>), grid, dim3(256), shmem, st, k, s.grad, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
+    ensure_dynamic_lds(k_dense<false, MWT, RT, TEX>, shmem, granted, "dense_match");
+    SV_LAUNCH(K_DENSE, (k_dense<false, MWT, RT, TEX>), grid, dim3(256), shmem, st, k, s.grad, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
 }
 
 void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
@@ -1692,21 +1694,25 @@ void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
     const dim3 grid((k.d.W + DENSE_TW - 1) / DENSE_TW, k.d.sub ? (k.d.H + 1) / 2 : k.d.H, n);
     if (s.counters) {
         static std::atomic<size_t> granted_c[64];
-        ensure_dynamic_lds(k_dense<true, 0, 0>, shmem, granted_c, "dense_match");
-        SV_LAUNCH(K_DENSE, (k_dense<true, 0, 0>), grid, dim3(256), shmem, st, k, s.grad, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
+        ensure_dynamic_lds(k_dense<true, 0, 0, true>, shmem, granted_c, "dense_match");
+        SV_LAUNCH(K_DENSE, (k_dense<true, 0, 0, true>), grid, dim3(256), shmem, st, k, s.grad, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
         return;
     }
     // the usual disparity ranges (64 / 128 / 192 / 256) with the presets' plane radii (2: ROBOTICS, 3: MIDDLEBURY) get kernels
     // compiled for them; anything else the generic one
     const int MW = k.d.MW, R = k.plane_radius;
-    if (MW == 4 && R == 3) return launch_dense_as<4, 3>(k, s, grid, shmem, st);
-    if (MW == 8 && R == 3) return launch_dense_as<8, 3>(k, s, grid, shmem, st);
-    if (MW == 2 && R == 3) return launch_dense_as<2, 3>(k, s, grid, shmem, st);
-    if (MW == 6 && R == 3) return launch_dense_as<6, 3>(k, s, grid, shmem, st);
-    if (MW == 4 && R == 2) return launch_dense_as<4, 2>(k, s, grid, shmem, st);
-    if (MW == 8 && R == 2) return launch_dense_as<8, 2>(k, s, grid, shmem, st);
-    if (MW == 2 && R == 2) return launch_dense_as<2, 2>(k, s, grid, shmem, st);
-    launch_dense_as<0, 0>(k, s, grid, shmem, st);
+    if (R == 3 && k.match_texture <= 0) {  // MIDDLEBURY / the driver's preset: no texture test
+        if (MW == 4) return launch_dense_as<4, 3, false>(k, s, grid, shmem, st);
+        if (MW == 8) return launch_dense_as<8, 3, false>(k, s, grid, shmem, st);
+        if (MW == 2) return launch_dense_as<2, 3, false>(k, s, grid, shmem, st);
+        if (MW == 6) return launch_dense_as<6, 3, false>(k, s, grid, shmem, st);
+    }
+    if (MW == 4 && R == 3) return launch_dense_as<4, 3, true>(k, s, grid, shmem, st);
+    if (MW == 8 && R == 3) return launch_dense_as<8, 3, true>(k, s, grid, shmem, st);
+    if (MW == 4 && R == 2) return launch_dense_as<4, 2, true>(k, s, grid, shmem, st);
+    if (MW == 8 && R == 2) return launch_dense_as<8, 2, true>(k, s, grid, shmem, st);
+    if (MW == 2 && R == 2) return launch_dense_as<2, 2, true>(k, s, grid, shmem, st);
+    launch_dense_as<0, 0, true>(k, s, grid, shmem, st);
 }
 
 // ------------------------------------------------------------------------------------------------------------
