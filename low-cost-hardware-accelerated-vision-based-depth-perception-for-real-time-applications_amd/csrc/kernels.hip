@@ -1630,7 +1630,11 @@ __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const
 #pragma unroll
     for (int j = 0; j < DENSE_TW / 256; j++) {
         const int u = min(x0 + j * 256 + (int)threadIdx.x, d.W - 1);
-        cell_off[j] = gy * (uint32_t)(d.gw * MW) + __umul24((uint32_t)(int)floorf((float)u / (float)d.grid_size), (uint32_t)MW);
+        // floor(u / (float)grid_size) of elas.cpp:745 equals u / grid_size for these integers (the float quotient of a non-multiple is at
+        // least 1 / grid_size away from an integer, far more than its rounding error), and (u * cell_mul) >> 16 equals that for every
+        // column of the image - the engine checked it (fill_kparams) - or cell_mul is 0 and the float division stays
+        const uint32_t cx = k.cell_mul ? (__umul24((uint32_t)u, k.cell_mul) >> 16) : (uint32_t)(int)floorf((float)u / (float)d.grid_size);
+        cell_off[j] = gy * (uint32_t)(d.gw * MW) + __umul24(cx, (uint32_t)MW);
     }
     int ncand = 0, npix = 0, npath[5] = {0, 0, 0, 0, 0};
 #pragma unroll

@@ -39,6 +39,7 @@ struct KParams {
     int add_corners;
     int ccl_cap;             // runs a 16-row band may hold in the LDS tables of k_ccl_band before its map takes the slow path
     int rt_cap;              // triangles a raster tile list may hold before its map falls back to global atomics (<= 512)
+    uint32_t cell_mul;       // (u * cell_mul) >> 16 == u / grid_size for every column u < W (checked on the host), or 0: divide
 };
 
 // Scratch of the GPU triangulation for sets that do not fit LDS (delaunay_gpu.hip, launch_delaunay_gpu_large): per set 2 * cap
