@@ -313,7 +313,7 @@ void fill_kparams(sv_handle *h) {
     // needs incon_window_size <= 5 (any lattice size: its state lives in global memory)
     const char *force_host = getenv("SV_HOST_FILTER");
     h->gpu_filter = !(force_host && atoi(force_host) != 0) && p.incon_window_size >= 0 && p.incon_window_size <= 5 &&
-                    p.incon_min_support >= 0 && p.incon_min_support <= 60 && p.incon_threshold >= 0;  // c_late lives in 6 bits
+                    p.incon_min_support >= 0 && p.incon_min_support <= 60 && p.incon_threshold >= 0 && p.incon_threshold < 4096;  // c_late lives in 6 bits; the classify kernel's sentinel is 16384
     // (sv_create additionally keeps the filters on the host for chunk < 4: the GPU version is a ~0.4 ms latency chain,
     //  worth it only when many pairs share it)
 }

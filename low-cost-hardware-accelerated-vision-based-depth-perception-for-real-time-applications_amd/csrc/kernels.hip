@@ -556,47 +556,63 @@ __device__ __forceinline__ int cs_state(uint32_t w) { return (int)((w >> 16) & 0
 
 __global__ __launch_bounds__(FCL_THREADS) void k_filter_classify(Dims d, int win, int thr, int need, const int16_t *__restrict__ dcan, uint32_t *__restrict__ fcs,
                                                                  uint32_t *__restrict__ useg, int32_t *__restrict__ ucnt) {
+    // LDS: the lattice columns this block's 256 points and their windows touch, each padded to P = Hc + 10 rows; everything that is
+    // not a valid lattice value - invalid points, rows / columns outside the lattice - holds FCL_SENT, which is further than any
+    // threshold from every disparity, so a neighbour costs a read, a subtract, one unsigned compare (|a - b| <= t  <=>
+    // (unsigned)(b - a + t) <= 2t) and an add-with-carry: no bounds tests, no validity tests
+    constexpr int FCL_SENT = 0x4000;
     extern __shared__ int16_t fcl_lds[];
     __shared__ int s_wcnt[FCL_THREADS / 64];
-    const int pair = blockIdx.y, Hc = d.Hc, Wc = d.Wc, lat = Wc * Hc;
+    const int pair = blockIdx.y, Hc = d.Hc, Wc = d.Wc, lat = Wc * Hc, P = Hc + 10;
     const int16_t *G = dcan + (size_t)pair * lat;
-    const int first = blockIdx.x * FCL_THREADS, margin = 5 * Hc + 5;
-    const int s0 = first - margin, span = FCL_THREADS + 2 * margin;
-    for (int i = threadIdx.x; i < span; i += FCL_THREADS) {
-        const int g = s0 + i;
-        fcl_lds[i] = (g >= 0 && g < lat) ? G[g] : (int16_t)-1;
+    const int first = blockIdx.x * FCL_THREADS, last = min(first + FCL_THREADS, lat) - 1;
+    const int c0 = first / Hc - 5, ncol = last / Hc - first / Hc + 11;  // staged columns c0 .. c0 + ncol - 1
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int c = wave; c < ncol; c += FCL_THREADS / 64) {
+        const int u = c0 + c;
+        const bool col_in = u >= 0 && u < Wc;
+        for (int r = lane; r < P; r += 64) {
+            const int v = r - 5;
+            int x = FCL_SENT;
+            if (col_in && v >= 0 && v < Hc) {
+                x = G[(size_t)u * Hc + v];
+                x = x < 0 ? FCL_SENT : x;
+            }
+            fcl_lds[c * P + r] = (int16_t)x;
+        }
     }
     __syncthreads();
     const int idx = first + threadIdx.x;
-    const int16_t *T = fcl_lds - s0;  // T[g] for g inside the span
-    const int dd = idx < lat ? (int)T[idx] : -1;
     uint8_t state = FST_NONE;
-    if (dd >= 0) {
+    int dd = -1;
+    if (idx < lat) {
         const int u = idx / Hc, v = idx - u * Hc;
-        int c_late = 0, c_early = 0;
+        const int16_t *ctr = fcl_lds + (u - c0) * P + 5 + v;  // the point itself; neighbour (du, dv) at ctr[du * P + dv]
+        const int x = ctr[0];
+        if (x != FCL_SENT) {
+            dd = x;
+            const uint32_t lo = (uint32_t)(dd - thr), span = 2u * (uint32_t)thr;
+            uint32_t c_late = 0, c_early = 0;
 #pragma unroll
-        for (int du = -5; du <= 5; du++) {
-            const int u2 = u + du;
-            const bool col_ok = du >= -win && du <= win && u2 >= 0 && u2 < Wc;
-            const int16_t *col = T + (col_ok ? u2 : u) * Hc;
+            for (int du = -5; du <= 5; du++) {
+                if (du < -win || du > win) continue;  // (wave-uniform)
+                const int16_t *col = ctr + du * P;
 #pragma unroll
-            for (int dv = -5; dv <= 5; dv++) {
-                const int v2 = v + dv;
-                const bool ok = col_ok && dv >= -win && dv <= win && v2 >= 0 && v2 < Hc;
-                const int d2 = col[ok ? v2 : v];
-                const int hit = ok & (d2 >= 0) & (abs(dd - d2) <= thr);
-                if (du > 0 || (du == 0 && dv >= 0))
-                    c_late += hit;
-                else
-                    c_early += hit;
+                for (int dv = -5; dv <= 5; dv++) {
+                    if (dv < -win || dv > win) continue;
+                    const uint32_t hit = ((uint32_t)(int)col[dv] - lo) <= span ? 1u : 0u;
+                    if (du > 0 || (du == 0 && dv >= 0))
+                        c_late += hit;
+                    else
+                        c_early += hit;
+                }
             }
+            state = (uint8_t)((int)c_late >= need ? FST_KEEP : ((int)(c_late + c_early) < need) ? FST_DROP : (FST_UNC | (c_late << 2)));
         }
-        state = (uint8_t)(c_late >= need ? FST_KEEP : (c_late + c_early < need) ? FST_DROP : (FST_UNC | (c_late << 2)));
+        fcs[(size_t)pair * filter_cs_stride(lat) + FCS_PAD + idx] = (uint32_t)(uint16_t)dd | ((uint32_t)state << 16);
     }
-    if (idx < lat) fcs[(size_t)pair * filter_cs_stride(lat) + FCS_PAD + idx] = (uint32_t)(uint16_t)dd | ((uint32_t)state << 16);
     const bool unc = (state & 3) == FST_UNC;
     const unsigned long long m = __ballot(unc);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) s_wcnt[wave] = (int)__popcll(m);
     __syncthreads();
     int base = 0, total = 0;
@@ -1027,7 +1043,7 @@ void launch_support_filter(const KParams &k, int win, int thr, int need, const S
     int32_t *ucnt = reinterpret_cast<int32_t *>(ulist + cap * lat), *bcnt = ucnt + cap * (size_t)nb;
     uint32_t *fcs = reinterpret_cast<uint32_t *>(bcnt + cap * (size_t)nb2);  // value | state << 16 per point, padded per pair
     int16_t *latB = reinterpret_cast<int16_t *>(fcs + cap * filter_cs_stride((int)lat)), *latC = latB + cap * lat;
-    const size_t cl_lds = sizeof(int16_t) * (FCL_THREADS + 2 * (size_t)(5 * k.d.Hc + 5));
+    const size_t cl_lds = sizeof(int16_t) * (size_t)((FCL_THREADS + k.d.Hc - 1) / k.d.Hc + 12) * (size_t)(k.d.Hc + 10);  // columns a block and its windows touch, padded rows
     const int SW = filter_strip(k.d.Hc), SH = filter_strip(k.d.Wc);
     const size_t v_lds = filter_strip_lds(SW, k.d.Hc), h_lds = filter_strip_lds(SH, k.d.Wc);
     static std::atomic<size_t> granted[64], granted_v[64], granted_h[64];
