@@ -69,7 +69,7 @@ LATENCY_WORKERS = 7  # latency handles: the calling thread + 7 pool threads buil
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 # integer byte-absdiff peak: 1024 SIMDs x 64 lanes x 4 bytes per v_sad_u8, one wave instruction per 4 cycles (tools/valu_rate.hip), 2.4 GHz
 SAD_PEAK_BYTE_OPS = 1024 * 64 * 4 / 4 * 2.4e9
-KERNEL_TRACE_NAMES = {"descriptor": ["k_descriptor", "k_sobel"], "support_match": ["k_support"], "support_filter": ["k_filter_classify", "k_filter_resolve", "k_filter_vertical", "k_filter_horizontal", "k_filter_count", "k_filter_collect", "k_filter_corners"], "grid_mark": ["k_grid_mark"],
+KERNEL_TRACE_NAMES = {"descriptor": ["k_descriptor", "k_sobel"], "support_match": ["k_support"], "support_filter": ["k_filter_classify", "k_filter_resolve", "k_filter_vertical", "k_filter_horizontal", "k_filter_collect", "k_filter_corners"], "grid_mark": ["k_grid_mark"],
                       "grid_dilate": ["k_grid_dilate"], "plane_fit": ["k_planes"], "triangles_raster": ["k_raster_tiles"], "triangles_raster_fallback": ["k_raster"],
                       "dense_match": ["k_dense"], "lr_check": ["k_lr", "k_lr2"], "delaunay_gpu": ["dg::k_delaunay_blob", "dg::k_dgl_subtrees_blob", "dg::k_dgl_top_blob"], "ccl_band": ["k_ccl_band"],
                       "ccl_finish": ["k_ccl_border", "k_ccl_total", "k_ccl_apply", "k_ccl_slow", "k_ccl_merge"], "gap_rows": ["k_gap_rows"], "gap_cols": ["k_gap_cols"],

@@ -496,15 +496,15 @@ void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
 //     kept-flags of the previous five points: everything that does not depend on the walk (is the point valid, does it have a
 //     match among the five ORIGINAL later neighbours, which of the five earlier neighbours match) is computed for all points
 //     in parallel into one byte per point; the walk itself is five dependent instructions per point on LDS bytes.
-//     Seven small launches, grid-wide except the resolve step (whose work is the few uncertain points); state in global
-//     memory (13 bytes per lattice point), no size limit:
+//     Six small launches, grid-wide except the resolve step (whose work is the few uncertain points); state in global
+//     memory (16 bytes per lattice point), no size limit:
 //       k_filter_classify    one thread per lattice point: the 121-neighbour counts; ordered list of each block's uncertain points
 //       k_filter_resolve     one workgroup per pair: refinement rounds + sequential rest over the uncertain points only
-//       k_filter_vertical    one workgroup per strip of 16 lattice columns: flag bytes in parallel, one lane per column walks them
-//       k_filter_horizontal  one workgroup per strip of 16 lattice rows: the same along the rows
-//       k_filter_count / k_filter_collect / k_filter_corners
-//                            ordered compaction over blocks of 1024 lattice points (counts, then positions = sum of the
-//                            predecessors' counts), nearest point per image corner as a 64-bit key minimum, corner points
+//       k_filter_vertical    one workgroup per strip of 8 lattice columns: flag bytes in parallel, one lane per column walks them
+//       k_filter_horizontal  one workgroup per strip of 8 lattice rows: the same along the rows; counts the points per collect block
+//       k_filter_collect / k_filter_corners
+//                            ordered compaction over blocks of 1024 lattice points (positions = sum of the predecessors'
+//                            counts), nearest point per image corner as a 64-bit key minimum, corner points
 //     Lattice layout: transposed, T[u*Hc + v] (scan order == index order).
 // ------------------------------------------------------------------------------------------------------------
 #define FST_NONE 0
@@ -632,8 +632,10 @@ __global__ __launch_bounds__(FCL_THREADS) void k_filter_classify(Dims d, int win
 // over the threads however they cluster in the lattice (they do: along depth edges).
 #define RSV_MAX_BLOCKS 8192  // classify blocks per pair whose prefix sums fit the LDS table (lattices up to 2 M points)
 __global__ __launch_bounds__(RSV_THREADS) void k_filter_resolve(Dims d, int win, int thr, int need, uint32_t *fcs, const uint32_t *__restrict__ useg,
-                                                                const int32_t *__restrict__ ucnt, int nb, uint32_t *__restrict__ ulist, uint32_t *__restrict__ urest) {
+                                                                const int32_t *__restrict__ ucnt, int nb, uint32_t *__restrict__ ulist, uint32_t *__restrict__ urest, int32_t *__restrict__ bcnt,
+                                                                int nb2) {
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < nb2; i += RSV_THREADS) bcnt[(size_t)pair * nb2 + i] = 0;  // the collect blocks' point counts: the horizontal pass adds to them
     const int Hc = d.Hc, lat = d.Wc * Hc;
     uint32_t *cs = fcs + (size_t)pair * filter_cs_stride(lat) + FCS_PAD;  // cs[idx]: value | state << 16
     uint8_t *stb = reinterpret_cast<uint8_t *>(cs) + 2;                   // the state byte of point idx: stb[4 * idx]
@@ -849,13 +851,15 @@ __global__ __launch_bounds__(FRD_THREADS) void k_filter_vertical(Dims d, int SW,
 
 // horizontal: a strip of `SH` lattice rows (SH a power of two <= 64).  LDS: values [Wc + 10][SH] int16, flags [SH][LS], kept
 // words [SH][KS].
-__global__ __launch_bounds__(FRD_THREADS) void k_filter_horizontal(Dims d, int SH, const int16_t *__restrict__ latB, int16_t *__restrict__ latC) {
+__global__ __launch_bounds__(FRD_THREADS) void k_filter_horizontal(Dims d, int SH, const int16_t *__restrict__ latB, int16_t *__restrict__ latC, int32_t *bcnt, int nb2) {
     extern __shared__ int16_t frd_lds[];
     const int pair = blockIdx.y, Wc = d.Wc, Hc = d.Hc, LS = filter_line_stride(Wc), KS = filter_kept_stride(Wc);
     const int v0 = blockIdx.x * SH, nv = min(SH, Hc - v0);
     int16_t *val = frd_lds;
     uint16_t *kb = reinterpret_cast<uint16_t *>(val + (size_t)(Wc + 10) * SH + (((Wc + 10) * SH) & 1));
     uint8_t *fl = reinterpret_cast<uint8_t *>(kb + (size_t)SH * KS + ((SH * KS) & 1));
+    int *hist = reinterpret_cast<int *>(fl + (((size_t)SH * LS + 3) & ~(size_t)3));  // [nb2] points this strip adds to each collect block
+    for (int i = threadIdx.x; i < nb2; i += FRD_THREADS) hist[i] = 0;
     const size_t g0 = (size_t)pair * Wc * Hc + v0;
     const int r = threadIdx.x & (SH - 1), ug = threadIdx.x / SH, ustep = FRD_THREADS / SH;
     for (int u = ug - 5; u < Wc + 5; u += ustep) val[(u + 5) * SH + r] = (u >= 0 && u < Wc && r < nv) ? latB[g0 + (size_t)u * Hc + r] : (int16_t)-1;
@@ -874,12 +878,20 @@ __global__ __launch_bounds__(FRD_THREADS) void k_filter_horizontal(Dims d, int S
     if ((int)threadIdx.x < nv) redundancy_walk(fl + threadIdx.x * LS, Wc, kb + threadIdx.x * KS);
     __syncthreads();
     if (r < nv)
-        for (int u = ug; u < Wc; u += ustep) latC[g0 + (size_t)u * Hc + r] = ((kb[r * KS + (u >> 4)] >> (u & 15)) & 1) ? val[(u + 5) * SH + r] : (int16_t)-1;
+        for (int u = ug; u < Wc; u += ustep) {
+            const bool kept = (kb[r * KS + (u >> 4)] >> (u & 15)) & 1;
+            latC[g0 + (size_t)u * Hc + r] = kept ? val[(u + 5) * SH + r] : (int16_t)-1;
+            // the collection (elas.cpp:424-428) leaves out lattice row 0 and column 0; its blocks are FLT_THREADS consecutive indices
+            if (kept && u >= 1 && v0 + r >= 1) atomicAdd(&hist[(u * Hc + v0 + r) / FLT_THREADS], 1);
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb2; i += FRD_THREADS)
+        if (hist[i]) atomicAdd(&bcnt[(size_t)pair * nb2 + i], hist[i]);
 }
 
 // ---- (5) collection in scan order (elas.cpp:424-428; lattice row / column 0 excluded) and corner points (elas.cpp:235-264), as
-// two grid-wide launches over blocks of FLT_THREADS consecutive lattice indices - the kernel boundary is the only
-// synchronisation.  k_filter_count: points each block will emit.  k_filter_collect: a block's first list position is the sum
+// blocks of FLT_THREADS consecutive lattice indices - kernel boundaries are the only synchronisation.  The horizontal pass
+// leaves the number of points each block will emit (bcnt, cleared by the resolve step).  k_filter_collect: a block's first list position is the sum
 // of its predecessors' counts (<= 1 300 values even for the largest lattice); it writes its points and offers the nearest
 // one per image corner as a key (distance^2, list position, disparity) - "first minimum in list order" (:246-253) is the
 // minimum of (distance, position); the pair's block 0 of a third, tiny launch (k_filter_corners) reduces the keys and appends
@@ -893,22 +905,6 @@ __device__ __forceinline__ bool collect_pred(const Dims &d, const int16_t *__res
         dv = C[i];
     }
     return dv >= 0 && u >= 1 && v >= 1;
-}
-
-__global__ __launch_bounds__(FLT_THREADS) void k_filter_count(Dims d, const int16_t *__restrict__ latC, int32_t *__restrict__ bcnt) {
-    const int pair = blockIdx.y, lat = d.Wc * d.Hc;
-    __shared__ int s_wave[FLT_THREADS / 64];
-    int u, v, dv;
-    const bool pred = collect_pred(d, latC + (size_t)pair * lat, blockIdx.x * FLT_THREADS + threadIdx.x, lat, u, v, dv);
-    const unsigned long long m = __ballot(pred);
-    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = (int)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int tot = 0;
-#pragma unroll
-        for (int w = 0; w < FLT_THREADS / 64; w++) tot += s_wave[w];
-        bcnt[(size_t)pair * gridDim.x + blockIdx.x] = tot;
-    }
 }
 
 __global__ __launch_bounds__(FLT_THREADS) void k_filter_collect(KParams k, const int16_t *__restrict__ latC, const int32_t *__restrict__ bcnt, unsigned long long *__restrict__ bkey,
@@ -1022,9 +1018,10 @@ __global__ __launch_bounds__(64) void k_filter_corners(KParams k, const int32_t 
 static size_t filter_strip_lds(int s, int n) {
     return (size_t)s * (n + 10) * 2 + 2 + ((size_t)s * filter_kept_stride(n) + 1) * 2 + (size_t)s * filter_line_stride(n);
 }
-// strip width: 16 lines (many workgroups, short flag phases), fewer when a line is so long that the tile would exceed 96 KB
+// strip width: 8 lines (many workgroups, short flag phases: 11.5 + 20 us per 32-pair KITTI launch for the two passes against 14 + 22
+// with 16 lines and 18 + 33 with 32), fewer when a line is so long that the tile would exceed 96 KB
 static int filter_strip(int line_len) {
-    int s = 16;
+    int s = 8;
     while (s > 1 && filter_strip_lds(s, line_len) > 96 * 1024) s >>= 1;
     return s;
 }
@@ -1045,7 +1042,7 @@ void launch_support_filter(const KParams &k, int win, int thr, int need, const S
     int16_t *latB = reinterpret_cast<int16_t *>(fcs + cap * filter_cs_stride((int)lat)), *latC = latB + cap * lat;
     const size_t cl_lds = sizeof(int16_t) * (size_t)((FCL_THREADS + k.d.Hc - 1) / k.d.Hc + 12) * (size_t)(k.d.Hc + 10);  // columns a block and its windows touch, padded rows
     const int SW = filter_strip(k.d.Hc), SH = filter_strip(k.d.Wc);
-    const size_t v_lds = filter_strip_lds(SW, k.d.Hc), h_lds = filter_strip_lds(SH, k.d.Wc);
+    const size_t v_lds = filter_strip_lds(SW, k.d.Hc), h_lds = filter_strip_lds(SH, k.d.Wc) + 8 + sizeof(int) * (size_t)nb2;
     static std::atomic<size_t> granted[64], granted_v[64], granted_h[64];
     ensure_dynamic_lds(k_filter_classify, cl_lds, granted, "support_filter");
     ensure_dynamic_lds(k_filter_vertical, v_lds, granted_v, "support_filter (vertical)");
@@ -1054,10 +1051,9 @@ void launch_support_filter(const KParams &k, int win, int thr, int need, const S
     if (nb > RSV_MAX_BLOCKS) throw std::runtime_error("support_filter: lattice too large for the resolve step's block table");
     // (urest: the remaining points after the rounds; they overwrite nothing the rounds' list still needs - a buffer of its own: latC is free until the horizontal pass)
     SV_LAUNCH(K_SUPPORT_FILTER, k_filter_resolve, dim3(n), dim3(RSV_THREADS), sizeof(int) * ((size_t)nb + 1), st, k.d, win, thr, need, fcs, useg, ucnt, nb, ulist,
-              reinterpret_cast<uint32_t *>(latB));
+              reinterpret_cast<uint32_t *>(latB), bcnt, nb2);
     SV_LAUNCH(K_SUPPORT_FILTER, k_filter_vertical, dim3((k.d.Wc + SW - 1) / SW, n), dim3(FRD_THREADS), v_lds, st, k.d, SW, fcs, latB);
-    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_horizontal, dim3((k.d.Hc + SH - 1) / SH, n), dim3(FRD_THREADS), h_lds, st, k.d, SH, latB, latC);
-    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_count, dim3(nb2, n), dim3(FLT_THREADS), 0, st, k.d, latC, bcnt);
+    SV_LAUNCH(K_SUPPORT_FILTER, k_filter_horizontal, dim3((k.d.Hc + SH - 1) / SH, n), dim3(FRD_THREADS), h_lds, st, k.d, SH, latB, latC, bcnt, nb2);
     SV_LAUNCH(K_SUPPORT_FILTER, k_filter_collect, dim3(nb2, n), dim3(FLT_THREADS), 0, st, k, latC, bcnt, bkey, s.fsup);
     SV_LAUNCH(K_SUPPORT_FILTER, k_filter_corners, dim3(n), dim3(64), 0, st, k, bcnt, bkey, nb2, s.fsup, s.fnsup);
 }
