@@ -3,7 +3,7 @@ balancing, on the GPU only and with a fixed 35 % GPU share; every step's maps mu
   STEPS=120 python tools/soak.py"""
 import importlib, os, sys, time, hashlib
 import numpy as np, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 PKG = "low-cost-hardware-accelerated-vision-based-depth-perception-for-real-time-applications_amd"
 eng = importlib.import_module(PKG + ".engine"); synth = importlib.import_module(PKG + ".synth")
 W, H, D, B = 1242, 375, 128, 256
