@@ -53,3 +53,19 @@ def test_bench_without_launcher_starts_its_own_ranks():
     assert p.returncode != 0
     assert p.stderr.count("bench.py needs a GPU") >= 1 and "WORLD_SIZE=" not in p.stderr
     assert p.stdout.strip() == ""
+
+
+def test_bench_tables_are_consistent():
+    """bench.py's static tables: every workload has a parity-gate fixture in tests/golden/digests.json of its own size and disparity
+    range, a gather chunk, and SURVEY 8(d)'s stage bytes add up to 88 N (+ 2 N for the Sobel kernel's own read of the gray pair)."""
+    sys.path.insert(0, util.ROOT)
+    import bench
+    dig = util.digests()
+    for name, (W, H, D, B, *_rest) in bench.WORKLOADS.items():
+        e = dig[bench.GATES[name]]
+        assert e["shape"] == [H, W] and e["disp_max"] == D - 1 and e["preset"] == "driver", name
+        assert set(("final1", "final2")) <= set(e["stages"]) and 1 <= bench.GATHER_CHUNK[name] <= B
+    N = 1242 * 375
+    a = bench.algorithmic_bytes_8d(N)
+    assert sum(a.values()) == 90 * N and a["dense_match"] == 10 * N
+    assert "k_filter_horizontal" in bench.KERNEL_TRACE_NAMES["support_filter"] and "dg::k_dgl_top_blob" in bench.KERNEL_TRACE_NAMES["delaunay_gpu"]
