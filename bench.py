@@ -189,6 +189,24 @@ def cpu_baseline(sample_pairs, synth, subsampling=False, scale=1, all_cores_pair
     return one, many
 
 
+def host_throughput_dmap(eng, e, batch, Hm, Wm, steps, pinned, reps=1):
+    """The same with the driver's 8-bit disparity images as the output (sv_submit_batch_host_dmap): a quarter of the download."""
+    B = batch.shape[0]
+    alloc = eng.pinned_array if pinned else (lambda shape, dt: np.zeros(shape, dt))
+    L, R = alloc((B, H, W), np.uint8), alloc((B, H, W), np.uint8)
+    L[:], R[:] = batch[:, 0], batch[:, 1]
+    dm = alloc((B, Hm, Wm), np.uint8)
+    e.process_host_dmap(L, R, dmap=dm)
+    rates = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e.submit_host_dmap(L, R, dm)
+        e.wait()
+        rates.append(B * steps / (time.perf_counter() - t0))
+    return sorted(rates)
+
+
 def host_throughput(eng, e, batch, Hm, Wm, steps, pinned, want_d2, reps=1):
     """`steps` host-memory batches submitted back to back (sv_submit_batch_host) and waited for: pairs/s, PCIe inclusive; `reps`
     repetitions on the same buffers (sorted)."""
@@ -263,12 +281,14 @@ def host_to_host(eng, e, params, batch, steps, lat_pair, reps=3):
     Hm, Wm = (H // 2, W // 2) if params.subsampling else (H, W)
     in_b, map_b = 2 * W * H, 4 * Wm * Hm
     out = {"definition": "gray L+R u8 in host memory -> f32 maps back in host memory, %d pairs per batch, %d batches streamed (sv_submit_batch_host), median of %d repetitions" % (batch.shape[0], steps, reps),
-           "bytes_per_pair": {"in": in_b, "d1": map_b}, "pcie_ceiling_GBps": pcie_ceiling()}
+           "bytes_per_pair": {"in": in_b, "d1": map_b, "dmap_u8": map_b // 4}, "pcie_ceiling_GBps": pcie_ceiling()}
     for kind in ("pinned", "pageable"):
         runs1 = host_throughput(eng, e, batch, Hm, Wm, steps, kind == "pinned", False, reps)
         runs2 = host_throughput(eng, e, batch, Hm, Wm, steps, kind == "pinned", True, reps)
+        runs8 = host_throughput_dmap(eng, e, batch, Hm, Wm, steps, kind == "pinned", reps)
         r1, r2 = runs1[len(runs1) // 2], runs2[len(runs2) // 2]
-        out[kind] = {"pairs_per_s_d1": round(r1, 1), "pairs_per_s_d1_runs": [round(x, 1) for x in runs1], "pairs_per_s_d1_d2": round(r2, 1), "pairs_per_s_d1_d2_runs": [round(x, 1) for x in runs2],
+        out[kind] = {"pairs_per_s_dmap_u8": round(runs8[len(runs8) // 2], 1), "pairs_per_s_dmap_u8_runs": [round(x, 1) for x in runs8],
+                     "pairs_per_s_d1": round(r1, 1), "pairs_per_s_d1_runs": [round(x, 1) for x in runs1], "pairs_per_s_d1_d2": round(r2, 1), "pairs_per_s_d1_d2_runs": [round(x, 1) for x in runs2],
                      "pcie_GBps_d1": {"h2d": round(r1 * in_b / 1e9, 2), "d2h": round(r1 * map_b / 1e9, 2)},
                      "pcie_GBps_d1_d2": {"h2d": round(r2 * in_b / 1e9, 2), "d2h": round(r2 * 2 * map_b / 1e9, 2)}}
     out["latency_ms_batch1_host"] = {k: host_latency(eng, params, lat_pair[0], lat_pair[1], k == "pinned") for k in ("pinned", "pageable")}

@@ -142,6 +142,12 @@ int sv_wait_batches(sv_handle *h, int n);
  * sv_submit_batch_host is the streaming form (buffers stay valid and untouched until sv_wait). */
 int sv_process_batch_host(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status);
 int sv_submit_batch_host(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status);
+/* The same with the DRIVER's output format: dmap = saturate(round_half_even(4 * D1)) as uint8 [B][height][width] (what the reference's
+ * generateDisparityMap returns: leftdpf.convertTo(dmap, CV_8UC1, 4.0), stereo_vision.cpp:316; [B][height/2][width/2] with
+ * params.subsampling), converted on the device: a quarter of the bytes come back over PCIe.  Images of pairs with < 3 support
+ * points are not written.  Page-locked or pageable memory, like above. */
+int sv_process_batch_host_dmap(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, uint8_t *dmap, int32_t *status);
+int sv_submit_batch_host_dmap(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, uint8_t *dmap, int32_t *status);
 /* Page-locked host memory for the calls above (NULL on failure). */
 void *sv_host_alloc(size_t bytes);
 void sv_host_free(void *p);

@@ -72,6 +72,7 @@ struct Job {
     const uint8_t *left = nullptr, *right = nullptr;
     int batch = 0, stride = 0;
     float *d1 = nullptr, *d2 = nullptr;
+    uint8_t *dmap = nullptr;  // host-memory jobs only: the caller wants the driver's 8-bit disparity image instead of the float maps
     int32_t *status = nullptr;
     int nchunks = 0;
     int issued2 = 0;  // chunks whose second GPU phase has been enqueued (guarded by sv_handle::mu)
@@ -98,6 +99,7 @@ struct Slot {
     float *d_out = nullptr;    // [2][cap][Nm]     final maps (left block, right block)
     uint8_t *h_in = nullptr;   // page-locked, same layout as d_in
     float *h_out = nullptr;    // page-locked, same layout as d_out
+    uint8_t *d_out8 = nullptr, *h_out8 = nullptr;  // [cap][Nm] 8-bit disparity images of a chunk (device staging / page-locked mirror): dmap jobs
     hipEvent_t ev_in = nullptr, ev_lr = nullptr, ev_p2 = nullptr, ev_out = nullptr;
     // inputs of phase 1 for the chunk in flight (device pointers: the job's own, or the staging buffers)
     const uint8_t *in_left = nullptr, *in_right = nullptr;
@@ -155,6 +157,7 @@ struct sv_handle {
     std::vector<hipStream_t> sP2;
     hipStream_t sIn = nullptr, sOut = nullptr, sOut2 = nullptr;  // host-memory jobs: image uploads / map downloads (two streams: two DMA engines), overlapping the kernels
     bool host_dev_ready = false, host_pin_in_ready = false, host_pin_out_ready = false;  // lazily allocated staging (guarded by host_mu)
+    bool host_dev8_ready = false, host_pin_out8_ready = false;
     std::mutex host_mu;
     // control threads + queues
     std::thread t_issue, t_dispatch, t_finish, t_drain, t_deliver;
@@ -547,7 +550,7 @@ bool is_pinned_host(const void *p, size_t bytes) {
 // Staging of the host-memory path, allocated at the first host job (device-memory users never pay for it): per slot the
 // packed gray images of a chunk and its two final maps on the device, and - only when a caller hands over pageable memory -
 // page-locked mirrors of both.
-void ensure_host_staging(sv_handle *h, bool need_pin_in, bool need_pin_out) {
+void ensure_host_staging(sv_handle *h, bool need_pin_in, bool need_pin_out, bool dmap = false) {
     std::lock_guard<std::mutex> lk(h->host_mu);
     const Dims &d = h->kp.d;
     const size_t cap = (size_t)h->chunk;
@@ -571,9 +574,17 @@ void ensure_host_staging(sv_handle *h, bool need_pin_in, bool need_pin_out) {
         for (Slot *sl : h->slots) HIP_TRY(hipHostMalloc((void **)&sl->h_in, 2 * cap * (size_t)d.N, hipHostMallocDefault));
         h->host_pin_in_ready = true;
     }
-    if (need_pin_out && !h->host_pin_out_ready) {
+    if (need_pin_out && !dmap && !h->host_pin_out_ready) {
         for (Slot *sl : h->slots) HIP_TRY(hipHostMalloc((void **)&sl->h_out, 2 * cap * (size_t)d.Nm * sizeof(float), hipHostMallocDefault));
         h->host_pin_out_ready = true;
+    }
+    if (dmap && !h->host_dev8_ready) {
+        for (Slot *sl : h->slots) HIP_TRY(hipMalloc((void **)&sl->d_out8, cap * (size_t)d.Nm));
+        h->host_dev8_ready = true;
+    }
+    if (dmap && need_pin_out && !h->host_pin_out8_ready) {
+        for (Slot *sl : h->slots) HIP_TRY(hipHostMalloc((void **)&sl->h_out8, cap * (size_t)d.Nm, hipHostMallocDefault));
+        h->host_pin_out8_ready = true;
     }
 }
 
@@ -615,9 +626,24 @@ void upload_chunk(sv_handle *h, Slot *s, hipStream_t st, int copy_helpers) {
 void download_maps(sv_handle *h, Slot *s, int side, hipStream_t st, hipStream_t st2 = nullptr) {
     const Dims &d = h->kp.d;
     const Job &job = *s->job;
+    const size_t cap = (size_t)s->dev.cap, Nm = (size_t)d.Nm;
+    if (job.dmap) {  // the 8-bit disparity images of the chunk (side 0 only): a quarter of the float maps' bytes
+        if (side) return;
+        uint8_t *dst8 = job.pin_out ? job.dmap + (size_t)s->i0 * Nm : s->h_out8;
+        for (int j = 0; j < s->n;) {  // maximal runs of processed pairs
+            if (s->h_blob[(size_t)j * META_WORDS] < 3) {
+                j++;
+                continue;
+            }
+            int e = j + 1;
+            while (e < s->n && s->h_blob[(size_t)e * META_WORDS] >= 3) e++;
+            HIP_TRY(hipMemcpyAsync(dst8 + (size_t)j * Nm, s->d_out8 + (size_t)j * Nm, (size_t)(e - j) * Nm, hipMemcpyDeviceToHost, st));
+            j = e;
+        }
+        return;
+    }
     float *user = side ? job.d2 : job.d1;
     if (!user) return;
-    const size_t cap = (size_t)s->dev.cap, Nm = (size_t)d.Nm;
     const float *dev = s->d_out + side * cap * Nm;
     float *dst = job.pin_out ? user + (size_t)s->i0 * Nm : s->h_out + side * cap * Nm;
     for (int j = 0; j < s->n;) {  // maximal runs of processed pairs
@@ -642,6 +668,12 @@ void deliver_maps(sv_handle *h, Slot *s, int copy_helpers) {
     if (job.pin_out) return;
     const size_t cap = (size_t)s->dev.cap, Nm = (size_t)d.Nm;
     CopyList cl;
+    if (job.dmap) {
+        for (int j = 0; j < s->n; j++)
+            if (s->h_blob[(size_t)j * META_WORDS] >= 3) cl.add(job.dmap + (size_t)(s->i0 + j) * Nm, s->h_out8 + (size_t)j * Nm, Nm);
+        if (!cl.job->pieces.empty()) cl.run(h, copy_helpers);
+        return;
+    }
     for (int side = 0; side < 2; side++) {
         float *user = side ? job.d2 : job.d1;
         if (!user) continue;
@@ -993,7 +1025,7 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
     s->grid_issued = false;
     launch_triangles(k, s->dev, n, max_points, st);
     launch_dense(k, s->dev, n, st);
-    float *u1 = job.d1 + (size_t)s->i0 * d.Nm, *u2 = job.d2 ? job.d2 + (size_t)s->i0 * d.Nm : nullptr;  // the caller's maps are [batch][Hm][Wm]
+    float *u1 = job.d1 ? job.d1 + (size_t)s->i0 * d.Nm : nullptr, *u2 = job.d2 ? job.d2 + (size_t)s->i0 * d.Nm : nullptr;  // the caller's maps are [batch][Hm][Wm]
     if (job.host) {  // host-memory job: the maps are written to the slot's device staging and downloaded from there
         u1 = s->d_out;
         u2 = job.d2 ? s->d_out + (size_t)s->dev.cap * d.Nm : nullptr;
@@ -1033,6 +1065,8 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
         launch_output(km, s->dev, n, cur, u1, only_left ? nullptr : u2, st);
     }
     if (active) dbg_maps_nproc(h, st, "final", cur, s->dev.disp, n - 1);
+    if (job.host && job.dmap && launch_disp_to_u8(s->d_out, (size_t)n * d.Nm, s->d_out8, st) != 0)  // leftdpf.convertTo(dmap, CV_8UC1, 4.0), stereo_vision.cpp:316
+        throw std::runtime_error("disparity to 8-bit conversion failed to launch");
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev_free, st));
     if (job.host) HIP_TRY(hipEventRecord(s->ev_p2, st));
@@ -1342,6 +1376,8 @@ void free_slot(Slot *sl) {
     if (sl->d_out) (void)hipFree(sl->d_out);
     if (sl->h_in) (void)hipHostFree(sl->h_in);
     if (sl->h_out) (void)hipHostFree(sl->h_out);
+    if (sl->d_out8) (void)hipFree(sl->d_out8);
+    if (sl->h_out8) (void)hipHostFree(sl->h_out8);
     for (hipEvent_t e : {sl->ev_in, sl->ev_lr, sl->ev_p2, sl->ev_out})
         if (e) (void)hipEventDestroy(e);
 }
@@ -1373,10 +1409,11 @@ int prepare_host_job(sv_handle *h, Job *job) {
     const size_t in_bytes = (size_t)job->batch * d.H * job->stride, out_bytes = (size_t)job->batch * d.Nm * sizeof(float);
     (void)hipSetDevice(h->cfg.device);
     job->pin_in = is_pinned_host(job->left, in_bytes) && is_pinned_host(job->right, in_bytes);
-    job->pin_out = is_pinned_host(job->d1, out_bytes) && (!job->d2 || is_pinned_host(job->d2, out_bytes));
+    job->pin_out = job->dmap ? is_pinned_host(job->dmap, (size_t)job->batch * d.Nm)
+                             : is_pinned_host(job->d1, out_bytes) && (!job->d2 || is_pinned_host(job->d2, out_bytes));
     if (getenv("SV_HOST_FORCE_STAGING")) job->pin_in = job->pin_out = false;  // tests: the pageable route with page-locked buffers
     try {
-        ensure_host_staging(h, !job->pin_in, !job->pin_out);
+        ensure_host_staging(h, !job->pin_in, !job->pin_out, job->dmap != nullptr);
     } catch (const std::exception &e) {
         h->error = e.what();
         return SV_ERR_HIP;
@@ -1384,9 +1421,9 @@ int prepare_host_job(sv_handle *h, Job *job) {
     return SV_OK;
 }
 
-int submit_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status, bool host = false) {
+int submit_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status, bool host = false, uint8_t *dmap = nullptr) {
     if (!h) return SV_ERR_ARG;
-    if (!left || !right || !d1 || batch < 0 || stride < h->cfg.width) {
+    if (!left || !right || (!d1 && !(host && dmap)) || batch < 0 || stride < h->cfg.width) {
         h->error = "bad argument (null pointer, negative batch, or stride < width)";
         return SV_ERR_ARG;
     }
@@ -1398,6 +1435,7 @@ int submit_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batc
     job->stride = stride;
     job->d1 = d1;
     job->d2 = d2;
+    job->dmap = dmap;
     job->status = status;
     job->nchunks = (batch + h->chunk - 1) / h->chunk;
     if (host) {
@@ -1828,6 +1866,19 @@ int sv_process_batch_host(sv_handle *h, const uint8_t *left, const uint8_t *righ
 
 int sv_submit_batch_host(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, float *d1, float *d2, int32_t *status) {
     return submit_job(h, left, right, batch, stride, d1, d2, status, true);
+}
+
+int sv_submit_batch_host_dmap(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, uint8_t *dmap, int32_t *status) {
+    if (h && !dmap) {
+        h->error = "bad argument (null dmap)";
+        return SV_ERR_ARG;
+    }
+    return submit_job(h, left, right, batch, stride, nullptr, nullptr, status, true, dmap);
+}
+
+int sv_process_batch_host_dmap(sv_handle *h, const uint8_t *left, const uint8_t *right, int batch, int stride, uint8_t *dmap, int32_t *status) {
+    const int rc = sv_submit_batch_host_dmap(h, left, right, batch, stride, dmap, status);
+    return rc != SV_OK ? rc : wait_jobs(h);
 }
 
 void *sv_host_alloc(size_t bytes) {

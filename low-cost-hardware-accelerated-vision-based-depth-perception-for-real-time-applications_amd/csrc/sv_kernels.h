@@ -108,6 +108,7 @@ void launch_gap_cols(const KParams &k, const SlotDev &s, int n, int nproc, hipSt
 void launch_amean(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st, const float *src, float *dst);
 void launch_median(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st, const float *src, float *dst, float *user_d1, float *user_d2);
 void launch_output(const KParams &k, const SlotDev &s, int n, const float *src, float *d1, float *d2, hipStream_t st);
+int launch_disp_to_u8(const float *disp, size_t n, unsigned char *out, hipStream_t st);  // legacy_kernels.hip: saturate(round_half_even(4 d)), stereo_vision.cpp:316
 
 // GPU triangulation (delaunay_gpu.hip): one workgroup per vertex set, sets[s] = {first entry in order/xy, vertices after the
 // duplicate scan, entries of xy, offset of the set's triangle list in tri_out (in int32 units)}

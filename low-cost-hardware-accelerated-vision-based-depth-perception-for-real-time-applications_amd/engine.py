@@ -101,6 +101,10 @@ def lib():
     L.sv_host_free.restype = None
     L.sv_query.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sv_query.restype = ctypes.c_int
+    for name in ("sv_process_batch_host_dmap", "sv_submit_batch_host_dmap"):
+        f = getattr(L, name)
+        f.argtypes = [ctypes.c_void_p, u8p, u8p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, i32p]
+        f.restype = ctypes.c_int
     for name in ("sv_process_batch_device", "sv_process_batch_host", "sv_submit_batch_device", "sv_submit_batch_host"):
         f = getattr(L, name)
         f.argtypes = [ctypes.c_void_p, u8p, u8p, ctypes.c_int, ctypes.c_int, f32p, f32p, i32p]
@@ -255,6 +259,36 @@ class StereoEngine:
         st = status.ctypes.data_as(ctypes.c_void_p) if status is not None else None
         self._check(lib().sv_submit_batch_host(self._h, left_c.ctypes.data, right_c.ctypes.data, B, self.width, d1.ctypes.data,
                                                d2.ctypes.data if d2 is not None else None, st))
+
+    def _host_dmap_args(self, left, right, dmap):
+        left = np.ascontiguousarray(left, dtype=np.uint8)
+        right = np.ascontiguousarray(right, dtype=np.uint8)
+        if left.ndim == 2:
+            left, right = left[None], right[None]
+        B, H, W = left.shape
+        if (H, W) != (self.height, self.width) or right.shape != left.shape:
+            raise ValueError("images must be [B,%d,%d]" % (self.height, self.width))
+        shape = (B, self.map_height, self.map_width)
+        if dmap is None:
+            dmap = np.zeros(shape, np.uint8)
+        if not (isinstance(dmap, np.ndarray) and dmap.dtype == np.uint8 and dmap.flags.c_contiguous and dmap.shape == shape):
+            raise ValueError("dmap must be a contiguous uint8 array %s" % (shape,))
+        return left, right, dmap, B
+
+    def process_host_dmap(self, left, right, dmap=None):
+        """numpy [B,H,W] uint8 in, the driver's 8-bit disparity images out (saturate(round_half_even(4 * D1)), stereo_vision.cpp:316)."""
+        left, right, dmap, B = self._host_dmap_args(left, right, dmap)
+        status = np.zeros(B, np.int32)
+        self._check(lib().sv_process_batch_host_dmap(self._h, left.ctypes.data, right.ctypes.data, B, self.width, dmap.ctypes.data, status.ctypes.data))
+        return dmap, status
+
+    def submit_host_dmap(self, left, right, dmap, status=None):
+        """Streaming form of process_host_dmap: returns at once; the arrays must stay alive and untouched until wait()."""
+        left_c, right_c, dmap, B = self._host_dmap_args(left, right, dmap)
+        if left_c is not left and not np.shares_memory(left_c, left) or right_c is not right and not np.shares_memory(right_c, right):
+            raise ValueError("submit_host_dmap needs contiguous uint8 arrays (a temporary copy would be freed before the engine reads it)")
+        st = status.ctypes.data_as(ctypes.c_void_p) if status is not None else None
+        self._check(lib().sv_submit_batch_host_dmap(self._h, left_c.ctypes.data, right_c.ctypes.data, B, self.width, dmap.ctypes.data, st))
 
     def elas_process(self, I1, I2):
         """Elas::process(I1, I2, D1, D2, dims) for one pair (elas.h:153-162)."""

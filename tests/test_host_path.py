@@ -166,3 +166,47 @@ def test_device_batch_arguments_are_validated(eng):
         e.wait()
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("memory", ["pinned", "pageable"])
+def test_host_batch_with_the_drivers_8bit_output(eng, batch13, memory):
+    """sv_process_batch_host_dmap / sv_submit_batch_host_dmap: the driver's output format (dmap = saturate(round_half_even(4 * D1)),
+    stereo_vision.cpp:316) straight from the device - equals the conversion of the float maps of the same handle; several chunks,
+    a ragged last one, streamed submissions, mixed with float jobs; an image of a pair with < 3 support points stays untouched."""
+    batch, _want = batch13
+    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), chunk=4, n_slots=3, n_workers=3)
+    alloc = eng.pinned_array if memory == "pinned" else (lambda shape, dt: np.zeros(shape, dt))
+    try:
+        L, R = alloc(batch[:, 0].shape, np.uint8), alloc(batch[:, 0].shape, np.uint8)
+        L[:], R[:] = batch[:, 0], batch[:, 1]
+        L[5] = 0
+        R[5] = 0  # textureless: only the six corner points with the driver preset -> still >= 3; see the robotics part below
+        d1, _, st = e.process_host(L, R, want_d2=False)
+        want = np.clip(np.rint(d1 * np.float32(4.0)), 0, 255).astype(np.uint8)
+        dm = alloc(want.shape, np.uint8)
+        dm[:] = 77
+        got, st2 = e.process_host_dmap(L, R, dmap=dm)
+        assert np.array_equal(st, st2) and np.array_equal(got, want)
+        a, b = alloc(want.shape, np.uint8), alloc(want.shape, np.uint8)
+        f1 = alloc(d1.shape, np.float32)
+        e.submit_host_dmap(L, R, a)
+        e.submit_host(L, R, f1)
+        e.submit_host_dmap(L, R, b)
+        e.wait()
+        assert np.array_equal(a, want) and np.array_equal(b, want) and np.array_equal(f1, d1)
+    finally:
+        e.close()
+    p = eng.SvParams.preset("robotics")
+    p.disp_max = D - 1
+    e = eng.StereoEngine(W, H, p, chunk=4, n_slots=2, n_workers=2)
+    try:
+        Z = np.zeros_like(batch[:3, 0])
+        Z[1] = batch[1, 0]
+        ZR = np.zeros_like(Z)
+        ZR[1] = batch[1, 1]
+        dm = np.full(Z.shape, 99, np.uint8)
+        got, st = e.process_host_dmap(Z, ZR, dmap=dm)
+        assert st[0] < 3 and st[2] < 3 and st[1] >= 3
+        assert (got[0] == 99).all() and (got[2] == 99).all() and not (got[1] == 99).all()  # elas.cpp:63-69: untouched outputs
+    finally:
+        e.close()
