@@ -204,12 +204,12 @@ def host_throughput_dmap(eng, e, batch, Hm, Wm, steps, pinned, reps=1):
             e.submit_host_dmap(L, R, dm)
         e.wait()
         rates.append(B * steps / (time.perf_counter() - t0))
-    return sorted(rates)
+    return rates
 
 
 def host_throughput(eng, e, batch, Hm, Wm, steps, pinned, want_d2, reps=1):
     """`steps` host-memory batches submitted back to back (sv_submit_batch_host) and waited for: pairs/s, PCIe inclusive; `reps`
-    repetitions on the same buffers (sorted)."""
+    repetitions on the same buffers (in the order measured)."""
     B = batch.shape[0]
     alloc = eng.pinned_array if pinned else (lambda shape, dt: np.zeros(shape, dt))
     L, R = alloc((B, H, W), np.uint8), alloc((B, H, W), np.uint8)
@@ -224,7 +224,7 @@ def host_throughput(eng, e, batch, Hm, Wm, steps, pinned, want_d2, reps=1):
             e.submit_host(L, R, d1, d2)
         e.wait()
         rates.append(B * steps / (time.perf_counter() - t0))
-    return sorted(rates)
+    return rates  # in the order they were measured
 
 
 def host_latency(eng, params, l1, r1, pinned, calls=200):
@@ -286,8 +286,9 @@ def host_to_host(eng, e, params, batch, steps, lat_pair, reps=3):
         runs1 = host_throughput(eng, e, batch, Hm, Wm, steps, kind == "pinned", False, reps)
         runs2 = host_throughput(eng, e, batch, Hm, Wm, steps, kind == "pinned", True, reps)
         runs8 = host_throughput_dmap(eng, e, batch, Hm, Wm, steps, kind == "pinned", reps)
-        r1, r2 = runs1[len(runs1) // 2], runs2[len(runs2) // 2]
-        out[kind] = {"pairs_per_s_dmap_u8": round(runs8[len(runs8) // 2], 1), "pairs_per_s_dmap_u8_runs": [round(x, 1) for x in runs8],
+        med = lambda xs: sorted(xs)[len(xs) // 2]
+        r1, r2 = med(runs1), med(runs2)
+        out[kind] = {"pairs_per_s_dmap_u8": round(med(runs8), 1), "pairs_per_s_dmap_u8_runs": [round(x, 1) for x in runs8],
                      "pairs_per_s_d1": round(r1, 1), "pairs_per_s_d1_runs": [round(x, 1) for x in runs1], "pairs_per_s_d1_d2": round(r2, 1), "pairs_per_s_d1_d2_runs": [round(x, 1) for x in runs2],
                      "pcie_GBps_d1": {"h2d": round(r1 * in_b / 1e9, 2), "d2h": round(r1 * map_b / 1e9, 2)},
                      "pcie_GBps_d1_d2": {"h2d": round(r2 * in_b / 1e9, 2), "d2h": round(r2 * 2 * map_b / 1e9, 2)}}
