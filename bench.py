@@ -583,6 +583,15 @@ def run_config(ctx, name, steps_req, warmup, min_seconds, headline, gather):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         steps = int(t.item())
     my_elapsed = timed_region(torch, engine, left, right, bufs[:1], steps, barrier, sync_steps=args.sync_steps and headline)
+    if min_seconds > 0:  # the estimate came from a few batches (pipeline fill included): should the region have come out short, time it again, longer
+        t = torch.tensor([my_elapsed], dtype=torch.float64, device=coll_dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if float(t.item()) < 0.97 * min_seconds:
+            steps = int(np.ceil(steps * 1.08 * min_seconds / max(float(t.item()), 1e-6)))
+            if headline and not args.no_kernel_timing:
+                engine.timing(True, only=None if args.time_all_kernels else tuple({res["_dom"], max(serial_k, key=lambda k: serial_k[k][0])}))  # (resets the kernel's event totals)
+            my_elapsed = timed_region(torch, engine, left, right, bufs[:1], steps, barrier, sync_steps=args.sync_steps and headline)
     res["_ktimes"] = engine.kernel_times() if headline and not args.no_kernel_timing else {}
     engine.timing(False)
     engine_info["gpu_triangulation_share"] = engine.gpu_triangulation_share()  # host mode: what the dispatcher's load balancing handed to the GPU kernel
