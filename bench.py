@@ -15,7 +15,14 @@ Before anything is timed the engine must reproduce the reference's maps for the 
 (`parity_gate`: sha256 against tests/golden/digests.json; exit code 3 otherwise).  The timed region lasts at least
 --min-seconds (5 s): `steps` on the line is the number of steps actually timed, `ms_per_step` x `steps` the timed wall.
 
+After the timed region every map its last step produced is compared with the same engine's idle-pipeline run of the same batch,
+and pair 0 with the reference's digests (`parity_after`; exit code 3 on a mismatch) - the gate alone would not see a race that
+only shows under full streaming.  The line ends with a compact `trailer` (headline, host-to-host, D=256 / 4K rates, latency,
+host-share figure, parity) so that a reader of the line's tail sees them.
+
 Also on the JSON line:
+  value_at_host_share_8   the headline measured by a fresh process restricted to 1/8 of this process's CPUs with LOCAL_WORLD_SIZE=8
+                  (one rank's host budget on an 8-rank node; launcher.restrict_to_host_share), before this process touches the GPU
   configs         BASELINE.json's other configurations, each on its own engine behind its own parity gate: kitti_d256
                   (configs[3]) and 4k_d192 (configs[4]; with N > 1 its maps are gathered on rank 0 inside the timed region)
   roofline        the kernel with the largest total time over ALL kernels of the pipelined configuration (the one that is
@@ -59,7 +66,8 @@ WORKLOADS = {  # name: (W, H, D, default pairs per GPU per step, chunk, slots, s
 }
 GATES = {"kitti_d128": "kitti0_d128", "kitti_d256": "kitti0_d256", "4k_d192": "synth5000_4k_d192"}  # parity-gate pair: entry of tests/golden/digests.json
 GATHER_CHUNK = {"kitti_d128": 64, "kitti_d256": 64, "4k_d192": 16}  # pairs per gather collective ("chunked (e.g. 16 pairs)")
-SUBCONFIG_DISTINCT = {"4k_d192": 4}  # sub-measurements synthesise fewer distinct pairs (a 4K pair takes ~1 s)
+SUBCONFIG_DISTINCT = {"4k_d192": 16}  # distinct pairs a sub-measurement synthesises (a 4K pair takes ~1 s)
+SUBCONFIG_MIN_SECONDS = 5.0  # the sub-measurements are timed as long as the headline
 METRIC = {
     "kitti_d128": "stereo pairs/sec, KITTI 1242x375 D=128 (ms/frame at batch 1 in latency_ms_batch1)",
     "kitti_d256": "stereo pairs/sec, KITTI 1242x375 D=256 (LDS-pressure configuration; ms/frame at batch 1 in latency_ms_batch1)",
@@ -332,6 +340,31 @@ def load_real_pair_for(Wx, Hx):
     return None
 
 
+def load_real_pairs(Wx, Hx, Dx):
+    """Every real KITTI pair committed under tests/golden/ (gray PNGs written by make_golden.py) that has a digest entry for this
+    disparity range: [(digest key, left, right)], pair 0 first."""
+    if (Wx, Hx) != (1242, 375):
+        return []
+    dig, out = golden_digests(), []
+    try:
+        from PIL import Image
+    except ImportError:
+        return []
+    names = sorted((os.path.basename(f)[5:-9] for f in glob.glob(os.path.join(ROOT, "tests", "golden", "kitti*_left.png")) if os.path.basename(f)[5:-9].isdigit()), key=int)
+    for n in names:
+        key = "kitti%s_d%d" % (n, Dx)
+        if key not in dig:
+            continue
+        try:
+            gl = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "kitti%s_left.png" % n)))
+            gr = np.asarray(Image.open(os.path.join(ROOT, "tests", "golden", "kitti%s_right.png" % n)))
+        except OSError:
+            continue
+        if gl.shape == (Hx, Wx) and gr.shape == (Hx, Wx):
+            out.append((key, np.ascontiguousarray(gl), np.ascontiguousarray(gr)))
+    return out
+
+
 def golden_digests():
     try:
         with open(os.path.join(ROOT, "tests", "golden", "digests.json")) as f:
@@ -349,13 +382,15 @@ def parity_gate(engine, torch, synth, name, subsampling):
     key = GATES[name] + ("_sub" if subsampling else "")
     entry = golden_digests().get(key)
     if entry is None:
-        return {"status": "unavailable", "case": key, "why": "no golden digest for this configuration"}
+        print("parity gate %s: no golden digest for this configuration (tests/golden/digests.json) - nothing is timed without a gate; --no-gate for profiling runs" % key, file=sys.stderr)
+        raise SystemExit(3)
     if "synth" in entry:
         L, R = synth.make_pair(**entry["synth"])
     else:
         pair = load_real_pair_for(Wx, Hx)
         if pair is None:
-            return {"status": "unavailable", "case": key, "why": "gray fixture missing"}
+            print("parity gate %s: the gray fixture of the gate pair is missing (tests/golden/)" % key, file=sys.stderr)
+            raise SystemExit(3)
         L, R = pair
     import hashlib
     sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
@@ -372,7 +407,35 @@ def parity_gate(engine, torch, synth, name, subsampling):
         print("parity gate %s FAILED: %s differ from the reference's maps (sha256 %s, expected %s)" %
               (key, bad, [got[k][:16] for k in bad], [entry["stages"][k][:16] for k in bad]), file=sys.stderr)
         raise SystemExit(3)
-    return {"status": "pass", "case": key, "checked": "sha256 of d1[0] and d2[0] (raw float32 bytes) == tests/golden/digests.json:%s.stages.final1/final2 (the reference's own output, tolerance 0)" % key}
+    return {"status": "pass", "case": key, "_entry": entry, "_input_sha": [sha(L), sha(R)], "checked": "sha256 of d1[0] and d2[0] (raw float32 bytes) == tests/golden/digests.json:%s.stages.final1/final2 (the reference's own output, tolerance 0)" % key}
+
+
+def parity_after(torch, gate, pair0, d1, d2, ref1, ref2, what):
+    """After a timed region: (1) every map its LAST step left in the output buffers must equal, bit for bit, what the same engine
+    produced for the same batch in an idle pipeline before timing (one batch, waited for): a race that only shows under full
+    streaming - all slots and streams busy, host and GPU triangulation mixed, batches back to back - changes some map;
+    (2) when pair 0 of the batch is the gate pair, its two maps must hash to the reference's digests
+    (tests/golden/digests.json).  Exit code 3 otherwise: a rate whose outputs are wrong is not a result."""
+    import hashlib
+    torch.cuda.synchronize()
+    same = bool(torch.equal(d1, ref1)) and bool(torch.equal(d2, ref2))
+    res = {"status": "pass", "all_maps_equal_idle_run": same, "maps_compared": int(d1.shape[0]) * 2, "region": what}
+    if not same:
+        bad = [int(i) for i in torch.nonzero((d1 != ref1).flatten(1).any(1) | (d2 != ref2).flatten(1).any(1)).flatten().tolist()[:8]]
+        print("parity after %s FAILED: maps of pairs %s differ from the idle-pipeline run of the same batch" % (what, bad), file=sys.stderr)
+        raise SystemExit(3)
+    entry = gate.get("_entry") if isinstance(gate, dict) else None
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    if entry is not None and [sha(pair0[0]), sha(pair0[1])] == gate.get("_input_sha"):
+        got = {"final1": sha(d1[0].cpu().numpy()), "final2": sha(d2[0].cpu().numpy())}
+        bad = [k for k in got if got[k] != entry["stages"][k]]
+        if bad:
+            print("parity after %s FAILED: %s of pair 0 differ from the reference's maps (%s)" % (what, bad, gate.get("case")), file=sys.stderr)
+            raise SystemExit(3)
+        res["pair0_vs_reference_digest"] = "pass (%s)" % gate.get("case")
+    else:
+        res["pair0_vs_reference_digest"] = "n/a: pair 0 of this batch is not the gate pair"
+    return res
 
 
 class GatherRun:
@@ -549,6 +612,8 @@ def run_config(ctx, name, steps_req, warmup, min_seconds, headline, gather):
     gate = parity_gate(engine, torch, synth, name, sub) if not args.no_gate else {"status": "skipped"}
     for _ in range(max(1, warmup)):
         engine.process_device(left, right, d1, d2)
+    torch.cuda.synchronize()
+    ref1, ref2 = d1.clone(), d2.clone()  # this batch's maps from an idle pipeline: what the timed steps' outputs are compared with afterwards
     # seconds per step of the streamed form (what the timed region runs), from a few batches submitted back to back
     n_est = 4 if Wx < 2000 else 2
     torch.cuda.synchronize()
@@ -594,6 +659,7 @@ def run_config(ctx, name, steps_req, warmup, min_seconds, headline, gather):
             my_elapsed = timed_region(torch, engine, left, right, bufs[:1], steps, barrier, sync_steps=args.sync_steps and headline)
     res["_ktimes"] = engine.kernel_times() if headline and not args.no_kernel_timing else {}
     engine.timing(False)
+    after = parity_after(torch, gate, (batch[0, 0], batch[0, 1]), d1, d2, ref1, ref2, "the timed region (last of %d streamed steps)" % steps) if not args.no_gate else {"status": "skipped"}
     engine_info["gpu_triangulation_share"] = engine.gpu_triangulation_share()  # host mode: what the dispatcher's load balancing handed to the GPU kernel
     elapsed = par.max_over_ranks(my_elapsed, device=coll_dev)
     per_rank = [B * steps / my_elapsed]
@@ -604,7 +670,7 @@ def run_config(ctx, name, steps_req, warmup, min_seconds, headline, gather):
         per_rank = [B * steps / float(x) for x in t.tolist()]
     res.update({"pairs_per_s": round(B * world * steps / elapsed, 2), "ms_per_step": round(1e3 * elapsed / steps, 3), "steps": steps, "steps_requested": steps_req, "warmup": max(1, warmup),
                 "timed_seconds": round(elapsed, 3), "pairs_per_gpu_per_step": B, "per_rank_pairs_per_s": [round(x, 1) for x in per_rank],
-                "parity_gate": gate, "engine": engine_info, "valid_fraction": round(float((d1 >= 0).float().mean().item()), 4),
+                "parity_gate": {k: v for k, v in gate.items() if not k.startswith("_")}, "parity_after": after, "engine": engine_info, "valid_fraction": round(float((d1 >= 0).float().mean().item()), 4),
                 "checksum_rank0": float(d1.double().sum().item())})
     # ---- the same run with the finished left maps gathered on rank 0 (RCCL), chunk by chunk, overlapping the kernels
     if gather and world > 1:
@@ -616,20 +682,31 @@ def run_config(ctx, name, steps_req, warmup, min_seconds, headline, gather):
         for key, u8 in (("with_gather", None), ("with_gather_u8", eng)):  # the float maps; the driver's 8-bit disparity images (4 x d, stereo_vision.cpp:316)
             gr = GatherRun(torch, par, engine, B, Hm, Wm, g, local_rank, backend, u8=u8)
             g_el = par.max_over_ranks(timed_region(torch, engine, left, right, bufs, gsteps, barrier, gather=gr), device=coll_dev)
-            ok = True
-            if rank == 0:  # rank order == pair order; rank 0's own block must be its own maps of the last step
-                mine = bufs[(gsteps - 1) % 2][0]
-                if u8 is not None:
-                    mine = eng.disparity_to_u8(mine)
-                    torch.cuda.synchronize()
+            # every rank's block on the root must be that rank's own maps of the last step: rank 0's block is compared directly, the
+            # others through per-pair checksums (sum of the map's words) that every rank computes over its own maps and all ranks
+            # exchange - a collective that misplaces or corrupts a remote chunk fails the run (exit code 3)
+            mine = bufs[(gsteps - 1) % 2][0]
+            if u8 is not None:
+                mine = eng.disparity_to_u8(mine)
+            torch.cuda.synchronize()
+            pair_sums = lambda t: (t.reshape(t.shape[0], -1).view(torch.int32) if t.dtype == torch.float32 else t.reshape(t.shape[0], -1)).to(torch.int64).sum(1)
+            sums = torch.zeros((world, B), dtype=torch.int64, device=coll_dev)
+            sums[rank] = pair_sums(mine).to(coll_dev)
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+            ok, blocks_ok = True, None
+            if rank == 0:
                 ok = bool(torch.equal(gr.cg.root[0].to(mine.device), mine))
+                blocks_ok = [bool(torch.equal(pair_sums(gr.cg.root[r]).to(coll_dev), sums[r])) for r in range(world)]
+                if not ok or not all(blocks_ok):
+                    print("gather check FAILED (%s): root block 0 equals own maps: %s; per-rank blocks match their ranks' checksums: %s" % (key, ok, blocks_ok), file=sys.stderr)
+                    raise SystemExit(3)
             esz = 1 if u8 is not None else 4
             into_root = (world - 1) * B * Hm * Wm * esz * gsteps
             res[key] = {"pairs_per_s": round(B * world * gsteps / g_el, 2), "ms_per_step": round(1e3 * g_el / gsteps, 3), "steps": gsteps,
                         "collective": "dist.gather of %d-pair chunks into one preallocated [world,B,H,W] %s buffer on rank 0, issued per finished chunk (sv_wait_batches), overlapping later chunks' kernels"
                                       % (g, "u8 (saturate(round(4 d)), converted on the gather's side stream)" if u8 is not None else "f32"),
                         "chunk_pairs": g, "bytes_into_root_per_step": into_root // gsteps, "root_ingest_GBps": round(into_root / g_el / 1e9, 2),
-                        "backend": backend, "root_block0_equals_own_maps": ok}
+                        "backend": backend, "root_block0_equals_own_maps": ok, "root_blocks_match_rank_checksums": blocks_ok}
             del gr
     # ---- batch-1 latency on rank 0 (ms/frame), SURVEY.md 8d config 2: the gate pair's size, one pair per call, device memory in and out
     lat_ms = None
@@ -668,7 +745,9 @@ def public(d):
 
 
 def main():
-    ap = argparse.ArgumentParser()
+    ap = argparse.ArgumentParser(description="NOTE: --steps is a MINIMUM. The timed region lasts at least --min-seconds (default 5 s), so more steps than --steps are usually run: "
+                                 "`steps` on the JSON line is the number actually timed (ms_per_step x steps = timed_seconds), `steps_requested` the argument. "
+                                 "--min-seconds 0 times exactly --steps.")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=4)
@@ -693,6 +772,9 @@ def main():
     ap.add_argument("--synthetic-only", action="store_true", help="all pairs synthetic (default: kitti_mini pair 0 + synthetic pairs, SURVEY.md 8d config 3)")
     ap.add_argument("--real-pair", action="store_true", help="fill the whole batch with copies of the committed kitti_mini pair 0")
     ap.add_argument("--subsampling", action="store_true", help="Elas::parameters::subsampling (the reference's s1 benchmark rows): half-resolution maps")
+    ap.add_argument("--host-share", type=int, default=8, help="also measure one rank under the host budget of an N-rank node (0 = skip): a fresh child process whose CPU affinity is "
+                    "1/N of this process's usable CPUs and LOCAL_WORLD_SIZE=N, restricted before anything touches the GPU (`value_at_host_share_N` on the line)")
+    ap.add_argument("--host-share-child", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--gather", action="store_true", help="N > 1: also time the headline with the finished left maps gathered on rank 0 (chunked, overlapped; always on for 4k_d192)")
     args = ap.parse_args()
 
@@ -701,6 +783,24 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launcher = importlib.import_module(PKG + ".launcher")
         sys.exit(launcher.spawn_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+
+    # ---- one rank under the host budget of an N-rank node (row (e) evidence on a one-GPU box).  The child restricts itself before
+    # it imports torch or touches the GPU; this process has not touched the GPU yet either, so the child has the device to itself.
+    host_share, kept_cpus = None, None
+    if args.host_share_child > 0:
+        launcher = importlib.import_module(PKG + ".launcher")
+        kept_cpus = launcher.restrict_to_host_share(args.host_share_child, int(os.environ.get("LOCAL_RANK", "0")))
+    elif args.host_share > 1 and args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_configs:
+        launcher = importlib.import_module(PKG + ".launcher")
+        cmd = [sys.executable, os.path.abspath(__file__), "--host-share-child", str(args.host_share), "--host-share", "0", "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--min-seconds", str(args.min_seconds), "--workload", args.workload, "--no-host", "--no-configs", "--no-latency", "--no-real", "--no-kernel-timing", "--cpu-sample", "0"]
+        for flag, on in (("--subsampling", args.subsampling), ("--synthetic-only", args.synthetic_only), ("--real-pair", args.real_pair), ("--no-gate", args.no_gate)):
+            if on:
+                cmd.append(flag)
+        for opt, v in (("--batch", args.batch), ("--chunk", args.chunk), ("--slots", args.slots), ("--streams", args.streams)):
+            if v:
+                cmd += [opt, str(v)]
+        host_share = launcher.run_host_share_child(cmd)
 
     global W, H, D
     W, H, D = WORKLOADS[args.workload][:3]
@@ -740,20 +840,36 @@ def main():
     d1, d2 = hl["_bufs"][0]
     steps = hl["steps"]
 
-    # ---- the same engine on a batch of copies of the real pair (real maps are far more fragmented than synthetic ones)
+    # ---- the same engine on real frames only: the committed kitti_mini pairs (tests/golden/kitti*_left.png: frames 0, 3, 7, 10, ...)
+    # cycled through the batch (real maps are far more fragmented than synthetic ones); afterwards every distinct frame's maps
+    # must hash to the reference's digests
     real_rate = None
     if rank == 0 and world == 1 and real is not None and not args.no_real and not args.real_pair:
-        rl = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(real[0], (B, H, W)))).cuda()
-        rr = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(real[1], (B, H, W)))).cuda()
+        import hashlib
+        rp = load_real_pairs(W, H, D)
+        idx = [i % len(rp) for i in range(B)]
+        rl = torch.from_numpy(np.stack([rp[i][1] for i in idx])).cuda()
+        rr = torch.from_numpy(np.stack([rp[i][2] for i in idx])).cuda()
         engine.process_device(rl, rr, d1, d2)
-        rsteps = max(3, steps // 4)
+        rsteps = max(3, steps // 2)
         torch.cuda.synchronize()
         r0 = time.perf_counter()
         for _ in range(rsteps):
             engine.submit_device(rl, rr, d1, d2)
         engine.wait()
         torch.cuda.synchronize()
-        real_rate = {"value": round(B * rsteps / (time.perf_counter() - r0), 1), "unit": "pairs/s", "data": "kitti_mini pair 0 x %d" % B, "steps": rsteps}
+        r_el = time.perf_counter() - r0
+        dig, sha = golden_digests(), (lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest())
+        bad = []
+        if not args.subsampling:
+            for j, (key, _, _) in enumerate(rp):
+                if sha(d1[j].cpu().numpy()) != dig[key]["stages"]["final1"] or sha(d2[j].cpu().numpy()) != dig[key]["stages"]["final2"]:
+                    bad.append(key)
+        if bad and not args.no_gate:
+            print("parity after the real-frame region FAILED: maps of %s differ from the reference's" % bad, file=sys.stderr)
+            raise SystemExit(3)
+        real_rate = {"value": round(B * rsteps / r_el, 1), "unit": "pairs/s", "data": "kitti_mini frames %s cycled to %d pairs" % (",".join(k[5:].split("_")[0] for k, _, _ in rp), B),
+                     "steps": rsteps, "seconds": round(r_el, 2), "parity_after": ("n/a (subsampling)" if args.subsampling else "pass: d1 and d2 of every distinct frame hash to tests/golden/digests.json") if not bad else "FAILED " + str(bad)}
         del rl, rr
 
     # ---- host memory in / out through the same engine (PCIe inclusive)
@@ -767,12 +883,12 @@ def main():
     del hl["_engine"], hl["_bufs"], hl["_left"], hl["_right"], d1, d2
     torch.cuda.empty_cache()
 
-    # ---- BASELINE.json's other configurations, each on its own engine with its own parity gate (>= 2 s of steps each):
+    # ---- BASELINE.json's other configurations, each on its own engine with its own parity gate (>= 5 s of steps each):
     # configs[3] KITTI D=256 (one GPU) and configs[4] 4K D=192, 128 pairs per GPU, gathered on rank 0 when N > 1
     configs = {}
     if args.workload == "kitti_d128" and not args.no_configs and not args.subsampling:
         for cname in (("kitti_d256", "4k_d192") if world == 1 else ("4k_d192",)):
-            r = public(run_config(ctx, cname, 3, 2, 2.0, False, gather=(cname == "4k_d192")))
+            r = public(run_config(ctx, cname, 3, 2, SUBCONFIG_MIN_SECONDS, False, gather=(cname == "4k_d192")))
             r["config"] = "%dx%d D=%d, %d pairs per GPU per step, %d GPU(s)" % (WORKLOADS[cname][0], WORKLOADS[cname][1], WORKLOADS[cname][2], r["pairs_per_gpu_per_step"], world)
             configs[cname] = r
 
@@ -787,7 +903,7 @@ def main():
             "ms_per_step": hl["ms_per_step"], "timed_seconds": hl["timed_seconds"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": hl["data"],
-            "parity_gate": hl["parity_gate"]["status"], "parity_gate_detail": hl["parity_gate"],
+            "parity_gate": hl["parity_gate"]["status"], "parity_gate_detail": hl["parity_gate"], "parity_after": hl["parity_after"],
             "config": {"workload": "%s_%dx%d_D%d_batch%d_per_gpu_streamed" % (args.workload.split("_")[0], W, H, D, B), "width": W, "height": H, "disp_max": D - 1,
                        "preset": "driver(MIDDLEBURY+only_left+adaptive_mean+median)" + ("+subsampling" if args.subsampling else ""), "pairs_per_gpu_per_step": B,
                        "parallelism": "batch-sharded x%d, no data-path collective" % world, "engine": hl["engine"]},
@@ -802,6 +918,20 @@ def main():
         if h2h:
             out["value_host_to_host"] = h2h["pinned"]["pairs_per_s_d1"]
             out["value_host_to_host_spread"] = h2h["pinned"]["pairs_per_s_d1_runs"]
+        if kept_cpus is not None:
+            out["host_share_child"] = {"share": args.host_share_child, "cpus": kept_cpus, "local_world_size": os.environ.get("LOCAL_WORLD_SIZE")}
+        if args.host_share > 1 and args.host_share_child == 0:
+            key = "value_at_host_share_%d" % args.host_share
+            if host_share and host_share.get("parity_gate") in ("pass", "skipped") and "value" in host_share:
+                out[key] = host_share["value"]
+                out["host_share"] = {"what": "the headline measured by a fresh process with the host budget of one rank of a %d-rank node: CPU affinity restricted to usable CPUs / %d and LOCAL_WORLD_SIZE=%d "
+                                             "before anything touched the GPU (launcher.restrict_to_host_share); same engine defaults, same batch, same parity gate and parity_after" % (args.host_share, args.host_share, args.host_share),
+                                     "value": host_share["value"], "ratio_to_value": round(host_share["value"] / rate, 4), "cpus": (host_share.get("host_share_child") or {}).get("cpus"),
+                                     "engine": (host_share.get("config") or {}).get("engine"), "steps": host_share.get("steps"), "timed_seconds": host_share.get("timed_seconds"),
+                                     "parity_gate": host_share.get("parity_gate"), "parity_after": (host_share.get("parity_after") or {}).get("status")}
+            else:
+                out[key] = None
+                out["host_share"] = {"error": "the host-share child did not produce a gated result"}
         if ktimes and serial_k:
             N = W * H
             step = params.candidate_stepsize
@@ -906,6 +1036,16 @@ def main():
             out["cpu_baseline"] = one
             if many:
                 out["cpu_baseline_all_cores"] = many
+        # the keys a reader of the line's tail needs, last (the line is ~15 KB; a tail keeps its end)
+        out["trailer"] = {
+            "value": rate, "parity_gate": hl["parity_gate"]["status"], "parity_after": hl["parity_after"]["status"],
+            "value_host_to_host": out.get("value_host_to_host"), "value_real_frames": (real_rate or {}).get("value"),
+            "value_at_host_share_%d" % args.host_share: out.get("value_at_host_share_%d" % args.host_share),
+            "kitti_d256_pairs_per_s": (configs.get("kitti_d256") or {}).get("pairs_per_s"), "4k_d192_pairs_per_s": (configs.get("4k_d192") or {}).get("pairs_per_s"),
+            "configs_parity": {k: [v["parity_gate"]["status"], v["parity_after"]["status"]] for k, v in configs.items()},
+            "latency_ms_batch1_median": (hl["latency_ms_batch1"] or {}).get("median"),
+            "roofline_frac": (out.get("roofline") or {}).get("frac"), "cpu_baseline_pairs_per_s": (out.get("cpu_baseline") or {}).get("value"),
+        }
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -8,10 +8,13 @@ relays rank 0's JSON line (its other stdout lines go to stderr) and returns the 
 
 The reference has no counterpart (one GPU, blocking copies: src/parallel_includes/elas/elas_gpu.cu:537-563).
 """
+import json
 import os
+import signal
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 
@@ -61,8 +64,6 @@ def spawn_ranks(argv, nranks, out=None, err=None, timeout=None, poll=0.05):
                 p.kill()
                 p.wait()
 
-    import threading
-
     def relay():
         for line in procs[0].stdout:  # result lines (JSON objects) to `out`; library chatter on stdout ("[Gloo] Rank 0 is connected ...") to `err`
             dst = out if line.lstrip().startswith("{") else err
@@ -73,6 +74,16 @@ def spawn_ranks(argv, nranks, out=None, err=None, timeout=None, poll=0.05):
     t.start()
     t0 = time.time()
     rc = 0
+    # A SIGTERM / SIGHUP to the launcher (a harness timeout, a closed terminal) must not leave N GPU-holding ranks behind: the
+    # handler turns the signal into an exception in the loop below, which stops the children (exact PIDs) and exits 128 + signal.
+    restore = {}
+
+    def on_signal(signum, _frame):
+        raise SystemExit(128 + signum)
+
+    if threading.current_thread() is threading.main_thread():
+        for sg in (signal.SIGTERM, signal.SIGHUP):
+            restore[sg] = signal.signal(sg, on_signal)
     try:
         while True:
             codes = [p.poll() for p in procs]
@@ -91,5 +102,78 @@ def spawn_ranks(argv, nranks, out=None, err=None, timeout=None, poll=0.05):
     except BaseException:
         stop_all()
         raise
+    finally:
+        for sg, old in restore.items():
+            signal.signal(sg, old)
     t.join(timeout=10.0)
     return rc
+
+
+def usable_cpus():
+    """CPUs this process may use: the cgroup CPU quota when there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except (OSError, ValueError, IndexError):
+        pass
+    return max(1, n)
+
+
+def gpu_numa_cpus(local_rank=0):
+    """CPUs of the NUMA node the local_rank-th usable GPU hangs off, read from sysfs WITHOUT touching the GPU: KFD topology nodes in
+    order (the order the HIP runtime enumerates), those whose render node this process may open.  Empty set when anything is missing."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        gpus = []
+        for n in sorted(os.listdir(base), key=int):
+            props = dict(ln.split()[:2] for ln in open(os.path.join(base, n, "properties")) if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) == 0:
+                continue
+            minor = int(props.get("drm_render_minor", "-1"))
+            if minor < 0 or not os.access("/dev/dri/renderD%d" % minor, os.R_OK | os.W_OK):
+                continue
+            loc, dom = int(props.get("location_id", "0")), int(props.get("domain", "0"))
+            gpus.append("%04x:%02x:%02x.%d" % (dom, (loc >> 8) & 0xFF, (loc >> 3) & 0x1F, loc & 7))
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % gpus[local_rank]).read())
+        if node < 0:
+            return set()
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        return cpus
+    except (OSError, ValueError, IndexError, KeyError):
+        return set()
+
+
+def restrict_to_host_share(share, local_rank=0):
+    """Gives this process the host budget one rank has on a node with `share` ranks: CPU affinity = usable_cpus() / share CPUs (of
+    the GPU's NUMA node when sysfs tells which, else the first ones of the mask) and LOCAL_WORLD_SIZE = share.  To be called BEFORE
+    anything touches the GPU or starts a thread pool.  Returns the CPUs kept."""
+    allowed = sorted(os.sched_getaffinity(0))
+    n = max(1, usable_cpus() // max(1, share))
+    near = [c for c in allowed if c in gpu_numa_cpus(local_rank)]
+    keep = (near if len(near) >= n else allowed)[:n]
+    os.sched_setaffinity(0, keep)
+    os.environ["LOCAL_WORLD_SIZE"] = str(share)
+    return keep
+
+
+def run_host_share_child(argv, timeout=900):
+    """Runs `argv` (a bench.py command that restricts itself with restrict_to_host_share) as ONE fresh child and returns its JSON line
+    as a dict (None when it failed).  The caller must not have initialised the GPU yet: the child has the device to itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        p = subprocess.run(list(argv), env=env, stdin=subprocess.DEVNULL, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return None
+    for line in reversed(p.stdout.splitlines()):
+        if line.lstrip().startswith("{"):
+            try:
+                return json.loads(line)
+            except ValueError:
+                break
+    sys.stderr.write("host-share child failed (exit %d): %s\n" % (p.returncode, p.stderr[-2000:]))
+    return None

@@ -14,6 +14,11 @@ import util  # noqa: E402
 def main():
     mode = sys.argv[1] if len(sys.argv) > 1 else "gather"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if mode == "sleep":  # the launcher's signal test: report the PID, then wait to be stopped
+        print("pid %d" % os.getpid(), file=sys.stderr, flush=True)
+        import time
+        time.sleep(300)
+        sys.exit(0)
     if mode == "fail" and rank == 1:
         sys.exit(7)  # before the rendezvous: the other rank blocks in init_process_group until the launcher stops it
     import torch

@@ -15,7 +15,7 @@ import util
 WORKER = os.path.join(util.HERE, "mp_gather_worker.py")
 
 
-@pytest.mark.parametrize("nranks", [2, 3])
+@pytest.mark.parametrize("nranks", [2, 3, 8])  # 8: the ranks of one MI355X node
 def test_launcher_runs_ranks_and_relays_rank0(nranks):
     launcher = util.pkg("launcher")
     out = io.StringIO()
@@ -33,6 +33,34 @@ def test_launcher_propagates_a_failing_rank_and_stops_the_others():
     rc = launcher.spawn_ranks([sys.executable, WORKER, "fail"], 2, out=io.StringIO(), timeout=240)
     assert rc == 7
     assert time.time() - t0 < 120  # rank 0 was stopped, not waited for until the rendezvous timed out
+
+
+def test_launcher_stops_its_ranks_when_it_is_terminated():
+    """A SIGTERM to the launcher (a harness timeout) must not leave the ranks behind: they are stopped, exit code 128 + 15."""
+    import signal
+    code = ("import sys, importlib; sys.path.insert(0, %r); l = importlib.import_module(%r + '.launcher'); "
+            "sys.exit(l.spawn_ranks([sys.executable, %r, 'sleep'], 2, timeout=240))" % (util.ROOT, util.PKG, WORKER))
+    p = subprocess.Popen([sys.executable, "-c", code], stderr=subprocess.PIPE, stdout=subprocess.DEVNULL, text=True)
+    pids = []
+    while len(pids) < 2:
+        line = p.stderr.readline()
+        assert line, "the ranks did not start"
+        if line.startswith("pid "):
+            pids.append(int(line.split()[1]))
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=60) == 128 + signal.SIGTERM
+    for pid in pids:  # gone (reaped by the launcher before it exited)
+        with pytest.raises(ProcessLookupError):
+            os.kill(pid, 0)
+
+
+def test_host_share_restriction_before_any_gpu_call():
+    """launcher.restrict_to_host_share: affinity = usable CPUs / share, LOCAL_WORLD_SIZE = share, without importing torch."""
+    code = ("import os, sys, json, importlib; sys.path.insert(0, %r); l = importlib.import_module(%r + '.launcher'); before = l.usable_cpus(); "
+            "kept = l.restrict_to_host_share(4); print(json.dumps([before, kept, sorted(os.sched_getaffinity(0)), os.environ['LOCAL_WORLD_SIZE'], 'torch' in sys.modules]))"
+            % (util.ROOT, util.PKG))
+    before, kept, now, lws, torch_loaded = json.loads(subprocess.check_output([sys.executable, "-c", code], text=True))
+    assert len(kept) == max(1, before // 4) and kept == now and lws == "4" and torch_loaded is False
 
 
 def test_launcher_module_is_stdlib_only():
