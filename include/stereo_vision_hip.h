@@ -103,9 +103,11 @@ enum sv_query_key {
     SV_Q_SLOTS = 2,              /* chunks in flight */
     SV_Q_GPU_LATTICE_FILTER = 3, /* 1: support-lattice filters on the GPU, 0: on the host pool */
     SV_Q_GPU_TRIANGULATION = 4,  /* 1: Delaunay divide-and-conquer on the GPU (few host threads), 0: on the host pool */
-    SV_Q_GPU_TRIANGULATION_FALLBACKS = 6, /* vertex sets handed to the GPU kernel's share that the host triangulated after all (larger
-                                             than the kernels take: 131 072 vertices) */
+    SV_Q_GPU_TRIANGULATION_FALLBACKS = 6, /* vertex sets handed to the GPU kernel's share that the host triangulated after all (coincident points,
+                                             whose survivor the reference's quicksort decides; more vertices than the kernels take) */
     SV_Q_NUMA_BOUND = 7,         /* 1: the handle's host threads are bound to the CPUs of the GPU's NUMA node (SV_NO_AFFINITY=1 disables) */
+    SV_Q_RESIDENT = 8,           /* 1: the GPU's share of the chunks is built "resident" - the support lists never leave the device: sort, duplicate scan,
+                                    k-d order and triangulation in one kernel after the lattice filter; the host only reads 8 meta words per pair */
     SV_Q_GPU_TRIANGULATION_SHARE = 5 /* per mille of the pairs so far whose triangulations the GPU kernel built (in the host mode the
                                         dispatcher hands it a share of a chunk while the pool is behind; results are identical) */
 };
@@ -199,6 +201,15 @@ int sv_host_delaunay_par(const int32_t *xy, int n, int32_t *tri_out, int cap, in
  * ordering on the host), `reps` copies of the set in one launch, kernel time in *kernel_ms (may be NULL).  n <= 4000: one workgroup per set, mesh in LDS;
  * larger sets (<= 256 000): subtrees in LDS, upper merges in a global-memory mesh (SV_DG_SUBMAX lowers the 4000 for tests). */
 int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int reps, double *kernel_ms);
+
+/* Test hooks: the preparation of a vertex set for the triangulation - (x, y) sort, duplicate scan, k-d order (reference:
+ * triangle.cpp:5183-5360, 5889-5903) - on the host and on the GPU (csrc/delaunay_gpu.hip: dg_prepare; vertices on the support lattice
+ * of a width x height image with lattice step `step` and disparities <= disp_max, n <= 4096).  Both write the ids of the m surviving
+ * vertices in the order the divide-and-conquer recursion consumes them and return m.  Coincident vertices: the host keeps the one the
+ * reference's quicksort puts first; the GPU form keeps the lowest id when they carry the same disparity (disp[i], may be NULL = unknown)
+ * - they are then the same support point twice and interchangeable - and returns -1 (a set it leaves to the host) otherwise. */
+int sv_host_kd_order(const int32_t *xy, int n, int32_t *ids_out);
+int sv_gpu_kd_order(const int32_t *xy, const int32_t *disp, int n, int width, int height, int step, int disp_max, int32_t *ids_out);
 
 /* ---- (A) the reference's exported symbols ------------------------------------------------------------- */
 

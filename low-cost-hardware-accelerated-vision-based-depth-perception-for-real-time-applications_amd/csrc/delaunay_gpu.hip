@@ -516,21 +516,24 @@ struct DgSet {
     __device__ __forceinline__ int y(int i) const { return yb[(size_t)i * stride]; }
 };
 
-// LDS carve-up for a tree of n vertices with np coordinate entries: node results (heap order), triangles, coordinates, k-d ordered ids
+// LDS carve-up for a tree of n vertices with np coordinate entries: coordinates, k-d ordered ids, node results (heap order), triangles.
+// The coordinates and the order come first: the on-GPU preparation (dg_prepare) produces the order in place and uses the region behind
+// it - node results and triangles, not yet in use then - as its scratch.
 struct DgLds {
-    DG_LDS uint32_t *res;  // [2 << depth]: farleft | farright << 16
-    DG_LDS DG_VOLATILE DTri *T;
     DG_LDS int16_t *px, *py;
     DG_LDS uint16_t *ord;
+    DG_LDS uint32_t *res;  // [2 << depth]: farleft | farright << 16
+    DG_LDS DG_VOLATILE DTri *T;
 };
+__host__ __device__ inline size_t dg_head_words(int n, int np) { return (size_t)(np + (np & 1)) + ((size_t)n + 1) / 2; }  // px, py, ord in 32-bit words
 __device__ __forceinline__ DgLds dg_carve(DG_LDS uint32_t *base, int n, int np) {
-    const int nslots = 2 * n - 1, depth = dg_depth(n);
+    const int depth = dg_depth(n);
     DgLds L;
-    L.res = base;
-    L.T = (DG_LDS DG_VOLATILE DTri *)(base + (2 << depth));
-    L.px = (DG_LDS int16_t *)(L.T + nslots + (nslots & 1));
+    L.px = (DG_LDS int16_t *)base;
     L.py = L.px + np + (np & 1);
     L.ord = (DG_LDS uint16_t *)(L.py + np + (np & 1));
+    L.res = base + dg_head_words(n, np);
+    L.T = (DG_LDS DG_VOLATILE DTri *)(L.res + (2 << depth));
     return L;
 }
 
@@ -569,7 +572,24 @@ __device__ __forceinline__ void dg_emit(int nslots, F vtx, uint32_t ghost, int32
     if (tid == 0) *count = s_total;
 }
 
-// A whole set in LDS (m <= DG_SUB_MAX).
+// The tree of a set whose coordinates and k-d order are in LDS already (m <= DG_SUB_MAX): bottom-up, then the triangle list.
+__device__ __forceinline__ void dg_build_and_emit(const DgLds &L, int m, int32_t *__restrict__ out, int32_t *__restrict__ count) {
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        L.T[0].nbr[0] = L.T[0].nbr[1] = L.T[0].nbr[2] = 0;
+        L.T[0].vtx[0] = L.T[0].vtx[1] = L.T[0].vtx[2] = (uint16_t)GHOST;
+    }
+    __syncthreads();
+    const Mesh M{L.T, L.px, L.py};
+    for (int d = dg_depth(m); d >= 0; d--) {
+        for (int j = tid; j < (1 << d); j += DG_THREADS) d_process_node(M, L.res, L.ord, m, d, j);
+        __syncthreads();
+    }
+    DG_LDS DG_VOLATILE DTri *T = L.T;
+    dg_emit(2 * m - 1, [T](int t, int k) { return (uint32_t)T[t].vtx[k]; }, GHOST, out, count);
+}
+
+// A whole set in LDS (m <= DG_SUB_MAX), k-d order from memory.
 __device__ __forceinline__ void dg_triangulate(const DgSet &S) {
     extern __shared__ uint32_t dg_lds[];
     const int tid = threadIdx.x, m = S.m, npts = S.npts;
@@ -583,18 +603,7 @@ __device__ __forceinline__ void dg_triangulate(const DgSet &S) {
         L.py[i] = (int16_t)S.y(i);
     }
     for (int i = tid; i < m; i += DG_THREADS) L.ord[i] = (uint16_t)S.order[i];
-    if (tid == 0) {
-        L.T[0].nbr[0] = L.T[0].nbr[1] = L.T[0].nbr[2] = 0;
-        L.T[0].vtx[0] = L.T[0].vtx[1] = L.T[0].vtx[2] = (uint16_t)GHOST;
-    }
-    __syncthreads();
-    const Mesh M{L.T, L.px, L.py};
-    for (int d = dg_depth(m); d >= 0; d--) {
-        for (int j = tid; j < (1 << d); j += DG_THREADS) d_process_node(M, L.res, L.ord, m, d, j);
-        __syncthreads();
-    }
-    DG_LDS DG_VOLATILE DTri *T = L.T;
-    dg_emit(2 * m - 1, [T](int t, int k) { return (uint32_t)T[t].vtx[k]; }, GHOST, S.out, S.count);
+    dg_build_and_emit(L, m, S.out, S.count);
 }
 
 // Subtree j of the cut depth of a large set: triangulated in LDS with local vertex numbers (position in the k-d order), then
@@ -664,6 +673,226 @@ __device__ __forceinline__ void dg_top(const DgSet &S, int sub_max, GTri *gT, co
     dg_emit(2 * m - 1, [gT](int t, int k) { return (uint32_t)gT[t].vtx[k]; }, GHOST32, S.out, S.count);
 }
 
+// ---- preparation on the GPU: (x, y) order, duplicate scan, k-d order ----------------------------------------------------------
+// What Delaunay::prepare (host_stage.cpp) does for the host triangulation - and what the reference does with a randomised quicksort,
+// a duplicate scan and randomised quickselects (triangle.cpp:5183-5360, 5889-5903) - for a vertex set that lives on the support
+// lattice of an image: every vertex is a cell (column x, lattice row of y) of a sparse 2-D grid, so
+//   * the (x, y) order is the column-major enumeration of a bit map of occupied cells: a vertex's rank is the number of set bits in
+//     front of its own (prefix sums over the bit map's words), the (y, x) order the same on the row-major bit map;
+//   * two vertices in one cell are coincident points.  Which of them survives the reference's duplicate scan depends on the pivot
+//     sequence of its quicksort (the library's LCG).  The case real images produce - 7 of the 21 kitti_mini frames - is the image
+//     corner (W-1, 0) whose nearest support point has disparity 0: elas.cpp:258-259 then adds the right-image corner (W-1+0, 0, 0), the
+//     SAME (u, v, d) triple as the left-image corner.  Coincident vertices with equal disparity are interchangeable - same coordinates
+//     in both images, same plane equations; only the index that appears in the triangle lists differs, and no map depends on it - so
+//     the lowest id is kept here.  Coincident vertices with DIFFERENT disparities (possible with lr_threshold > 2) are not: such a set
+//     is reported and the host stage triangulates it the reference's way;
+//   * the alternating cuts are index splits of one order and stable partitions of the other (see Delaunay::kd_order): all nodes of
+//     one depth of the cut tree at once, one prefix sum over "goes left" flags per depth.
+// Everything is in LDS, in the region the node results and the triangles use afterwards.
+struct DgPrep {      // lattice geometry, from the image size (engine.cpp: delaunay_prep_dims)
+    int xmin, cols;  // vertex columns: x - xmin in [0, cols)  (x = u or u - d, corner points included: -disp_max .. W - 1 + disp_max)
+    int step, ylast; // row(y) = y / step; the image's last line ylast = H - 1 (corner points) gets a row of its own when it is no lattice row
+    int rows;        // lattice rows + 1
+    int W1, W2;      // 32-bit words per column of the column-major bit map / per row of the row-major one
+    int bm_words;    // max(cols * W1, rows * W2)
+};
+
+constexpr int DG_DUP_MAX = 16;  // coincident vertices a set may have (beyond the first of each cell) before it is handed to the host
+
+__host__ __device__ inline size_t dg_prep_scratch_words(const DgPrep &pp, int m) {  // bit map, word prefixes (u16), X, Y (u32), idx, xr (u16), chunk table, scan cells, duplicates, dropped flags
+    return (size_t)pp.bm_words + ((size_t)pp.bm_words + 1) / 2 + 2 * (size_t)m + 2 * (((size_t)m + 1) / 2) + DG_THREADS + 16 + 2 * DG_DUP_MAX + ((size_t)m + 31) / 32;
+}
+
+constexpr int DG_PREP_CHUNK = 16;                          // consecutive positions a thread owns in the k-d passes
+constexpr int DG_PREP_MAX = DG_THREADS * DG_PREP_CHUNK;    // 4096 vertices
+
+__device__ __forceinline__ int dg_block_scan(int val, DG_LDS int *cells, int *total) {  // exclusive prefix sum over the workgroup's DG_THREADS values
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = val;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        incl += lane >= off ? o : 0;
+    }
+    if (lane == 63) cells[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < DG_THREADS / 64; w++) {
+        const int c = cells[w];
+        base += w < wave ? c : 0;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - val;
+}
+
+// Exclusive prefix sums of the set bits of the bit map's words: pm[w] = bits set in words [0, w).  Returns through *total the bit count.
+__device__ __forceinline__ void dg_word_prefix(DG_LDS const uint32_t *bm, DG_LDS uint16_t *pm, int nwords, DG_LDS int *cells, int *total) {
+    const int per = (nwords + DG_THREADS - 1) / DG_THREADS;
+    const int w0 = min((int)threadIdx.x * per, nwords), w1 = min(w0 + per, nwords);
+    int mine = 0;
+    for (int w = w0; w < w1; w++) mine += __popc(bm[w]);
+    int acc = dg_block_scan(mine, cells, total);
+    for (int w = w0; w < w1; w++) {
+        pm[w] = (uint16_t)acc;
+        acc += __popc(bm[w]);
+    }
+    __syncthreads();
+}
+
+// px / py hold the npts vertices' coordinates, dsp[i * dstride] their disparities (nullptr: unknown).  Writes ord[0 .. m) = the ids of the
+// m surviving vertices in k-d order and returns m, or returns -1 (uniformly) when the set has coincident points that are not
+// interchangeable or does not fit the bit maps - the caller leaves such a set to the host.
+__device__ __forceinline__ int dg_prepare(const DgLds &L, int npts, const DgPrep &pp, const int32_t *__restrict__ dsp, int dstride) {
+    const int tid = threadIdx.x;
+    int m = npts;
+    DG_LDS uint32_t *bm = L.res;
+    DG_LDS uint16_t *pm = (DG_LDS uint16_t *)(bm + pp.bm_words);
+    DG_LDS uint32_t *X = bm + pp.bm_words + (pp.bm_words + 1) / 2, *Y = X + m;
+    DG_LDS uint16_t *idx = (DG_LDS uint16_t *)(Y + m), *xr = idx + m + (m & 1);
+    DG_LDS uint32_t *chunk = (DG_LDS uint32_t *)(xr + m + (m & 1));  // per thread: prefix of its chunk's flags | flag bits << 16
+    DG_LDS int *cells = (DG_LDS int *)(chunk + DG_THREADS);           // [0..3] wavefront totals, [4] "unusable" flag, [5] coincident vertices seen, [6] vertices dropped
+    DG_LDS int *dup_id = cells + 16, *dup_min = dup_id + DG_DUP_MAX;   // the vertices that found their cell taken; lowest id of each one's cell
+    DG_LDS uint32_t *dropped = (DG_LDS uint32_t *)(dup_min + DG_DUP_MAX);  // bit i: vertex i is a coincident point that does not survive
+    if (tid == 0) cells[4] = (m > DG_PREP_MAX || m > 0xFFFF) ? 1 : 0, cells[5] = 0, cells[6] = 0;
+    for (int w = tid; w < (m + 31) / 32; w += DG_THREADS) dropped[w] = 0u;
+    // ---- (x, y) ranks: column-major bit map
+    for (int w = tid; w < pp.bm_words; w += DG_THREADS) bm[w] = 0u;
+    __syncthreads();
+    for (int i = tid; i < m; i += DG_THREADS) {
+        const int x = (int)L.px[i] - pp.xmin, y = L.py[i];
+        const int row = (y == pp.ylast && pp.ylast % pp.step != 0) ? pp.rows - 1 : y / pp.step;
+        if (x < 0 || x >= pp.cols || y < 0 || row >= pp.rows) {
+            cells[4] = 1;
+            continue;
+        }
+        const uint32_t bit = 1u << (row & 31);
+        if (__hip_atomic_fetch_or(&bm[x * pp.W1 + (row >> 5)], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & bit) {  // two vertices in one cell
+            const int q = __hip_atomic_fetch_add(&cells[5], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (q < DG_DUP_MAX && dsp)
+                dup_id[q] = i, dup_min[q] = i;
+            else
+                cells[4] = 1;
+        }
+    }
+    __syncthreads();
+    if (cells[4]) return -1;  // (uniform: read after the barrier)
+    const int ndup = cells[5];
+    if (ndup > 0) {
+        // every vertex that shares a cell with one of the listed vertices is a member of that coincident group: the group's lowest id
+        // survives, provided all members carry the same disparity (then they are the same support point twice)
+        for (int i = tid; i < m; i += DG_THREADS)
+            for (int q = 0; q < ndup; q++) {
+                const int c = dup_id[q];
+                if (L.px[i] == L.px[c] && L.py[i] == L.py[c]) {
+                    if (dsp[(size_t)i * dstride] != dsp[(size_t)c * dstride]) cells[4] = 1;
+                    __hip_atomic_fetch_min(&dup_min[q], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        __syncthreads();
+        if (cells[4]) return -1;
+        for (int i = tid; i < m; i += DG_THREADS)
+            for (int q = 0; q < ndup; q++) {
+                const int c = dup_id[q];
+                if (L.px[i] == L.px[c] && L.py[i] == L.py[c] && i != dup_min[q]) {
+                    if (!(__hip_atomic_fetch_or(&dropped[i >> 5], 1u << (i & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & (1u << (i & 31))))
+                        __hip_atomic_fetch_add(&cells[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    break;
+                }
+            }
+        __syncthreads();
+    }
+    const int nall = m;  // vertices with coordinates; m: the survivors
+    m = nall - cells[6];
+    int total;
+    dg_word_prefix(bm, pm, pp.cols * pp.W1, cells, &total);
+    for (int i = tid; i < nall; i += DG_THREADS) {
+        if ((dropped[i >> 5] >> (i & 31)) & 1u) continue;
+        const int x = (int)L.px[i] - pp.xmin, y = L.py[i];
+        const int row = (y == pp.ylast && pp.ylast % pp.step != 0) ? pp.rows - 1 : y / pp.step;
+        const int w = x * pp.W1 + (row >> 5);
+        const int r = (int)pm[w] + __popc(bm[w] & ((1u << (row & 31)) - 1u));
+        xr[i] = (uint16_t)r;
+        idx[r] = (uint16_t)i;
+    }
+    __syncthreads();
+    // ---- (y, x) ranks: row-major bit map in the same memory
+    for (int w = tid; w < pp.bm_words; w += DG_THREADS) bm[w] = 0u;
+    __syncthreads();
+    for (int i = tid; i < nall; i += DG_THREADS) {
+        const int x = (int)L.px[i] - pp.xmin, y = L.py[i];
+        const int row = (y == pp.ylast && pp.ylast % pp.step != 0) ? pp.rows - 1 : y / pp.step;
+        __hip_atomic_fetch_or(&bm[row * pp.W2 + (x >> 5)], 1u << (x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    dg_word_prefix(bm, pm, pp.rows * pp.W2, cells, &total);
+    for (int i = tid; i < nall; i += DG_THREADS) {
+        if ((dropped[i >> 5] >> (i & 31)) & 1u) continue;
+        const int x = (int)L.px[i] - pp.xmin, y = L.py[i];
+        const int row = (y == pp.ylast && pp.ylast % pp.step != 0) ? pp.rows - 1 : y / pp.step;
+        const int w = row * pp.W2 + (x >> 5);
+        const uint32_t yrank = (uint32_t)pm[w] + (uint32_t)__popc(bm[w] & ((1u << (x & 31)) - 1u));
+        const uint32_t e = (yrank << 16) | (uint32_t)xr[i];  // a vertex as (rank by (y, x)) << 16 | rank by (x, y)
+        X[xr[i]] = e;
+        Y[yrank] = e;
+    }
+    __syncthreads();
+    // ---- alternating cuts, one depth of the tree per pass.  A thread owns DG_PREP_CHUNK consecutive POSITIONS; the node a position
+    // belongs to is a range [lo, lo + n) that halves from pass to pass (n >> 1 to the left, the rest to the right, like the recursion).
+    int lo[DG_PREP_CHUNK], nn[DG_PREP_CHUNK];
+#pragma unroll
+    for (int k = 0; k < DG_PREP_CHUNK; k++) lo[k] = 0, nn[k] = m;
+    const int p0 = tid * DG_PREP_CHUNK;
+    const int depth = dg_depth(m);
+    for (int dd = 0; dd < depth; dd++) {
+        const bool by_x = (dd & 1) == 0;                      // cut by x: X splits by index, Y is partitioned (and the other way round)
+        DG_LDS uint32_t *src = by_x ? Y : X;
+        DG_LDS const uint32_t *ref = by_x ? X : Y;
+        uint32_t e[DG_PREP_CHUNK];
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < DG_PREP_CHUNK; k++) {
+            const int i = p0 + k;
+            e[k] = 0;
+            if (i < m) {
+                e[k] = src[i];
+                if (nn[k] > 3) {
+                    const uint32_t pe = ref[lo[k] + (nn[k] >> 1)];
+                    const uint32_t pivot = by_x ? (pe & 0xFFFFu) : (pe >> 16), r = by_x ? (e[k] & 0xFFFFu) : (e[k] >> 16);
+                    bits |= (r < pivot ? 1u : 0u) << k;
+                }
+            }
+        }
+        const int base = dg_block_scan(__popc(bits), cells, &total);
+        chunk[tid] = (uint32_t)base | (bits << 16);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < DG_PREP_CHUNK; k++) {
+            const int i = p0 + k;
+            if (i < m && nn[k] > 3) {
+                const uint32_t c0 = chunk[lo[k] / DG_PREP_CHUNK];
+                const int at_lo = (int)(c0 & 0xFFFFu) + __popc((c0 >> 16) & ((1u << (lo[k] % DG_PREP_CHUNK)) - 1u));
+                const int before = base + __popc(bits & ((1u << k) - 1u)) - at_lo;  // "goes left" flags of this node in front of position i
+                const int nl = nn[k] >> 1;
+                const int dest = ((bits >> k) & 1u) ? lo[k] + before : lo[k] + nl + (i - lo[k] - before);
+                src[dest] = e[k];  // in place: every element of the pass has been read (barrier above)
+                if (i >= lo[k] + nl) {
+                    lo[k] += nl;
+                    nn[k] -= nl;
+                } else {
+                    nn[k] = nl;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < m; i += DG_THREADS) L.ord[i] = idx[X[i] & 0xFFFFu];  // leaves are in (x, y) order: the X arrangement is the result
+    __syncthreads();
+    return m;
+}
+
 // Test-hook form: sets[s] = {offset of the set's first entry in `order` / `xy`, m (vertices after the duplicate scan), n_points
 // (entries of xy), offset of its triangle list in tri_out}.  order: vertex ids in k-d order; xy: (x, y) per id.
 __device__ __forceinline__ DgSet dg_set_from_list(const int4 st, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count) {
@@ -702,6 +931,70 @@ __global__ __launch_bounds__(DG_THREADS) void k_delaunay(const int4 *__restrict_
 __global__ __launch_bounds__(DG_THREADS) void k_delaunay_blob(int32_t *__restrict__ blob, int sub_max) {
     DgSet S;
     if (dg_set_from_blob(blob, blockIdx.x, sub_max, false, S)) dg_triangulate(S);
+}
+
+// The resident form: the chunk's support-point lists never leave the device.  set = pair * 2 + side; `fsup` / `fnsup` are the lattice
+// filter's output ([cap][max_pts][3] triples (u, v, d), [cap] counts).  The kernel lays the pair's part of the blob out itself - at a
+// fixed place per pair, with the offsets the host stage would have chosen inside it - copies the support points there, prepares the
+// vertex set (dg_prepare) and triangulates it.  Meta words (engine.cpp): [0] points, [1] their offset, [2]/[4] triangles left / right,
+// [3]/[5] their offsets, [7] = 1.  A side this kernel cannot do - coincident points, or more than sub_max vertices (what the launch has
+// LDS for) - gets its triangle count set to -1: the host stage builds it and phase 2 uploads the list.
+__global__ __launch_bounds__(DG_THREADS) void k_delaunay_resident(const int32_t *__restrict__ fsup, const int32_t *__restrict__ fnsup, int32_t *__restrict__ blob, int cap, int max_pts,
+                                                                 int pair_words, int sub_max, DgPrep pp) {
+    extern __shared__ uint32_t dg_lds[];
+    const int tid = threadIdx.x, pair = blockIdx.x >> 1, side = blockIdx.x & 1;
+    int32_t *meta = blob + (size_t)pair * META_WORDS;
+    int ns = fnsup[pair];
+    if (ns < 0 || ns > max_pts) ns = 0;  // (never: the filter counts what it wrote)
+    const int off_sup = cap * META_WORDS + pair * pair_words, off_t1 = off_sup + 3 * ns, off_t2 = off_t1 + 6 * ns;
+    if (side == 0 && tid == 0) {
+        meta[0] = ns;
+        meta[1] = off_sup;
+        meta[3] = off_t1;
+        meta[5] = off_t2;
+        meta[6] = 0;
+        meta[7] = 1;
+    }
+    if (ns < 3) {
+        if (tid == 0) meta[2 + 2 * side] = 0;
+        return;
+    }
+    const int32_t *sup = fsup + (size_t)pair * max_pts * 3;
+    if (side == 0)
+        for (int i = tid; i < 3 * ns; i += DG_THREADS) blob[off_sup + i] = sup[i];
+    if (ns > sub_max) {  // more vertices than this launch has LDS for: handed back to the host stage
+        if (tid == 0) meta[2 + 2 * side] = -1;
+        return;
+    }
+    const DgLds L = dg_carve((DG_LDS uint32_t *)dg_lds, ns, ns);
+    for (int i = tid; i < ns; i += DG_THREADS) {
+        const int u = sup[3 * i], v = sup[3 * i + 1], dsp = sup[3 * i + 2];
+        L.px[i] = (int16_t)(side ? u - dsp : u);  // elas.cpp:449-461: left image (u, v), right image (u - d, v)
+        L.py[i] = (int16_t)v;
+    }
+    __syncthreads();
+    const int m = dg_prepare(L, ns, pp, sup + 2, 3);
+    if (m < 0) {
+        if (tid == 0) meta[2 + 2 * side] = -1;
+        return;
+    }
+    dg_build_and_emit(L, m, blob + (side ? off_t2 : off_t1), meta + 2 + 2 * side);
+}
+
+// Test hook: only the preparation of one vertex set given as (x, y) pairs; ord_out[0] = m or -1, then the ids in k-d order.
+__global__ __launch_bounds__(DG_THREADS) void k_dg_prepare_test(const int32_t *__restrict__ xy, const int32_t *__restrict__ dsp, int n, int32_t *__restrict__ ord_out, DgPrep pp) {
+    extern __shared__ uint32_t dg_lds[];
+    const int tid = threadIdx.x;
+    const DgLds L = dg_carve((DG_LDS uint32_t *)dg_lds, n, n);
+    for (int i = tid; i < n; i += DG_THREADS) {
+        L.px[i] = (int16_t)xy[2 * i];
+        L.py[i] = (int16_t)xy[2 * i + 1];
+    }
+    __syncthreads();
+    const int m = dg_prepare(L, n, pp, dsp, 1);
+    if (tid == 0) ord_out[0] = m;
+    if (m > 0)
+        for (int i = tid; i < m; i += DG_THREADS) ord_out[1 + i] = L.ord[i];
 }
 
 // Large sets: scratch per set = GTri[2 * cap], (x, y)[cap], node results [4 << DG_CUT_MAX] (cap: the largest set the scratch holds)
@@ -748,7 +1041,51 @@ using namespace dg;
 #ifndef DG_HOST_EMULATION
 size_t delaunay_gpu_lds_bytes(int m, int npts) {
     const size_t nslots = 2 * (size_t)m - 1;
-    return sizeof(uint32_t) * (2 << dg_depth(m)) + sizeof(DTri) * (nslots + (nslots & 1)) + sizeof(int16_t) * 2 * ((size_t)npts + (npts & 1)) + sizeof(uint16_t) * (size_t)m + 16;
+    return sizeof(uint32_t) * (dg_head_words(m, npts) + (2 << dg_depth(m))) + sizeof(DTri) * (nslots + (nslots & 1)) + 16;
+}
+
+// Lattice geometry of the on-GPU preparation for images of W x H with lattice step `step` and disparities up to disp_max.
+static DgPrep dg_prep_dims(int W, int H, int step, int disp_max) {
+    DgPrep pp;
+    pp.xmin = -disp_max;
+    pp.cols = W + 2 * disp_max + 1;
+    pp.step = step;
+    pp.ylast = H - 1;
+    pp.rows = (H + step - 1) / step + 1;
+    pp.W1 = (pp.rows + 31) / 32;
+    pp.W2 = (pp.cols + 31) / 32;
+    pp.bm_words = pp.cols * pp.W1 > pp.rows * pp.W2 ? pp.cols * pp.W1 : pp.rows * pp.W2;
+    return pp;
+}
+
+// LDS of the resident kernel for sets of up to m vertices: coordinates and order, then the larger of the preparation's scratch and
+// the triangulation's node results + triangles
+size_t delaunay_resident_lds_bytes(int W, int H, int step, int disp_max, int m) {
+    const DgPrep pp = dg_prep_dims(W, H, step, disp_max);
+    const size_t nslots = 2 * (size_t)m - 1;
+    const size_t tri = sizeof(uint32_t) * (2 << dg_depth(m)) + sizeof(DTri) * (nslots + (nslots & 1));
+    const size_t prep = sizeof(uint32_t) * dg_prep_scratch_words(pp, m);
+    return sizeof(uint32_t) * dg_head_words(m, m) + (tri > prep ? tri : prep) + 16;
+}
+int delaunay_prep_max_points() { return DG_PREP_MAX; }
+
+// Both triangulations of every pair of a chunk from the lattice filter's lists on the device (k_delaunay_resident).  ns_max: an upper
+// bound of the chunk's support counts that take the LDS path (sizes the LDS request).
+void launch_delaunay_resident(const int32_t *fsup, const int32_t *fnsup, int32_t *blob, int cap, int max_pts, int pair_words, int n_pairs, int ns_max, int sub_max, int W, int H, int step,
+                              int disp_max, hipStream_t st) {
+    const size_t lds = delaunay_resident_lds_bytes(W, H, step, disp_max, ns_max < 3 ? 3 : ns_max);
+    static std::atomic<size_t> granted[64];
+    ensure_dynamic_lds(k_delaunay_resident, lds, granted, "delaunay_gpu (resident)");
+    SV_LAUNCH(K_DELAUNAY, k_delaunay_resident, dim3(2 * n_pairs), dim3(DG_THREADS), lds, st, fsup, fnsup, blob, cap, max_pts, pair_words, sub_max, dg_prep_dims(W, H, step, disp_max));
+}
+
+// Test hook: the preparation alone for one set of (x, y) pairs on the lattice of a W x H image; ord_out[0] = m or -1, then m ids
+int launch_delaunay_prepare_test(const int32_t *d_xy, const int32_t *d_dsp, int n, int32_t *d_ord_out, int W, int H, int step, int disp_max, hipStream_t st) {
+    const size_t lds = delaunay_resident_lds_bytes(W, H, step, disp_max, n < 3 ? 3 : n);
+    if (lds > 160 * 1024 || n > DG_PREP_MAX) return -1;
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void *>(k_dg_prepare_test), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_dg_prepare_test, dim3(1), dim3(DG_THREADS), lds, st, d_xy, d_dsp, n, d_ord_out, dg_prep_dims(W, H, step, disp_max));
+    return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int delaunay_gpu_max_points() { return DG_SUB_MAX; }

@@ -65,6 +65,9 @@ struct HostScratch {  // per pool thread
     std::vector<int16_t> lattice;
 };
 
+// words of a pair's part of the device blob when the device lays it out itself (resident chunks): support points, two triangle lists, two vertex orders
+static int blob_pair_words(const Dims &d) { return 3 * d.max_pts + 2 * 3 * d.max_tri + 2 * (d.max_pts + 1) + 64; }
+
 // support points per pair fetched with the bulk D2H (more are fetched on demand): a sixth of the lattice, at least 4096
 static int fsup_copy_pts(const Dims &d) { return std::min(d.max_pts, std::max(4096, d.Wc * d.Hc / 6)); }
 
@@ -106,6 +109,7 @@ struct Slot {
     size_t in_pair = 0;
     int in_stride = 0;
     int gpu_pct = 0;            // share of this chunk's pairs whose triangulations go to the GPU kernel (set by the dispatcher)
+    bool resident = false;      // this chunk's support lists stay on the device: preparation + triangulation by k_delaunay_resident in phase 1 (set by the issuer)
     bool grid_issued = false;   // latency mode: the candidate grid of this chunk was launched while the host still triangulated
     bool delivered_ok = false;  // host-memory jobs: the download succeeded (drainer -> deliverer)
     bool out_enqueued = false;  // host-memory jobs: phase 2 was enqueued (ev_lr / ev_p2 are pending), the maps can be downloaded
@@ -146,6 +150,10 @@ struct sv_handle {
     bool gpu_share_auto = false;  // host mode: the dispatcher moves that share up while the pool falls behind the GPU, down while it idles
     int auto_pct = 0, auto_acc = 0;  // (dispatcher thread only)
     bool share_sliced = false;    // the GPU kernel's share as a slice of every chunk instead of whole chunks
+    bool resident_ok = false;     // the GPU's share of the chunks is built without the support lists ever leaving the device (k_delaunay_resident)
+    std::atomic<int> shared_pct{0};   // host mode with a balanced share: the dispatcher's current share, read by the issuer (who decides per chunk)
+    int issue_acc = 0;                // (issuer thread only) accumulator that turns the share into whole chunks
+    std::atomic<int> ns_bound{0};     // vertices the resident kernel's LDS request is sized for: follows the support counts the chunks really have
     std::atomic<int64_t> gpu_tri_fallbacks{0};  // vertex sets of flagged pairs that the host triangulated after all (too large, or degenerate)
     std::atomic<int64_t> gpu_tri_pairs{0}, tri_pairs{0};  // pairs triangulated by the GPU kernel / all pairs, since creation
     bool node_bound = false;  // the handle's threads are bound to the CPUs of the GPU's NUMA node
@@ -451,10 +459,19 @@ void issue_phase1(sv_handle *h, Slot *s) {
         h->pf_turn ^= 1;
         HIP_TRY(hipStreamWaitEvent(tail, s->ev_sup, 0));
         launch_support_filter(k, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s->dev, s->n, tail);
-        HIP_TRY(hipMemcpyAsync(s->h_fnsup, s->dev.fnsup, sizeof(int32_t) * (size_t)s->n, hipMemcpyDeviceToHost, tail));
-        const size_t w = sizeof(int32_t) * 3 * (size_t)fsup_copy_pts(d);
-        HIP_TRY(hipMemcpy2DAsync(s->h_fsup, w, s->dev.fsup, sizeof(int32_t) * 3 * (size_t)d.max_pts, w, (size_t)s->n,
-                                 hipMemcpyDeviceToHost, tail));
+        if (s->resident) {
+            // the support lists stay where they are: preparation and triangulation of both sides of every pair in one launch, straight
+            // from the filter's buffers into the blob (laid out by the kernel); only the meta words come back - counts for the launch
+            // sizes of phase 2 and the callers' status, and a triangle count of -1 for a side the host has to build (coincident points)
+            launch_delaunay_resident(s->dev.fsup, s->dev.fnsup, s->dev.blob, s->dev.cap, d.max_pts, blob_pair_words(d), s->n, h->ns_bound.load(std::memory_order_relaxed), h->dg_sub_max,
+                                     d.W, d.H, d.step, d.disp_max, tail);
+            HIP_TRY(hipMemcpyAsync(s->h_blob, s->dev.blob, sizeof(int32_t) * META_WORDS * (size_t)s->n, hipMemcpyDeviceToHost, tail));
+        } else {
+            HIP_TRY(hipMemcpyAsync(s->h_fnsup, s->dev.fnsup, sizeof(int32_t) * (size_t)s->n, hipMemcpyDeviceToHost, tail));
+            const size_t w = sizeof(int32_t) * 3 * (size_t)fsup_copy_pts(d);
+            HIP_TRY(hipMemcpy2DAsync(s->h_fsup, w, s->dev.fsup, sizeof(int32_t) * 3 * (size_t)d.max_pts, w, (size_t)s->n,
+                                     hipMemcpyDeviceToHost, tail));
+        }
     }
     if (!h->gpu_filter || h->cfg.keep_debug)
         HIP_TRY(hipMemcpyAsync(s->h_dcan, s->dev.dcan, sizeof(int16_t) * (size_t)s->n * lat, hipMemcpyDeviceToHost, tail));
@@ -718,6 +735,19 @@ void issuer_main(sv_handle *h) {
             s->job = job;
             s->i0 = c * h->chunk;
             s->n = std::min(h->chunk, job->batch - s->i0);
+            // who triangulates this chunk: the GPU mode keeps every chunk resident; with a balanced share every 1 / share-th chunk
+            s->resident = false;
+            if (h->resident_ok) {
+                if (h->gpu_delaunay_pct >= 100) {
+                    s->resident = true;
+                } else {
+                    h->issue_acc += h->gpu_share_auto ? h->shared_pct.load(std::memory_order_relaxed) : h->gpu_delaunay_pct;
+                    if (h->issue_acc >= 100) {
+                        h->issue_acc -= 100;
+                        s->resident = true;
+                    }
+                }
+            }
             try {
                 if (drain) HIP_TRY(hipEventSynchronize(s->ev_free));
                 if (!h->failed) {
@@ -825,6 +855,38 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
     const int lat = d.Wc * d.Hc;
     int32_t *blob = s->h_blob;
     int32_t *meta = blob + (size_t)t.pair * META_WORDS;
+    if (t.side == -2) {
+        // a pair of a resident chunk with a side the kernel handed back: fetch its support list and build that side the reference's way;
+        // the triangle list goes to the place the device laid out for it (the host blob mirrors the device blob), phase 2 uploads it
+        const int ns = meta[0];
+        if ((int)sc->sup.size() < d.max_pts * 3) sc->sup.resize((size_t)d.max_pts * 3);
+        if (ns > d.max_pts || hipMemcpy(sc->sup.data(), s->dev.fsup + (size_t)t.pair * d.max_pts * 3, sizeof(int32_t) * 3 * (size_t)ns, hipMemcpyDeviceToHost) != hipSuccess) {
+            note_error(h, "hipMemcpy of a support list failed");
+            meta[0] = 0;
+        } else {
+            if ((int)sc->xy.size() < 2 * ns) sc->xy.resize(2 * ns);
+            for (int side = 0; side < 2; side++) {
+                if (meta[2 + 2 * side] >= 0) continue;
+                for (int q = 0; q < ns; q++) {  // elas.cpp:449-461: left uses (u,v), right (u-d,v)
+                    sc->xy[2 * q] = side ? sc->sup[3 * q] - sc->sup[3 * q + 2] : sc->sup[3 * q];
+                    sc->xy[2 * q + 1] = sc->sup[3 * q + 1];
+                }
+                const auto t0 = std::chrono::steady_clock::now();
+                const int nt = sc->dl.triangulate(sc->xy.data(), ns, blob + meta[3 + 2 * side], 2 * ns);
+                if (h->timing) h->host_delaunay_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                if (nt < 0 || nt > d.max_tri) {
+                    note_error(h, "triangle capacity exceeded");
+                    meta[2 + 2 * side] = 0;
+                } else {
+                    meta[2 + 2 * side] = nt;
+                }
+                meta[6] |= 1 << side;
+                h->gpu_tri_fallbacks.fetch_add(1, std::memory_order_relaxed);
+            }
+        }
+        pair_done(h, s);
+        return;
+    }
     if (t.side >= 0) {
         triangulate_side(h, sc, s, t.pair, t.side);
         if (__atomic_add_fetch(&meta[6], 1, __ATOMIC_ACQ_REL) == 2) pair_done(h, s);
@@ -956,19 +1018,60 @@ void dispatcher_main(sv_handle *h) {
             chunk_host_done(h, s);
             continue;
         }
+        if (h->gpu_share_auto) {  // (the balance itself: see below; with resident chunks the issuer applies it, chunk by chunk)
+            const int backlog = h->queue_len.load(std::memory_order_acquire);
+            if (backlog > s->n) h->auto_pct = std::min(h->auto_pct + 2, 95);
+            else if (backlog * 4 <= s->n) h->auto_pct = std::max(h->auto_pct - 2, 0);
+            h->shared_pct.store(h->auto_pct, std::memory_order_relaxed);
+        }
+        if (s->resident) {
+            // The device built this chunk's blob: the meta words are here (h_blob).  What is left for the host: the callers' status, the
+            // size the next launches' LDS request follows, and the sides the kernel handed back (triangle count -1: coincident points
+            // - the reference's quicksort decides which of them survives -, or more vertices than the launch had LDS for).
+            int nfb = 0, seen = 0;
+            for (int j = 0; j < s->n; j++) {
+                int32_t *meta = s->h_blob + (size_t)j * META_WORDS;
+                const int ns = meta[0];
+                if (s->job->status) s->job->status[s->i0 + j] = ns;
+                meta[6] = 0;  // host copy: which sides the host stage builds (bit 0 left, bit 1 right)
+                seen = std::max(seen, ns);
+                if (ns >= 3 && (meta[2] < 0 || meta[4] < 0)) nfb++;
+            }
+            h->tri_pairs.fetch_add(s->n, std::memory_order_relaxed);
+            h->gpu_tri_pairs.fetch_add(s->n, std::memory_order_relaxed);
+            {  // grow at once, shrink slowly: a launch whose LDS request is too small hands its large sets to the host
+                const int target = std::min(h->dg_sub_max, seen + seen / 4 + 64), cur = h->ns_bound.load(std::memory_order_relaxed);
+                h->ns_bound.store(target > cur ? target : cur - (cur - target + 3) / 4, std::memory_order_relaxed);
+            }
+            s->gpu_pct = 0;
+            if (nfb == 0) {
+                chunk_host_done(h, s);
+                continue;
+            }
+            s->pending.store(nfb);
+            {
+                std::lock_guard<std::mutex> lk(h->qmu);
+                for (int j = 0; j < s->n; j++) {
+                    const int32_t *meta = s->h_blob + (size_t)j * META_WORDS;
+                    if (meta[0] >= 3 && (meta[2] < 0 || meta[4] < 0)) {
+                        h->queue.push_back(Task{s, j, -2});
+                        h->queue_len.fetch_add(1, std::memory_order_release);
+                    }
+                }
+            }
+            h->qcv.notify_all();
+            continue;
+        }
         s->blob_off.store((size_t)s->dev.cap * META_WORDS);
         s->pending.store(s->n);
-        s->gpu_pct = h->gpu_delaunay_pct;
-        if (h->gpu_share_auto) {
+        s->gpu_pct = h->resident_ok ? 0 : h->gpu_delaunay_pct;
+        if (h->gpu_share_auto && !h->resident_ok) {
             // Tasks of earlier chunks that no pool thread has picked up yet when the next lattice arrives: the pool is behind the GPU,
             // so the triangulation kernel takes a larger share of this chunk; a short queue gives the share back to the pool.  (One
             // chunk at a time - a single slot, a profile's serial pass - never finds a backlog and stays on the host.)
-            const int backlog = h->queue_len.load(std::memory_order_acquire);
             // (thresholds from sweeps on one MI355X: more than one chunk of unstarted tasks: up 2 points, less than a quarter: down 2 -
             //  steps of 5 at 1.5 / 0.5 chunks gave the same mean rate with more scatter; settles at 13-30 % with 14 threads, 26 % with 12,
             //  47 % with 10, 60 % with 8, 74 % with 6, 86 % with 4 - each 1-2 % above what the all-GPU mode reaches)
-            if (backlog > s->n) h->auto_pct = std::min(h->auto_pct + 2, 95);
-            else if (backlog * 4 <= s->n) h->auto_pct = std::max(h->auto_pct - 2, 0);
             // The share is handed out in whole chunks (every 1 / share-th chunk goes to the GPU kernel entirely) rather than as a
             // slice of every chunk: the kernel is a latency chain of ~0.9 ms whatever the number of sets (one workgroup each), so
             // fewer, fuller launches cost the same GPU time per set and a quarter of the launches.  SV_GPU_DELAUNAY_SLICED=1: the old way.
@@ -1007,8 +1110,21 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
         dbg_put(h, "tri1", blob + meta[3], (size_t)meta[2] * 3);
         dbg_put(h, "tri2", blob + meta[5], (size_t)meta[4] * 3);
     }
-    HIP_TRY(hipMemcpyAsync(s->dev.blob, blob, off * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    if (s->gpu_pct > 0) {  // triangle lists still missing: built on the device from the vertex orders the host left in the blob
+    if (s->resident) {  // the device has the blob already; only what the host stage built for handed-back sides goes up
+        for (int j = 0; j < n; j++) {
+            int32_t *meta = blob + (size_t)j * META_WORDS;
+            const int mask = meta[6];
+            if (!mask) continue;
+            meta[6] = 0;
+            for (int side = 0; side < 2; side++)
+                if ((mask >> side) & 1 && meta[2 + 2 * side] > 0)
+                    HIP_TRY(hipMemcpyAsync(s->dev.blob + meta[3 + 2 * side], blob + meta[3 + 2 * side], sizeof(int32_t) * 3 * (size_t)meta[2 + 2 * side], hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(s->dev.blob + (size_t)j * META_WORDS, meta, sizeof(int32_t) * META_WORDS, hipMemcpyHostToDevice, st));
+        }
+    } else {
+        HIP_TRY(hipMemcpyAsync(s->dev.blob, blob, off * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    }
+    if (!s->resident && s->gpu_pct > 0) {  // triangle lists still missing: built on the device from the vertex orders the host left in the blob
         int ns_max = 0, ns_large = 0;  // largest flagged set the LDS kernel takes / the cut path takes (larger ones: the host did them)
         for (int j = 0; j < n; j++) {
             const int ns = blob[(size_t)j * META_WORDS];
@@ -1747,6 +1863,14 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     // start where the balance was measured to settle (4 ... 14 threads); a handle with fewer than four slots cannot build up a backlog
     if (h->gpu_share_auto && nslots >= 4) h->auto_pct = std::max(0, std::min(95, 117 - 7 * npool));
     if (!(h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0)) h->dg_limit = h->dg_sub_max;  // the pool triangulates everything: no scratch
+    // The GPU's share of the chunks is "resident" - support lists never leave the device, preparation and triangulation in one kernel of
+    // phase 1 - where the lattice filter runs on the GPU and a pair's lists fit the LDS kernel (KITTI-sized lattices: ~2 000 points; a
+    // 4K lattice's 21 000 take the cut path, whose vertex orders still come from the host).  SV_RESIDENT=0: the round-3 path.
+    h->resident_ok = h->gpu_filter && !cfg->keep_debug && h->chunk >= 4 && (h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0) && h->dg_limit == h->dg_sub_max &&
+                     std::min(h->kp.d.max_pts, fsup_copy_pts(h->kp.d)) <= h->dg_sub_max + h->dg_sub_max / 4 && h->kp.d.disp_max + h->kp.d.W < 30000;
+    if (const char *e = getenv("SV_RESIDENT")) h->resident_ok = h->resident_ok && atoi(e) != 0;
+    h->ns_bound.store(std::min(h->dg_sub_max, delaunay_prep_max_points()));
+    h->shared_pct.store(h->auto_pct);
     h->block_sync = h->chunk >= 4;
     if (const char *e = getenv("SV_EVENT_SYNC")) h->block_sync = strcmp(e, "block") == 0;
     try {
@@ -1848,6 +1972,7 @@ int sv_query(const sv_handle *h, int what) {
         case SV_Q_GPU_LATTICE_FILTER: return h->gpu_filter ? 1 : 0;
         case SV_Q_GPU_TRIANGULATION: return h->gpu_delaunay ? 1 : 0;
         case SV_Q_NUMA_BOUND: return h->node_bound ? 1 : 0;
+        case SV_Q_RESIDENT: return h->resident_ok ? 1 : 0;
         case SV_Q_GPU_TRIANGULATION_FALLBACKS: return (int)std::min<int64_t>(h->gpu_tri_fallbacks.load(), 0x7FFFFFFF);
         case SV_Q_GPU_TRIANGULATION_SHARE: {
             const int64_t all = h->tri_pairs.load(), g = h->gpu_tri_pairs.load();
@@ -2080,6 +2205,37 @@ int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int rep
     for (void *p : {(void *)d_order, (void *)d_xy, (void *)d_tri, (void *)d_cnt, (void *)d_sets, scr.tri, (void *)scr.xy, (void *)scr.res})
         if (p) (void)hipFree(p);
     return rc == SV_OK ? nt : rc;
+}
+
+// Test hooks: the preparation of a vertex set (sort, duplicate scan, k-d order) on the host (what Delaunay::prepare leaves: the ids of
+// the surviving vertices in the order the recursion consumes them) and on the GPU (delaunay_gpu.hip: dg_prepare, for vertices on the
+// support lattice of a width x height image).  Both return m and write m ids; the GPU form returns -1 for a set it leaves to the host
+// (coincident points, or vertices outside the lattice's bit maps).
+int sv_host_kd_order(const int32_t *xy, int n, int32_t *ids_out) {
+    if (!xy || !ids_out || n < 0) return SV_ERR_ARG;
+    Delaunay dl;
+    return dl.kd_ordered_ids(xy, n, ids_out);
+}
+
+int sv_gpu_kd_order(const int32_t *xy, const int32_t *disp, int n, int width, int height, int step, int disp_max, int32_t *ids_out) {
+    if (!xy || !ids_out || n < 3 || n > delaunay_prep_max_points() || step < 1 || width < 1 || height < 1 || disp_max < 0) return SV_ERR_ARG;
+    int32_t *d_xy = nullptr, *d_ord = nullptr, *d_dsp = nullptr;
+    int rc = SV_ERR_HIP;
+    std::vector<int32_t> ord((size_t)n + 1, 0);
+    if (hipMalloc((void **)&d_xy, sizeof(int32_t) * 2 * n) == hipSuccess && hipMalloc((void **)&d_ord, sizeof(int32_t) * ((size_t)n + 1)) == hipSuccess &&
+        hipMemcpy(d_xy, xy, sizeof(int32_t) * 2 * n, hipMemcpyHostToDevice) == hipSuccess &&
+        (!disp || (hipMalloc((void **)&d_dsp, sizeof(int32_t) * n) == hipSuccess && hipMemcpy(d_dsp, disp, sizeof(int32_t) * n, hipMemcpyHostToDevice) == hipSuccess))) {
+        if (launch_delaunay_prepare_test(d_xy, d_dsp, n, d_ord, width, height, step, disp_max, nullptr) != 0) {
+            rc = SV_ERR_UNSUPPORTED;
+        } else if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(ord.data(), d_ord, sizeof(int32_t) * ((size_t)n + 1), hipMemcpyDeviceToHost) == hipSuccess) {
+            rc = ord[0];
+            if (rc > 0) memcpy(ids_out, ord.data() + 1, sizeof(int32_t) * (size_t)rc);
+        }
+    }
+    if (d_xy) (void)hipFree(d_xy);
+    if (d_ord) (void)hipFree(d_ord);
+    if (d_dsp) (void)hipFree(d_dsp);
+    return rc;
 }
 
 // Test hook: the adaptive mean divides by v_rcp_f32 + one FMA correction instead of the IEEE sequence; this compares the two for all

@@ -116,6 +116,14 @@ size_t delaunay_gpu_lds_bytes(int m, int npts);
 int delaunay_gpu_max_points();
 void launch_delaunay_blob(int32_t *blob, int n_pairs, size_t lds, int sub_max, hipStream_t st);  // sets of more than sub_max points are left to ..._large
 int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, size_t lds, hipStream_t st);
+// The resident form (k_delaunay_resident): support lists straight from the lattice filter's device buffers, preparation (sort,
+// duplicate scan, k-d order) and triangulation in one kernel, the pair's part of the blob laid out on the device at a fixed place
+// (pair_words per pair behind the meta words).  Sides it reports with a triangle count of -1 (coincident points) are the host's.
+size_t delaunay_resident_lds_bytes(int W, int H, int step, int disp_max, int m);
+int delaunay_prep_max_points();
+void launch_delaunay_resident(const int32_t *fsup, const int32_t *fnsup, int32_t *blob, int cap, int max_pts, int pair_words, int n_pairs, int ns_max, int sub_max, int W, int H, int step,
+                              int disp_max, hipStream_t st);
+int launch_delaunay_prepare_test(const int32_t *d_xy, const int32_t *d_dsp, int n, int32_t *d_ord_out, int W, int H, int step, int disp_max, hipStream_t st);  // d_dsp: disparities, may be nullptr
 // ... sets that do not fit LDS (more than delaunay_gpu_max_points() vertices): subtrees in LDS, the upper merges in a global-memory
 // mesh.  Scratch per set: 2 * cap triangles of 24 bytes, cap (x, y) pairs, node results (delaunay_scratch_bytes).
 int delaunay_gpu_large_max_points();

@@ -317,6 +317,7 @@ class StereoEngine:
         keys = ["host_threads", "chunk", "slots", "gpu_lattice_filter", "gpu_triangulation"]
         out = {k: int(L.sv_query(self._h, i)) for i, k in enumerate(keys)}
         out["numa_bound"] = int(L.sv_query(self._h, 7))
+        out["resident"] = int(L.sv_query(self._h, 8))
         return out
 
     def gpu_triangulation_share(self):
@@ -446,6 +447,41 @@ def gpu_delaunay(xy, reps=1):
     if nt < 0:
         raise StereoError("sv_gpu_delaunay failed (%d): %s" % (nt, L.sv_last_error(None).decode()))
     return out[:nt].copy(), ms.value
+
+
+def host_kd_order(xy):
+    """Test hook: ids of the vertices that survive the duplicate scan, in the order the triangulation's recursion consumes them
+    (host: radix sort / the reference's quicksort when points coincide, duplicate scan, k-d order)."""
+    xy = np.ascontiguousarray(xy, dtype=np.int32)
+    out = np.empty(xy.shape[0], np.int32)
+    L = lib()
+    L.sv_host_kd_order.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    m = L.sv_host_kd_order(xy.ctypes.data, xy.shape[0], out.ctypes.data)
+    if m < 0:
+        raise StereoError("sv_host_kd_order failed (%d)" % m)
+    return out[:m].copy()
+
+
+def gpu_kd_order(xy, width, height, step, disp_max, disp=None):
+    """Test hook: the same on the GPU (delaunay_gpu.hip: dg_prepare) for vertices on the support lattice of a width x height image;
+    disp: the vertices' disparities (coincident vertices with equal disparity are interchangeable: the lowest id is kept).  None for
+    a set the kernel leaves to the host (coincident points that are not interchangeable)."""
+    share_hip_runtime_with_torch()
+    xy = np.ascontiguousarray(xy, dtype=np.int32)
+    out = np.empty(xy.shape[0], np.int32)
+    dp = None
+    if disp is not None:
+        disp = np.ascontiguousarray(disp, dtype=np.int32)
+        assert disp.shape[0] == xy.shape[0]
+        dp = disp.ctypes.data
+    L = lib()
+    L.sv_gpu_kd_order.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    m = L.sv_gpu_kd_order(xy.ctypes.data, dp, xy.shape[0], int(width), int(height), int(step), int(disp_max), out.ctypes.data)
+    if m == -1:
+        return None
+    if m < 0:
+        raise StereoError("sv_gpu_kd_order failed (%d)" % m)
+    return out[:m].copy()
 
 
 def host_delaunay(xy, split=False, helper_delay_us=0, depth=1):

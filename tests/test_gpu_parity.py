@@ -615,3 +615,122 @@ def test_handle_on_second_device(eng, oracle):
     for i in range(B):
         o1, o2, _ = oracle.process(po, batch[i, 0], batch[i, 1])
         assert np.array_equal(d1[i].view(np.uint8), o1.view(np.uint8)) and np.array_equal(d2[i].view(np.uint8), o2.view(np.uint8)), i
+
+
+def _lattice_set(rng, W, H, step, D, n_lat, side, small_d=False, zero_corner=False):
+    """Support-point-like vertex set: n_lat lattice points in scan order (u outer, v inner) with random disparities + the six corner
+    points (elas.cpp:235-264), as the (x, y) the triangulation of `side` sees (elas.cpp:449-461); also returns the disparities."""
+    Wc, Hc = -(-W // step), -(-H // step)
+    cells = np.sort(rng.choice((Wc - 1) * (Hc - 1), n_lat, replace=False))
+    u, v = (cells // (Hc - 1) + 1) * step, (cells % (Hc - 1) + 1) * step
+    d = rng.integers(0, 4 if small_d else D + 1, n_lat)
+    cd = rng.integers(1, D + 1, 4)
+    if zero_corner:
+        cd[2] = 0  # the top-right corner's nearest support point has disparity 0: (W-1, 0, 0) twice, in both images
+    U = np.concatenate([u, [0, 0, W - 1, W - 1, W - 1 + cd[2], W - 1 + cd[3]]])
+    V = np.concatenate([v, [0, H - 1, 0, H - 1, 0, H - 1]])
+    Dd = np.concatenate([d, [cd[0], cd[1], cd[2], cd[3], cd[2], cd[3]]])
+    return np.stack([U - Dd if side else U, V], 1).astype(np.int32), Dd.astype(np.int32)
+
+
+def test_gpu_vertex_preparation_matches_host(eng):
+    """Sort, duplicate scan and k-d order of a vertex set on the GPU (delaunay_gpu.hip: dg_prepare - ranks from bit maps of the
+    occupied lattice cells, the alternating cuts one tree depth per pass) against Delaunay::prepare of the host stage, which follows
+    the reference (triangle.cpp:5183-5360, 5889-5903).  Without coincident points: exactly the host's order.  Coincident points with
+    equal disparities (the corner point with disparity 0, 7 of the 21 kitti_mini frames) are the same support point twice: the
+    kernel keeps the lowest id, the host whichever the reference's quicksort puts first - the same vertices in the same order up
+    to that label.  Coincident points with different disparities are not interchangeable: the kernel must hand the set back."""
+    rng = np.random.default_rng(3)
+    handed_back = merged = 0
+    for it in range(150):
+        W, H, step, D = [(1242, 375, 5, 127), (320, 120, 5, 63), (1242, 375, 5, 255), (640, 480, 3, 100), (203, 97, 5, 31), (1242, 375, 6, 127)][it % 6]
+        Wc, Hc = -(-W // step), -(-H // step)
+        n_lat = int(rng.integers(3, min(3700, (Wc - 1) * (Hc - 1))))
+        side = it % 2
+        xy, dd = _lattice_set(rng, W, H, step, D, n_lat, side=side, small_d=(it % 4 == 0) or (it % 5 == 0), zero_corner=(it % 5 == 0))
+        if it % 5 == 0 and side:  # keep the right image free of other coincidences: one disparity everywhere except the corners
+            dd[:-6] = 2
+            xy, _ = _lattice_set(np.random.default_rng(it), W, H, step, D, n_lat, side=0)
+            U = xy[:, 0].copy()
+            U[-2:] = xy[-4:-2, 0] + dd[-2:]
+            xy = np.stack([U - dd, xy[:, 1]], 1).astype(np.int32)
+        want, got = eng.host_kd_order(xy), eng.gpu_kd_order(xy, W, H, step, D, disp=dd)
+        keys = xy[:, 0].astype(np.int64) * 100000 + xy[:, 1]
+        interchangeable = all(len(set(dd[keys == k])) == 1 for k in np.unique(keys[np.isin(keys, keys[np.unique(keys, return_counts=True, return_index=True)[1]])]) if (keys == k).sum() > 1)
+        unique = len(np.unique(keys)) == len(keys)
+        if got is None:
+            handed_back += 1
+            assert not unique and not interchangeable, "case %d: handed back although every coincident group is interchangeable" % it
+            continue
+        assert unique or interchangeable, "case %d: coincident points with different disparities not noticed" % it
+        assert len(got) == len(want) == len(np.unique(keys))
+        if unique:
+            assert np.array_equal(got, want), "case %d: order differs" % it
+        else:
+            merged += 1
+            assert np.array_equal(xy[got], xy[want]) and np.array_equal(dd[got], dd[want]), "case %d: order differs" % it
+            assert all(got[i] == min(np.nonzero(keys == keys[got[i]])[0]) for i in range(len(got))), "case %d: not the lowest id of a coincident group" % it
+    assert handed_back > 0 and merged > 0
+
+
+@pytest.mark.parametrize("name", ["kitti0_d128", "kitti10_d128", "cones_crop_robotics", "synth7_d64"])
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_resident_and_round3_triangulation_paths_agree(eng, oracle, monkeypatch, name, resident):
+    """All-GPU triangulation with the support lists resident on the device (k_delaunay_resident: the host reads 8 meta words per pair)
+    and with SV_RESIDENT=0 the round-3 path (lists to the host, vertex order from the pool, k_delaunay_blob): same maps, bit for bit."""
+    monkeypatch.setenv("SV_GPU_DELAUNAY", "1")
+    monkeypatch.setenv("SV_RESIDENT", resident)
+    entry = DIG[name]
+    L, R = util.case_images(entry)
+    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=3, n_streams=2, n_workers=1)
+    try:
+        assert e.query()["resident"] == int(resident)
+        d1, d2, st = e.process_host(np.stack([L] * 9), np.stack([R] * 9))
+    finally:
+        e.close()
+    assert (st == entry["n_support"]).all()
+    for i in range(9):
+        assert util.sha(d1[i]) == entry["stages"]["final1"] and util.sha(d2[i]) == entry["stages"]["final2"]
+
+
+def test_resident_chunks_hand_coincident_points_to_the_host(eng, oracle, monkeypatch):
+    """lr_threshold = 6 lets two support points of one lattice row match the same right-image column (|d1 - d2| = 5 or 10): coincident
+    vertices in the right image with DIFFERENT disparities, whose survivor the reference's randomised quicksort decides.  The resident
+    kernel must hand such a side to the host stage (counted as fallbacks) and the maps must still equal the oracle's."""
+    monkeypatch.setenv("SV_GPU_DELAUNAY", "1")
+    synth = util.pkg("synth")
+    H, W, D, B = 120, 320, 64, 13
+    batch = synth.make_batch(900, B, H, W, D)
+    p, po = eng.SvParams.driver(D - 1), ElasParams.driver(D - 1)
+    for q in (p, po):
+        q.lr_threshold, q.support_threshold, q.incon_min_support, q.incon_threshold = 6, 1.0, 1, 30
+    e = eng.StereoEngine(W, H, p, chunk=4, n_slots=3, n_streams=2, n_workers=2)
+    try:
+        assert e.query()["resident"] == 1
+        d1, d2, st = e.process_host(batch[:, 0], batch[:, 1])
+        fallbacks = e.gpu_triangulation_fallbacks()
+    finally:
+        e.close()
+    for i in range(B):
+        o1, o2, _ = oracle.process(po, batch[i, 0], batch[i, 1])
+        assert np.array_equal(d1[i].view(np.uint8), o1.view(np.uint8)) and np.array_equal(d2[i].view(np.uint8), o2.view(np.uint8)), i
+    assert fallbacks > 0, "no pair of this batch had coincident points: the test does not exercise the hand-back"
+
+
+@pytest.mark.parametrize("name", ["kitti20_d128"])
+def test_resident_chunks_keep_the_zero_disparity_corner_on_the_device(eng, oracle, monkeypatch, name):
+    """kitti_mini frame 20: the top-right image corner takes disparity 0, so elas.cpp:258-259 adds the support point (W-1, 0, 0) a
+    second time - coincident vertices in both images, one third of the kitti_mini frames.  They are interchangeable (same triple), so
+    the resident kernel drops one itself: no side is handed to the host, and the maps are the reference's."""
+    monkeypatch.setenv("SV_GPU_DELAUNAY", "1")
+    entry = DIG[name]
+    L, R = util.case_images(entry)
+    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=2, n_streams=2, n_workers=1)
+    try:
+        d1, d2, st = e.process_host(np.stack([L] * 5), np.stack([R] * 5))
+        assert e.query()["resident"] == 1 and e.gpu_triangulation_fallbacks() == 0
+    finally:
+        e.close()
+    assert (st == entry["n_support"]).all()
+    for i in range(5):
+        assert util.sha(d1[i]) == entry["stages"]["final1"] and util.sha(d2[i]) == entry["stages"]["final2"]
