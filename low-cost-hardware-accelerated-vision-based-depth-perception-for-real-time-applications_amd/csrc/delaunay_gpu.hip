@@ -34,38 +34,92 @@ namespace dg {
 constexpr uint32_t GHOST = 0xFFFFu;
 constexpr int DG_THREADS = 256;
 
+// A triangle of an LDS mesh: three neighbour handles ((slot << 2) | orientation, slot 0 = outer space) and three vertex ids (GHOST = the
+// vertex at infinity of a bounding triangle), 16 bits each, as three 32-bit words:
+//   w[0] = nbr0 | nbr1 << 16    w[1] = nbr2 | vtx0 << 16    w[2] = vtx1 | vtx2 << 16
+// A merge is one lane's chain of dependent LDS accesses (~30 ns each, tools/valu_rate2.hip), so the seam walk reads a triangle as ONE
+// access - three ds_read_b32 in flight together - into registers (TR) and picks its fields there; round 3 read every 16-bit field by
+// itself (volatile, a full wait each): ~3 us per seam step against ~0.4 us now.  Stores stay single 16-bit fields.
 struct DTri {
-    uint16_t nbr[3];  // neighbour handle across edge o: (slot << 2) | orientation; slot 0 = outer space
-    uint16_t vtx[3];  // vertex ids, GHOST = the vertex at infinity of a bounding triangle
+    uint32_t w[3];
 };
+struct TR {  // a triangle in registers
+    uint32_t w0, w1, w2;
+};
+__device__ __forceinline__ uint32_t tr_nbr(const TR &t, uint32_t o) { return (uint32_t)(((((uint64_t)t.w1) << 32) | t.w0) >> (16u * o)) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t tr_vtx(const TR &t, uint32_t k) { return (uint32_t)(((((uint64_t)t.w2) << 32) | t.w1) >> (16u * k + 16u)) & 0xFFFFu; }
 
-// The triangle array is accessed through a DG_VOLATILE pointer: hipcc's SLP vectoriser (ROCm 7.2, -O2 and above) fuses the 16-bit
-// field accesses of neighbouring statements into wider ones across stores that may hit the same triangle through another handle
-// and the merge then walks a stale mesh (reproduced on a 7-vertex set; -fno-slp-vectorize or -O1 give the right mesh).
-#ifdef DG_NO_VOLATILE  // experiment: rely on -fno-slp-vectorize instead
-#define DG_VOLATILE
-#else
-#define DG_VOLATILE volatile
-#endif
 #ifdef DG_HOST_EMULATION
 #define DG_LDS
 #else
 #define DG_LDS __attribute__((address_space(3)))  // explicit LDS pointers: ds_* instructions instead of flat_* ones
 #endif
+// The loads are inline assembly on the device: hipcc's SLP vectoriser (ROCm 7.2, -O2 and above) fuses plain field accesses of
+// neighbouring statements into wider ones ACROSS stores that may hit the same triangle through another handle (reproduced on a
+// 7-vertex set in round 2), and a volatile access is followed by a full wait.  LDS operations of one wavefront execute in issue order,
+// so a load issued after a store sees it; "memory" keeps the compiler from moving either across the other.
 struct Mesh {  // a set (or a subtree of a large set) in LDS
-    typedef uint16_t idx_t;
-    static constexpr uint32_t NOVTX = 0xFFFFu;
-    static constexpr bool GUARDED = false;
-    static constexpr uint32_t step_limit = 0;
-    DG_LDS DG_VOLATILE DTri *T;
-    DG_LDS const int16_t *px, *py;
-    __device__ __forceinline__ int32_t vx(uint32_t v) const { return px[v]; }
-    __device__ __forceinline__ int32_t vy(uint32_t v) const { return py[v]; }
+    DG_LDS uint32_t *W;          // triangles, 3 words each
+    DG_LDS const uint32_t *pxy;  // vertices: (x & 0xFFFF) | y << 16, both signed 16-bit
+#ifdef DG_HOST_EMULATION
+    TR load(uint32_t slot) const { return TR{W[3 * slot], W[3 * slot + 1], W[3 * slot + 2]}; }
+    void load2(uint32_t a, uint32_t b, TR &ta, TR &tb) const { ta = load(a), tb = load(b); }
+    uint32_t coords(uint32_t v) const { return pxy[v]; }
+    void coords2(uint32_t a, uint32_t b, uint32_t &ca, uint32_t &cb) const { ca = pxy[a], cb = pxy[b]; }
+    uint32_t field(uint32_t slot, uint32_t f) const { return reinterpret_cast<const uint16_t *>(W)[6 * slot + f]; }
+    void set_field(uint32_t slot, uint32_t f, uint32_t v) const { reinterpret_cast<uint16_t *>(W)[6 * slot + f] = (uint16_t)v; }
+    void store(uint32_t slot, const TR &t) const { W[3 * slot] = t.w0, W[3 * slot + 1] = t.w1, W[3 * slot + 2] = t.w2; }
+#else
+    __device__ __forceinline__ TR load(uint32_t slot) const {
+        TR t;
+        const uint32_t a = (uint32_t)(size_t)W + 12u * slot;
+        asm volatile("ds_read_b32 %0, %3\n\tds_read_b32 %1, %3 offset:4\n\tds_read_b32 %2, %3 offset:8\n\ts_waitcnt lgkmcnt(0)" : "=&v"(t.w0), "=&v"(t.w1), "=&v"(t.w2) : "v"(a) : "memory");
+        return t;
+    }
+    __device__ __forceinline__ void load2(uint32_t sa, uint32_t sb, TR &ta, TR &tb) const {  // two independent triangles, one latency
+        const uint32_t a = (uint32_t)(size_t)W + 12u * sa, b = (uint32_t)(size_t)W + 12u * sb;
+        asm volatile(
+            "ds_read_b32 %0, %6\n\tds_read_b32 %1, %6 offset:4\n\tds_read_b32 %2, %6 offset:8\n\tds_read_b32 %3, %7\n\tds_read_b32 %4, %7 offset:4\n\tds_read_b32 %5, %7 offset:8\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(ta.w0), "=&v"(ta.w1), "=&v"(ta.w2), "=&v"(tb.w0), "=&v"(tb.w1), "=&v"(tb.w2)
+            : "v"(a), "v"(b)
+            : "memory");
+    }
+    __device__ __forceinline__ uint32_t coords(uint32_t v) const {
+        uint32_t c;
+        const uint32_t a = (uint32_t)(size_t)pxy + 4u * v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(c) : "v"(a) : "memory");
+        return c;
+    }
+    __device__ __forceinline__ void coords2(uint32_t va, uint32_t vb, uint32_t &ca, uint32_t &cb) const {
+        const uint32_t a = (uint32_t)(size_t)pxy + 4u * va, b = (uint32_t)(size_t)pxy + 4u * vb;
+        asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(ca), "=&v"(cb) : "v"(a), "v"(b) : "memory");
+    }
+    __device__ __forceinline__ uint32_t field(uint32_t slot, uint32_t f) const {  // one 16-bit field (f = 0..2: neighbours, 3..5: vertices)
+        uint32_t c;
+        const uint32_t a = (uint32_t)(size_t)W + 12u * slot + 2u * f;
+        asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(c) : "v"(a) : "memory");
+        return c;
+    }
+    __device__ __forceinline__ void set_field(uint32_t slot, uint32_t f, uint32_t v) const {
+        const uint32_t a = (uint32_t)(size_t)W + 12u * slot + 2u * f;
+        asm volatile("ds_write_b16 %0, %1" : : "v"(a), "v"(v) : "memory");
+    }
+    __device__ __forceinline__ void store(uint32_t slot, const TR &t) const {
+        const uint32_t a = (uint32_t)(size_t)W + 12u * slot;
+        asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4\n\tds_write_b32 %0, %3 offset:8" : : "v"(a), "v"(t.w0), "v"(t.w1), "v"(t.w2) : "memory");
+    }
+#endif
+    __device__ __forceinline__ void bond(uint32_t a, uint32_t b) const {  // triangle.cpp: bond(): the two handles become each other's neighbour
+        set_field(a >> 2, a & 3u, b);
+        set_field(b >> 2, b & 3u, a);
+    }
 };
 
 // A field of a global-memory mesh.  Relaxed agent-scope atomics: single 32-bit accesses that bypass the vector cache (other
 // workgroups / an earlier kernel wrote the mesh), keep their order per address, are left alone by the SLP vectoriser (see DG_VOLATILE)
 // and - unlike volatile accesses, each of which is followed by a full s_waitcnt - overlap when they are independent.
+#define DG_VOLATILE volatile
 struct GField {
     uint32_t v;
 #ifdef DG_HOST_EMULATION
@@ -161,81 +215,86 @@ __device__ __forceinline__ uint32_t d_make(const MT &M, uint32_t slot) {  // tri
     return slot << 2;
 }
 
-// triangle.cpp:5670-5815, the two- and three-vertex cases; a[] = vertex ids, slots [slot, slot + 2) resp. [slot, slot + 4)
+// ---- LDS mesh: vertices with coordinates, predicates ------------------------------------------------------------------------
+struct DVL {  // a vertex of an LDS mesh with its coordinates (the GHOST vertex has none: they are never used)
+    uint32_t id;
+    int32_t x, y;
+};
+__device__ __forceinline__ DVL dvl(uint32_t id, uint32_t c) { return DVL{id, (int32_t)(int16_t)(c & 0xFFFFu), (int32_t)c >> 16}; }
+__device__ __forceinline__ uint32_t vsafe(uint32_t id) { return id == GHOST ? 0u : id; }
+__device__ __forceinline__ DVL ld_vertex(const Mesh &M, uint32_t id) { return dvl(id, M.coords(vsafe(id))); }
+__device__ __forceinline__ void ld_vertex2(const Mesh &M, uint32_t ia, uint32_t ib, DVL &a, DVL &b) {
+    uint32_t ca, cb;
+    M.coords2(vsafe(ia), vsafe(ib), ca, cb);
+    a = dvl(ia, ca), b = dvl(ib, cb);
+}
+
+// Orientation: coordinates are 16-bit, the two products 32 x 32 -> 64 bits (v_mad_i64_i32).
+__device__ __forceinline__ int64_t lv_orient(const DVL &a, const DVL &b, const DVL &c) {
+    return (int64_t)(a.x - c.x) * (int64_t)(b.y - c.y) - (int64_t)(a.y - c.y) * (int64_t)(b.x - c.x);
+}
+// In-circle.  NARROW: every coordinate difference of the set is below 2^14 in magnitude (the engine's sets: columns within
+// [-disp_max, W + disp_max), W <= 8192, disp_max <= 1023) - then the lifted terms (< 2^29) and the 2 x 2 minors (< 2^29) are exact in
+// 32 bits and only the three final products need 64: ~25 instructions instead of ~150.
+template <bool NARROW>
+__device__ __forceinline__ int64_t lv_incirc(const DVL &a, const DVL &b, const DVL &c, const DVL &d) {
+    if (NARROW) {
+        const int32_t adx = a.x - d.x, ady = a.y - d.y, bdx = b.x - d.x, bdy = b.y - d.y, cdx = c.x - d.x, cdy = c.y - d.y;
+        const int32_t al = adx * adx + ady * ady, bl = bdx * bdx + bdy * bdy, cl = cdx * cdx + cdy * cdy;
+        return (int64_t)al * (int64_t)(bdx * cdy - cdx * bdy) + (int64_t)bl * (int64_t)(cdx * ady - adx * cdy) + (int64_t)cl * (int64_t)(adx * bdy - bdx * ady);
+    }
+    const int64_t adx = a.x - d.x, ady = a.y - d.y, bdx = b.x - d.x, bdy = b.y - d.y, cdx = c.x - d.x, cdy = c.y - d.y;
+    return (adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) + (bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy) + (cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
+}
+
+// A triangle assembled in registers from its six fields (the leaves and the two new triangles of a merge are stored whole)
+__device__ __forceinline__ TR tr_pack(uint32_t n0, uint32_t n1, uint32_t n2, uint32_t v0, uint32_t v1, uint32_t v2) {
+    return TR{(n0 & 0xFFFFu) | (n1 << 16), (n2 & 0xFFFFu) | (v0 << 16), (v1 & 0xFFFFu) | (v2 << 16)};
+}
+
+// triangle.cpp:5670-5815, the two- and three-vertex cases; a[] = vertex ids, slots [slot, slot + 2) resp. [slot, slot + 4).
+// The bonds and corners below are what that code leaves (restated field by field from the round-3 kernel, which followed it handle
+// by handle); H(s, o) = handle of slot s at orientation o.
 __device__ __forceinline__ void d_leaf(const Mesh &M, DG_LDS const uint16_t *a, int n, uint32_t slot, uint32_t &farleft, uint32_t &farright) {
-    typedef uint16_t IDX;
+#define DG_H(s, o) ((((uint32_t)(s)) << 2) | (uint32_t)(o))
+    const uint32_t a0 = a[0], a1 = a[1];
     if (n == 2) {
-        uint32_t l = d_make(M, slot), r = d_make(M, slot + 1);
-        D_ORG(l) = a[0];
-        D_DEST(l) = a[1];
-        D_ORG(r) = a[1];
-        D_DEST(r) = a[0];
-        D_BOND(l, r);
-        l = hprev(l);
-        r = hnext(r);
-        D_BOND(l, r);
-        l = hprev(l);
-        r = hnext(r);
-        D_BOND(l, r);
-        farright = r;
-        farleft = hprev(r);
+        // l = slot: org a0 (vtx[1]), dest a1 (vtx[2]); r = slot + 1: org a1, dest a0.  Bonds: (l,0)-(r,0), (l,2)-(r,1), (l,1)-(r,2).
+        const uint32_t l = slot, r = slot + 1;
+        M.store(l, tr_pack(DG_H(r, 0), DG_H(r, 2), DG_H(r, 1), GHOST, a0, a1));
+        M.store(r, tr_pack(DG_H(l, 0), DG_H(l, 2), DG_H(l, 1), GHOST, a1, a0));
+        farright = DG_H(r, 2);  // r after two hnext: 0 -> 1 -> 2
+        farleft = DG_H(r, 1);   // hprev of that
         return;
     }
-    uint32_t mid = d_make(M, slot), t1 = d_make(M, slot + 1), t2 = d_make(M, slot + 2), t3 = d_make(M, slot + 3);
-    const int64_t area = d_orient(M, a[0], a[1], a[2]);
+    const uint32_t a2 = a[2];
+    DVL v0, v1;
+    ld_vertex2(M, a0, a1, v0, v1);
+    const DVL v2 = ld_vertex(M, a2);
+    const int64_t area = lv_orient(v0, v1, v2);
+    const uint32_t mid = slot, t1 = slot + 1, t2 = slot + 2, t3 = slot + 3;
     if (area == 0) {
-        D_ORG(mid) = a[0];
-        D_DEST(mid) = a[1];
-        D_ORG(t1) = a[1];
-        D_DEST(t1) = a[0];
-        D_ORG(t2) = a[2];
-        D_DEST(t2) = a[1];
-        D_ORG(t3) = a[1];
-        D_DEST(t3) = a[2];
-        D_BOND(mid, t1);
-        D_BOND(t2, t3);
-        mid = hnext(mid);
-        t1 = hprev(t1);
-        t2 = hnext(t2);
-        t3 = hprev(t3);
-        D_BOND(mid, t3);
-        D_BOND(t1, t2);
-        mid = hnext(mid);
-        t1 = hprev(t1);
-        t2 = hnext(t2);
-        t3 = hprev(t3);
-        D_BOND(mid, t1);
-        D_BOND(t2, t3);
-        farleft = t1;
-        farright = t2;
+        // three collinear vertices: two edges, four bounding triangles.  Corners: mid org a0 dest a1; t1 org a1 dest a0; t2 org a2 dest a1;
+        // t3 org a1 dest a2.  Bonds: (mid,0)-(t1,0), (t2,0)-(t3,0), (mid,1)-(t3,2), (t1,2)-(t2,1), (mid,2)-(t1,1), (t2,2)-(t3,1).
+        M.store(mid, tr_pack(DG_H(t1, 0), DG_H(t3, 2), DG_H(t1, 1), GHOST, a0, a1));
+        M.store(t1, tr_pack(DG_H(mid, 0), DG_H(mid, 2), DG_H(t2, 1), GHOST, a1, a0));
+        M.store(t2, tr_pack(DG_H(t3, 0), DG_H(t1, 2), DG_H(t3, 1), GHOST, a2, a1));
+        M.store(t3, tr_pack(DG_H(t2, 0), DG_H(t2, 2), DG_H(mid, 1), GHOST, a1, a2));
+        farleft = DG_H(t1, 1);   // t1 after two hprev: 0 -> 2 -> 1
+        farright = DG_H(t2, 2);  // t2 after two hnext: 0 -> 1 -> 2
     } else {
-        const uint16_t second = area > 0 ? a[1] : a[2], third = area > 0 ? a[2] : a[1];
-        D_ORG(mid) = a[0];
-        D_DEST(t1) = a[0];
-        D_ORG(t3) = a[0];
-        D_DEST(mid) = second;
-        D_ORG(t1) = second;
-        D_DEST(t2) = second;
-        D_APEX(mid) = third;
-        D_ORG(t2) = third;
-        D_DEST(t3) = third;
-        D_BOND(mid, t1);
-        mid = hnext(mid);
-        D_BOND(mid, t2);
-        mid = hnext(mid);
-        D_BOND(mid, t3);
-        t1 = hprev(t1);
-        t2 = hnext(t2);
-        D_BOND(t1, t2);
-        t1 = hprev(t1);
-        t3 = hprev(t3);
-        D_BOND(t1, t3);
-        t2 = hnext(t2);
-        t3 = hprev(t3);
-        D_BOND(t2, t3);
-        farleft = t1;
-        farright = area > 0 ? t2 : hnext(farleft);
+        // one real triangle `mid` (a0, second, third counter-clockwise) and three bounding ones.
+        const uint32_t second = area > 0 ? a1 : a2, third = area > 0 ? a2 : a1;
+        // mid: org a0 (vtx[1]), dest second (vtx[2]), apex third (vtx[0]); t1: org second, dest a0; t2: org third, dest second; t3: org a0, dest third
+        // Bonds: (mid,0)-(t1,0), (mid,1)-(t2,0), (mid,2)-(t3,0), (t1,2)-(t2,1), (t1,1)-(t3,2), (t2,2)-(t3,1).
+        M.store(mid, tr_pack(DG_H(t1, 0), DG_H(t2, 0), DG_H(t3, 0), third, a0, second));
+        M.store(t1, tr_pack(DG_H(mid, 0), DG_H(t3, 2), DG_H(t2, 1), GHOST, second, a0));
+        M.store(t2, tr_pack(DG_H(mid, 1), DG_H(t1, 2), DG_H(t3, 1), GHOST, third, second));
+        M.store(t3, tr_pack(DG_H(mid, 2), DG_H(t2, 2), DG_H(t1, 1), GHOST, a0, third));
+        farleft = DG_H(t1, 1);  // t1 after two hprev
+        farright = area > 0 ? DG_H(t2, 2) : DG_H(t1, 2);  // t2 after two hnext; else hnext(farleft)
     }
+#undef DG_H
 }
 
 // triangle.cpp:5362-5651; the two new triangles take slots `slot` and `slot + 1`
@@ -449,7 +508,207 @@ __device__ __forceinline__ bool d_node(int m, int d, int j, int &lo, int &n, uin
     return true;
 }
 
+// triangle.cpp:5362-5651 on an LDS mesh; the two new triangles take slots `slot` and `slot + 1`.  Same steps as d_merge above (which
+// serves the global-memory mesh), with every triangle it looks at held in registers (TR) from ONE LDS access, the coordinates of the
+// moving vertices kept beside their ids, the two sides' next candidates fetched together, and the in-circle test in 32-bit terms.
+// A register copy is only used until the next store that could touch its triangle; after a flip both triangles are read again.
+template <bool NARROW>
+__device__ __forceinline__ void d_merge_lds(const Mesh &M, uint32_t &farleft, uint32_t innerleft, uint32_t innerright, uint32_t &farright, int axis, uint32_t slot) {
+    TR TL, TRr;  // the triangles of innerleft / innerright
+    M.load2(innerleft >> 2, innerright >> 2, TL, TRr);
+    DVL ild, ila, iro, ira;  // dest / apex of innerleft, org / apex of innerright
+    ld_vertex2(M, tr_vtx(TL, prev3(innerleft & 3u)), tr_vtx(TL, innerleft & 3u), ild, ila);
+    ld_vertex2(M, tr_vtx(TRr, next3(innerright & 3u)), tr_vtx(TRr, innerright & 3u), iro, ira);
+    if (axis == 1) {  // horizontal cut: walk the four extreme handles to the bottom-/top-most hull vertices
+        {
+            TR t = M.load(farleft >> 2);
+            DVL flp, fla;
+            ld_vertex2(M, tr_vtx(t, next3(farleft & 3u)), tr_vtx(t, farleft & 3u), flp, fla);
+            while (fla.y < flp.y) {
+                farleft = tr_nbr(t, next3(farleft & 3u));
+                t = M.load(farleft >> 2);
+                flp = fla;
+                fla = ld_vertex(M, tr_vtx(t, farleft & 3u));
+            }
+        }
+        {
+            uint32_t chk = tr_nbr(TL, innerleft & 3u);
+            TR t = M.load(chk >> 2);
+            DVL cv = ld_vertex(M, tr_vtx(t, chk & 3u));
+            while (cv.y > ild.y) {
+                innerleft = hnext(chk);
+                TL = t;  // same triangle, next orientation
+                ila = ild;
+                ild = cv;
+                chk = tr_nbr(TL, innerleft & 3u);
+                t = M.load(chk >> 2);
+                cv = ld_vertex(M, tr_vtx(t, chk & 3u));
+            }
+        }
+        while (ira.y < iro.y) {
+            innerright = tr_nbr(TRr, next3(innerright & 3u));
+            TRr = M.load(innerright >> 2);
+            iro = ira;
+            ira = ld_vertex(M, tr_vtx(TRr, innerright & 3u));
+        }
+        {
+            TR t = M.load(farright >> 2);
+            DVL frp = ld_vertex(M, tr_vtx(t, prev3(farright & 3u)));
+            uint32_t chk = tr_nbr(t, farright & 3u);
+            t = M.load(chk >> 2);
+            DVL cv = ld_vertex(M, tr_vtx(t, chk & 3u));
+            while (cv.y > frp.y) {
+                farright = hnext(chk);
+                frp = cv;
+                chk = tr_nbr(t, farright & 3u);
+                t = M.load(chk >> 2);
+                cv = ld_vertex(M, tr_vtx(t, chk & 3u));
+            }
+        }
+    }
+    for (bool changed = true; changed;) {  // lower common tangent
+        changed = false;
+        if (lv_orient(ild, ila, iro) > 0) {
+            innerleft = tr_nbr(TL, prev3(innerleft & 3u));
+            TL = M.load(innerleft >> 2);
+            ild = ila;
+            ila = ld_vertex(M, tr_vtx(TL, innerleft & 3u));
+            changed = true;
+        }
+        if (lv_orient(ira, iro, ild) > 0) {
+            innerright = tr_nbr(TRr, next3(innerright & 3u));
+            TRr = M.load(innerright >> 2);
+            iro = ira;
+            ira = ld_vertex(M, tr_vtx(TRr, innerright & 3u));
+            changed = true;
+        }
+    }
+    uint32_t leftcand = tr_nbr(TL, innerleft & 3u), rightcand = tr_nbr(TRr, innerright & 3u);
+    // the first new triangle: base = slot at orientation 2 after its two bonds; org(base) = iro (vtx[0]), dest(base) = ild (vtx[1])
+    M.store(slot, tr_pack(innerleft, innerright, 0u, iro.id, ild.id, GHOST));
+    M.set_field(innerleft >> 2, innerleft & 3u, (slot << 2) | 0u);
+    M.set_field(innerright >> 2, innerright & 3u, (slot << 2) | 1u);
+    uint32_t base = (slot << 2) | 2u;
+    if (ild.id == M.field(farleft >> 2, 3u + next3(farleft & 3u))) farleft = hnext(base);
+    if (iro.id == M.field(farright >> 2, 3u + prev3(farright & 3u))) farright = hprev(base);
+    DVL ll = ild, lr = iro, ul, ur;
+    TR TLc, TRc;  // the triangles of leftcand / rightcand
+    M.load2(leftcand >> 2, rightcand >> 2, TLc, TRc);
+    ld_vertex2(M, tr_vtx(TLc, leftcand & 3u), tr_vtx(TRc, rightcand & 3u), ul, ur);
+    for (;;) {
+        const bool leftdone = lv_orient(ul, ll, lr) <= 0, rightdone = lv_orient(ur, ll, lr) <= 0;
+        if (leftdone && rightdone) {
+            // the second new triangle `top`: org ll (vtx[1]), dest lr (vtx[2]); bonds (top,0)-base, (top,1)-rightcand, (top,2)-leftcand
+            const uint32_t top = slot + 1;
+            M.store(top, tr_pack(base, rightcand, leftcand, GHOST, ll.id, lr.id));
+            M.set_field(base >> 2, base & 3u, (top << 2) | 0u);
+            M.set_field(rightcand >> 2, rightcand & 3u, (top << 2) | 1u);
+            M.set_field(leftcand >> 2, leftcand & 3u, (top << 2) | 2u);
+            if (axis == 1) {  // back to left-/right-most handles
+                {
+                    TR t = M.load(farleft >> 2);
+                    DVL flp = ld_vertex(M, tr_vtx(t, next3(farleft & 3u)));
+                    uint32_t chk = tr_nbr(t, farleft & 3u);
+                    t = M.load(chk >> 2);
+                    DVL cv = ld_vertex(M, tr_vtx(t, chk & 3u));
+                    while (cv.x < flp.x) {
+                        farleft = hprev(chk);
+                        flp = cv;
+                        chk = tr_nbr(t, farleft & 3u);
+                        t = M.load(chk >> 2);
+                        cv = ld_vertex(M, tr_vtx(t, chk & 3u));
+                    }
+                }
+                {
+                    TR t = M.load(farright >> 2);
+                    DVL frp, fra;
+                    ld_vertex2(M, tr_vtx(t, prev3(farright & 3u)), tr_vtx(t, farright & 3u), frp, fra);
+                    while (fra.x > frp.x) {
+                        farright = tr_nbr(t, prev3(farright & 3u));
+                        t = M.load(farright >> 2);
+                        frp = fra;
+                        fra = ld_vertex(M, tr_vtx(t, farright & 3u));
+                    }
+                }
+            }
+            return;
+        }
+        // both sides' next candidates: the triangles across the candidates' far edges and their apexes (one latency each for the pair)
+        uint32_t nxl = tr_nbr(TLc, prev3(leftcand & 3u)), nxr = tr_nbr(TRc, next3(rightcand & 3u));
+        TR TNl, TNr;
+        M.load2(nxl >> 2, nxr >> 2, TNl, TNr);
+        DVL nal, nar;
+        ld_vertex2(M, tr_vtx(TNl, nxl & 3u), tr_vtx(TNr, nxr & 3u), nal, nar);
+        if (!leftdone && nal.id != GHOST) {  // flip away left edges that the circle through ll, lr, ul invalidates
+            bool bad = lv_incirc<NARROW>(ll, lr, ul, nal) > 0, flipped = bad;
+            while (bad) {
+                const uint32_t nx1 = hnext(nxl), nx2 = hnext(nx1);
+                const uint32_t topc = tr_nbr(TNl, nx1 & 3u), sidec = tr_nbr(TNl, nx2 & 3u);
+                M.bond(nx2, topc);
+                M.bond(leftcand, sidec);
+                leftcand = hnext(leftcand);
+                const uint32_t outerc = M.field(leftcand >> 2, leftcand & 3u);  // (read after the stores: they may have written it)
+                M.bond(nx1, outerc);
+                M.set_field(leftcand >> 2, 3u + next3(leftcand & 3u), ll.id);
+                M.set_field(leftcand >> 2, 3u + prev3(leftcand & 3u), GHOST);
+                M.set_field(leftcand >> 2, 3u + (leftcand & 3u), nal.id);
+                M.set_field(nx1 >> 2, 3u + next3(nx1 & 3u), GHOST);
+                M.set_field(nx1 >> 2, 3u + prev3(nx1 & 3u), ul.id);
+                M.set_field(nx1 >> 2, 3u + (nx1 & 3u), nal.id);
+                ul = nal;
+                nxl = sidec;
+                TNl = M.load(nxl >> 2);
+                nal = ld_vertex(M, tr_vtx(TNl, nxl & 3u));
+                bad = nal.id != GHOST && lv_incirc<NARROW>(ll, lr, ul, nal) > 0;
+            }
+            if (flipped) TLc = M.load(leftcand >> 2);
+        }
+        if (!rightdone && nar.id != GHOST) {
+            bool bad = lv_incirc<NARROW>(ll, lr, ur, nar) > 0, flipped = bad;
+            while (bad) {
+                const uint32_t nx1 = hprev(nxr), nx2 = hprev(nx1);
+                const uint32_t topc = tr_nbr(TNr, nx1 & 3u), sidec = tr_nbr(TNr, nx2 & 3u);
+                M.bond(nx2, topc);
+                M.bond(rightcand, sidec);
+                rightcand = hprev(rightcand);
+                const uint32_t outerc = M.field(rightcand >> 2, rightcand & 3u);
+                M.bond(nx1, outerc);
+                M.set_field(rightcand >> 2, 3u + next3(rightcand & 3u), GHOST);
+                M.set_field(rightcand >> 2, 3u + prev3(rightcand & 3u), lr.id);
+                M.set_field(rightcand >> 2, 3u + (rightcand & 3u), nar.id);
+                M.set_field(nx1 >> 2, 3u + next3(nx1 & 3u), ur.id);
+                M.set_field(nx1 >> 2, 3u + prev3(nx1 & 3u), GHOST);
+                M.set_field(nx1 >> 2, 3u + (nx1 & 3u), nar.id);
+                ur = nar;
+                nxr = sidec;
+                TNr = M.load(nxr >> 2);
+                nar = ld_vertex(M, tr_vtx(TNr, nxr & 3u));
+                bad = nar.id != GHOST && lv_incirc<NARROW>(ll, lr, ur, nar) > 0;
+            }
+            if (flipped) TRc = M.load(rightcand >> 2);
+        }
+        if (leftdone || (!rightdone && lv_incirc<NARROW>(ul, ll, lr, ur) > 0)) {
+            M.bond(base, rightcand);
+            base = hprev(rightcand);
+            M.set_field(base >> 2, 3u + prev3(base & 3u), ll.id);  // dest(base)
+            lr = ur;
+            rightcand = tr_nbr(TRc, base & 3u);  // sym(base): a field of the old candidate's triangle that the bond above did not write
+            TRc = M.load(rightcand >> 2);
+            ur = ld_vertex(M, tr_vtx(TRc, rightcand & 3u));
+        } else {
+            M.bond(base, leftcand);
+            base = hnext(leftcand);
+            M.set_field(base >> 2, 3u + next3(base & 3u), lr.id);  // org(base)
+            ll = ul;
+            leftcand = tr_nbr(TLc, base & 3u);
+            TLc = M.load(leftcand >> 2);
+            ul = ld_vertex(M, tr_vtx(TLc, leftcand & 3u));
+        }
+    }
+}
+
 // Leaf construction or merge of node j of depth d; res[] holds (farleft | farright << 16) per node in heap order.
+template <bool NARROW>
 __device__ __forceinline__ void d_process_node(const Mesh &M, DG_LDS uint32_t *res, DG_LDS const uint16_t *ord, int m, int d, int j, int axis0 = 0) {
     int lo, n, axis;
     uint32_t slot;
@@ -461,7 +720,7 @@ __device__ __forceinline__ void d_process_node(const Mesh &M, DG_LDS uint32_t *r
         const uint32_t rl = res[(2 << d) + 2 * j], rr = res[(2 << d) + 2 * j + 1];  // children: heap index 2h, 2h+1 with h = (1<<d)+j
         fl = rl & 0xFFFFu;
         fr = rr >> 16;
-        d_merge(M, fl, rl >> 16, rr & 0xFFFFu, fr, axis, slot + 2 * n - 4);
+        d_merge_lds<NARROW>(M, fl, rl >> 16, rr & 0xFFFFu, fr, axis, slot + 2 * n - 4);
     }
     res[(1 << d) + j] = fl | (fr << 16);
 }
@@ -520,20 +779,22 @@ struct DgSet {
 // The coordinates and the order come first: the on-GPU preparation (dg_prepare) produces the order in place and uses the region behind
 // it - node results and triangles, not yet in use then - as its scratch.
 struct DgLds {
-    DG_LDS int16_t *px, *py;
+    DG_LDS uint32_t *pxy;  // vertices: (x & 0xFFFF) | y << 16
     DG_LDS uint16_t *ord;
     DG_LDS uint32_t *res;  // [2 << depth]: farleft | farright << 16
-    DG_LDS DG_VOLATILE DTri *T;
+    DG_LDS uint32_t *W;    // triangles, 3 words each
+    __device__ __forceinline__ int vx(int i) const { return (int)(int16_t)(pxy[i] & 0xFFFFu); }
+    __device__ __forceinline__ int vy(int i) const { return (int)pxy[i] >> 16; }
+    __device__ __forceinline__ void set_vertex(int i, int x, int y) const { pxy[i] = ((uint32_t)x & 0xFFFFu) | ((uint32_t)y << 16); }
 };
-__host__ __device__ inline size_t dg_head_words(int n, int np) { return (size_t)(np + (np & 1)) + ((size_t)n + 1) / 2; }  // px, py, ord in 32-bit words
+__host__ __device__ inline size_t dg_head_words(int n, int np) { return (size_t)np + ((size_t)n + 1) / 2; }  // coordinates, order in 32-bit words
 __device__ __forceinline__ DgLds dg_carve(DG_LDS uint32_t *base, int n, int np) {
     const int depth = dg_depth(n);
     DgLds L;
-    L.px = (DG_LDS int16_t *)base;
-    L.py = L.px + np + (np & 1);
-    L.ord = (DG_LDS uint16_t *)(L.py + np + (np & 1));
+    L.pxy = base;
+    L.ord = (DG_LDS uint16_t *)(base + np);
     L.res = base + dg_head_words(n, np);
-    L.T = (DG_LDS DG_VOLATILE DTri *)(L.res + (2 << depth));
+    L.W = L.res + (2 << depth);
     return L;
 }
 
@@ -573,24 +834,26 @@ __device__ __forceinline__ void dg_emit(int nslots, F vtx, uint32_t ghost, int32
 }
 
 // The tree of a set whose coordinates and k-d order are in LDS already (m <= DG_SUB_MAX): bottom-up, then the triangle list.
-__device__ __forceinline__ void dg_build_and_emit(const DgLds &L, int m, int32_t *__restrict__ out, int32_t *__restrict__ count) {
+// clk (test hook, may be nullptr): clk[0] = start, clk[1 + d] = end of tree depth d in wall_clock64 ticks (100 MHz), for the first workgroup
+template <bool NARROW>
+__device__ __forceinline__ void dg_build_and_emit(const DgLds &L, int m, int32_t *__restrict__ out, int32_t *__restrict__ count, long long *clk = nullptr) {
     const int tid = threadIdx.x;
-    if (tid == 0) {
-        L.T[0].nbr[0] = L.T[0].nbr[1] = L.T[0].nbr[2] = 0;
-        L.T[0].vtx[0] = L.T[0].vtx[1] = L.T[0].vtx[2] = (uint16_t)GHOST;
-    }
+    if (tid == 0) L.W[0] = 0u, L.W[1] = GHOST << 16, L.W[2] = GHOST | (GHOST << 16);  // slot 0, "outer space"
     __syncthreads();
-    const Mesh M{L.T, L.px, L.py};
+    if (clk && tid == 0 && blockIdx.x == 0) clk[0] = wall_clock64();
+    const Mesh M{L.W, L.pxy};
     for (int d = dg_depth(m); d >= 0; d--) {
-        for (int j = tid; j < (1 << d); j += DG_THREADS) d_process_node(M, L.res, L.ord, m, d, j);
+        for (int j = tid; j < (1 << d); j += DG_THREADS) d_process_node<NARROW>(M, L.res, L.ord, m, d, j);
         __syncthreads();
+        if (clk && tid == 0 && blockIdx.x == 0) clk[1 + d] = wall_clock64();
     }
-    DG_LDS DG_VOLATILE DTri *T = L.T;
-    dg_emit(2 * m - 1, [T](int t, int k) { return (uint32_t)T[t].vtx[k]; }, GHOST, out, count);
+    DG_LDS const uint16_t *F = (DG_LDS const uint16_t *)L.W;
+    dg_emit(2 * m - 1, [F](int t, int k) { return (uint32_t)F[6 * t + 3 + k]; }, GHOST, out, count);
 }
 
 // A whole set in LDS (m <= DG_SUB_MAX), k-d order from memory.
-__device__ __forceinline__ void dg_triangulate(const DgSet &S) {
+template <bool NARROW>
+__device__ __forceinline__ void dg_triangulate(const DgSet &S, long long *clk = nullptr) {
     extern __shared__ uint32_t dg_lds[];
     const int tid = threadIdx.x, m = S.m, npts = S.npts;
     if (m < 3) {
@@ -598,17 +861,15 @@ __device__ __forceinline__ void dg_triangulate(const DgSet &S) {
         return;
     }
     const DgLds L = dg_carve((DG_LDS uint32_t *)dg_lds, m, npts);
-    for (int i = tid; i < npts; i += DG_THREADS) {
-        L.px[i] = (int16_t)S.x(i);
-        L.py[i] = (int16_t)S.y(i);
-    }
+    for (int i = tid; i < npts; i += DG_THREADS) L.set_vertex(i, S.x(i), S.y(i));
     for (int i = tid; i < m; i += DG_THREADS) L.ord[i] = (uint16_t)S.order[i];
-    dg_build_and_emit(L, m, S.out, S.count);
+    dg_build_and_emit<NARROW>(L, m, S.out, S.count, clk);
 }
 
 // Subtree j of the cut depth of a large set: triangulated in LDS with local vertex numbers (position in the k-d order), then
 // written to the set's global mesh gT in the slot numbers and vertex ids of the whole set; gxy gets the vertices' coordinates,
 // gres[2h], gres[2h + 1] the far-left / far-right handles of heap node h = 2^c + j.
+template <bool NARROW>
 __device__ __forceinline__ void dg_subtree(const DgSet &S, int sub_max, int j, GTri *__restrict__ gT, int32_t *__restrict__ gxy, uint32_t *__restrict__ gres) {
     extern __shared__ uint32_t dg_lds[];
     const int tid = threadIdx.x;
@@ -621,28 +882,25 @@ __device__ __forceinline__ void dg_subtree(const DgSet &S, int sub_max, int j, G
     for (int i = tid; i < n; i += DG_THREADS) {
         const int id = S.order[lo + i];
         const int x = S.x(id), y = S.y(id);
-        L.px[i] = (int16_t)x;
-        L.py[i] = (int16_t)y;
+        L.set_vertex(i, x, y);
         L.ord[i] = (uint16_t)i;
         gxy[2 * (size_t)id] = x;
         gxy[2 * (size_t)id + 1] = y;
     }
-    if (tid == 0) {
-        L.T[0].nbr[0] = L.T[0].nbr[1] = L.T[0].nbr[2] = 0;
-        L.T[0].vtx[0] = L.T[0].vtx[1] = L.T[0].vtx[2] = (uint16_t)GHOST;
-    }
+    if (tid == 0) L.W[0] = 0u, L.W[1] = GHOST << 16, L.W[2] = GHOST | (GHOST << 16);
     __syncthreads();
-    const Mesh M{L.T, L.px, L.py};
+    const Mesh M{L.W, L.pxy};
     for (int d = dg_depth(n); d >= 0; d--) {
-        for (int q = tid; q < (1 << d); q += DG_THREADS) d_process_node(M, L.res, L.ord, n, d, q, axis0);
+        for (int q = tid; q < (1 << d); q += DG_THREADS) d_process_node<NARROW>(M, L.res, L.ord, n, d, q, axis0);
         __syncthreads();
     }
+    DG_LDS const uint16_t *F = (DG_LDS const uint16_t *)L.W;
     for (int t = 1 + tid; t < 2 * n - 1; t += DG_THREADS) {
         uint32_t *g = reinterpret_cast<uint32_t *>(gT + (slot0 + t - 1));  // plain stores: the merges run in the next kernel
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            g[k] = dg_global_handle(L.T[t].nbr[k], slot0);
-            const uint32_t v = L.T[t].vtx[k];
+            g[k] = dg_global_handle(F[6 * t + k], slot0);
+            const uint32_t v = F[6 * t + 3 + k];
             g[3 + k] = v == GHOST ? GHOST32 : (uint32_t)S.order[lo + v];
         }
     }
@@ -742,7 +1000,7 @@ __device__ __forceinline__ void dg_word_prefix(DG_LDS const uint32_t *bm, DG_LDS
     __syncthreads();
 }
 
-// px / py hold the npts vertices' coordinates, dsp[i * dstride] their disparities (nullptr: unknown).  Writes ord[0 .. m) = the ids of the
+// pxy holds the npts vertices' coordinates, dsp[i * dstride] their disparities (nullptr: unknown).  Writes ord[0 .. m) = the ids of the
 // m surviving vertices in k-d order and returns m, or returns -1 (uniformly) when the set has coincident points that are not
 // interchangeable or does not fit the bit maps - the caller leaves such a set to the host.
 __device__ __forceinline__ int dg_prepare(const DgLds &L, int npts, const DgPrep &pp, const int32_t *__restrict__ dsp, int dstride) {
@@ -762,7 +1020,7 @@ __device__ __forceinline__ int dg_prepare(const DgLds &L, int npts, const DgPrep
     for (int w = tid; w < pp.bm_words; w += DG_THREADS) bm[w] = 0u;
     __syncthreads();
     for (int i = tid; i < m; i += DG_THREADS) {
-        const int x = (int)L.px[i] - pp.xmin, y = L.py[i];
+        const int x = L.vx(i) - pp.xmin, y = L.vy(i);
         const int row = (y == pp.ylast && pp.ylast % pp.step != 0) ? pp.rows - 1 : y / pp.step;
         if (x < 0 || x >= pp.cols || y < 0 || row >= pp.rows) {
             cells[4] = 1;
@@ -786,7 +1044,7 @@ __device__ __forceinline__ int dg_prepare(const DgLds &L, int npts, const DgPrep
         for (int i = tid; i < m; i += DG_THREADS)
             for (int q = 0; q < ndup; q++) {
                 const int c = dup_id[q];
-                if (L.px[i] == L.px[c] && L.py[i] == L.py[c]) {
+                if (L.pxy[i] == L.pxy[c]) {
                     if (dsp[(size_t)i * dstride] != dsp[(size_t)c * dstride]) cells[4] = 1;
                     __hip_atomic_fetch_min(&dup_min[q], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
@@ -796,7 +1054,7 @@ __device__ __forceinline__ int dg_prepare(const DgLds &L, int npts, const DgPrep
         for (int i = tid; i < m; i += DG_THREADS)
             for (int q = 0; q < ndup; q++) {
                 const int c = dup_id[q];
-                if (L.px[i] == L.px[c] && L.py[i] == L.py[c] && i != dup_min[q]) {
+                if (L.pxy[i] == L.pxy[c] && i != dup_min[q]) {
                     if (!(__hip_atomic_fetch_or(&dropped[i >> 5], 1u << (i & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & (1u << (i & 31))))
                         __hip_atomic_fetch_add(&cells[6], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     break;
@@ -810,7 +1068,7 @@ __device__ __forceinline__ int dg_prepare(const DgLds &L, int npts, const DgPrep
     dg_word_prefix(bm, pm, pp.cols * pp.W1, cells, &total);
     for (int i = tid; i < nall; i += DG_THREADS) {
         if ((dropped[i >> 5] >> (i & 31)) & 1u) continue;
-        const int x = (int)L.px[i] - pp.xmin, y = L.py[i];
+        const int x = L.vx(i) - pp.xmin, y = L.vy(i);
         const int row = (y == pp.ylast && pp.ylast % pp.step != 0) ? pp.rows - 1 : y / pp.step;
         const int w = x * pp.W1 + (row >> 5);
         const int r = (int)pm[w] + __popc(bm[w] & ((1u << (row & 31)) - 1u));
@@ -822,7 +1080,7 @@ __device__ __forceinline__ int dg_prepare(const DgLds &L, int npts, const DgPrep
     for (int w = tid; w < pp.bm_words; w += DG_THREADS) bm[w] = 0u;
     __syncthreads();
     for (int i = tid; i < nall; i += DG_THREADS) {
-        const int x = (int)L.px[i] - pp.xmin, y = L.py[i];
+        const int x = L.vx(i) - pp.xmin, y = L.vy(i);
         const int row = (y == pp.ylast && pp.ylast % pp.step != 0) ? pp.rows - 1 : y / pp.step;
         __hip_atomic_fetch_or(&bm[row * pp.W2 + (x >> 5)], 1u << (x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
@@ -830,7 +1088,7 @@ __device__ __forceinline__ int dg_prepare(const DgLds &L, int npts, const DgPrep
     dg_word_prefix(bm, pm, pp.rows * pp.W2, cells, &total);
     for (int i = tid; i < nall; i += DG_THREADS) {
         if ((dropped[i >> 5] >> (i & 31)) & 1u) continue;
-        const int x = (int)L.px[i] - pp.xmin, y = L.py[i];
+        const int x = L.vx(i) - pp.xmin, y = L.vy(i);
         const int row = (y == pp.ylast && pp.ylast % pp.step != 0) ? pp.rows - 1 : y / pp.step;
         const int w = row * pp.W2 + (x >> 5);
         const uint32_t yrank = (uint32_t)pm[w] + (uint32_t)__popc(bm[w] & ((1u << (x & 31)) - 1u));
@@ -923,14 +1181,19 @@ __device__ __forceinline__ bool dg_set_from_blob(int32_t *blob, int set, int sub
     return true;
 }
 
+// narrow: every coordinate difference of every set is below 2^14 in magnitude (lv_incirc)
 __global__ __launch_bounds__(DG_THREADS) void k_delaunay(const int4 *__restrict__ sets, const int32_t *__restrict__ order, const int32_t *__restrict__ xy,
-                                                        int32_t *__restrict__ tri_out, int32_t *__restrict__ tri_count) {
-    dg_triangulate(dg_set_from_list(sets[blockIdx.x], order, xy, tri_out, tri_count + blockIdx.x));
+                                                        int32_t *__restrict__ tri_out, int32_t *__restrict__ tri_count, int narrow, long long *clk) {
+    const DgSet S = dg_set_from_list(sets[blockIdx.x], order, xy, tri_out, tri_count + blockIdx.x);
+    if (narrow)
+        dg_triangulate<true>(S, clk);
+    else
+        dg_triangulate<false>(S, clk);
 }
 
 __global__ __launch_bounds__(DG_THREADS) void k_delaunay_blob(int32_t *__restrict__ blob, int sub_max) {
     DgSet S;
-    if (dg_set_from_blob(blob, blockIdx.x, sub_max, false, S)) dg_triangulate(S);
+    if (dg_set_from_blob(blob, blockIdx.x, sub_max, false, S)) dg_triangulate<true>(S);  // (the engine's sets are narrow)
 }
 
 // The resident form: the chunk's support-point lists never leave the device.  set = pair * 2 + side; `fsup` / `fnsup` are the lattice
@@ -969,8 +1232,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_delaunay_resident(const int32_t 
     const DgLds L = dg_carve((DG_LDS uint32_t *)dg_lds, ns, ns);
     for (int i = tid; i < ns; i += DG_THREADS) {
         const int u = sup[3 * i], v = sup[3 * i + 1], dsp = sup[3 * i + 2];
-        L.px[i] = (int16_t)(side ? u - dsp : u);  // elas.cpp:449-461: left image (u, v), right image (u - d, v)
-        L.py[i] = (int16_t)v;
+        L.set_vertex(i, side ? u - dsp : u, v);  // elas.cpp:449-461: left image (u, v), right image (u - d, v)
     }
     __syncthreads();
     const int m = dg_prepare(L, ns, pp, sup + 2, 3);
@@ -978,7 +1240,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_delaunay_resident(const int32_t 
         if (tid == 0) meta[2 + 2 * side] = -1;
         return;
     }
-    dg_build_and_emit(L, m, blob + (side ? off_t2 : off_t1), meta + 2 + 2 * side);
+    dg_build_and_emit<true>(L, m, blob + (side ? off_t2 : off_t1), meta + 2 + 2 * side);  // (narrow: columns within [-disp_max, W + disp_max), W <= 8192)
 }
 
 // Test hook: only the preparation of one vertex set given as (x, y) pairs; ord_out[0] = m or -1, then the ids in k-d order.
@@ -986,10 +1248,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_dg_prepare_test(const int32_t *_
     extern __shared__ uint32_t dg_lds[];
     const int tid = threadIdx.x;
     const DgLds L = dg_carve((DG_LDS uint32_t *)dg_lds, n, n);
-    for (int i = tid; i < n; i += DG_THREADS) {
-        L.px[i] = (int16_t)xy[2 * i];
-        L.py[i] = (int16_t)xy[2 * i + 1];
-    }
+    for (int i = tid; i < n; i += DG_THREADS) L.set_vertex(i, xy[2 * i], xy[2 * i + 1]);
     __syncthreads();
     const int m = dg_prepare(L, n, pp, dsp, 1);
     if (tid == 0) ord_out[0] = m;
@@ -1009,9 +1268,13 @@ struct DgScratch {
 };
 
 __global__ __launch_bounds__(DG_THREADS) void k_dgl_subtrees(const int4 *__restrict__ sets, const int32_t *__restrict__ order, const int32_t *__restrict__ xy,
-                                                            int32_t *__restrict__ tri_out, int32_t *__restrict__ tri_count, int sub_max, DgScratch sc) {
+                                                            int32_t *__restrict__ tri_out, int32_t *__restrict__ tri_count, int sub_max, DgScratch sc, int narrow) {
     const int set = blockIdx.y;
-    dg_subtree(dg_set_from_list(sets[set], order, xy, tri_out, tri_count + set), sub_max, blockIdx.x, sc.T(set), sc.XY(set), sc.R(set));
+    const DgSet S = dg_set_from_list(sets[set], order, xy, tri_out, tri_count + set);
+    if (narrow)
+        dg_subtree<true>(S, sub_max, blockIdx.x, sc.T(set), sc.XY(set), sc.R(set));
+    else
+        dg_subtree<false>(S, sub_max, blockIdx.x, sc.T(set), sc.XY(set), sc.R(set));
 }
 
 __global__ __launch_bounds__(DG_THREADS) void k_dgl_top(const int4 *__restrict__ sets, const int32_t *__restrict__ order, const int32_t *__restrict__ xy,
@@ -1023,7 +1286,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_dgl_top(const int4 *__restrict__
 __global__ __launch_bounds__(DG_THREADS) void k_dgl_subtrees_blob(int32_t *__restrict__ blob, int sub_max, DgScratch sc) {
     const int set = blockIdx.y;
     DgSet S;
-    if (dg_set_from_blob(blob, set, sub_max, true, S) && S.npts <= sc.cap) dg_subtree(S, sub_max, blockIdx.x, sc.T(set), sc.XY(set), sc.R(set));
+    if (dg_set_from_blob(blob, set, sub_max, true, S) && S.npts <= sc.cap) dg_subtree<true>(S, sub_max, blockIdx.x, sc.T(set), sc.XY(set), sc.R(set));
 }
 
 __global__ __launch_bounds__(DG_THREADS) void k_dgl_top_blob(int32_t *__restrict__ blob, int sub_max, DgScratch sc) {
@@ -1041,7 +1304,7 @@ using namespace dg;
 #ifndef DG_HOST_EMULATION
 size_t delaunay_gpu_lds_bytes(int m, int npts) {
     const size_t nslots = 2 * (size_t)m - 1;
-    return sizeof(uint32_t) * (dg_head_words(m, npts) + (2 << dg_depth(m))) + sizeof(DTri) * (nslots + (nslots & 1)) + 16;
+    return sizeof(uint32_t) * (dg_head_words(m, npts) + (2 << dg_depth(m))) + sizeof(DTri) * nslots + 16;
 }
 
 // Lattice geometry of the on-GPU preparation for images of W x H with lattice step `step` and disparities up to disp_max.
@@ -1063,7 +1326,7 @@ static DgPrep dg_prep_dims(int W, int H, int step, int disp_max) {
 size_t delaunay_resident_lds_bytes(int W, int H, int step, int disp_max, int m) {
     const DgPrep pp = dg_prep_dims(W, H, step, disp_max);
     const size_t nslots = 2 * (size_t)m - 1;
-    const size_t tri = sizeof(uint32_t) * (2 << dg_depth(m)) + sizeof(DTri) * (nslots + (nslots & 1));
+    const size_t tri = sizeof(uint32_t) * (2 << dg_depth(m)) + sizeof(DTri) * nslots;
     const size_t prep = sizeof(uint32_t) * dg_prep_scratch_words(pp, m);
     return sizeof(uint32_t) * dg_head_words(m, m) + (tri > prep ? tri : prep) + 16;
 }
@@ -1102,7 +1365,7 @@ size_t delaunay_scratch_bytes(int cap, int nsets, size_t *tri_bytes, size_t *xy_
 static DgScratch dg_scratch(const DelaunayScratch &h) { return DgScratch{(GTri *)h.tri, h.xy, h.res, h.cap}; }
 
 // Launches one workgroup per set; lds = the largest delaunay_gpu_lds_bytes among them (<= 160 KB).
-int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, size_t lds, hipStream_t st) {
+int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, size_t lds, int narrow, hipStream_t st, long long *d_level_clock) {
     if (lds > 64 * 1024) {
         static std::atomic<size_t> granted[64];  // per device
         int dev = 0;
@@ -1113,7 +1376,7 @@ int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const
             g.store(lds);
         }
     }
-    hipLaunchKernelGGL(k_delaunay, dim3(nsets), dim3(DG_THREADS), lds, st, sets, order, xy, tri_out, tri_count);
+    hipLaunchKernelGGL(k_delaunay, dim3(nsets), dim3(DG_THREADS), lds, st, sets, order, xy, tri_out, tri_count, narrow, d_level_clock);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -1127,7 +1390,7 @@ void launch_delaunay_blob(int32_t *blob, int n_pairs, size_t lds, int sub_max, h
 // Sets of more than sub_max vertices: 2^c subtrees per set in LDS, then the upper merges in the scratch mesh (one launch each for all
 // sets; workgroups of sets that are not large, or of subtrees a set does not have, return at once).  m_max: the largest set.
 int launch_delaunay_gpu_large(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, int m_max, int sub_max,
-                              const DelaunayScratch &scratch, hipStream_t st) {
+                              const DelaunayScratch &scratch, int narrow, hipStream_t st) {
     if (sub_max < 6 || sub_max > DG_SUB_MAX || m_max > scratch.cap || dg_cut_depth(m_max, sub_max) > DG_CUT_MAX) return -1;
     const size_t lds = delaunay_gpu_lds_bytes(sub_max, sub_max);
     static std::atomic<size_t> granted[64];
@@ -1136,7 +1399,7 @@ int launch_delaunay_gpu_large(const int4 *sets, int nsets, const int32_t *order,
     } catch (const std::exception &) {
         return -1;
     }
-    hipLaunchKernelGGL(k_dgl_subtrees, dim3(1 << dg_cut_depth(m_max, sub_max), nsets), dim3(DG_THREADS), lds, st, sets, order, xy, tri_out, tri_count, sub_max, dg_scratch(scratch));
+    hipLaunchKernelGGL(k_dgl_subtrees, dim3(1 << dg_cut_depth(m_max, sub_max), nsets), dim3(DG_THREADS), lds, st, sets, order, xy, tri_out, tri_count, sub_max, dg_scratch(scratch), narrow);
     hipLaunchKernelGGL(k_dgl_top, dim3(nsets), dim3(DG_THREADS), 0, st, sets, order, xy, tri_out, tri_count, sub_max, dg_scratch(scratch));
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

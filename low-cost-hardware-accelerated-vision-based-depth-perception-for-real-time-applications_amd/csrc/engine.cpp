@@ -2157,6 +2157,14 @@ int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int rep
     int4 *d_sets = nullptr;
     DelaunayScratch scr;
     int rc = SV_OK, nt = 0;
+    int narrow = 1;  // all coordinate differences below 2^14: the kernels' 32-bit in-circle terms are exact
+    {
+        int32_t lo[2] = {xy[0], xy[1]}, hi[2] = {xy[0], xy[1]};
+        for (int i = 0; i < n; i++)
+            for (int c = 0; c < 2; c++) lo[c] = std::min(lo[c], xy[2 * i + c]), hi[c] = std::max(hi[c], xy[2 * i + c]);
+        if ((int64_t)hi[0] - lo[0] >= (1 << 14) || (int64_t)hi[1] - lo[1] >= (1 << 14)) narrow = 0;
+        if (lo[0] < -32768 || lo[1] < -32768 || hi[0] > 32767 || hi[1] > 32767) return SV_ERR_UNSUPPORTED;  // 16-bit coordinates in the LDS mesh
+    }
     const size_t tri_words = (size_t)3 * 2 * n;
     try {
         HIP_TRY(hipMalloc((void **)&d_order, sizeof(int32_t) * n));
@@ -2181,9 +2189,26 @@ int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int rep
             HIP_TRY(hipMalloc((void **)&scr.res, rb));
             scr.cap = n;
             HIP_TRY(hipEventRecord(e0, nullptr));  // (after the allocations)
-            if (launch_delaunay_gpu_large(d_sets, reps, d_order, d_xy, d_tri, d_cnt, m, sub_max, scr, nullptr) != 0) throw std::runtime_error("k_dgl launch failed");
-        } else if (launch_delaunay_gpu(d_sets, reps, d_order, d_xy, d_tri, d_cnt, delaunay_gpu_lds_bytes(m, n), nullptr) != 0) {
-            throw std::runtime_error("k_delaunay launch failed");
+            if (launch_delaunay_gpu_large(d_sets, reps, d_order, d_xy, d_tri, d_cnt, m, sub_max, scr, narrow, nullptr) != 0) throw std::runtime_error("k_dgl launch failed");
+        } else {
+            long long *d_clk = nullptr;
+            const bool want_clk = getenv("SV_DG_LEVEL_CLOCK") != nullptr;  // tools/gpu_delaunay_check.py: time per tree depth (100 MHz ticks) to stderr
+            if (want_clk) HIP_TRY(hipMalloc((void **)&d_clk, sizeof(long long) * 32));
+            if (want_clk) HIP_TRY(hipMemset(d_clk, 0, sizeof(long long) * 32));
+            if (launch_delaunay_gpu(d_sets, reps, d_order, d_xy, d_tri, d_cnt, delaunay_gpu_lds_bytes(m, n), narrow, nullptr, d_clk) != 0) throw std::runtime_error("k_delaunay launch failed");
+            if (want_clk) {
+                long long c[32];
+                HIP_TRY(hipMemcpy(c, d_clk, sizeof(c), hipMemcpyDeviceToHost));
+                (void)hipFree(d_clk);
+                fprintf(stderr, "triangulation of %d vertices, us per tree depth (deepest first):", m);
+                long long prev = c[0];
+                for (int d = 30; d >= 0; d--)
+                    if (c[1 + d]) {
+                        fprintf(stderr, " d%d %.1f", d, 0.01 * (double)(c[1 + d] - prev));
+                        prev = c[1 + d];
+                    }
+                fprintf(stderr, "\n");
+            }
         }
         HIP_TRY(hipEventRecord(e1, nullptr));
         HIP_TRY(hipEventSynchronize(e1));

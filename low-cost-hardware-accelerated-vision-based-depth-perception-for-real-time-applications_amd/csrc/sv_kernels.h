@@ -115,7 +115,8 @@ int launch_disp_to_u8(const float *disp, size_t n, unsigned char *out, hipStream
 size_t delaunay_gpu_lds_bytes(int m, int npts);
 int delaunay_gpu_max_points();
 void launch_delaunay_blob(int32_t *blob, int n_pairs, size_t lds, int sub_max, hipStream_t st);  // sets of more than sub_max points are left to ..._large
-int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, size_t lds, hipStream_t st);
+int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, size_t lds, int narrow, hipStream_t st,
+                        long long *d_level_clock = nullptr);  // narrow: all coordinate differences < 2^14
 // The resident form (k_delaunay_resident): support lists straight from the lattice filter's device buffers, preparation (sort,
 // duplicate scan, k-d order) and triangulation in one kernel, the pair's part of the blob laid out on the device at a fixed place
 // (pair_words per pair behind the meta words).  Sides it reports with a triangle count of -1 (coincident points) are the host's.
@@ -129,7 +130,7 @@ int launch_delaunay_prepare_test(const int32_t *d_xy, const int32_t *d_dsp, int 
 int delaunay_gpu_large_max_points();
 size_t delaunay_scratch_bytes(int cap, int nsets, size_t *tri_bytes, size_t *xy_bytes, size_t *res_bytes);
 int launch_delaunay_gpu_large(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, int m_max, int sub_max,
-                              const DelaunayScratch &scratch, hipStream_t st);
+                              const DelaunayScratch &scratch, int narrow, hipStream_t st);
 void launch_delaunay_blob_large(int32_t *blob, int n_pairs, int ns_max, int sub_max, const DelaunayScratch &scratch, hipStream_t st);
 
 // names of the kernels behind each wrapper, in launch order, for timing reports

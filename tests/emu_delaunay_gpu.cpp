@@ -33,19 +33,24 @@ int main() {
         const int nslots = 2 * m - 1;
         std::vector<uint32_t> res(2 << 12, 0);
         std::vector<sv::dg::DTri> T(nslots);
-        std::vector<int16_t> px(n), py(n);
+        std::vector<uint32_t> pxy(n);
         std::vector<uint16_t> ord(m);
-        for (int i = 0; i < n; i++) { px[i] = (int16_t)xy[2 * i]; py[i] = (int16_t)xy[2 * i + 1]; }
+        for (int i = 0; i < n; i++) pxy[i] = ((uint32_t)xy[2 * i] & 0xFFFFu) | ((uint32_t)xy[2 * i + 1] << 16);
         for (int i = 0; i < m; i++) ord[i] = (uint16_t)ids[i];
-        memset((void *)&T[0], 0, sizeof(sv::dg::DTri));
-        T[0].vtx[0] = T[0].vtx[1] = T[0].vtx[2] = 0xFFFF;
-        const sv::dg::Mesh M{T.data(), px.data(), py.data()};
+        T[0].w[0] = 0, T[0].w[1] = 0xFFFFu << 16, T[0].w[2] = 0xFFFFFFFFu;
+        const sv::dg::Mesh M{&T[0].w[0], pxy.data()};
+        const uint16_t *F = reinterpret_cast<const uint16_t *>(T.data());
         for (int d = 12; d >= 0; d--)
-            for (int j = (1 << d) - 1; j >= 0; j--) sv::dg::d_process_node(M, res.data(), ord.data(), m, d, j);
+            for (int j = (1 << d) - 1; j >= 0; j--) {
+                if (it % 2)  // the engine's sets are narrow (32-bit in-circle terms); both forms must give the same mesh on them
+                    sv::dg::d_process_node<true>(M, res.data(), ord.data(), m, d, j);
+                else
+                    sv::dg::d_process_node<false>(M, res.data(), ord.data(), m, d, j);
+            }
         std::vector<int32_t> got;
         for (int t = 1; t < nslots; t++) {
-            if (T[t].vtx[0] == 0xFFFF || T[t].vtx[1] == 0xFFFF || T[t].vtx[2] == 0xFFFF) continue;
-            got.push_back(T[t].vtx[1]); got.push_back(T[t].vtx[2]); got.push_back(T[t].vtx[0]);
+            if (F[6 * t + 3] == 0xFFFF || F[6 * t + 4] == 0xFFFF || F[6 * t + 5] == 0xFFFF) continue;
+            got.push_back(F[6 * t + 4]); got.push_back(F[6 * t + 5]); got.push_back(F[6 * t + 3]);
         }
         if ((int)got.size() != 3 * nw || memcmp(got.data(), want.data(), sizeof(int32_t) * got.size())) {
             bad++;
@@ -84,18 +89,18 @@ int main() {
             const int depth = sv::dg::dg_depth(ns);
             std::vector<uint32_t> res(2 << depth, 0);
             std::vector<sv::dg::DTri> T(2 * ns - 1);
-            std::vector<int16_t> px(ns), py(ns);
+            std::vector<uint32_t> pxy(ns);
             std::vector<uint16_t> ord(ns);
-            for (int i = 0; i < ns; i++) { px[i] = (int16_t)xy[2 * ids[lo + i]]; py[i] = (int16_t)xy[2 * ids[lo + i] + 1]; ord[i] = (uint16_t)i; }
-            memset((void *)&T[0], 0, sizeof(sv::dg::DTri));
-            T[0].vtx[0] = T[0].vtx[1] = T[0].vtx[2] = 0xFFFF;
-            const sv::dg::Mesh M{T.data(), px.data(), py.data()};
+            for (int i = 0; i < ns; i++) { pxy[i] = ((uint32_t)xy[2 * ids[lo + i]] & 0xFFFFu) | ((uint32_t)xy[2 * ids[lo + i] + 1] << 16); ord[i] = (uint16_t)i; }
+            T[0].w[0] = 0, T[0].w[1] = 0xFFFFu << 16, T[0].w[2] = 0xFFFFFFFFu;
+            const sv::dg::Mesh M{&T[0].w[0], pxy.data()};
+            const uint16_t *F = reinterpret_cast<const uint16_t *>(T.data());
             for (int d = depth; d >= 0; d--)
-                for (int q = (1 << d) - 1; q >= 0; q--) sv::dg::d_process_node(M, res.data(), ord.data(), ns, d, q, axis0);
+                for (int q = (1 << d) - 1; q >= 0; q--) sv::dg::d_process_node<true>(M, res.data(), ord.data(), ns, d, q, axis0);
             for (int t = 1; t < 2 * ns - 1; t++)
                 for (int k = 0; k < 3; k++) {
-                    G[slot0 + t - 1].nbr[k] = sv::dg::dg_global_handle(T[t].nbr[k], slot0);
-                    G[slot0 + t - 1].vtx[k] = T[t].vtx[k] == 0xFFFF ? sv::dg::GHOST32 : (uint32_t)ids[lo + T[t].vtx[k]];
+                    G[slot0 + t - 1].nbr[k] = sv::dg::dg_global_handle(F[6 * t + k], slot0);
+                    G[slot0 + t - 1].vtx[k] = F[6 * t + 3 + k] == 0xFFFF ? sv::dg::GHOST32 : (uint32_t)ids[lo + F[6 * t + 3 + k]];
                 }
             gres[2 * ((1 << c) + j)] = sv::dg::dg_global_handle(res[1] & 0xFFFFu, slot0);
             gres[2 * ((1 << c) + j) + 1] = sv::dg::dg_global_handle(res[1] >> 16, slot0);
