@@ -2487,8 +2487,8 @@ __global__ __launch_bounds__(256) void k_check_amean_div(unsigned long long *mis
     for (int e = 112; e <= 142; e++)                         // a in [2^-15, 2^16)
         for (int sgn = 0; sgn < 2; sgn++) {
             const float a = __uint_as_float(((uint32_t)sgn << 31) | ((uint32_t)e << 23) | mant);
-            for (int di = 1; di <= 16; di++) {
-                const float d = (float)(2 * di);
+            for (int di = 1; di <= 32; di++) {  // 2, 4, ..., 32 (weights 4 / 2 / 0: k_amean_sub) and 0.5, 1, ..., 8 (weights 1 / 0.5 / 0: k_amean)
+                const float d = di <= 16 ? (float)(2 * di) : 0.5f * (float)(di - 16);
                 const uint32_t want = __float_as_uint(a / d);
                 if (want != __float_as_uint(amean_div(a, d))) {
                     if (bad == 0) first_a = __float_as_uint(a), first_d = __float_as_uint(d);
@@ -2498,8 +2498,8 @@ __global__ __launch_bounds__(256) void k_check_amean_div(unsigned long long *mis
             }
         }
     if (mant == 0)  // a = 0
-        for (int di = 1; di <= 16; di++)
-            if (__float_as_uint(amean_div(0.0f, (float)(2 * di))) != 0u) bad++;
+        for (int di = 1; di <= 32; di++)
+            if (__float_as_uint(amean_div(0.0f, di <= 16 ? (float)(2 * di) : 0.5f * (float)(di - 16))) != 0u) bad++;
     if (bad && atomicAdd(mism, bad) == 0) {
         mism[1] = first_a;
         mism[2] = first_d;
@@ -2512,32 +2512,75 @@ int launch_check_amean_div(unsigned long long *d_mism, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
-// xs[j] = window value held in ring slot j (the pixel of the window whose index is congruent to j mod 8), xc = centre value.
-// Returns true and the filtered value when the reference would store it.  Everything is statically indexed: the
-// slot <-> pixel rotation is done on the load addresses, not on registers.
-__device__ __forceinline__ bool amean8(const float xs[8], float xc, float &out) {
-    float w[8], f[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const float t = 4.0f - absq(xs[j] - xc);
-        w[j] = __builtin_fmaxf(t, 0.0f);  // _mm_max_ps(xconst0, t); t is never NaN (nor -0: absq() is a power of two), so one v_max_f32 does it
-        f[j] = xs[j] * w[j];
-    }
-    const float weight_sum = (w[0] + w[4]) + (w[1] + w[5]) + (w[2] + w[6]) + (w[3] + w[7]);  // elas.cpp:1427-1434
-    const float factor_sum = (f[0] + f[4]) + (f[1] + f[5]) + (f[2] + f[6]) + (f[3] + f[7]);
-    if (weight_sum > 0) {
-        const float dd = amean_div(factor_sum, weight_sum);
-        if (dd >= 0) {
-            out = dd;
-            return true;
-        }
-    }
-    return false;
+// ---- full resolution: several outputs per thread along the pass direction ---------------------------------------------------------
+// The weight of a tap depends on |tap - centre| only through the masked bits (absq), and a - b and b - a differ in the sign bit alone,
+// which the mask drops: w(a, b) = w(b, a).  A thread therefore takes EIGHT consecutive centres of a line: their windows (centre-4 ..
+// centre+3) cover 15 values, 38 distinct pairs instead of 8 x 7 = 56 taps, and the 15 values come from LDS once instead of 72 times.
+// Weights are kept divided by four - 1, 0.5 or 0: one v_fma_f32 with the clamp modifier, fma(absq(a - b), -0.25, 1) clamped to [0, 1],
+// gives max(4 - absq, 0) / 4 exactly (absq is 2^odd >= 2 or below 2^-96) - so every product x * w is exact, every partial sum is the
+// reference's partial sum divided by four (scaling by a power of two commutes with rounding), and the quotient is the same real number:
+// same bits.  The centre's own tap has weight 1, so weight_sum >= 1: the reference's weight_sum > 0 test (:1436) cannot fail.
+// Ring slot of a pixel = its index mod 8 (:1404-1411); a run starts at a multiple of 4, so the slot of value i is static
+// whatever the centre, and so is the lane-sum order (:1427-1434) - slots (0+4) + (1+5) + (2+6) + (3+7).
+__device__ __forceinline__ float amean_w4(float a, float b, float minus_quarter) {  // weight / 4 of a tap against a centre (symmetric)
+    const float q = absq(a - b);
+    float w;
+    asm("v_fma_f32 %0, %1, %2, 1.0 clamp" : "=v"(w) : "v"(q), "v"(minus_quarter));
+    return w;
 }
 
-// Both passes in one kernel: a 64x32 output tile needs the horizontal result on rows y-4..y+3, which needs the input on
+// v[0 .. NC + 6]: the line's values at positions P-4 .. P+NC+2 (P a multiple of 4); centre c (0..NC-1) is v[c + 4].  res[c] / ok[c]: the
+// filtered value and whether the reference stores it (the quotient is >= 0, :1437).  Ring slots: value i sits in slot (i + 4) & 7 when P
+// is a multiple of 8 and in slot i & 7 otherwise - slots j and j + 4 trade places, and the lane sums add exactly those two first.
+template <int NC>
+__device__ __forceinline__ void amean_run(const float (&v)[NC + 7], float (&res)[NC], bool (&ok)[NC]) {
+    const float mq = -0.25f;
+    float wt[NC + 7][4];  // wt[a][d - 1] = weight between v[a] and v[a + d]; only the pairs some centre needs exist after unrolling
+#pragma unroll
+    for (int a = 0; a < NC + 7; a++)
+#pragma unroll
+        for (int dd = 1; dd <= 4; dd++) {
+            const int b = a + dd;
+            const bool need = b <= NC + 6 && ((a >= 4 && a <= NC + 3 && dd <= 3) || (b >= 4 && b <= NC + 3));  // a is a centre with tap +dd, or b one with tap -dd
+            wt[a][dd - 1] = need ? amean_w4(v[a], v[b], mq) : 0.0f;
+        }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const int ctr = c + 4;
+        float x[8], w[8];
+        bool self[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {  // ring slot j of this centre's window
+            const int i = c + ((j - 4 - c) & 7);
+            self[j] = i == ctr;
+            x[j] = v[i];
+            w[j] = i == ctr ? 1.0f : (i < ctr ? wt[i][ctr - i - 1] : wt[ctr][i - ctr - 1]);
+        }
+        float p[4], ws[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {  // f[k] + f[k + 4] with f = x * w exact: one rounding, in the fma
+            if (self[k])
+                p[k] = __builtin_fmaf(x[k + 4], w[k + 4], x[k]);
+            else if (self[k + 4])
+                p[k] = __builtin_fmaf(x[k], w[k], x[k + 4]);
+            else
+                p[k] = __builtin_fmaf(x[k + 4], w[k + 4], x[k] * w[k]);
+            ws[k] = w[k] + w[k + 4];
+        }
+        const float weight_sum = ((ws[0] + ws[1]) + ws[2]) + ws[3];  // elas.cpp:1427-1434 (multiples of 0.5 up to 8: exact in any order)
+        const float factor_sum = ((p[0] + p[1]) + p[2]) + p[3];
+        const float dd = amean_div(factor_sum, weight_sum);
+        res[c] = dd;
+        ok[c] = dd >= 0;
+    }
+}
+
+// Both passes in one kernel: a 64 x 32 output tile needs the horizontal result on rows y-4..y+3, which needs the input on
 // columns x-4..x+3; both live in LDS, so every input value is fetched from memory ~1.4 times instead of 16.  Out of place
-// (src -> dst): the vertical pass of another workgroup must never see this one's output.
+// (src -> dst): the vertical pass of another workgroup must never see this one's output.  A task = AM_NC consecutive centres of a line.
+#define AM_TW 64
+#define AM_TH 32
+#define AM_NC 4
 #define PF_TW 64
 #define PF_TH 32
 
@@ -2547,76 +2590,68 @@ __global__ __launch_bounds__(256) void k_amean(KParams k, int nproc, const int32
     if (blob[(m / nproc) * META_WORDS] < 3) return;
     const size_t off = map_offset(d, m, nproc);
     const float *S = src + off;
-    const int x0 = blockIdx.x * PF_TW, y0 = blockIdx.y * PF_TH;
-    __shared__ float sD[PF_TH + 7][PF_TW + 8];  // D_copy (:1307-1318): rows y0-4.., columns x0-4..; invalid -> -10
-    __shared__ float sT[PF_TH + 7][PF_TW];      // D_tmp after the horizontal pass: rows y0-4.., columns x0..
+    const int x0 = blockIdx.x * AM_TW, y0 = blockIdx.y * AM_TH;
+    constexpr int ROWS = AM_TH + 7, DCOLS = AM_TW + 8, NV = AM_NC + 7;
+    __shared__ __attribute__((aligned(16))) float sD[ROWS][DCOLS];  // D_copy (:1307-1318): rows y0-4.., columns x0-4..; invalid -> -10
+    __shared__ __attribute__((aligned(16))) float sT[ROWS][AM_TW];  // D_tmp after the horizontal pass: rows y0-4.., columns x0..
     {  // all of a thread's tile loads are requested before the first one is used (one load per loop trip is a chain of latencies)
-        constexpr int NLD = ((PF_TH + 7) * (PF_TW + 8) + 255) / 256;
+        constexpr int NLD = (ROWS * DCOLS + 255) / 256;
         float val[NLD];
 #pragma unroll
         for (int t = 0; t < NLD; t++) {
             const int i = threadIdx.x + t * 256;
-            const int r = i / (PF_TW + 8), c = i - r * (PF_TW + 8);
+            const int r = i / DCOLS, c = i - r * DCOLS;
             const int y = y0 - 4 + r, x = x0 - 4 + c;
-            const bool in = i < (PF_TH + 7) * (PF_TW + 8) && y >= 0 && y < d.H && x >= 0 && x < d.W;
+            const bool in = i < ROWS * DCOLS && y >= 0 && y < d.H && x >= 0 && x < d.W;
             val[t] = in ? S[(size_t)y * d.W + x] : -10.0f;
         }
 #pragma unroll
         for (int t = 0; t < NLD; t++) {
             const int i = threadIdx.x + t * 256;
-            if (i < (PF_TH + 7) * (PF_TW + 8)) (&sD[0][0])[i] = val[t] < 0 ? -10.0f : val[t];
+            if (i < ROWS * DCOLS) (&sD[0][0])[i] = val[t] < 0 ? -10.0f : val[t];
         }
     }
     __syncthreads();
-    // A thread keeps its column and walks rows wave, wave+4, ...: the ring rotation ((j - first) & 7) is then the same for all of
-    // its items, so the eight tap addresses are computed once and every later load is base + constant.
-    const int cx = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float *sDf = &sD[0][0], *sTf = &sT[0][0];
-    {  // horizontal pass (:1402-1441); first = x - 4 with x0 a multiple of 8: slot j holds tile column cx + ((j - cx + 4) & 7)
-        const float *hp[8];
+#pragma unroll 1
+    for (int task = threadIdx.x; task < ROWS * (AM_TW / AM_NC); task += 256) {  // horizontal pass (:1402-1441): centres x0 + NC g .. of tile row r
+        const int r = task / (AM_TW / AM_NC), g = task % (AM_TW / AM_NC);
+        const int y = y0 - 4 + r;
+        const float *q = &sD[r][AM_NC * g];  // columns x - 4 .. of the run's first centre x
+        float v[NV];
 #pragma unroll
-        for (int j = 0; j < 8; j++) hp[j] = sDf + wv * (PF_TW + 8) + cx + ((j - cx + 4) & 7);
-        const int x = x0 + cx;
-        const bool xin = x >= 4 && x <= d.W - 4;
+        for (int i = 0; i < NV; i++) v[i] = q[i];
+        float res[AM_NC];
+        bool ok[AM_NC];
+        amean_run<AM_NC>(v, res, ok);
+        const bool yin = y >= 3 && y < d.H - 3;
 #pragma unroll
-        for (int t = 0; t < (PF_TH + 7 + 3) / 4; t++) {
-            const int r = wv + 4 * t;
-            if (r >= PF_TH + 7) break;
-            const int y = y0 - 4 + r;
-            const float self = sDf[wv * (PF_TW + 8) + cx + 4 + t * 4 * (PF_TW + 8)];
-            float out = self < 0 ? -10.0f : 0.0f;  // D_tmp: -10 where invalid (:1313-1318), canonical 0 elsewhere (:1308)
-            if (xin && y >= 3 && y < d.H - 3) {
-                float xs[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) xs[j] = hp[j][t * 4 * (PF_TW + 8)];
-                float res;
-                if (amean8(xs, self, res)) out = res;
-            }
-            sTf[wv * PF_TW + cx + t * 4 * PF_TW] = out;
+        for (int c = 0; c < AM_NC; c++) {
+            const int x = x0 + AM_NC * g + c;
+            const float self = v[c + 4];
+            sT[r][AM_NC * g + c] = (yin && x >= 4 && x <= d.W - 4 && ok[c]) ? res[c] : (self < 0 ? -10.0f : 0.0f);  // D_tmp: -10 where invalid (:1313-1318), canonical 0 elsewhere (:1308)
         }
     }
     __syncthreads();
-    {  // vertical pass (:1445-1484); first = y - 4 with y0 a multiple of 8: slot j holds tile row ry + ((j - ry + 4) & 7).  ry = wv + 4t:
-       // for odd t that rotation differs by 4 from the one of t = 0, i.e. slots j and j+4 trade places - and amean8 adds exactly those
-       // pairs first, so the sums are the same bits.
-        const float *vp[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) vp[j] = sTf + (wv + ((j - wv + 4) & 7)) * PF_TW + cx;
+#pragma unroll 1
+    for (int task = threadIdx.x; task < AM_TW * (AM_TH / AM_NC); task += 256) {  // vertical pass (:1445-1484): centres y0 + NC g .. of tile column cx
+        const int cx = task & (AM_TW - 1), g = task / AM_TW;
         const int x = x0 + cx;
+        if (x >= d.W) continue;
+        float v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) v[i] = sT[AM_NC * g + i][cx];  // rows y - 4 .. of the run's first centre y
+        float res[AM_NC];
+        bool ok[AM_NC];
+        amean_run<AM_NC>(v, res, ok);
         const bool xin = x >= 3 && x < d.W - 3;
 #pragma unroll
-        for (int t = 0; t < PF_TH / 4; t++) {
-            const int ry = wv + 4 * t;
-            const int y = y0 + ry;
-            if (y >= d.H || x >= d.W) continue;
-            float val = S[(size_t)y * d.W + x];  // untouched unless the filter produces a value
-            if (xin && y >= 4 && y <= d.H - 4) {
-                float xs[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) xs[j] = vp[j][t * 4 * PF_TW];
-                float res;
-                if (amean8(xs, sTf[(wv + 4) * PF_TW + cx + t * 4 * PF_TW], res)) val = res;
-            }
+        for (int c = 0; c < AM_NC; c++) {
+            const int y = y0 + AM_NC * g + c;
+            if (y >= d.H) break;
+            // untouched unless the filter produces a value.  The tile copy stands for the map's own value: it differs from it only where the
+            // map holds a negative value other than -10, and every stage in front of this one (L/R check, speckle, gap) writes -10 for invalid
+            float val = sD[AM_NC * g + c + 4][cx + 4];
+            if (xin && y >= 4 && y <= d.H - 4 && ok[c]) val = res[c];
             dst[off + (size_t)y * d.W + x] = val;
         }
     }
@@ -2698,11 +2733,10 @@ __global__ __launch_bounds__(256) void k_amean_sub(KParams k, int nproc, const i
 }
 
 void launch_amean(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st, const float *src, float *dst) {
-    dim3 grid((k.d.W + PF_TW - 1) / PF_TW, (k.d.H + PF_TH - 1) / PF_TH, n * nproc);
     if (k.d.sub)
-        SV_LAUNCH(K_AMEAN, k_amean_sub, grid, dim3(256), 0, st, k, nproc, s.blob, src, dst);
+        SV_LAUNCH(K_AMEAN, k_amean_sub, dim3((k.d.W + PF_TW - 1) / PF_TW, (k.d.H + PF_TH - 1) / PF_TH, n * nproc), dim3(256), 0, st, k, nproc, s.blob, src, dst);
     else
-        SV_LAUNCH(K_AMEAN, k_amean, grid, dim3(256), 0, st, k, nproc, s.blob, src, dst);
+        SV_LAUNCH(K_AMEAN, k_amean, dim3((k.d.W + AM_TW - 1) / AM_TW, (k.d.H + AM_TH - 1) / AM_TH, n * nproc), dim3(256), 0, st, k, nproc, s.blob, src, dst);
 }
 
 // ------------------------------------------------------------------------------------------------------------
