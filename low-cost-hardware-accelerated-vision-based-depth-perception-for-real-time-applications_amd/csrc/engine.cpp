@@ -300,10 +300,10 @@ void fill_kparams(sv_handle *h) {
         const long room = (144L * 1024 - 256 - 8L * ((d.W + 63) / 64) * 28) / 12;
         k.ccl_cap = (int)std::max(1L, std::min((long)k.ccl_cap, room));
     }
-    {  // multiply-shift for the grid column of a pixel (k_dense): valid only if it reproduces the division for every column
+    {  // multiply-shift for the grid column and row of a pixel (k_dense): valid only if it reproduces the division for every column and row
         const uint32_t gs = (uint32_t)p.grid_size, m = (65536u + gs - 1u) / gs;
-        bool ok = m < (1u << 24) && d.W <= (1 << 16);
-        for (uint32_t u = 0; ok && u < (uint32_t)d.W; u++) ok = ((u * m) >> 16) == u / gs && (int)floorf((float)u / (float)gs) == (int)(u / gs);
+        bool ok = m < (1u << 24) && d.W <= (1 << 16) && d.H <= (1 << 16);
+        for (uint32_t u = 0; ok && u < (uint32_t)std::max(d.W, d.H); u++) ok = ((u * m) >> 16) == u / gs && (int)floorf((float)u / (float)gs) == (int)(u / gs);
         k.cell_mul = ok ? m : 0u;
     }
     k.rt_cap = 512;
