@@ -68,7 +68,8 @@ def main():
     Image.fromarray(cr).save(os.path.join(HERE, "cones_crop_right.png"), optimize=True)
 
     more = {}
-    for f in (10, 20):  # two more frames of the sequence (digests only): real maps are far more fragmented than the synthetic pairs
+    for f in (3, 7, 10, 13, 17, 20):  # more frames of the sequence (digests only): real maps are far more fragmented than the synthetic pairs;
+        # frames 13, 17 and 20 have the corner support point with disparity 0 twice (coincident vertices for the triangulation)
         gl = gray_cv4(REF + "/datasets/kitti_mini/image_02/data/%010d.png" % f)
         gr = gray_cv4(REF + "/datasets/kitti_mini/image_03/data/%010d.png" % f)
         Image.fromarray(gl).save(os.path.join(HERE, "kitti%d_left.png" % f), optimize=True)
@@ -85,8 +86,13 @@ def main():
         dict(name="kitti0_d128", image="kitti0", preset="driver", disp_max=127,
              keep=["support", "tri1", "tri2", "planes1", "planes2", "wta1", "wta2", "lr1", "speckle1", "gap1", "amean1", "final1"]),
         dict(name="kitti0_d256", image="kitti0", preset="driver", disp_max=255, keep=["support", "tri1", "tri2", "wta1", "wta2", "final1"]),
+        dict(name="kitti3_d128", image="kitti3", preset="driver", disp_max=127, keep=[]),
+        dict(name="kitti7_d128", image="kitti7", preset="driver", disp_max=127, keep=[]),
         dict(name="kitti10_d128", image="kitti10", preset="driver", disp_max=127, keep=[]),
+        dict(name="kitti13_d128", image="kitti13", preset="driver", disp_max=127, keep=[]),
+        dict(name="kitti17_d128", image="kitti17", preset="driver", disp_max=127, keep=[]),
         dict(name="kitti20_d128", image="kitti20", preset="driver", disp_max=127, keep=[]),
+        dict(name="kitti0_d256_sub", image="kitti0", preset="driver", disp_max=255, subsampling=1, keep=[]),
         dict(name="kitti0_crop_d64", image="kitti0_crop", preset="driver", disp_max=63, keep=STAGES),
         dict(name="cones_crop_robotics", image="cones_crop", preset="robotics", disp_max=63, keep=["support", "tri1", "tri2", "wta1", "wta2", "final1"]),
         dict(name="cones_crop_middlebury", image="cones_crop", preset="middlebury", disp_max=63, keep=["support", "wta1", "final1", "final2"]),

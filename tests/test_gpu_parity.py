@@ -673,7 +673,7 @@ def test_gpu_vertex_preparation_matches_host(eng):
     assert handed_back > 0 and merged > 0
 
 
-@pytest.mark.parametrize("name", ["kitti0_d128", "kitti10_d128", "cones_crop_robotics", "synth7_d64"])
+@pytest.mark.parametrize("name", ["kitti0_d128", "kitti3_d128", "kitti7_d128", "kitti10_d128", "kitti0_d256_sub", "cones_crop_robotics", "synth7_d64"])
 @pytest.mark.parametrize("resident", ["1", "0"])
 def test_resident_and_round3_triangulation_paths_agree(eng, oracle, monkeypatch, name, resident):
     """All-GPU triangulation with the support lists resident on the device (k_delaunay_resident: the host reads 8 meta words per pair)
@@ -717,9 +717,9 @@ def test_resident_chunks_hand_coincident_points_to_the_host(eng, oracle, monkeyp
     assert fallbacks > 0, "no pair of this batch had coincident points: the test does not exercise the hand-back"
 
 
-@pytest.mark.parametrize("name", ["kitti20_d128"])
+@pytest.mark.parametrize("name", ["kitti13_d128", "kitti17_d128", "kitti20_d128"])
 def test_resident_chunks_keep_the_zero_disparity_corner_on_the_device(eng, oracle, monkeypatch, name):
-    """kitti_mini frame 20: the top-right image corner takes disparity 0, so elas.cpp:258-259 adds the support point (W-1, 0, 0) a
+    """kitti_mini frames 13, 17, 20: the top-right image corner takes disparity 0, so elas.cpp:258-259 adds the support point (W-1, 0, 0) a
     second time - coincident vertices in both images, one third of the kitti_mini frames.  They are interchangeable (same triple), so
     the resident kernel drops one itself: no side is handed to the host, and the maps are the reference's."""
     monkeypatch.setenv("SV_GPU_DELAUNAY", "1")

@@ -102,3 +102,40 @@ def test_random_parameter_sets(ref, oracle):
             continue
         bad = [k for k in util.STAGES if not np.array_equal(ref.stage(k).view(np.uint8), oracle.stage(k).view(np.uint8))]
         assert not bad, (bad, vals)
+
+
+REF_DATA = "/root/reference/datasets"  # read in place, build container only (it does not exist on the GPU box; marker `ref` skips there)
+
+
+def _gray_cv4(path):
+    """OpenCV-4.x BGR2GRAY weights, as tests/golden/make_golden.py applies them."""
+    from PIL import Image
+    a = np.asarray(Image.open(path).convert("RGB")).astype(np.int64)
+    r, g, b = a[..., 0], a[..., 1], a[..., 2]
+    return ((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8)
+
+
+@pytest.mark.parametrize("frame", range(21))
+def test_every_kitti_mini_pair(ref, oracle, frame):
+    """All 21 pairs the reference ships under datasets/kitti_mini, D = 128, the driver's preset: every stage of the restatement
+    equals the compiled reference's (DESIGN.md section 1(c) claims it; the committed goldens hold frames 0, 3, 7, 10, 13, 17, 20)."""
+    import os
+    lp = "%s/kitti_mini/image_02/data/%010d.png" % (REF_DATA, frame)
+    if not os.path.exists(lp):
+        pytest.skip("the reference's datasets are not here")
+    L, R = _gray_cv4(lp), _gray_cv4(lp.replace("image_02", "image_03"))
+    _compare(ref, oracle, ElasParams.driver(127), L, R)
+
+
+@pytest.mark.parametrize("name", ["aloe", "cones", "raindeer", "urban1", "urban2", "urban3", "urban4"])
+@pytest.mark.parametrize("preset", ["robotics", "middlebury"])
+def test_every_bundled_profile_pair(ref, oracle, name, preset):
+    """The seven Middlebury / urban pairs of datasets/profile with both presets (disp_max 255, the presets' own value)."""
+    import os
+    from PIL import Image
+    lp = "%s/profile/%s_left.pgm" % (REF_DATA, name)
+    if not os.path.exists(lp):
+        pytest.skip("the reference's datasets are not here")
+    L = np.ascontiguousarray(np.asarray(Image.open(lp)))
+    R = np.ascontiguousarray(np.asarray(Image.open(lp.replace("_left", "_right"))))
+    _compare(ref, oracle, ElasParams.preset(preset), L, R)

@@ -38,7 +38,7 @@ def case_images(entry):
     if "synth" in entry:
         return pkg("synth").make_pair(**entry["synth"])
     img = entry["image"]
-    if img in ("kitti0", "kitti10", "kitti20"):
+    if img.startswith("kitti") and img[5:].isdigit():
         return load_png(img + "_left.png"), load_png(img + "_right.png")
     if img == "kitti0_crop":
         l, r = load_png("kitti0_left.png"), load_png("kitti0_right.png")
