@@ -80,18 +80,33 @@ typedef enum sv_status {
 
 typedef struct sv_handle sv_handle;
 
-/* Engine configuration beyond the ELAS parameters. */
+/* Engine configuration beyond the ELAS parameters.  Every field is an int32; 0 always means "the default" (zero-initialise the struct and
+ * set what you need).  The policy fields below n_slots used to be environment variables; the variables are still read - in ONE place,
+ * engine.cpp: apply_env_overrides - and override the fields, so that a deployment can be steered without a rebuild; two handles of
+ * one process can be configured differently through the fields. */
 typedef struct sv_config {
     int32_t width;      /* image width  (>= 32) */
     int32_t height;     /* image height (>= 32) */
     int32_t device;     /* HIP device ordinal */
     int32_t n_workers;  /* host pool threads for the CPU stage between the two GPU phases (0 = default: the cgroup CPU quota / the
-                         * affinity mask, shared between the ranks of a node, at most 16 without a quota).  The triangulations are split between
-                         * this pool and the GPU kernel by the pool's backlog (all of them on the GPU with one or two threads): sv_query */
+                         * affinity mask, shared between the ranks of a node, at most 16 without a quota) */
     int32_t chunk;      /* pairs per GPU launch = pairs per pipeline slot (0 = default 64, less for large images) */
     int32_t keep_debug; /* != 0: keep per-stage intermediates of the LAST processed pair for sv_debug_get */
     int32_t n_streams;  /* HIP streams the second GPU phase alternates over (0 = default 4); phase 1 has its own streams */
     int32_t n_slots;    /* buffer slots (chunks in flight) of the 3-stage pipeline (0 = default 8, within a quarter of the free HBM / 64 GB) */
+    /* ---- policy (0 = automatic) */
+    int32_t gpu_lattice_filter;    /* support-lattice filters: 0 auto (GPU for chunk >= 4), 1 GPU, 2 host pool             [SV_GPU_FILTER=1 / SV_HOST_FILTER=1] */
+    int32_t gpu_triangulation;     /* who triangulates: 0 auto (pool and GPU balanced by the pool's backlog; GPU alone with < 3 host threads),
+                                      1 GPU, 2 host pool, 3 a fixed share of gpu_triangulation_pct percent on the GPU    [SV_GPU_DELAUNAY=1/0, SV_GPU_DELAUNAY_PCT=n, SV_GPU_DELAUNAY_AUTO=0] */
+    int32_t gpu_triangulation_pct; /* the share for mode 3 (1..100) */
+    int32_t resident;              /* the GPU's share without the support lists ever leaving the device: 0 auto (on), 2 off  [SV_RESIDENT=0] */
+    int32_t dg_sub_max;            /* > 0: vertices a set may have to be triangulated whole in LDS (default 4000; experiments, tests) [SV_DG_SUBMAX] */
+    int32_t dg_max_points;         /* > 0: largest vertex set the GPU kernels take, larger ones go to the pool (tests)       [SV_GPU_DELAUNAY_MAX] */
+    int32_t affinity;              /* host threads on the CPUs of the GPU's NUMA node: 0 auto (when the node has enough allowed CPUs), 2 never [SV_NO_AFFINITY=1] */
+    int32_t inline_latency_path;   /* single pairs on a chunk-1 handle driven by the calling thread: 0 auto (on), 2 off       [SV_NO_INLINE=1] */
+    int32_t event_sync;            /* how host threads wait for the GPU: 0 auto (sleep for chunk >= 4, spin below), 1 sleep, 2 spin [SV_EVENT_SYNC=block|spin] */
+    int32_t share_sliced;          /* != 0: a balanced GPU share as a slice of every chunk instead of whole chunks (round-2 behaviour, non-resident only) [SV_GPU_DELAUNAY_SLICED=1] */
+    int32_t reserved[6];           /* must be 0 */
 } sv_config;
 
 int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out);
@@ -158,6 +173,13 @@ void sv_host_free(void *p);
  * host pointers, like the reference.  On a chunk = 1 handle the calling thread drives the pair itself through persistent
  * device buffers (latency mode). */
 int sv_elas_process(sv_handle *h, const uint8_t *I1, const uint8_t *I2, float *D1, float *D2, const int32_t *dims);
+
+/* Test hooks on a live handle (waits for submitted work first).  Keys: "ccl_cap" (runs a band of the speckle stage may hold before a
+ * map takes the per-pixel path), "rt_cap" (triangles a raster tile list may hold), "host_force_staging" (host-memory jobs take the
+ * pageable route whatever the caller's memory is), "ns_bound" (vertices the next resident launches request LDS for: smaller sets than
+ * the chunk has are handed to the host stage), "pool_sleep" (latency handles: pool threads sleep instead of polling), "lat_trace"
+ * (wall-clock split of the latency path, printed by sv_destroy).  Returns SV_OK or SV_ERR_ARG for an unknown key. */
+int sv_debug_set(sv_handle *h, const char *key, int value);
 
 /* Per-stage intermediates of the last pair processed (cfg.keep_debug != 0).  Names and layouts follow
  * oracle/elas_oracle.h: desc1 desc2 dcan_raw support tri1 tri2 planes1 planes2 grid1 grid2 wta1 wta2 lr1 lr2

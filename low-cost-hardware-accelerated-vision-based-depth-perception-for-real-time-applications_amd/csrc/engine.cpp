@@ -150,6 +150,9 @@ struct sv_handle {
     bool gpu_share_auto = false;  // host mode: the dispatcher moves that share up while the pool falls behind the GPU, down while it idles
     int auto_pct = 0, auto_acc = 0;  // (dispatcher thread only)
     bool share_sliced = false;    // the GPU kernel's share as a slice of every chunk instead of whole chunks
+    int dbg_ccl_cap = 0, dbg_rt_cap = -1;  // sv_debug_set: overrides of the speckle stage's run-table size / the raster tile lists' size
+    bool force_staging = false;            // sv_debug_set "host_force_staging"
+    bool pool_sleep = false;               // sv_debug_set "pool_sleep"
     bool resident_ok = false;     // the GPU's share of the chunks is built without the support lists ever leaving the device (k_delaunay_resident)
     std::atomic<int> shared_pct{0};   // host mode with a balanced share: the dispatcher's current share, read by the issuer (who decides per chunk)
     int issue_acc = 0;                // (issuer thread only) accumulator that turns the share into whole chunks
@@ -223,6 +226,35 @@ namespace {
         }                                                                                                     \
     } while (0)
 
+// The only place this file reads the environment.
+bool env_int(const char *name, int *out) {
+    const char *e = getenv(name);
+    if (!e || !*e) return false;
+    if (out) *out = !strcmp(e, "block") ? 1 : (!strcmp(e, "spin") ? 2 : atoi(e));
+    return true;
+}
+
+// Environment variables override the policy fields of sv_config (include/stereo_vision_hip.h names the variable beside each field):
+// a deployment can be steered without a rebuild, and everything that steers a handle is visible in ONE struct afterwards.
+void apply_env_overrides(sv_config &c) {
+    int v;
+    if (env_int("SV_GPU_FILTER", &v) && v) c.gpu_lattice_filter = 1;
+    if (env_int("SV_HOST_FILTER", &v) && v) c.gpu_lattice_filter = 2;
+    if (env_int("SV_GPU_DELAUNAY", &v)) {  // 1: all on the GPU; 0: never by the handle's own choice (balanced even with few host threads)
+        if (v) c.gpu_triangulation = 1;
+        else if (c.gpu_triangulation == 0 || c.gpu_triangulation == 1) c.gpu_triangulation = 4;
+    }
+    if (env_int("SV_GPU_DELAUNAY_PCT", &v)) c.gpu_triangulation = 3, c.gpu_triangulation_pct = std::max(0, std::min(100, v));
+    if (env_int("SV_GPU_DELAUNAY_AUTO", &v) && !v && (c.gpu_triangulation == 0 || c.gpu_triangulation == 4)) c.gpu_triangulation = 2;
+    if (env_int("SV_GPU_DELAUNAY_SLICED", &v)) c.share_sliced = 1;
+    if (env_int("SV_GPU_DELAUNAY_MAX", &v)) c.dg_max_points = std::max(16, v);
+    if (env_int("SV_DG_SUBMAX", &v)) c.dg_sub_max = std::max(6, v);
+    if (env_int("SV_RESIDENT", &v)) c.resident = v ? 0 : 2;
+    if (env_int("SV_NO_AFFINITY", &v)) c.affinity = 2;
+    if (env_int("SV_NO_INLINE", &v)) c.inline_latency_path = 2;
+    if (env_int("SV_EVENT_SYNC", &v)) c.event_sync = v == 1 ? 1 : 2;
+}
+
 int validate(const sv_params &p, const sv_config &c, std::string &err) {
     char b[256];
     if (p.disp_min != 0) {
@@ -295,7 +327,7 @@ void fill_kparams(sv_handle *h) {
     // fragmented: kitti_mini pair 0 has up to 170 runs per row, i.e. 1 400 per 8-row band.  4096 runs per band (512 per row) for
     // images up to 2048 columns, more for wider ones, within 144 KB of the CU's 160 KB; beyond that a map takes the slow path.
     k.ccl_cap = std::max(4096, std::min(8192, ((d.W * 2 + 1023) / 1024) * 1024));
-    if (const char *e = getenv("SV_DEBUG_CCL_CAP")) k.ccl_cap = std::max(1, atoi(e));  // tests: force the per-pixel slow path
+    if (h->dbg_ccl_cap > 0) k.ccl_cap = h->dbg_ccl_cap;  // tests (sv_debug_set "ccl_cap"): force the per-pixel slow path
     {
         const long room = (144L * 1024 - 256 - 8L * ((d.W + 63) / 64) * 28) / 12;
         k.ccl_cap = (int)std::max(1L, std::min((long)k.ccl_cap, room));
@@ -307,7 +339,7 @@ void fill_kparams(sv_handle *h) {
         k.cell_mul = ok ? m : 0u;
     }
     k.rt_cap = 512;
-    if (const char *e = getenv("SV_DEBUG_RT_CAP")) k.rt_cap = std::max(0, std::min(512, atoi(e)));  // tests: force the raster fallback
+    if (h->dbg_rt_cap >= 0) k.rt_cap = std::min(512, h->dbg_rt_cap);  // tests (sv_debug_set "rt_cap"): force the raster fallback
     // the post-matching stages see the map as their image: W/H/N are the map size, and at half resolution the speckle and
     // gap limits shrink (elas.cpp:1017-1022, 1130-1135)
     KParams &km = h->kp_map;
@@ -322,8 +354,7 @@ void fill_kparams(sv_handle *h) {
     h->nproc = p.postprocess_only_left ? 1 : 2;
     // the on-GPU lattice filter unrolls the 11 x 11 window and resolves a point's earlier neighbours with one 64-lane ballot:
     // needs incon_window_size <= 5 (any lattice size: its state lives in global memory)
-    const char *force_host = getenv("SV_HOST_FILTER");
-    h->gpu_filter = !(force_host && atoi(force_host) != 0) && p.incon_window_size >= 0 && p.incon_window_size <= 5 &&
+    h->gpu_filter = h->cfg.gpu_lattice_filter != 2 && p.incon_window_size >= 0 && p.incon_window_size <= 5 &&
                     p.incon_min_support >= 0 && p.incon_min_support <= 60 && p.incon_threshold >= 0 && p.incon_threshold < 4096;  // c_late lives in 6 bits; the classify kernel's sentinel is 16384
     // (sv_create additionally keeps the filters on the host for chunk < 4: the GPU version is a ~0.4 ms latency chain,
     //  worth it only when many pairs share it)
@@ -463,8 +494,9 @@ void issue_phase1(sv_handle *h, Slot *s) {
             // the support lists stay where they are: preparation and triangulation of both sides of every pair in one launch, straight
             // from the filter's buffers into the blob (laid out by the kernel); only the meta words come back - counts for the launch
             // sizes of phase 2 and the callers' status, and a triangle count of -1 for a side the host has to build (coincident points)
-            launch_delaunay_resident(s->dev.fsup, s->dev.fnsup, s->dev.blob, s->dev.cap, d.max_pts, blob_pair_words(d), s->n, h->ns_bound.load(std::memory_order_relaxed), h->dg_sub_max,
-                                     d.W, d.H, d.step, d.disp_max, tail);
+            // (the launch requests LDS for sets of up to `bound` vertices and hands larger ones back: the bound follows the chunks' real counts)
+            const int bound = std::min(h->ns_bound.load(std::memory_order_relaxed), h->dg_sub_max);
+            launch_delaunay_resident(s->dev.fsup, s->dev.fnsup, s->dev.blob, s->dev.cap, d.max_pts, blob_pair_words(d), s->n, bound, bound, d.W, d.H, d.step, d.disp_max, tail);
             HIP_TRY(hipMemcpyAsync(s->h_blob, s->dev.blob, sizeof(int32_t) * META_WORDS * (size_t)s->n, hipMemcpyDeviceToHost, tail));
         } else {
             HIP_TRY(hipMemcpyAsync(s->h_fnsup, s->dev.fnsup, sizeof(int32_t) * (size_t)s->n, hipMemcpyDeviceToHost, tail));
@@ -975,9 +1007,9 @@ void pool_main(sv_handle *h, HostScratch *sc) {
     // Latency mode (chunk 1): a frame hands over pieces of its two triangulations several times within ~0.2 ms, and waking a
     // thread that sleeps on the condition variable costs 30-50 us each time.  There the pool polls the queue length for a
     // while (about a frame period of continuous use) before it goes to sleep; throughput handles sleep at once.
-    const int spin_rounds = h->chunk == 1 && !getenv("SV_POOL_SLEEP") ? 400000 : 0;
     for (;;) {
         Task t;
+        const int spin_rounds = h->chunk == 1 && !h->pool_sleep ? 400000 : 0;
         for (int i = 0; i < spin_rounds && h->queue_len.load(std::memory_order_acquire) == 0; i++) __builtin_ia32_pause();
         {
             std::unique_lock<std::mutex> lk(h->qmu);
@@ -1340,9 +1372,11 @@ double host_cpu_share(bool *quota) {
     if (sched_getaffinity(0, sizeof(set), &set) == 0) aff = std::max(1, CPU_COUNT(&set));
     if (!have_quota || cpus > aff) cpus = aff;
     int ranks = 1;
-    if (const char *e = getenv("LOCAL_WORLD_SIZE")) ranks = std::max(1, atoi(e));
+    if (env_int("LOCAL_WORLD_SIZE", &ranks)) ranks = std::max(1, ranks);
     if (quota) *quota = have_quota;
-    return cpus / ranks;
+    // a quota is the node's budget and is shared between the node's ranks; an affinity mask narrower than that share is the rank's own
+    // already (a launcher that pins its ranks) and is not divided again
+    return have_quota ? std::min((double)aff, std::max(1.0, cpus / ranks)) : cpus / ranks;
 }
 
 int default_pool_size() {
@@ -1360,7 +1394,6 @@ int default_pool_size() {
 // the sockets.  Empty (no binding) when the topology cannot be read, the node has no allowed CPU, or SV_NO_AFFINITY is set.
 bool gpu_node_cpus(int device, cpu_set_t *out) {
     CPU_ZERO(out);
-    if (getenv("SV_NO_AFFINITY")) return false;
     char bdf[64] = {0}, path[256], buf[4096];
     if (hipDeviceGetPCIBusId(bdf, sizeof(bdf), device) != hipSuccess) return false;
     for (char *c = bdf; *c; c++) *c = (char)tolower(*c);
@@ -1527,7 +1560,7 @@ int prepare_host_job(sv_handle *h, Job *job) {
     job->pin_in = is_pinned_host(job->left, in_bytes) && is_pinned_host(job->right, in_bytes);
     job->pin_out = job->dmap ? is_pinned_host(job->dmap, (size_t)job->batch * d.Nm)
                              : is_pinned_host(job->d1, out_bytes) && (!job->d2 || is_pinned_host(job->d2, out_bytes));
-    if (getenv("SV_HOST_FORCE_STAGING")) job->pin_in = job->pin_out = false;  // tests: the pageable route with page-locked buffers
+    if (h->force_staging) job->pin_in = job->pin_out = false;  // tests (sv_debug_set "host_force_staging"): the pageable route with page-locked buffers
     try {
         ensure_host_staging(h, !job->pin_in, !job->pin_out, job->dmap != nullptr);
     } catch (const std::exception &e) {
@@ -1798,6 +1831,8 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     h->tc_issue.mask = h->tc_finish.mask = &h->timing_mask;
     h->p = *params;
     h->cfg = *cfg;
+    apply_env_overrides(h->cfg);
+    cfg = &h->cfg;  // from here on: the caller's configuration with the environment's overrides
     fill_kparams(h);
     int npool = cfg->n_workers > 0 ? cfg->n_workers : default_pool_size();
     // defaults: 64 pairs per launch, 8 slots, 4 phase-2 streams, scaled down so that the slots stay within a memory budget
@@ -1810,12 +1845,12 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     // sixth of the lattice - a 4K pair has 21 000 of 330 000 lattice points) - not for the lattice.  A KITTI lattice's lists
     // (~2 000 points, 4 096 copied) fit the LDS kernel: no scratch there.  Sets beyond the limit are triangulated by the pool.
     h->dg_limit = h->dg_sub_max = delaunay_gpu_max_points();
-    if (const char *e = getenv("SV_DG_SUBMAX")) h->dg_sub_max = std::max(6, std::min(h->dg_sub_max, atoi(e)));  // experiments / tests
+    if (cfg->dg_sub_max > 0) h->dg_sub_max = std::max(6, std::min(h->dg_sub_max, cfg->dg_sub_max));  // experiments / tests
     if (!cfg->keep_debug) {
         const int want = std::min({h->kp.d.max_pts, delaunay_gpu_large_max_points(), 131072, fsup_copy_pts(h->kp.d)});
-        if (want > h->dg_sub_max + h->dg_sub_max / 4 || (getenv("SV_DG_SUBMAX") && want > h->dg_sub_max)) h->dg_limit = want;
+        if (want > h->dg_sub_max + h->dg_sub_max / 4 || (cfg->dg_sub_max > 0 && want > h->dg_sub_max)) h->dg_limit = want;
     }
-    if (const char *e = getenv("SV_GPU_DELAUNAY_MAX")) h->dg_limit = std::min(h->dg_limit, std::max(atoi(e), 16));  // tests: larger sets fall back to the pool
+    if (cfg->dg_max_points > 0) h->dg_limit = std::min(h->dg_limit, std::max(cfg->dg_max_points, 16));  // tests: larger sets fall back to the pool
     if (cfg->chunk <= 0 || cfg->n_slots <= 0) {
         size_t free_b = 0, total_b = 0;
         (void)hipSetDevice(cfg->device);
@@ -1843,36 +1878,32 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         np2 = 1;
         h->chunk = 1;
     }
-    if (h->chunk < 4 && !getenv("SV_GPU_FILTER")) h->gpu_filter = false;
-    // Who triangulates: the pool, the GPU kernel (delaunay_gpu.hip), or both.  All on the GPU (the pool then only sorts and orders the
-    // vertices) on request or with one or two pool threads; never with keep_debug (the parity tests read the host's triangle lists)
-    // and not for single pairs (faster on the host).  Otherwise the dispatcher splits every chunk by the pool's backlog.  Measured
-    // at the end of round 2, sustained over 20 000 pairs on one MI355X: all-GPU 39 600 - 40 200 pairs/s with any pool; pool only
-    // 40 100 - 40 400 with 14 threads (33 000 with 13); balanced 43 100 / 42 200 / 41 800 / 41 200 / 40 800 / 40 400 with
-    // 14 / 12 / 10 / 8 / 6 / 4 threads.
-    h->gpu_delaunay = !cfg->keep_debug && h->chunk >= 4 && npool < 3;
-    if (const char *e = getenv("SV_GPU_DELAUNAY")) h->gpu_delaunay = atoi(e) != 0 && !cfg->keep_debug;
-    // (SV_GPU_DELAUNAY_PCT fixes that share; without it the dispatcher balances it by the pool's backlog, see dispatcher_main.)
+    if (h->chunk < 4 && cfg->gpu_lattice_filter != 1) h->gpu_filter = false;
+    // Who triangulates (cfg.gpu_triangulation): the pool, the GPU kernels (delaunay_gpu.hip), or both.  Automatic: all on the GPU with one
+    // or two pool threads, else balanced - the dispatcher moves a share of the chunks to the GPU while the pool falls behind it.  Never
+    // on the GPU with keep_debug (the parity tests read the host's triangle lists) and not for single pairs (faster on the host).
+    // Sustained on one MI355X, round 4 (resident GPU share): GPU alone 43 000 pairs/s with ONE host thread (20 400 in round 3, whose
+    // vertex orders came from the pool), balanced 45 400 with 14 threads.
+    const bool gpu_capable = !cfg->keep_debug && h->chunk >= 4;
+    const int mode = cfg->gpu_triangulation;
+    h->gpu_delaunay = gpu_capable && (mode == 1 || (mode == 0 && npool < 3));
     h->gpu_delaunay_pct = h->gpu_delaunay ? 100 : 0;
-    if (const char *e = getenv("SV_GPU_DELAUNAY_PCT")) h->gpu_delaunay_pct = (cfg->keep_debug || h->chunk < 4) ? 0 : std::max(0, std::min(100, atoi(e)));
+    if (mode == 3) h->gpu_delaunay_pct = gpu_capable ? std::max(0, std::min(100, cfg->gpu_triangulation_pct)) : 0;
     if (h->gpu_delaunay_pct >= 100) h->gpu_delaunay = true;
-    // host mode without a fixed share: the share follows the pool's backlog (42 600 against 40 100 pairs/s with 14 threads)
-    h->gpu_share_auto = !h->gpu_delaunay && !getenv("SV_GPU_DELAUNAY_PCT") && !cfg->keep_debug && h->chunk >= 4;
-    if (const char *e = getenv("SV_GPU_DELAUNAY_AUTO")) h->gpu_share_auto = h->gpu_share_auto && atoi(e) != 0;
-    h->share_sliced = getenv("SV_GPU_DELAUNAY_SLICED") != nullptr;
+    // no fixed share: it follows the pool's backlog (42 600 against 40 100 pairs/s with 14 threads in round 2)
+    h->gpu_share_auto = !h->gpu_delaunay && (mode == 0 || mode == 4) && gpu_capable;
+    h->share_sliced = cfg->share_sliced != 0;
     // start where the balance was measured to settle (4 ... 14 threads); a handle with fewer than four slots cannot build up a backlog
     if (h->gpu_share_auto && nslots >= 4) h->auto_pct = std::max(0, std::min(95, 117 - 7 * npool));
     if (!(h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0)) h->dg_limit = h->dg_sub_max;  // the pool triangulates everything: no scratch
     // The GPU's share of the chunks is "resident" - support lists never leave the device, preparation and triangulation in one kernel of
     // phase 1 - where the lattice filter runs on the GPU and a pair's lists fit the LDS kernel (KITTI-sized lattices: ~2 000 points; a
-    // 4K lattice's 21 000 take the cut path, whose vertex orders still come from the host).  SV_RESIDENT=0: the round-3 path.
-    h->resident_ok = h->gpu_filter && !cfg->keep_debug && h->chunk >= 4 && (h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0) && h->dg_limit == h->dg_sub_max &&
+    // 4K lattice's 21 000 take the cut path, whose vertex orders still come from the host).  cfg.resident = 2: the round-3 path.
+    h->resident_ok = cfg->resident != 2 && h->gpu_filter && gpu_capable && (h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0) && h->dg_limit == h->dg_sub_max &&
                      std::min(h->kp.d.max_pts, fsup_copy_pts(h->kp.d)) <= h->dg_sub_max + h->dg_sub_max / 4 && h->kp.d.disp_max + h->kp.d.W < 30000;
-    if (const char *e = getenv("SV_RESIDENT")) h->resident_ok = h->resident_ok && atoi(e) != 0;
     h->ns_bound.store(std::min(h->dg_sub_max, delaunay_prep_max_points()));
     h->shared_pct.store(h->auto_pct);
-    h->block_sync = h->chunk >= 4;
-    if (const char *e = getenv("SV_EVENT_SYNC")) h->block_sync = strcmp(e, "block") == 0;
+    h->block_sync = cfg->event_sync == 1 || (cfg->event_sync == 0 && h->chunk >= 4);
     try {
         HIP_TRY(hipSetDevice(cfg->device));
         HIP_TRY(hipStreamCreateWithFlags(&h->sP1, hipStreamNonBlocking));
@@ -1894,8 +1925,15 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         delete h;
         return SV_ERR_HIP;
     }
+    // Threads on the CPUs of the GPU's NUMA node - only when that node has room for them within this process's mask: a cpuset that spans
+    // sockets with few CPUs on the GPU's node (say 16 CPUs, 2 of them there) would otherwise squeeze ~20 threads onto those few.
     cpu_set_t node_cpus;
-    const cpu_set_t *bind = gpu_node_cpus(cfg->device, &node_cpus) ? &node_cpus : nullptr;
+    const cpu_set_t *bind = nullptr;
+    if (cfg->affinity != 2 && gpu_node_cpus(cfg->device, &node_cpus)) {
+        bool have_quota = false;
+        const int share = std::max(1, (int)host_cpu_share(&have_quota));
+        if (CPU_COUNT(&node_cpus) >= std::min(npool + 2, share)) bind = &node_cpus;
+    }
     h->node_bound = bind != nullptr;
     for (int i = 0; i < npool; i++) {
         HostScratch *sc = new HostScratch();
@@ -1904,8 +1942,12 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         bind_thread(h->pool.back(), bind);
     }
     h->inline_scratch = new HostScratch();
-    h->inline_ok = getenv("SV_NO_INLINE") == nullptr;
-    h->lat_trace = getenv("SV_LAT_TRACE") != nullptr;
+    h->inline_ok = cfg->inline_latency_path != 2;
+    {
+        int v = 0;
+        h->lat_trace = env_int("SV_LAT_TRACE", &v);  // (also sv_debug_set "lat_trace")
+        h->pool_sleep = env_int("SV_POOL_SLEEP", &v);
+    }
     h->t_issue = std::thread(issuer_main, h);
     h->t_dispatch = std::thread(dispatcher_main, h);
     h->t_finish = std::thread(finisher_main, h);
@@ -2023,6 +2065,34 @@ int sv_elas_process(sv_handle *h, const uint8_t *I1, const uint8_t *I2, float *D
         return SV_ERR_ARG;
     }
     return sv_process_batch_host(h, I1, I2, 1, dims[2], D1, D2, nullptr);
+}
+
+int sv_debug_set(sv_handle *h, const char *key, int value) {
+    if (!h || !key) return SV_ERR_ARG;
+    (void)wait_jobs(h);  // the kernels' parameter blocks only change while nothing is in flight
+    const std::string k(key);
+    const bool gpu_filter = h->gpu_filter;
+    if (k == "ccl_cap") {
+        h->dbg_ccl_cap = std::max(0, value);
+        fill_kparams(h);
+        h->gpu_filter = gpu_filter;
+    } else if (k == "rt_cap") {
+        h->dbg_rt_cap = value;
+        fill_kparams(h);
+        h->gpu_filter = gpu_filter;
+    } else if (k == "host_force_staging") {
+        h->force_staging = value != 0;
+    } else if (k == "ns_bound") {
+        h->ns_bound.store(std::max(3, std::min(value, h->dg_sub_max)));
+    } else if (k == "pool_sleep") {
+        h->pool_sleep = value != 0;
+    } else if (k == "lat_trace") {
+        h->lat_trace = value != 0;
+    } else {
+        h->error = "sv_debug_set: unknown key";
+        return SV_ERR_ARG;
+    }
+    return SV_OK;
 }
 
 int sv_debug_counters(sv_handle *h, int mode, uint64_t *out) {
@@ -2144,8 +2214,8 @@ int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int rep
     if (!xy || !tri_out || n < 3 || reps < 1) return SV_ERR_ARG;
     // sets of more than sub_max points take the cut path (subtrees in LDS, upper merges in a global-memory mesh);
     // SV_DG_SUBMAX lowers the limit so that tests reach deep cuts with small sets
-    int sub_max = delaunay_gpu_max_points();
-    if (const char *e = getenv("SV_DG_SUBMAX")) sub_max = std::max(6, std::min(sub_max, atoi(e)));
+    int sub_max = delaunay_gpu_max_points(), v = 0;
+    if (env_int("SV_DG_SUBMAX", &v)) sub_max = std::max(6, std::min(sub_max, v));
     const bool large = n > sub_max;
     if (large && (n > delaunay_gpu_large_max_points() || (size_t)n * reps > ((size_t)1 << 24))) return SV_ERR_UNSUPPORTED;
     Delaunay dl;
@@ -2192,7 +2262,7 @@ int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int rep
             if (launch_delaunay_gpu_large(d_sets, reps, d_order, d_xy, d_tri, d_cnt, m, sub_max, scr, narrow, nullptr) != 0) throw std::runtime_error("k_dgl launch failed");
         } else {
             long long *d_clk = nullptr;
-            const bool want_clk = getenv("SV_DG_LEVEL_CLOCK") != nullptr;  // tools/gpu_delaunay_check.py: time per tree depth (100 MHz ticks) to stderr
+            const bool want_clk = env_int("SV_DG_LEVEL_CLOCK", nullptr);  // tools/gpu_delaunay_check.py: time per tree depth (100 MHz ticks) to stderr
             if (want_clk) HIP_TRY(hipMalloc((void **)&d_clk, sizeof(long long) * 32));
             if (want_clk) HIP_TRY(hipMemset(d_clk, 0, sizeof(long long) * 32));
             if (launch_delaunay_gpu(d_sets, reps, d_order, d_xy, d_tri, d_cnt, delaunay_gpu_lds_bytes(m, n), narrow, nullptr, d_clk) != 0) throw std::runtime_error("k_delaunay launch failed");

@@ -51,8 +51,15 @@ class SvParams(ctypes.Structure):
 
 
 class SvConfig(ctypes.Structure):
+    """sv_config of include/stereo_vision_hip.h: 0 = the default for every field."""
     _fields_ = [("width", ctypes.c_int32), ("height", ctypes.c_int32), ("device", ctypes.c_int32), ("n_workers", ctypes.c_int32),
-                ("chunk", ctypes.c_int32), ("keep_debug", ctypes.c_int32), ("n_streams", ctypes.c_int32), ("n_slots", ctypes.c_int32)]
+                ("chunk", ctypes.c_int32), ("keep_debug", ctypes.c_int32), ("n_streams", ctypes.c_int32), ("n_slots", ctypes.c_int32),
+                ("gpu_lattice_filter", ctypes.c_int32), ("gpu_triangulation", ctypes.c_int32), ("gpu_triangulation_pct", ctypes.c_int32),
+                ("resident", ctypes.c_int32), ("dg_sub_max", ctypes.c_int32), ("dg_max_points", ctypes.c_int32), ("affinity", ctypes.c_int32),
+                ("inline_latency_path", ctypes.c_int32), ("event_sync", ctypes.c_int32), ("share_sliced", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6)]
+
+
+_TRIANGULATION_MODES = {None: 0, "auto": 0, "gpu": 1, "host": 2, "balanced": 4}
 
 
 _lib = None
@@ -142,13 +149,28 @@ class StereoEngine:
     d1, d2 = engine.process_device(left_u8_cuda, right_u8_cuda)     # torch tensors [B,H,W] -> float32 [B,H,W]
     """
 
-    def __init__(self, width, height, params=None, device=0, n_workers=0, chunk=0, keep_debug=False, n_streams=0, n_slots=0):
+    def __init__(self, width, height, params=None, device=0, n_workers=0, chunk=0, keep_debug=False, n_streams=0, n_slots=0, gpu_filter=None,
+                 triangulation=None, resident=None, dg_sub_max=0, dg_max_points=0, affinity=None, inline=None, share_sliced=False):
+        """gpu_filter: None (automatic) / True / False - where the support-lattice filters run.  triangulation: None or "auto", "gpu", "host",
+        "balanced" (by the pool's backlog, whatever its size) or an int 1..100 = that share of the chunks on the GPU.  resident / affinity /
+        inline: None (automatic) or False to switch the resident GPU share / the NUMA binding / the calling-thread latency path off.
+        dg_sub_max, dg_max_points: limits of the GPU triangulation (tests).  See sv_config in include/stereo_vision_hip.h."""
         L = lib()
         self.params = params if params is not None else SvParams.driver(127)
         self.width, self.height, self.device = int(width), int(height), int(device)
         # disparity map size: half the image in half-resolution mode (Elas::parameters::subsampling, elas.h:83-85, 160-161)
         self.map_height, self.map_width = (self.height // 2, self.width // 2) if self.params.subsampling else (self.height, self.width)
         cfg = SvConfig(self.width, self.height, self.device, int(n_workers), int(chunk), int(bool(keep_debug)), int(n_streams), int(n_slots))
+        cfg.gpu_lattice_filter = 0 if gpu_filter is None else (1 if gpu_filter else 2)
+        if isinstance(triangulation, int) and not isinstance(triangulation, bool):
+            cfg.gpu_triangulation, cfg.gpu_triangulation_pct = 3, int(triangulation)
+        else:
+            cfg.gpu_triangulation = _TRIANGULATION_MODES[triangulation]
+        cfg.resident = 2 if resident is False else 0
+        cfg.dg_sub_max, cfg.dg_max_points = int(dg_sub_max), int(dg_max_points)
+        cfg.affinity = 2 if affinity is False else 0
+        cfg.inline_latency_path = 2 if inline is False else 0
+        cfg.share_sliced = int(bool(share_sliced))
         h = ctypes.c_void_p()
         rc = L.sv_create(ctypes.byref(self.params), ctypes.byref(cfg), ctypes.byref(h))
         if rc != 0:
@@ -165,6 +187,12 @@ class StereoEngine:
             self.close()
         except Exception:
             pass
+
+    def debug_set(self, key, value):
+        """Test hooks on a live handle (sv_debug_set): "ccl_cap", "rt_cap", "host_force_staging", "ns_bound", "pool_sleep", "lat_trace"."""
+        L = lib()
+        L.sv_debug_set.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
+        self._check(L.sv_debug_set(self._h, key.encode(), int(value)))
 
     def _check(self, rc):
         if rc != 0:

@@ -21,11 +21,13 @@ def eng():
     return util.pkg("engine")
 
 
-def _run_debug(eng, entry):
+def _run_debug(eng, entry, gpu_filter=None, debug=None):
     L, R = util.case_images(entry)
     p = util.case_params(entry, eng.SvParams)
-    e = eng.StereoEngine(L.shape[1], L.shape[0], p, keep_debug=True)
+    e = eng.StereoEngine(L.shape[1], L.shape[0], p, keep_debug=True, gpu_filter=gpu_filter)
     try:
+        for key, value in (debug or {}).items():
+            e.debug_set(key, value)
         d1, d2, status = e.process_host(L, R)
         stages = {}
         for k in STAGES:
@@ -40,12 +42,10 @@ def _run_debug(eng, entry):
 
 @pytest.mark.parametrize("gpu_filter", [False, True])
 @pytest.mark.parametrize("name", sorted(DIG))
-def test_every_stage_matches_oracle_and_golden(eng, oracle, name, gpu_filter, monkeypatch):
+def test_every_stage_matches_oracle_and_golden(eng, oracle, name, gpu_filter):
     """gpu_filter: lattice filters on the GPU (k_support_filter, the throughput configuration) or on the host pool."""
-    if gpu_filter:
-        monkeypatch.setenv("SV_GPU_FILTER", "1")
     entry = DIG[name]
-    L, R, d1, d2, nsup, st = _run_debug(eng, entry)
+    L, R, d1, d2, nsup, st = _run_debug(eng, entry, gpu_filter=True if gpu_filter else None)
     assert nsup == entry["n_support"]
     oracle.run_stages(util.case_params(entry, ElasParams), L, R)
     bad = []
@@ -121,16 +121,12 @@ def test_small_and_odd_image_sizes(eng, oracle, W, H, D, gpu_filter, monkeypatch
     96 x 131 cases and segfaults on the five with at most 40 rows - two grid-cell rows leave its flat 3 x 3 dilation, elas.cpp:613-628,
     without a valid range; there the memory-safe restatement is what defines the result.)"""
     synth = util.pkg("synth")
-    if gpu_filter:
-        monkeypatch.setenv("SV_GPU_FILTER", "1")
-    else:
-        monkeypatch.setenv("SV_HOST_FILTER", "1")
     batch = synth.make_batch(9000 + W, 5, H, W, D)
     for preset in ("driver", "robotics"):
         p = eng.SvParams.driver(D - 1) if preset == "driver" else eng.SvParams.preset("robotics")
         po = ElasParams.driver(D - 1) if preset == "driver" else ElasParams.preset("robotics")
         p.disp_max = po.disp_max = D - 1
-        e = eng.StereoEngine(W, H, p, chunk=4, n_slots=2, n_workers=3)
+        e = eng.StereoEngine(W, H, p, chunk=4, n_slots=2, n_workers=3, gpu_filter=bool(gpu_filter))
         try:
             d1, d2, status = e.process_host(np.ascontiguousarray(batch[:, 0]), np.ascontiguousarray(batch[:, 1]))
         finally:
@@ -185,9 +181,8 @@ def test_determinism_full_size(eng):
 
 def test_raster_fallback_path(eng, oracle, monkeypatch):
     """Tile lists that overflow switch a map to the global-atomic rasteriser: force that with a tiny cap and check the maps."""
-    monkeypatch.setenv("SV_DEBUG_RT_CAP", "3")
     entry = DIG["kitti0_crop_d64"]
-    L, R, d1, d2, nsup, st = _run_debug(eng, entry)
+    L, R, d1, d2, nsup, st = _run_debug(eng, entry, debug={"rt_cap": 3})
     assert util.sha(st["wta1"]) == entry["stages"]["wta1"] and util.sha(st["wta2"]) == entry["stages"]["wta2"]
     assert util.sha(d1) == entry["stages"]["final1"] and util.sha(d2) == entry["stages"]["final2"]
 
@@ -269,10 +264,9 @@ def test_pipeline_with_gpu_triangulation(eng, oracle, monkeypatch, name):
     """SV_GPU_DELAUNAY=1 (what a handle with few host threads chooses by itself): the host pool only orders the vertices, the
     triangle lists are built on the device straight into the chunk's blob.  Same maps, bit for bit; the 4K strip's 7 500-point
     sets exceed the kernel's LDS and take the cut path (subtrees in LDS, upper merges in a global-memory mesh)."""
-    monkeypatch.setenv("SV_GPU_DELAUNAY", "1")
     entry = DIG[name]
     L, R = util.case_images(entry)
-    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=2, n_streams=2, n_workers=3)
+    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=2, n_streams=2, n_workers=3, triangulation="gpu")
     try:
         assert e.query()["gpu_triangulation"] == 1
         d1, d2, st = e.process_host(np.stack([L] * 5), np.stack([R] * 5))
@@ -288,11 +282,9 @@ def test_pipeline_with_gpu_triangulation(eng, oracle, monkeypatch, name):
 def test_pipeline_with_cut_triangulation(eng, oracle, monkeypatch, sub_max):
     """The cut path of the GPU triangulation inside the pipeline on ordinary images: with the LDS limit lowered to 700 (40)
     vertices the 2 100-point sets of a KITTI pair are built as 4 (64) subtrees plus the upper merges in global memory."""
-    monkeypatch.setenv("SV_GPU_DELAUNAY", "1")
-    monkeypatch.setenv("SV_DG_SUBMAX", sub_max)
     entry = DIG["kitti0_d128"]
     L, R = util.case_images(entry)
-    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=2, n_streams=2, n_workers=3)
+    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=2, n_streams=2, n_workers=3, triangulation="gpu", dg_sub_max=int(sub_max))
     try:
         d1, d2, st = e.process_host(np.stack([L] * 6), np.stack([R] * 6))
         assert e.gpu_triangulation_fallbacks() == 0
@@ -306,11 +298,9 @@ def test_pipeline_with_cut_triangulation(eng, oracle, monkeypatch, sub_max):
 def test_gpu_triangulation_falls_back_per_set(eng, oracle, monkeypatch):
     """Vertex sets beyond what the GPU kernels take (here capped at 5 000 points: the 4K strip has ~7 500) are triangulated by the
     pool inside a chunk whose other work stays on the GPU; the handle counts them (SV_Q_GPU_TRIANGULATION_FALLBACKS)."""
-    monkeypatch.setenv("SV_GPU_DELAUNAY", "1")
-    monkeypatch.setenv("SV_GPU_DELAUNAY_MAX", "5000")
     entry = DIG["synth5000_4kstrip_d192"]
     L, R = util.case_images(entry)
-    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=2, n_streams=2, n_workers=3)
+    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=2, n_streams=2, n_workers=3, triangulation="gpu", dg_max_points=5000)
     try:
         d1, d2, st = e.process_host(np.stack([L] * 5), np.stack([R] * 5))
         assert e.gpu_triangulation_fallbacks() == 10  # both sides of the five pairs
@@ -324,12 +314,10 @@ def test_gpu_triangulation_falls_back_per_set(eng, oracle, monkeypatch):
 def test_pipeline_with_mixed_triangulation(eng, oracle, monkeypatch):
     """SV_GPU_DELAUNAY_PCT=40: inside one chunk some pairs are triangulated by the pool, the others by the GPU kernel (per-pair
     flag in the blob's meta words); every pair still equals its own oracle result."""
-    monkeypatch.setenv("SV_GPU_DELAUNAY", "0")
-    monkeypatch.setenv("SV_GPU_DELAUNAY_PCT", "40")
     synth = util.pkg("synth")
     H, W, D, B = 120, 320, 64, 11
     batch = synth.make_batch(260, B, H, W, D)
-    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), chunk=4, n_slots=2, n_streams=2, n_workers=3)
+    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), chunk=4, n_slots=2, n_streams=2, n_workers=3, triangulation=40)
     try:
         assert e.query()["gpu_triangulation"] == 0
         d1, d2, st = e.process_host(batch[:, 0], batch[:, 1])
@@ -345,13 +333,11 @@ def test_pipeline_with_mixed_triangulation(eng, oracle, monkeypatch):
 def test_pipeline_with_balanced_triangulation(eng, oracle, monkeypatch):
     """Host mode with a pool that cannot keep up (2 threads): the dispatcher hands a growing share of each chunk to the GPU
     triangulation kernel (engine.cpp dispatcher_main); which pairs it takes depends on timing, the maps do not."""
-    monkeypatch.setenv("SV_GPU_DELAUNAY", "0")
-    monkeypatch.delenv("SV_GPU_DELAUNAY_PCT", raising=False)
     synth = util.pkg("synth")
     H, W, D, B = 375, 1242, 128, 4  # full-size pairs: two threads triangulate ~5 000 of them per second, the GPU asks for far more
     batch = synth.make_batch(411, B, H, W, D)
     l, r = np.concatenate([batch[:, 0]] * 32), np.concatenate([batch[:, 1]] * 32)
-    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), chunk=8, n_slots=6, n_streams=2, n_workers=2)
+    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), chunk=8, n_slots=6, n_streams=2, n_workers=2, triangulation="balanced")
     try:
         assert e.query()["gpu_triangulation"] == 0
         d1, d2, st = e.process_host(l, r)
@@ -388,11 +374,9 @@ def test_random_parameter_sets(eng, oracle):
 def test_latency_mode_single_pairs(eng, monkeypatch, inline):
     """chunk = 1, one pair per call: the calling thread drives the pair itself (run_inline); SV_NO_INLINE sends it through the
     queued pipeline instead.  Both must give the golden maps, also for a pair without support points in between."""
-    if not inline:
-        monkeypatch.setenv("SV_NO_INLINE", "1")
     entry = DIG["kitti0_d128"]
     L, R = util.case_images(entry)
-    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=1, n_slots=2, n_streams=1, n_workers=4)  # 4 workers: split triangulations
+    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=1, n_slots=2, n_streams=1, n_workers=4, inline=None if inline else False)  # 4 workers: split triangulations
     try:
         for rep in range(3):
             d1, d2, st = e.process_host(L, R)
@@ -407,10 +391,9 @@ def test_latency_mode_single_pairs(eng, monkeypatch, inline):
 def test_speckle_slow_path(eng, oracle, monkeypatch, cap):
     """Bands with more runs than the LDS run tables hold switch their map to the per-pixel union-find: force that with tiny
     tables (8: every map; 300: only some bands overflow) and check the speckle stage and the final maps."""
-    monkeypatch.setenv("SV_DEBUG_CCL_CAP", cap)
     for name in ("kitti0_crop_d64", "kitti0_d128"):
         entry = DIG[name]
-        L, R, d1, d2, nsup, st = _run_debug(eng, entry)
+        L, R, d1, d2, nsup, st = _run_debug(eng, entry, debug={"ccl_cap": int(cap)})
         assert util.sha(st["speckle1"]) == entry["stages"]["speckle1"]
         assert util.sha(d1) == entry["stages"]["final1"]
 
@@ -419,12 +402,10 @@ def test_speckle_slow_path(eng, oracle, monkeypatch, cap):
 def test_full_4k_pair(eng, oracle, gpu_filter, monkeypatch):
     """BASELINE config 5 shape: one full 3840x2160 synthetic pair at D=192 against the oracle (bit-exact); with the lattice
     filters on the host pool and on the GPU (a 768 x 432 lattice: the multi-kernel filter has no size limit)."""
-    if gpu_filter:
-        monkeypatch.setenv("SV_GPU_FILTER", "1")
     synth = util.pkg("synth")
     L, R = synth.make_pair(5001, 2160, 3840, 192, scale=3)
     p = eng.SvParams.driver(191)
-    e = eng.StereoEngine(3840, 2160, p, chunk=1, n_slots=1, n_streams=1, n_workers=2)
+    e = eng.StereoEngine(3840, 2160, p, chunk=1, n_slots=1, n_streams=1, n_workers=2, gpu_filter=True if gpu_filter else None)
     try:
         assert e.query()["gpu_lattice_filter"] == int(gpu_filter)
         d1, d2, status = e.process_host(L, R)
@@ -440,11 +421,9 @@ def test_full_4k_batch_without_host_triangulation(eng, oracle, monkeypatch):
     """Config 5 with everything between the two kernel phases on the GPU: lattice filters (SV_GPU_FILTER) and the 30 000-point
     triangulations (SV_GPU_DELAUNAY: subtrees in LDS + upper merges in a global-memory mesh); the two host threads only sort
     and order the vertices.  No set falls back to the host; maps bit-exact."""
-    monkeypatch.setenv("SV_GPU_FILTER", "1")
-    monkeypatch.setenv("SV_GPU_DELAUNAY", "1")
     synth = util.pkg("synth")
     L, R = synth.make_pair(5001, 2160, 3840, 192, scale=3)
-    e = eng.StereoEngine(3840, 2160, eng.SvParams.driver(191), chunk=4, n_slots=2, n_streams=2, n_workers=2)
+    e = eng.StereoEngine(3840, 2160, eng.SvParams.driver(191), chunk=4, n_slots=2, n_streams=2, n_workers=2, gpu_filter=True, triangulation="gpu")
     try:
         q = e.query()
         assert q["gpu_lattice_filter"] == 1 and q["gpu_triangulation"] == 1
@@ -678,11 +657,9 @@ def test_gpu_vertex_preparation_matches_host(eng):
 def test_resident_and_round3_triangulation_paths_agree(eng, oracle, monkeypatch, name, resident):
     """All-GPU triangulation with the support lists resident on the device (k_delaunay_resident: the host reads 8 meta words per pair)
     and with SV_RESIDENT=0 the round-3 path (lists to the host, vertex order from the pool, k_delaunay_blob): same maps, bit for bit."""
-    monkeypatch.setenv("SV_GPU_DELAUNAY", "1")
-    monkeypatch.setenv("SV_RESIDENT", resident)
     entry = DIG[name]
     L, R = util.case_images(entry)
-    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=3, n_streams=2, n_workers=1)
+    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=3, n_streams=2, n_workers=1, triangulation="gpu", resident=None if resident == "1" else False)
     try:
         assert e.query()["resident"] == int(resident)
         d1, d2, st = e.process_host(np.stack([L] * 9), np.stack([R] * 9))
@@ -697,14 +674,13 @@ def test_resident_chunks_hand_coincident_points_to_the_host(eng, oracle, monkeyp
     """lr_threshold = 6 lets two support points of one lattice row match the same right-image column (|d1 - d2| = 5 or 10): coincident
     vertices in the right image with DIFFERENT disparities, whose survivor the reference's randomised quicksort decides.  The resident
     kernel must hand such a side to the host stage (counted as fallbacks) and the maps must still equal the oracle's."""
-    monkeypatch.setenv("SV_GPU_DELAUNAY", "1")
     synth = util.pkg("synth")
     H, W, D, B = 120, 320, 64, 13
     batch = synth.make_batch(900, B, H, W, D)
     p, po = eng.SvParams.driver(D - 1), ElasParams.driver(D - 1)
     for q in (p, po):
         q.lr_threshold, q.support_threshold, q.incon_min_support, q.incon_threshold = 6, 1.0, 1, 30
-    e = eng.StereoEngine(W, H, p, chunk=4, n_slots=3, n_streams=2, n_workers=2)
+    e = eng.StereoEngine(W, H, p, chunk=4, n_slots=3, n_streams=2, n_workers=2, triangulation="gpu")
     try:
         assert e.query()["resident"] == 1
         d1, d2, st = e.process_host(batch[:, 0], batch[:, 1])
@@ -722,10 +698,9 @@ def test_resident_chunks_keep_the_zero_disparity_corner_on_the_device(eng, oracl
     """kitti_mini frames 13, 17, 20: the top-right image corner takes disparity 0, so elas.cpp:258-259 adds the support point (W-1, 0, 0) a
     second time - coincident vertices in both images, one third of the kitti_mini frames.  They are interchangeable (same triple), so
     the resident kernel drops one itself: no side is handed to the host, and the maps are the reference's."""
-    monkeypatch.setenv("SV_GPU_DELAUNAY", "1")
     entry = DIG[name]
     L, R = util.case_images(entry)
-    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=2, n_streams=2, n_workers=1)
+    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=2, n_streams=2, n_workers=1)  # (one host thread: the GPU triangulates by itself)
     try:
         d1, d2, st = e.process_host(np.stack([L] * 5), np.stack([R] * 5))
         assert e.query()["resident"] == 1 and e.gpu_triangulation_fallbacks() == 0
@@ -734,3 +709,37 @@ def test_resident_chunks_keep_the_zero_disparity_corner_on_the_device(eng, oracl
     assert (st == entry["n_support"]).all()
     for i in range(5):
         assert util.sha(d1[i]) == entry["stages"]["final1"] and util.sha(d2[i]) == entry["stages"]["final2"]
+
+
+def test_resident_launch_with_too_little_lds_hands_sets_to_the_host(eng, oracle):
+    """The resident kernel's LDS request follows the support counts of earlier chunks; a chunk whose sets are larger than the
+    request covers is handed to the host stage side by side (and the request grows).  Forced here with the "ns_bound" hook."""
+    entry = DIG["kitti0_d128"]
+    L, R = util.case_images(entry)
+    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=2, n_streams=2, n_workers=2, triangulation="gpu")
+    try:
+        e.debug_set("ns_bound", 500)  # kitti0 has 2 094 support points
+        d1, d2, st = e.process_host(np.stack([L] * 4), np.stack([R] * 4))
+        first = e.gpu_triangulation_fallbacks()
+        d1b, d2b, _ = e.process_host(np.stack([L] * 4), np.stack([R] * 4))
+        later = e.gpu_triangulation_fallbacks() - first
+    finally:
+        e.close()
+    assert first == 8 and later == 0  # both sides of the four pairs of the first chunk; the bound has grown since
+    for a, b in ((d1, d2), (d1b, d2b)):
+        for i in range(4):
+            assert util.sha(a[i]) == entry["stages"]["final1"] and util.sha(b[i]) == entry["stages"]["final2"]
+
+
+def test_policy_fields_of_the_configuration(eng):
+    """sv_config's policy fields decide what the environment variables used to: two handles of one process configured differently."""
+    p = eng.SvParams.driver(63)
+    a = eng.StereoEngine(320, 120, p, chunk=4, n_slots=2, n_workers=3, triangulation="host", gpu_filter=False, affinity=False)
+    b = eng.StereoEngine(320, 120, p, chunk=4, n_slots=2, n_workers=3, triangulation="gpu", gpu_filter=True)
+    try:
+        qa, qb = a.query(), b.query()
+    finally:
+        a.close()
+        b.close()
+    assert (qa["gpu_lattice_filter"], qa["gpu_triangulation"], qa["resident"], qa["numa_bound"]) == (0, 0, 0, 0)
+    assert (qb["gpu_lattice_filter"], qb["gpu_triangulation"], qb["resident"]) == (1, 1, 1)

@@ -43,8 +43,6 @@ def test_host_batch_streams_through_several_chunks(eng, batch13, memory, monkeyp
     """13 pairs, chunk 2, 4 slots: >= 3 chunks in flight, the last chunk is ragged; twice on the same handle."""
     batch, want = batch13
     B = batch.shape[0]
-    if memory == "pinned_forced_staging":
-        monkeypatch.setenv("SV_HOST_FORCE_STAGING", "1")
     if memory == "pageable":
         L, R = np.ascontiguousarray(batch[:, 0]), np.ascontiguousarray(batch[:, 1])
         d1, d2 = np.full((B, H, W), 7.0, np.float32), np.full((B, H, W), 7.0, np.float32)
@@ -54,6 +52,8 @@ def test_host_batch_streams_through_several_chunks(eng, batch13, memory, monkeyp
         d1, d2 = eng.pinned_array((B, H, W), np.float32), eng.pinned_array((B, H, W), np.float32)
     e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), n_workers=3, chunk=2, n_streams=2, n_slots=4)
     try:
+        if memory == "pinned_forced_staging":
+            e.debug_set("host_force_staging", 1)
         for _ in range(2):
             d1[:], d2[:] = 7.0, 7.0
             o1, o2, status = e.process_host(L, R, d1=d1, d2=d2)
