@@ -37,7 +37,7 @@ extern "C" {
 /* Field-for-field mirror of Elas::parameters (reference: src/serial_includes/elas/elas.h:60-145);
  * every bool is an int32 so the block is 23 four-byte words. */
 typedef struct sv_params {
-    int32_t disp_min;              /* elas.h:61  only 0 is supported (both reference presets use 0) */
+    int32_t disp_min;              /* elas.h:61  first disparity of the support matching's search (elas.cpp:318; negative = 0; both presets use 0) */
     int32_t disp_max;              /* elas.h:62  D = disp_max + 1, 10 <= disp_max <= 1023 */
     float support_threshold;       /* elas.h:63 */
     int32_t support_texture;       /* elas.h:64 */
@@ -74,7 +74,7 @@ typedef enum sv_status {
     SV_ERR_ARG = -1,         /* bad argument / unsupported parameter value */
     SV_ERR_HIP = -2,         /* a HIP runtime call failed */
     SV_ERR_NO_DEVICE = -3,   /* no usable GPU */
-    SV_ERR_UNSUPPORTED = -4, /* e.g. disp_min != 0 */
+    SV_ERR_UNSUPPORTED = -4, /* a test hook's input beyond what its kernel takes */
     SV_ERR_STATE = -5
 } sv_status;
 

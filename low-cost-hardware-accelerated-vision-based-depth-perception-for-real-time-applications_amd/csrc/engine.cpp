@@ -257,10 +257,6 @@ void apply_env_overrides(sv_config &c) {
 
 int validate(const sv_params &p, const sv_config &c, std::string &err) {
     char b[256];
-    if (p.disp_min != 0) {
-        err = "disp_min must be 0";
-        return SV_ERR_UNSUPPORTED;
-    }
     if (p.disp_max < 10 || p.disp_max > 1023) {
         err = "disp_max must be in [10,1023]";
         return SV_ERR_ARG;
@@ -306,6 +302,7 @@ void fill_kparams(sv_handle *h) {
     d.gh = (int)ceil((float)d.H / (float)p.grid_size);
     d.ncell = d.gw * d.gh;
     d.disp_max = p.disp_max;
+    d.disp_min = std::max(p.disp_min, 0);  // elas.cpp:318: only the support matching's range starts there
     d.D = p.disp_max + 1;
     d.MW = (d.D + 31) / 32;
     d.max_pts = (d.Wc - 1) * (d.Hc - 1) + 6;

@@ -385,12 +385,13 @@ __device__ __forceinline__ uint2 support_merge(const uint2 *rec, int point) {
     return m;
 }
 
-// elas.cpp:279 (border), :318-326 (range; disp_min = 0): the highest disparity to scan, -1 = no match possible
+// elas.cpp:279 (border), :318-326 (range [max(disp_min, 0), disp_max_valid], at least 11 disparities): the highest disparity to scan,
+// -1 = no match possible
 template <bool RIGHT>
 __device__ __forceinline__ int support_range(const Dims &d, int u, int v) {
     if (!(u >= 5 && u <= d.W - 6 && v >= 5 && v <= d.H - 6)) return -1;
     const int dmax = RIGHT ? min(d.disp_max, d.W - u - 5) : min(d.disp_max, u - 5);
-    return dmax < 10 ? -1 : dmax;
+    return dmax - d.disp_min < 10 ? -1 : dmax;
 }
 
 // elas.cpp:296-300 (texture of the centre descriptor), :364 (ratio test)
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, const uint8_
     const SupRows L{sL0, sL1, l_c0}, R{sR0, sR1, r_c0};
     const int point = threadIdx.x & (SUP_POINTS - 1), part = __builtin_amdgcn_readfirstlane(threadIdx.x / SUP_POINTS);  // wave-uniform
     const int uc = uc0 + point, u = uc * d.step;
-    const int qlen = (d.disp_max + SUP_SPLIT) / SUP_SPLIT, d_lo = part * qlen;  // this wavefront's share of [0, disp_max]
+    const int qlen = (d.disp_max - d.disp_min + SUP_SPLIT) / SUP_SPLIT, d_lo = d.disp_min + part * qlen;  // this wavefront's share of [disp_min, disp_max]
     // left -> right
     const int dmax1 = uc < uc1 ? support_range<false>(d, u, v) : -1;
     uint32_t texture = 0;  // of the centre descriptor (elas.cpp:296-300)

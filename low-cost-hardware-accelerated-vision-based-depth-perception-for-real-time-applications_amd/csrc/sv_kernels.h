@@ -18,6 +18,7 @@ struct Dims {
     int grid_size, gw, gh;   // candidate grid cells (elas.cpp:88-90)
     int ncell, MW;           // gw*gh cells, MW 32-bit mask words per cell (bit d set <=> disparity d is a candidate)
     int D, disp_max;         // D = disp_max + 1
+    int disp_min;            // max(Elas::parameters::disp_min, 0): first disparity the support matching scans (elas.cpp:318; nothing else uses it)
     int max_pts, max_tri;    // capacities of the per-pair support / triangle arrays
     int sub;                 // half-resolution mode (Elas::parameters::subsampling, elas.h:83-85)
     int Wm, Hm, Nm;          // disparity MAP size: W/2 x H/2 when sub, else W x H.  The post-matching kernels get a KParams whose

@@ -46,6 +46,7 @@ def params_for(case):
 
 def with_sub(p, case):
     p.subsampling = 1 if case.get("subsampling") else 0  # half-resolution mode (elas.h:83-85)
+    p.disp_min = int(case.get("disp_min", 0))            # first disparity of the support search (elas.h:61, elas.cpp:318)
     return p
 
 
@@ -94,6 +95,9 @@ def main():
         dict(name="kitti20_d128", image="kitti20", preset="driver", disp_max=127, keep=[]),
         dict(name="kitti0_d256_sub", image="kitti0", preset="driver", disp_max=255, subsampling=1, keep=[]),
         dict(name="kitti0_crop_d64", image="kitti0_crop", preset="driver", disp_max=63, keep=STAGES),
+        # disp_min > 0 (elas.h:61): the support matching's search starts there (elas.cpp:318-330), nothing else uses it
+        dict(name="kitti0_crop_d64_dmin6", image="kitti0_crop", preset="driver", disp_max=63, disp_min=6, keep=["support", "wta1", "final1"]),
+        dict(name="kitti0_d128_dmin20", image="kitti0", preset="driver", disp_max=127, disp_min=20, keep=[]),
         dict(name="cones_crop_robotics", image="cones_crop", preset="robotics", disp_max=63, keep=["support", "tri1", "tri2", "wta1", "wta2", "final1"]),
         dict(name="cones_crop_middlebury", image="cones_crop", preset="middlebury", disp_max=63, keep=["support", "wta1", "final1", "final2"]),
         dict(name="synth1000_d128", synth=dict(seed=1000, H=375, W=1242, D=128), preset="driver", disp_max=127, keep=[]),
@@ -122,6 +126,8 @@ def main():
                  "input_sha256": [sha(L), sha(R)], "stages": {k: sha(v) for k, v in st.items()}}
         if case.get("subsampling"):
             entry["subsampling"] = 1
+        if case.get("disp_min"):
+            entry["disp_min"] = int(case["disp_min"])
         if "synth" in case:
             entry["synth"] = case["synth"]
         else:

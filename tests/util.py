@@ -56,6 +56,7 @@ def case_params(entry, cls):
         p = cls.preset(entry["preset"])
         p.disp_max = entry["disp_max"]
     p.subsampling = 1 if entry.get("subsampling") else 0
+    p.disp_min = int(entry.get("disp_min", 0))
     return p
 
 

@@ -18,7 +18,7 @@ import util  # noqa: E402
 
 FIELDS = ["disp_max", "support_threshold", "support_texture", "candidate_stepsize", "incon_window_size", "incon_threshold", "incon_min_support",
           "add_corners", "grid_size", "beta", "gamma", "sigma", "sradius", "match_texture", "lr_threshold", "speckle_sim_threshold", "speckle_size",
-          "ipol_gap_width", "filter_median", "filter_adaptive_mean", "postprocess_only_left", "subsampling"]
+          "ipol_gap_width", "filter_median", "filter_adaptive_mean", "postprocess_only_left", "subsampling", "disp_min"]
 
 
 def random_params(rng):
@@ -31,7 +31,7 @@ def random_params(rng):
                 beta=float(rng.uniform(0.01, 0.05)), gamma=float(rng.uniform(1, 20)), sigma=sigma, sradius=sradius, match_texture=int(c([0, 1, 5])),
                 lr_threshold=int(c([0, 1, 2, 3])), speckle_sim_threshold=float(c([0.5, 1, 2, 3.5])), speckle_size=int(c([0, 10, 200, 1000])),
                 ipol_gap_width=int(c([0, 3, 7, 5000])), filter_median=int(c([0, 1])), filter_adaptive_mean=int(c([0, 1])),
-                postprocess_only_left=int(c([0, 1])), subsampling=int(c([0, 0, 1])))
+                postprocess_only_left=int(c([0, 1])), subsampling=int(c([0, 0, 1])), disp_min=int(c([0, 0, 0, 2, 5, -3])))  # (drawn last: the earlier draws stay what they were)
 
 
 def apply(p, vals):
