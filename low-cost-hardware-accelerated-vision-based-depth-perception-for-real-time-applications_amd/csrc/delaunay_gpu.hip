@@ -1151,6 +1151,230 @@ __device__ __forceinline__ int dg_prepare(const DgLds &L, int npts, const DgPrep
     return m;
 }
 
+// ---- the same preparation for sets beyond LDS (4K lattices: 21 000 - 30 000 vertices): one workgroup of 1 024 threads per set, bit
+// maps, rank prefixes and the two vertex orders in the slot's global-memory scratch (the workgroup runs on one CU: its loads and stores
+// of that scratch go through relaxed agent-scope atomics, like the global mesh's fields).  Same steps as dg_prepare; a position's node
+// is found by walking the halving tree from the root each pass (no per-position state in registers).
+constexpr int DGP_THREADS = 1024;
+
+struct DgPrepScratch {  // per set: bit map, word prefixes, three vertex-order arrays (X, Y, spare), idx, xr, pref - all 32-bit words
+    uint32_t *base;
+    int cap;       // vertices per set the arrays hold
+    int bm_words;  // words of the larger bit map
+    __host__ __device__ size_t words_per_set() const { return 2 * (size_t)bm_words + 6 * (size_t)cap; }
+    __device__ __forceinline__ uint32_t *set(int s) const { return base + (size_t)s * words_per_set(); }
+};
+
+__device__ __forceinline__ uint32_t gld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gst(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int dgp_block_scan(int val, int *cells, int *total) {  // exclusive prefix sum over DGP_THREADS values (cells: LDS, 16 ints)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int incl = val;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        incl += lane >= off ? o : 0;
+    }
+    if (lane == 63) cells[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < DGP_THREADS / 64; w++) {
+        const int c = cells[w];
+        base += w < wave ? c : 0;
+        tot += c;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - val;
+}
+
+__device__ __forceinline__ void dgp_word_prefix(const uint32_t *bm, uint32_t *pm, int nwords, int *cells) {
+    const int per = (nwords + DGP_THREADS - 1) / DGP_THREADS;
+    const int w0 = min((int)threadIdx.x * per, nwords), w1 = min(w0 + per, nwords);
+    int mine = 0, total;
+    for (int w = w0; w < w1; w++) mine += __popc(gld(bm + w));
+    int acc = dgp_block_scan(mine, cells, &total);
+    for (int w = w0; w < w1; w++) {
+        gst(pm + w, (uint32_t)acc);
+        acc += __popc(gld(bm + w));
+    }
+    __syncthreads();
+}
+
+// sup: the set's (u, v, d) triples; side: 0 left image (x = u), 1 right image (x = u - d).  Writes ord_out[0] = m and ord_out[1 .. m] = the
+// ids in k-d order, or ord_out[0] = -1 (coincident points that are not interchangeable, vertices outside the bit maps).  All
+// DGP_THREADS threads call it; returns m or -1 uniformly.
+__device__ __forceinline__ int dg_prepare_global(const int32_t *__restrict__ sup, int npts, int side, const DgPrep &pp, uint32_t *scr, int cap, int bm_words, int32_t *ord_out) {
+    __shared__ int cells[24];            // [0..15] wavefront totals, [16] unusable, [17] coincident vertices seen, [18] dropped
+    __shared__ int dup_id[DG_DUP_MAX], dup_min[DG_DUP_MAX];
+    const int tid = threadIdx.x;
+    uint32_t *bm = scr, *pm = bm + bm_words, *X = pm + bm_words, *Y = X + cap, *Z = Y + cap, *idx = Z + cap, *xr = idx + cap, *pref = xr + cap;
+    if (tid == 0) cells[16] = (npts > cap || npts > 0xFFFF) ? 1 : 0, cells[17] = 0, cells[18] = 0;
+    auto vx = [&](int i) { return sup[3 * i] - (side ? sup[3 * i + 2] : 0) - pp.xmin; };
+    auto vrow = [&](int i) {
+        const int y = sup[3 * i + 1];
+        return y < 0 ? pp.rows : ((y == pp.ylast && pp.ylast % pp.step != 0) ? pp.rows - 1 : y / pp.step);
+    };
+    for (int w = tid; w < bm_words; w += DGP_THREADS) gst(bm + w, 0u);
+    for (int i = tid; i < npts; i += DGP_THREADS) gst(pref + i, 0u);  // doubles as the "dropped" flags until the first pass
+    __syncthreads();
+    if (cells[16]) {
+        if (tid == 0) ord_out[0] = -1;
+        return -1;
+    }
+    // ---- (x, y) ranks: column-major bit map; coincident vertices
+    for (int i = tid; i < npts; i += DGP_THREADS) {
+        const int x = vx(i), row = vrow(i);
+        if (x < 0 || x >= pp.cols || row >= pp.rows) {
+            cells[16] = 1;
+            continue;
+        }
+        const uint32_t bit = 1u << (row & 31);
+        if (__hip_atomic_fetch_or(bm + x * pp.W1 + (row >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) {
+            const int q = atomicAdd(&cells[17], 1);
+            if (q < DG_DUP_MAX)
+                dup_id[q] = i, dup_min[q] = i;
+            else
+                cells[16] = 1;
+        }
+    }
+    __syncthreads();
+    const int ndup = cells[17];
+    if (!cells[16] && ndup > 0) {  // a coincident group survives as its lowest id when all its members carry the same disparity
+        for (int i = tid; i < npts; i += DGP_THREADS)
+            for (int q = 0; q < ndup; q++) {
+                const int c = dup_id[q];
+                if (vx(i) == vx(c) && sup[3 * i + 1] == sup[3 * c + 1]) {
+                    if (sup[3 * i + 2] != sup[3 * c + 2]) cells[16] = 1;
+                    atomicMin(&dup_min[q], i);
+                }
+            }
+        __syncthreads();
+        for (int i = tid; i < npts; i += DGP_THREADS)
+            for (int q = 0; q < ndup; q++) {
+                const int c = dup_id[q];
+                if (vx(i) == vx(c) && sup[3 * i + 1] == sup[3 * c + 1] && i != dup_min[q]) {
+                    if (__hip_atomic_exchange(pref + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicAdd(&cells[18], 1);
+                    break;
+                }
+            }
+    }
+    __syncthreads();
+    if (cells[16]) {
+        if (tid == 0) ord_out[0] = -1;
+        return -1;
+    }
+    const int m = npts - cells[18];
+    dgp_word_prefix(bm, pm, pp.cols * pp.W1, cells);
+    for (int i = tid; i < npts; i += DGP_THREADS) {
+        if (gld(pref + i)) continue;  // dropped
+        const int x = vx(i), row = vrow(i), w = x * pp.W1 + (row >> 5);
+        const uint32_t r = gld(pm + w) + (uint32_t)__popc(gld(bm + w) & ((1u << (row & 31)) - 1u));
+        gst(xr + i, r);
+        gst(idx + r, (uint32_t)i);
+    }
+    __syncthreads();
+    // ---- (y, x) ranks: row-major bit map in the same memory
+    for (int w = tid; w < bm_words; w += DGP_THREADS) gst(bm + w, 0u);
+    __syncthreads();
+    for (int i = tid; i < npts; i += DGP_THREADS) {
+        const int x = vx(i), row = vrow(i);
+        __hip_atomic_fetch_or(bm + row * pp.W2 + (x >> 5), 1u << (x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    dgp_word_prefix(bm, pm, pp.rows * pp.W2, cells);
+    for (int i = tid; i < npts; i += DGP_THREADS) {
+        if (gld(pref + i)) continue;
+        const int x = vx(i), row = vrow(i), w = row * pp.W2 + (x >> 5);
+        const uint32_t yrank = gld(pm + w) + (uint32_t)__popc(gld(bm + w) & ((1u << (x & 31)) - 1u)), xrank = gld(xr + i);
+        const uint32_t e = (yrank << 16) | xrank;
+        gst(X + xrank, e);
+        gst(Y + yrank, e);
+    }
+    __syncthreads();
+    // ---- alternating cuts, one depth per pass; the partitioned order goes to the spare array, which then takes its place
+    const int depth = dg_depth(m);
+    const int per = (m + DGP_THREADS - 1) / DGP_THREADS, c0 = min(tid * per, m), c1 = min(c0 + per, m);
+    uint32_t *ax = X, *ay = Y, *spare = Z;
+    for (int dd = 0; dd < depth; dd++) {
+        const bool by_x = (dd & 1) == 0;
+        uint32_t *src = by_x ? ay : ax;
+        const uint32_t *ref = by_x ? ax : ay;
+        int mine = 0;
+        for (int i = c0; i < c1; i++) {
+            int lo = 0, n = m;
+            for (int b = 0; b < dd && n > 3; b++) {  // the node of depth dd this position belongs to (or the leaf above it)
+                const int nl = n >> 1;
+                if (i >= lo + nl)
+                    lo += nl, n -= nl;
+                else
+                    n = nl;
+            }
+            uint32_t flag = 0;
+            // (a leaf reached before depth dd keeps n <= 3: not split)
+            if (n > 3) {
+                const uint32_t pe = gld(ref + lo + (n >> 1)), e = gld(src + i);
+                const uint32_t pivot = by_x ? (pe & 0xFFFFu) : (pe >> 16), r = by_x ? (e & 0xFFFFu) : (e >> 16);
+                flag = r < pivot ? 1u : 0u;
+            }
+            gst(pref + i, flag << 31);
+            mine += (int)flag;
+        }
+        int total;
+        int acc = dgp_block_scan(mine, cells, &total);
+        for (int i = c0; i < c1; i++) {
+            const uint32_t f = gld(pref + i) >> 31;
+            gst(pref + i, (f << 31) | (uint32_t)acc);
+            acc += (int)f;
+        }
+        __syncthreads();
+        for (int i = c0; i < c1; i++) {
+            int lo = 0, n = m;
+            for (int b = 0; b < dd && n > 3; b++) {
+                const int nl = n >> 1;
+                if (i >= lo + nl)
+                    lo += nl, n -= nl;
+                else
+                    n = nl;
+            }
+            const uint32_t e = gld(src + i);
+            int dest = i;
+            if (n > 3) {
+                const uint32_t pi = gld(pref + i), pl = gld(pref + lo);
+                const int before = (int)(pi & 0x7FFFFFFFu) - (int)(pl & 0x7FFFFFFFu), nl = n >> 1;
+                dest = (pi >> 31) ? lo + before : lo + nl + (i - lo - before);
+            }
+            gst(spare + dest, e);
+        }
+        __syncthreads();
+        if (by_x) {
+            uint32_t *t = ay;
+            ay = spare, spare = t;
+        } else {
+            uint32_t *t = ax;
+            ax = spare, spare = t;
+        }
+    }
+    for (int i = tid; i < m; i += DGP_THREADS) ord_out[1 + i] = (int32_t)gld(idx + (gld(ax + i) & 0xFFFFu));
+    if (tid == 0) ord_out[0] = m;
+    return m;
+}
+
+// Pipeline form for resident chunks: the sets of more than sub_max vertices (up to large_cap) of a chunk whose blob k_delaunay_resident
+// has laid out; leaves [m, ids ...] where the host stage would have left them, for k_dgl_subtrees_blob / k_dgl_top_blob.
+__global__ __launch_bounds__(DGP_THREADS) void k_dg_prepare_large_blob(int32_t *__restrict__ blob, int sub_max, int large_cap, DgPrep pp, DgPrepScratch sc) {
+    const int set = blockIdx.x, pair = set >> 1, side = set & 1;
+    int32_t *meta = blob + (size_t)pair * META_WORDS;
+    const int ns = meta[0];
+    if (ns <= sub_max || ns > large_cap || meta[7] == 0) return;
+    int32_t *ord = blob + meta[5] + (size_t)2 * ns * 3 + (size_t)side * (ns + 1);
+    const int m = dg_prepare_global(blob + meta[1], ns, side, pp, sc.set(set), sc.cap, sc.bm_words, ord);
+    if (m < 0 && threadIdx.x == 0) meta[2 + 2 * side] = -1;  // the host stage builds this side
+}
+
+
 // Test-hook form: sets[s] = {offset of the set's first entry in `order` / `xy`, m (vertices after the duplicate scan), n_points
 // (entries of xy), offset of its triangle list in tri_out}.  order: vertex ids in k-d order; xy: (x, y) per id.
 __device__ __forceinline__ DgSet dg_set_from_list(const int4 st, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count) {
@@ -1203,7 +1427,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_delaunay_blob(int32_t *__restric
 // [3]/[5] their offsets, [7] = 1.  A side this kernel cannot do - coincident points, or more than sub_max vertices (what the launch has
 // LDS for) - gets its triangle count set to -1: the host stage builds it and phase 2 uploads the list.
 __global__ __launch_bounds__(DG_THREADS) void k_delaunay_resident(const int32_t *__restrict__ fsup, const int32_t *__restrict__ fnsup, int32_t *__restrict__ blob, int cap, int max_pts,
-                                                                 int pair_words, int sub_max, DgPrep pp) {
+                                                                 int pair_words, int sub_max, int large_min, int large_cap, DgPrep pp) {
     extern __shared__ uint32_t dg_lds[];
     const int tid = threadIdx.x, pair = blockIdx.x >> 1, side = blockIdx.x & 1;
     int32_t *meta = blob + (size_t)pair * META_WORDS;
@@ -1225,8 +1449,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_delaunay_resident(const int32_t 
     const int32_t *sup = fsup + (size_t)pair * max_pts * 3;
     if (side == 0)
         for (int i = tid; i < 3 * ns; i += DG_THREADS) blob[off_sup + i] = sup[i];
-    if (ns > sub_max) {  // more vertices than this launch has LDS for: handed back to the host stage
-        if (tid == 0) meta[2 + 2 * side] = -1;
+    if (ns > sub_max) {
+        // more vertices than this launch has LDS for: a set of the cut path's size (large_min < ns <= large_cap) is prepared and
+        // triangulated by the kernels behind this one (k_dg_prepare_large_blob, k_dgl_*_blob), anything else goes back to the host stage
+        if (tid == 0) meta[2 + 2 * side] = (ns > large_min && ns <= large_cap) ? 0 : -1;
         return;
     }
     const DgLds L = dg_carve((DG_LDS uint32_t *)dg_lds, ns, ns);
@@ -1335,11 +1561,29 @@ int delaunay_prep_max_points() { return DG_PREP_MAX; }
 // Both triangulations of every pair of a chunk from the lattice filter's lists on the device (k_delaunay_resident).  ns_max: an upper
 // bound of the chunk's support counts that take the LDS path (sizes the LDS request).
 void launch_delaunay_resident(const int32_t *fsup, const int32_t *fnsup, int32_t *blob, int cap, int max_pts, int pair_words, int n_pairs, int ns_max, int sub_max, int W, int H, int step,
-                              int disp_max, hipStream_t st) {
-    const size_t lds = delaunay_resident_lds_bytes(W, H, step, disp_max, ns_max < 3 ? 3 : ns_max);
+                              int disp_max, hipStream_t st, int large_min, int large_cap) {
+    // (ns_max < 3: no set of this launch takes the LDS path - wide images whose bit maps do not fit LDS - the kernel only lays the blob out)
+    const size_t lds = ns_max < 3 ? 1024 : delaunay_resident_lds_bytes(W, H, step, disp_max, ns_max);
     static std::atomic<size_t> granted[64];
     ensure_dynamic_lds(k_delaunay_resident, lds, granted, "delaunay_gpu (resident)");
-    SV_LAUNCH(K_DELAUNAY, k_delaunay_resident, dim3(2 * n_pairs), dim3(DG_THREADS), lds, st, fsup, fnsup, blob, cap, max_pts, pair_words, sub_max, dg_prep_dims(W, H, step, disp_max));
+    SV_LAUNCH(K_DELAUNAY, k_delaunay_resident, dim3(2 * n_pairs), dim3(DG_THREADS), lds, st, fsup, fnsup, blob, cap, max_pts, pair_words, sub_max, large_min, large_cap,
+              dg_prep_dims(W, H, step, disp_max));
+}
+
+// Scratch of the large-set preparation: bytes per vertex set for sets of up to `cap` vertices on the lattice of a W x H image
+size_t delaunay_prep_large_bytes(int W, int H, int step, int disp_max, int cap) {
+    const DgPrep pp = dg_prep_dims(W, H, step, disp_max);
+    return sizeof(uint32_t) * (2 * (size_t)pp.bm_words + 6 * (size_t)cap);
+}
+
+// The sets of a resident chunk that are beyond LDS (sub_max < vertices <= large_cap): preparation, then the cut path's two kernels.
+// prep_scratch: 2 * n_pairs sets of delaunay_prep_large_bytes(.., scratch.cap).
+void launch_delaunay_resident_large(int32_t *blob, int n_pairs, int sub_max, int large_cap, int W, int H, int step, int disp_max, void *prep_scratch, const DelaunayScratch &scratch,
+                                    hipStream_t st) {
+    const DgPrep pp = dg_prep_dims(W, H, step, disp_max);
+    const DgPrepScratch ps{static_cast<uint32_t *>(prep_scratch), scratch.cap, pp.bm_words};
+    SV_LAUNCH(K_DELAUNAY, k_dg_prepare_large_blob, dim3(2 * n_pairs), dim3(DGP_THREADS), 0, st, blob, sub_max, large_cap < scratch.cap ? large_cap : scratch.cap, pp, ps);
+    launch_delaunay_blob_large(blob, n_pairs, large_cap < scratch.cap ? large_cap : scratch.cap, sub_max, scratch, st);
 }
 
 // Test hook: the preparation alone for one set of (x, y) pairs on the lattice of a W x H image; ord_out[0] = m or -1, then m ids

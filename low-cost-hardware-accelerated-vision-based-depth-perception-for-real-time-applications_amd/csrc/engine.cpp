@@ -157,6 +157,7 @@ struct sv_handle {
     std::atomic<int> shared_pct{0};   // host mode with a balanced share: the dispatcher's current share, read by the issuer (who decides per chunk)
     int issue_acc = 0;                // (issuer thread only) accumulator that turns the share into whole chunks
     std::atomic<int> ns_bound{0};     // vertices the resident kernel's LDS request is sized for: follows the support counts the chunks really have
+    int resident_lds_max = 0;         // largest vertex set whose preparation + triangulation fit 160 KB of LDS at this image size (0: none - wide images)
     std::atomic<int64_t> gpu_tri_fallbacks{0};  // vertex sets of flagged pairs that the host triangulated after all (too large, or degenerate)
     std::atomic<int64_t> gpu_tri_pairs{0}, tri_pairs{0};  // pairs triangulated by the GPU kernel / all pairs, since creation
     bool node_bound = false;  // the handle's threads are bound to the CPUs of the GPU's NUMA node
@@ -492,8 +493,11 @@ void issue_phase1(sv_handle *h, Slot *s) {
             // from the filter's buffers into the blob (laid out by the kernel); only the meta words come back - counts for the launch
             // sizes of phase 2 and the callers' status, and a triangle count of -1 for a side the host has to build (coincident points)
             // (the launch requests LDS for sets of up to `bound` vertices and hands larger ones back: the bound follows the chunks' real counts)
-            const int bound = std::min(h->ns_bound.load(std::memory_order_relaxed), h->dg_sub_max);
-            launch_delaunay_resident(s->dev.fsup, s->dev.fnsup, s->dev.blob, s->dev.cap, d.max_pts, blob_pair_words(d), s->n, bound, bound, d.W, d.H, d.step, d.disp_max, tail);
+            const int bound = std::min({h->ns_bound.load(std::memory_order_relaxed), h->dg_sub_max, h->resident_lds_max});
+            const bool large = s->dev.dg.prep != nullptr;  // sets beyond LDS (4K lattices): prepared in global memory, triangulated by the cut path
+            launch_delaunay_resident(s->dev.fsup, s->dev.fnsup, s->dev.blob, s->dev.cap, d.max_pts, blob_pair_words(d), s->n, bound, bound, d.W, d.H, d.step, d.disp_max, tail,
+                                     large ? h->dg_sub_max : 0x7FFFFFFF, large ? h->dg_limit : 0);
+            if (large) launch_delaunay_resident_large(s->dev.blob, s->n, h->dg_sub_max, h->dg_limit, d.W, d.H, d.step, d.disp_max, s->dev.dg.prep, s->dev.dg, tail);
             HIP_TRY(hipMemcpyAsync(s->h_blob, s->dev.blob, sizeof(int32_t) * META_WORDS * (size_t)s->n, hipMemcpyDeviceToHost, tail));
         } else {
             HIP_TRY(hipMemcpyAsync(s->h_fnsup, s->dev.fnsup, sizeof(int32_t) * (size_t)s->n, hipMemcpyDeviceToHost, tail));
@@ -1063,7 +1067,7 @@ void dispatcher_main(sv_handle *h) {
                 const int ns = meta[0];
                 if (s->job->status) s->job->status[s->i0 + j] = ns;
                 meta[6] = 0;  // host copy: which sides the host stage builds (bit 0 left, bit 1 right)
-                seen = std::max(seen, ns);
+                if (ns <= h->dg_sub_max) seen = std::max(seen, ns);  // (larger sets take the cut path: they do not size the LDS request)
                 if (ns >= 3 && (meta[2] < 0 || meta[4] < 0)) nfb++;
             }
             h->tri_pairs.fetch_add(s->n, std::memory_order_relaxed);
@@ -1462,6 +1466,11 @@ void alloc_slot(sv_handle *h, Slot *sl) {
         dev_alloc(s.dg.xy, xb / sizeof(int32_t));
         dev_alloc(s.dg.res, rb / sizeof(uint32_t));
         s.dg.cap = h->dg_limit;
+        if (h->resident_ok) {  // resident chunks prepare their large sets on the device as well
+            uint8_t *pr = nullptr;
+            dev_alloc(pr, delaunay_prep_large_bytes(d.W, d.H, d.step, d.disp_max, h->dg_limit) * cap * 2);
+            s.dg.prep = pr;
+        }
     }
     {
         uint8_t *w = nullptr;
@@ -1508,7 +1517,7 @@ void alloc_slot(sv_handle *h, Slot *sl) {
 
 void free_slot(Slot *sl) {
     SlotDev &s = sl->dev;
-    void *dptrs[] = {s.dg.tri, s.dg.xy, s.dg.res, s.grad, s.dcan, s.fsup, s.fnsup, s.flt_ws, s.blob, s.rrec, s.tile_list, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize, s.ccl_ws};
+    void *dptrs[] = {s.dg.tri, s.dg.xy, s.dg.res, s.dg.prep, s.grad, s.dcan, s.fsup, s.fnsup, s.flt_ws, s.blob, s.rrec, s.tile_list, s.trirec, s.planes, s.gmaskA, s.gmaskB, s.tri_id, s.wta, s.disp, s.tmp, s.csize, s.ccl_ws};
     for (void *p : dptrs)
         if (p) (void)hipFree(p);
     if (sl->h_dcan) (void)hipHostFree(sl->h_dcan);
@@ -1856,7 +1865,8 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         //  latency chains - lattice filter, speckle merges, GPU triangulation - want many pairs per launch more than many slots)
         const double budget = std::min(64.0 * (1 << 30), 0.25 * (double)free_b);
         double per_pair = 66.0 * (double)h->kp.d.N + 4.0e6;
-        if (h->dg_limit > h->dg_sub_max) per_pair += (double)delaunay_scratch_bytes(h->dg_limit, 2, nullptr, nullptr, nullptr);  // two vertex sets per pair
+        if (h->dg_limit > h->dg_sub_max)  // two vertex sets per pair: the cut path's mesh and (resident chunks) the preparation's arrays
+            per_pair += (double)delaunay_scratch_bytes(h->dg_limit, 2, nullptr, nullptr, nullptr) + 2.0 * (double)delaunay_prep_large_bytes(h->kp.d.W, h->kp.d.H, h->kp.d.step, h->kp.d.disp_max, h->dg_limit);
         while ((double)h->chunk * nslots * per_pair > budget) {
             if (cfg->chunk <= 0 && h->chunk > 16)
                 h->chunk = (h->chunk + 1) / 2;
@@ -1895,9 +1905,21 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     if (!(h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0)) h->dg_limit = h->dg_sub_max;  // the pool triangulates everything: no scratch
     // The GPU's share of the chunks is "resident" - support lists never leave the device, preparation and triangulation in one kernel of
     // phase 1 - where the lattice filter runs on the GPU and a pair's lists fit the LDS kernel (KITTI-sized lattices: ~2 000 points; a
-    // 4K lattice's 21 000 take the cut path, whose vertex orders still come from the host).  cfg.resident = 2: the round-3 path.
-    h->resident_ok = cfg->resident != 2 && h->gpu_filter && gpu_capable && (h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0) && h->dg_limit == h->dg_sub_max &&
-                     std::min(h->kp.d.max_pts, fsup_copy_pts(h->kp.d)) <= h->dg_sub_max + h->dg_sub_max / 4 && h->kp.d.disp_max + h->kp.d.W < 30000;
+    // 4K lattice's 21 000 take the cut path: k_dg_prepare_large_blob orders them in the slot's scratch).  cfg.resident = 2: the round-3 path.
+    // Lists beyond the LDS kernel (dg_limit > dg_sub_max: the slots have the cut path's scratch) are prepared in global memory.
+    h->resident_ok = cfg->resident != 2 && h->gpu_filter && gpu_capable && (h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0) &&
+                     std::min(h->kp.d.max_pts, fsup_copy_pts(h->kp.d)) <= std::max(h->dg_sub_max + h->dg_sub_max / 4, h->dg_limit) && h->kp.d.disp_max + h->kp.d.W < 30000 &&
+                     h->dg_limit < 65536;
+    {  // the LDS path's limit at this image size: the bit maps of the preparation grow with the image (a 4K lattice's do not fit at all)
+        // (156 KB: the kernel has ~1 KB of static LDS beside the dynamic request, 160 KB in all)
+        const Dims &d = h->kp.d;
+        int lo = 0, hi = std::min(h->dg_sub_max, delaunay_prep_max_points());
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) / 2;
+            if (mid >= 3 && delaunay_resident_lds_bytes(d.W, d.H, d.step, d.disp_max, mid) <= 156 * 1024) lo = mid; else hi = mid - 1;
+        }
+        h->resident_lds_max = lo < 3 ? 0 : lo;
+    }
     h->ns_bound.store(std::min(h->dg_sub_max, delaunay_prep_max_points()));
     h->shared_pct.store(h->auto_pct);
     h->block_sync = cfg->event_sync == 1 || (cfg->event_sync == 0 && h->chunk >= 4);

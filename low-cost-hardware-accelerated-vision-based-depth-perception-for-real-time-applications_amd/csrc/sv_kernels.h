@@ -50,6 +50,7 @@ struct DelaunayScratch {
     int32_t *xy = nullptr;
     uint32_t *res = nullptr;
     int cap = 0;  // vertices per set the scratch holds
+    void *prep = nullptr;  // resident chunks: scratch of the large sets' preparation (delaunay_prep_large_bytes per set), or nullptr
 };
 
 // Device buffers of one worker slot, each holding `cap` pairs back to back.
@@ -124,7 +125,11 @@ int launch_delaunay_gpu(const int4 *sets, int nsets, const int32_t *order, const
 size_t delaunay_resident_lds_bytes(int W, int H, int step, int disp_max, int m);
 int delaunay_prep_max_points();
 void launch_delaunay_resident(const int32_t *fsup, const int32_t *fnsup, int32_t *blob, int cap, int max_pts, int pair_words, int n_pairs, int ns_max, int sub_max, int W, int H, int step,
-                              int disp_max, hipStream_t st);
+                              int disp_max, hipStream_t st, int large_min = 0x7FFFFFFF, int large_cap = 0);
+// ... and its sets beyond LDS (large_min < vertices <= large_cap: left alone by the kernel above): preparation in global memory, then the cut path
+size_t delaunay_prep_large_bytes(int W, int H, int step, int disp_max, int cap);
+void launch_delaunay_resident_large(int32_t *blob, int n_pairs, int sub_max, int large_cap, int W, int H, int step, int disp_max, void *prep_scratch, const DelaunayScratch &scratch,
+                                    hipStream_t st);
 int launch_delaunay_prepare_test(const int32_t *d_xy, const int32_t *d_dsp, int n, int32_t *d_ord_out, int W, int H, int step, int disp_max, hipStream_t st);  // d_dsp: disparities, may be nullptr
 // ... sets that do not fit LDS (more than delaunay_gpu_max_points() vertices): subtrees in LDS, the upper merges in a global-memory
 // mesh.  Scratch per set: 2 * cap triangles of 24 bytes, cap (x, y) pairs, node results (delaunay_scratch_bytes).

@@ -418,15 +418,16 @@ def test_full_4k_pair(eng, oracle, gpu_filter, monkeypatch):
 
 
 def test_full_4k_batch_without_host_triangulation(eng, oracle, monkeypatch):
-    """Config 5 with everything between the two kernel phases on the GPU: lattice filters (SV_GPU_FILTER) and the 30 000-point
-    triangulations (SV_GPU_DELAUNAY: subtrees in LDS + upper merges in a global-memory mesh); the two host threads only sort
-    and order the vertices.  No set falls back to the host; maps bit-exact."""
+    """Config 5 with everything between the two kernel phases on the GPU: lattice filters, the vertex orders of the 21 000-point sets
+    (k_dg_prepare_large_blob: bit maps and alternating cuts in the slot's global-memory scratch) and their triangulations (subtrees in
+    LDS + upper merges in a global-memory mesh); the support lists never leave the device, the two host threads read 8 meta words per
+    pair.  No set falls back to the host; maps bit-exact."""
     synth = util.pkg("synth")
     L, R = synth.make_pair(5001, 2160, 3840, 192, scale=3)
     e = eng.StereoEngine(3840, 2160, eng.SvParams.driver(191), chunk=4, n_slots=2, n_streams=2, n_workers=2, gpu_filter=True, triangulation="gpu")
     try:
         q = e.query()
-        assert q["gpu_lattice_filter"] == 1 and q["gpu_triangulation"] == 1
+        assert q["gpu_lattice_filter"] == 1 and q["gpu_triangulation"] == 1 and q["resident"] == 1  # (the vertex orders too: k_dg_prepare_large_blob)
         d1, d2, status = e.process_host(np.stack([L] * 5), np.stack([R] * 5))
         assert e.gpu_triangulation_share() == 1.0 and e.gpu_triangulation_fallbacks() == 0
     finally:
