@@ -116,9 +116,10 @@ struct Mesh {  // a set (or a subtree of a large set) in LDS
     }
 };
 
-// A field of a global-memory mesh.  Relaxed agent-scope atomics: single 32-bit accesses that bypass the vector cache (other
-// workgroups / an earlier kernel wrote the mesh), keep their order per address, are left alone by the SLP vectoriser (see DG_VOLATILE)
-// and - unlike volatile accesses, each of which is followed by a full s_waitcnt - overlap when they are independent.
+// A field of a global-memory mesh.  Relaxed atomics: single 32-bit accesses that keep their order per address, are left alone by the
+// SLP vectoriser (see Mesh) and - unlike volatile accesses, each of which is followed by a full s_waitcnt - overlap when they are
+// independent.  Workgroup scope: the merges of a set run in ONE workgroup (what the subtree kernel wrote is visible since the kernel
+// boundary), so the accesses may use the CU's vector cache; round 3 had them at agent scope - every field a round trip to L2.
 #define DG_VOLATILE volatile
 struct GField {
     uint32_t v;
@@ -126,8 +127,8 @@ struct GField {
     operator uint32_t() const { return v; }
     void operator=(uint32_t x) { v = x; }
 #else
-    __device__ __forceinline__ operator uint32_t() const { return __hip_atomic_load(&v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ __forceinline__ void operator=(uint32_t x) { __hip_atomic_store(&v, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    __device__ __forceinline__ operator uint32_t() const { return __hip_atomic_load(&v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    __device__ __forceinline__ void operator=(uint32_t x) { __hip_atomic_store(&v, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 #endif
 };
 struct GTri {  // the same triangle in a global-memory mesh
@@ -925,7 +926,7 @@ __device__ __forceinline__ void dg_top(const DgSet &S, int sub_max, GTri *gT, co
     if (tid < 64)
         for (int d = c - 1; d >= 0; d--) {
             if (tid < (1 << d)) dg_top_node(M, (DG_VOLATILE uint32_t *)gres, m, d, tid);
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the lanes of this wavefront: what depth d wrote, depth d - 1 reads)
         }
     __syncthreads();
     dg_emit(2 * m - 1, [gT](int t, int k) { return (uint32_t)gT[t].vtx[k]; }, GHOST32, S.out, S.count);
@@ -1152,8 +1153,8 @@ __device__ __forceinline__ int dg_prepare(const DgLds &L, int npts, const DgPrep
 }
 
 // ---- the same preparation for sets beyond LDS (4K lattices: 21 000 - 30 000 vertices): one workgroup of 1 024 threads per set, bit
-// maps, rank prefixes and the two vertex orders in the slot's global-memory scratch (the workgroup runs on one CU: its loads and stores
-// of that scratch go through relaxed agent-scope atomics, like the global mesh's fields).  Same steps as dg_prepare; a position's node
+// maps, rank prefixes and the two vertex orders in the slot's global-memory scratch (the workgroup runs on one CU and is the only one that
+// touches its set's scratch: workgroup-scope accesses, the phases ordered by __syncthreads()).  Same steps as dg_prepare; a position's node
 // is found by walking the halving tree from the root each pass (no per-position state in registers).
 constexpr int DGP_THREADS = 1024;
 
@@ -1165,8 +1166,9 @@ struct DgPrepScratch {  // per set: bit map, word prefixes, three vertex-order a
     __device__ __forceinline__ uint32_t *set(int s) const { return base + (size_t)s * words_per_set(); }
 };
 
-__device__ __forceinline__ uint32_t gld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void gst(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (workgroup scope: the set's one workgroup runs on one CU, whose vector cache all its wavefronts share; __syncthreads() orders the phases)
+__device__ __forceinline__ uint32_t gld(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void gst(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 __device__ __forceinline__ int dgp_block_scan(int val, int *cells, int *total) {  // exclusive prefix sum over DGP_THREADS values (cells: LDS, 16 ints)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1232,7 +1234,7 @@ __device__ __forceinline__ int dg_prepare_global(const int32_t *__restrict__ sup
             continue;
         }
         const uint32_t bit = 1u << (row & 31);
-        if (__hip_atomic_fetch_or(bm + x * pp.W1 + (row >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit) {
+        if (__hip_atomic_fetch_or(bm + x * pp.W1 + (row >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & bit) {
             const int q = atomicAdd(&cells[17], 1);
             if (q < DG_DUP_MAX)
                 dup_id[q] = i, dup_min[q] = i;
@@ -1256,7 +1258,7 @@ __device__ __forceinline__ int dg_prepare_global(const int32_t *__restrict__ sup
             for (int q = 0; q < ndup; q++) {
                 const int c = dup_id[q];
                 if (vx(i) == vx(c) && sup[3 * i + 1] == sup[3 * c + 1] && i != dup_min[q]) {
-                    if (__hip_atomic_exchange(pref + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) atomicAdd(&cells[18], 1);
+                    if (__hip_atomic_exchange(pref + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) atomicAdd(&cells[18], 1);
                     break;
                 }
             }
@@ -1281,7 +1283,7 @@ __device__ __forceinline__ int dg_prepare_global(const int32_t *__restrict__ sup
     __syncthreads();
     for (int i = tid; i < npts; i += DGP_THREADS) {
         const int x = vx(i), row = vrow(i);
-        __hip_atomic_fetch_or(bm + row * pp.W2 + (x >> 5), 1u << (x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_or(bm + row * pp.W2 + (x >> 5), 1u << (x & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     __syncthreads();
     dgp_word_prefix(bm, pm, pp.rows * pp.W2, cells);
@@ -1294,14 +1296,17 @@ __device__ __forceinline__ int dg_prepare_global(const int32_t *__restrict__ sup
         gst(Y + yrank, e);
     }
     __syncthreads();
-    // ---- alternating cuts, one depth per pass; the partitioned order goes to the spare array, which then takes its place
+    // ---- alternating cuts, one depth per pass; the partitioned order goes to the spare array, which then takes its place.  Inside the
+    // passes the arrays are read with plain loads (the compiler keeps many in flight); what other threads of this workgroup wrote in the
+    // pass before is visible after the barrier (same CU, same vector cache).  An agent-scope fence would write back the XCD's L2 - full
+    // of the other streams' maps - four times per pass.
+    __syncthreads();
     const int depth = dg_depth(m);
     const int per = (m + DGP_THREADS - 1) / DGP_THREADS, c0 = min(tid * per, m), c1 = min(c0 + per, m);
     uint32_t *ax = X, *ay = Y, *spare = Z;
     for (int dd = 0; dd < depth; dd++) {
         const bool by_x = (dd & 1) == 0;
-        uint32_t *src = by_x ? ay : ax;
-        const uint32_t *ref = by_x ? ax : ay;
+        const uint32_t *src = by_x ? ay : ax, *ref = by_x ? ax : ay;
         int mine = 0;
         for (int i = c0; i < c1; i++) {
             int lo = 0, n = m;
@@ -1313,20 +1318,19 @@ __device__ __forceinline__ int dg_prepare_global(const int32_t *__restrict__ sup
                     n = nl;
             }
             uint32_t flag = 0;
-            // (a leaf reached before depth dd keeps n <= 3: not split)
-            if (n > 3) {
-                const uint32_t pe = gld(ref + lo + (n >> 1)), e = gld(src + i);
+            if (n > 3) {  // (a leaf reached before depth dd keeps n <= 3: not split)
+                const uint32_t pe = ref[lo + (n >> 1)], e = src[i];
                 const uint32_t pivot = by_x ? (pe & 0xFFFFu) : (pe >> 16), r = by_x ? (e & 0xFFFFu) : (e >> 16);
                 flag = r < pivot ? 1u : 0u;
             }
-            gst(pref + i, flag << 31);
+            pref[i] = flag << 31;  // (own positions only until the scan below)
             mine += (int)flag;
         }
         int total;
         int acc = dgp_block_scan(mine, cells, &total);
         for (int i = c0; i < c1; i++) {
-            const uint32_t f = gld(pref + i) >> 31;
-            gst(pref + i, (f << 31) | (uint32_t)acc);
+            const uint32_t f = pref[i] >> 31;
+            pref[i] = (f << 31) | (uint32_t)acc;
             acc += (int)f;
         }
         __syncthreads();
@@ -1339,14 +1343,14 @@ __device__ __forceinline__ int dg_prepare_global(const int32_t *__restrict__ sup
                 else
                     n = nl;
             }
-            const uint32_t e = gld(src + i);
+            const uint32_t e = src[i];
             int dest = i;
             if (n > 3) {
-                const uint32_t pi = gld(pref + i), pl = gld(pref + lo);
+                const uint32_t pi = pref[i], pl = pref[lo];
                 const int before = (int)(pi & 0x7FFFFFFFu) - (int)(pl & 0x7FFFFFFFu), nl = n >> 1;
                 dest = (pi >> 31) ? lo + before : lo + nl + (i - lo - before);
             }
-            gst(spare + dest, e);
+            spare[dest] = e;
         }
         __syncthreads();
         if (by_x) {
@@ -1357,7 +1361,7 @@ __device__ __forceinline__ int dg_prepare_global(const int32_t *__restrict__ sup
             ax = spare, spare = t;
         }
     }
-    for (int i = tid; i < m; i += DGP_THREADS) ord_out[1 + i] = (int32_t)gld(idx + (gld(ax + i) & 0xFFFFu));
+    for (int i = tid; i < m; i += DGP_THREADS) ord_out[1 + i] = (int32_t)idx[ax[i] & 0xFFFFu];
     if (tid == 0) ord_out[0] = m;
     return m;
 }

@@ -163,7 +163,8 @@ struct sv_handle {
     bool node_bound = false;  // the handle's threads are bound to the CPUs of the GPU's NUMA node
     bool gpu_filter = false;  // lattice filters on the GPU (k_support_filter) instead of the host pool
     std::vector<Slot *> slots;
-    hipStream_t sP1 = nullptr, sPF[2] = {nullptr, nullptr};  // phase 1; lattice filter + its D2H (two streams, taken in turns:
+    int n_pf = 2;                                             // filter streams in use: 2; 4 where the triangulation chain of a 4K chunk (8 ms) follows the filter on them
+    hipStream_t sP1 = nullptr, sPF[4] = {nullptr, nullptr, nullptr, nullptr};  // phase 1; lattice filter + its D2H (streams taken in turns:
                                                                 // a 4K lattice keeps its one workgroup per pair busy for milliseconds)
     int pf_turn = 0;                                             // (issuer thread only)
     std::vector<hipStream_t> sP2;
@@ -485,7 +486,7 @@ void issue_phase1(sv_handle *h, Slot *s) {
         // the filter is one long-running workgroup per pair: on its own stream it does not hold up the next chunk's phase 1
         HIP_TRY(hipEventRecord(s->ev_sup, h->sP1));
         tail = h->sPF[h->pf_turn];
-        h->pf_turn ^= 1;
+        h->pf_turn = (h->pf_turn + 1) % h->n_pf;
         HIP_TRY(hipStreamWaitEvent(tail, s->ev_sup, 0));
         launch_support_filter(k, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s->dev, s->n, tail);
         if (s->resident) {
@@ -1620,7 +1621,8 @@ int wait_jobs(sv_handle *h) {
     }
     (void)hipSetDevice(h->cfg.device);
     bool ok = hipStreamSynchronize(h->sP1) == hipSuccess;
-    for (hipStream_t st : h->sPF) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
+    for (hipStream_t st : h->sPF)
+        if (st) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
     for (hipStream_t st : h->sP2) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
     for (hipStream_t st : {h->sIn, h->sOut, h->sOut2})
         if (st) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
@@ -1926,7 +1928,8 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     try {
         HIP_TRY(hipSetDevice(cfg->device));
         HIP_TRY(hipStreamCreateWithFlags(&h->sP1, hipStreamNonBlocking));
-        for (hipStream_t &st : h->sPF) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        h->n_pf = (h->resident_ok && h->dg_limit > h->dg_sub_max) ? 4 : 2;
+        for (int i = 0; i < h->n_pf; i++) HIP_TRY(hipStreamCreateWithFlags(&h->sPF[i], hipStreamNonBlocking));
         for (int i = 0; i < np2; i++) {
             hipStream_t st;
             HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
