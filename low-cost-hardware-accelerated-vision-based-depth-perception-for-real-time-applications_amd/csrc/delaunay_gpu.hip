@@ -114,107 +114,72 @@ struct Mesh {  // a set (or a subtree of a large set) in LDS
         set_field(a >> 2, a & 3u, b);
         set_field(b >> 2, b & 3u, a);
     }
+    // the interface d_merge_mesh is written against (MeshG below has the same)
+    typedef TR TRT;
+    static constexpr uint32_t NOV = GHOST;      // "no vertex": the vertex at infinity
+    static constexpr bool GUARDED = false;      // (a merge on a mesh in LDS sees exactly what this workgroup wrote)
+    static constexpr uint32_t step_limit = 0;
+    static __device__ __forceinline__ uint32_t nbr(const TR &t, uint32_t o) { return tr_nbr(t, o); }
+    static __device__ __forceinline__ uint32_t vtx(const TR &t, uint32_t k) { return tr_vtx(t, k); }
+    static __device__ __forceinline__ TR pack(uint32_t n0, uint32_t n1, uint32_t n2, uint32_t v0, uint32_t v1, uint32_t v2) {
+        return TR{(n0 & 0xFFFFu) | (n1 << 16), (n2 & 0xFFFFu) | (v0 << 16), (v1 & 0xFFFFu) | (v2 << 16)};
+    }
 };
 
-// A field of a global-memory mesh.  Relaxed atomics: single 32-bit accesses that keep their order per address, are left alone by the
-// SLP vectoriser (see Mesh) and - unlike volatile accesses, each of which is followed by a full s_waitcnt - overlap when they are
-// independent.  Workgroup scope: the merges of a set run in ONE workgroup (what the subtree kernel wrote is visible since the kernel
-// boundary), so the accesses may use the CU's vector cache; round 3 had them at agent scope - every field a round trip to L2.
+// The same triangle in a global-memory mesh (the upper levels of a set that does not fit LDS): six 32-bit words - three neighbour
+// handles, three vertex ids of the set (GHOST32 = the vertex at infinity).  The merges of a set run in ONE workgroup (what the subtree
+// kernel wrote is visible since the kernel boundary), so its accesses are relaxed WORKGROUP-scope atomics: single 32-bit accesses that
+// keep their order per address, are left alone by the SLP vectoriser (see Mesh), overlap when they are independent, and may use the CU's
+// vector cache.  (Round 3 had them at agent scope - every field a round trip to L2 - and read field by field.)
 #define DG_VOLATILE volatile
-struct GField {
-    uint32_t v;
-#ifdef DG_HOST_EMULATION
-    operator uint32_t() const { return v; }
-    void operator=(uint32_t x) { v = x; }
-#else
-    __device__ __forceinline__ operator uint32_t() const { return __hip_atomic_load(&v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-    __device__ __forceinline__ void operator=(uint32_t x) { __hip_atomic_store(&v, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-#endif
-};
-struct GTri {  // the same triangle in a global-memory mesh
-    GField nbr[3];
-    GField vtx[3];
+struct GTri {
+    uint32_t w[6];  // nbr0 nbr1 nbr2 vtx0 vtx1 vtx2
 };
 constexpr uint32_t GHOST32 = 0xFFFFFFFFu;
+struct TRG {  // ... in registers
+    uint32_t n0, n1, n2, v0, v1, v2;
+};
 
-struct MeshG {  // the upper levels of a large set: global memory, 32-bit handles, vertex ids of the set
-    typedef uint32_t idx_t;
-    static constexpr uint32_t NOVTX = GHOST32;
-    // A merge on this mesh reads what other workgroups / an earlier kernel wrote; should it ever see a torn mesh, its walks may
-    // not end.  Every loop trip of a merge counts against step_limit (far above any real merge): a wrong list, never a hung GPU.
-    static constexpr bool GUARDED = true;
+struct MeshG {
     GTri *T;
     const int32_t *xy;  // (x, y) per vertex id
+    // A merge on this mesh reads what other workgroups / an earlier kernel wrote; should it ever see a torn mesh, its walks may
+    // not end.  Every loop trip of a merge counts against step_limit (far above any real merge): a wrong list, never a hung GPU.
     uint32_t step_limit;
-    __device__ __forceinline__ int32_t vx(uint32_t v) const { return xy[2 * (size_t)v]; }
-    __device__ __forceinline__ int32_t vy(uint32_t v) const { return xy[2 * (size_t)v + 1]; }
+    typedef TRG TRT;
+    static constexpr uint32_t NOV = GHOST32;
+    static constexpr bool GUARDED = true;
+#ifdef DG_HOST_EMULATION
+    static uint32_t ldw(const uint32_t *p) { return *p; }
+    static void stw(uint32_t *p, uint32_t v) { *p = v; }
+#else
+    static __device__ __forceinline__ uint32_t ldw(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+    static __device__ __forceinline__ void stw(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#endif
+    __device__ __forceinline__ TRG load(uint32_t slot) const {
+        const uint32_t *w = T[slot].w;
+        return TRG{ldw(w), ldw(w + 1), ldw(w + 2), ldw(w + 3), ldw(w + 4), ldw(w + 5)};
+    }
+    __device__ __forceinline__ void load2(uint32_t a, uint32_t b, TRG &ta, TRG &tb) const { ta = load(a), tb = load(b); }
+    __device__ __forceinline__ uint32_t field(uint32_t slot, uint32_t f) const { return ldw(T[slot].w + f); }
+    __device__ __forceinline__ void set_field(uint32_t slot, uint32_t f, uint32_t v) const { stw(T[slot].w + f, v); }
+    __device__ __forceinline__ void store(uint32_t slot, const TRG &t) const {
+        uint32_t *w = T[slot].w;
+        stw(w, t.n0), stw(w + 1, t.n1), stw(w + 2, t.n2), stw(w + 3, t.v0), stw(w + 4, t.v1), stw(w + 5, t.v2);
+    }
+    __device__ __forceinline__ void bond(uint32_t a, uint32_t b) const {
+        set_field(a >> 2, a & 3u, b);
+        set_field(b >> 2, b & 3u, a);
+    }
+    static __device__ __forceinline__ uint32_t nbr(const TRG &t, uint32_t o) { return o == 0 ? t.n0 : (o == 1 ? t.n1 : t.n2); }
+    static __device__ __forceinline__ uint32_t vtx(const TRG &t, uint32_t k) { return k == 0 ? t.v0 : (k == 1 ? t.v1 : t.v2); }
+    static __device__ __forceinline__ TRG pack(uint32_t n0, uint32_t n1, uint32_t n2, uint32_t v0, uint32_t v1, uint32_t v2) { return TRG{n0, n1, n2, v0, v1, v2}; }
 };
 
 __device__ __forceinline__ uint32_t next3(uint32_t o) { return (9u >> (2 * o)) & 3u; }
 __device__ __forceinline__ uint32_t prev3(uint32_t o) { return (18u >> (2 * o)) & 3u; }
 __device__ __forceinline__ uint32_t hnext(uint32_t h) { return (h & ~3u) | next3(h & 3u); }
 __device__ __forceinline__ uint32_t hprev(uint32_t h) { return (h & ~3u) | prev3(h & 3u); }
-
-#define D_SYM(h) ((uint32_t)M.T[(h) >> 2].nbr[(h)&3u])
-#define D_ORG(h) (M.T[(h) >> 2].vtx[next3((h)&3u)])
-#define D_DEST(h) (M.T[(h) >> 2].vtx[prev3((h)&3u)])
-#define D_APEX(h) (M.T[(h) >> 2].vtx[(h)&3u])
-#define D_BOND(a, b)                                  \
-    do {                                              \
-        const uint32_t a_ = (a), b_ = (b);            \
-        M.T[a_ >> 2].nbr[a_ & 3u] = (IDX)b_;          \
-        M.T[b_ >> 2].nbr[b_ & 3u] = (IDX)a_;          \
-    } while (0)
-#define D_PX(v) ((int64_t)M.vx(v))
-#define D_PY(v) ((int64_t)M.vy(v))
-
-template <class MT>
-__device__ __forceinline__ int64_t d_orient(const MT &M, uint32_t a, uint32_t b, uint32_t c) {
-    return (D_PX(a) - D_PX(c)) * (D_PY(b) - D_PY(c)) - (D_PY(a) - D_PY(c)) * (D_PX(b) - D_PX(c));
-}
-
-template <class MT>
-__device__ __forceinline__ int64_t d_incirc(const MT &M, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
-    const int64_t adx = D_PX(a) - D_PX(d), ady = D_PY(a) - D_PY(d);
-    const int64_t bdx = D_PX(b) - D_PX(d), bdy = D_PY(b) - D_PY(d);
-    const int64_t cdx = D_PX(c) - D_PX(d), cdy = D_PY(c) - D_PY(d);
-    return (adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) + (bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy) + (cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
-}
-
-// A vertex with its coordinates (the GHOST vertex has none: its coordinates are never used)
-struct DV {
-    uint32_t id;
-    int32_t x, y;
-};
-
-template <class MT>
-__device__ __forceinline__ DV d_vertex(const MT &M, uint32_t id) {
-    DV v;
-    v.id = id;
-    const uint32_t safe = id == MT::NOVTX ? 0u : id;
-    v.x = M.vx(safe);
-    v.y = M.vy(safe);
-    return v;
-}
-
-__device__ __forceinline__ int64_t dv_orient(const DV &a, const DV &b, const DV &c) {
-    return (int64_t)(a.x - c.x) * (b.y - c.y) - (int64_t)(a.y - c.y) * (b.x - c.x);
-}
-
-__device__ __forceinline__ int64_t dv_incirc(const DV &a, const DV &b, const DV &c, const DV &d) {
-    const int64_t adx = a.x - d.x, ady = a.y - d.y;
-    const int64_t bdx = b.x - d.x, bdy = b.y - d.y;
-    const int64_t cdx = c.x - d.x, cdy = c.y - d.y;
-    return (adx * adx + ady * ady) * (bdx * cdy - cdx * bdy) + (bdx * bdx + bdy * bdy) * (cdx * ady - adx * cdy) + (cdx * cdx + cdy * cdy) * (adx * bdy - bdx * ady);
-}
-
-template <class MT>
-__device__ __forceinline__ uint32_t d_make(const MT &M, uint32_t slot) {  // triangle.cpp:2068-2101
-    typedef typename MT::idx_t IDX;
-    M.T[slot].nbr[0] = 0, M.T[slot].nbr[1] = 0, M.T[slot].nbr[2] = 0;
-    M.T[slot].vtx[0] = (IDX)MT::NOVTX, M.T[slot].vtx[1] = (IDX)MT::NOVTX, M.T[slot].vtx[2] = (IDX)MT::NOVTX;
-    return slot << 2;
-}
 
 // ---- LDS mesh: vertices with coordinates, predicates ------------------------------------------------------------------------
 struct DVL {  // a vertex of an LDS mesh with its coordinates (the GHOST vertex has none: they are never used)
@@ -229,6 +194,11 @@ __device__ __forceinline__ void ld_vertex2(const Mesh &M, uint32_t ia, uint32_t 
     M.coords2(vsafe(ia), vsafe(ib), ca, cb);
     a = dvl(ia, ca), b = dvl(ib, cb);
 }
+__device__ __forceinline__ DVL ld_vertex(const MeshG &M, uint32_t id) {  // (coordinates are read-only here: plain loads)
+    const size_t v = id == GHOST32 ? 0u : id;
+    return DVL{id, M.xy[2 * v], M.xy[2 * v + 1]};
+}
+__device__ __forceinline__ void ld_vertex2(const MeshG &M, uint32_t ia, uint32_t ib, DVL &a, DVL &b) { a = ld_vertex(M, ia), b = ld_vertex(M, ib); }
 
 // Orientation: coordinates are 16-bit, the two products 32 x 32 -> 64 bits (v_mad_i64_i32).
 __device__ __forceinline__ int64_t lv_orient(const DVL &a, const DVL &b, const DVL &c) {
@@ -249,9 +219,7 @@ __device__ __forceinline__ int64_t lv_incirc(const DVL &a, const DVL &b, const D
 }
 
 // A triangle assembled in registers from its six fields (the leaves and the two new triangles of a merge are stored whole)
-__device__ __forceinline__ TR tr_pack(uint32_t n0, uint32_t n1, uint32_t n2, uint32_t v0, uint32_t v1, uint32_t v2) {
-    return TR{(n0 & 0xFFFFu) | (n1 << 16), (n2 & 0xFFFFu) | (v0 << 16), (v1 & 0xFFFFu) | (v2 << 16)};
-}
+__device__ __forceinline__ TR tr_pack(uint32_t n0, uint32_t n1, uint32_t n2, uint32_t v0, uint32_t v1, uint32_t v2) { return Mesh::pack(n0, n1, n2, v0, v1, v2); }
 
 // triangle.cpp:5670-5815, the two- and three-vertex cases; a[] = vertex ids, slots [slot, slot + 2) resp. [slot, slot + 4).
 // The bonds and corners below are what that code leaves (restated field by field from the round-3 kernel, which followed it handle
@@ -298,195 +266,6 @@ __device__ __forceinline__ void d_leaf(const Mesh &M, DG_LDS const uint16_t *a, 
 #undef DG_H
 }
 
-// triangle.cpp:5362-5651; the two new triangles take slots `slot` and `slot + 1`
-template <class MT>
-__device__ __forceinline__ void d_merge(const MT &M, uint32_t &farleft, uint32_t innerleft, uint32_t innerright, uint32_t &farright, int axis, uint32_t slot) {
-    typedef typename MT::idx_t IDX;
-    constexpr uint32_t GHOST = MT::NOVTX;  // (shadows the 16-bit constant of the namespace)
-    uint32_t steps = 0;
-#define D_STEP()                                                  \
-    do {                                                          \
-        if (MT::GUARDED && ++steps > M.step_limit) return;        \
-    } while (0)
-    uint32_t ild = D_DEST(innerleft), ila = D_APEX(innerleft);
-    uint32_t iro = D_ORG(innerright), ira = D_APEX(innerright);
-    if (axis == 1) {  // horizontal cut: walk the four extreme handles to the bottom-/top-most hull vertices
-        uint32_t flp = D_ORG(farleft), fla = D_APEX(farleft);
-        uint32_t frp = D_DEST(farright);
-        while (D_PY(fla) < D_PY(flp)) {
-            D_STEP();
-            farleft = D_SYM(hnext(farleft));
-            flp = fla;
-            fla = D_APEX(farleft);
-        }
-        uint32_t chk = D_SYM(innerleft);
-        uint32_t cv = D_APEX(chk);
-        while (D_PY(cv) > D_PY(ild)) {
-            D_STEP();
-            innerleft = hnext(chk);
-            ila = ild;
-            ild = cv;
-            chk = D_SYM(innerleft);
-            cv = D_APEX(chk);
-        }
-        while (D_PY(ira) < D_PY(iro)) {
-            D_STEP();
-            innerright = D_SYM(hnext(innerright));
-            iro = ira;
-            ira = D_APEX(innerright);
-        }
-        chk = D_SYM(farright);
-        cv = D_APEX(chk);
-        while (D_PY(cv) > D_PY(frp)) {
-            D_STEP();
-            farright = hnext(chk);
-            frp = cv;
-            chk = D_SYM(farright);
-            cv = D_APEX(chk);
-        }
-    }
-    for (bool changed = true; changed;) {  // lower common tangent
-        D_STEP();
-        changed = false;
-        if (d_orient(M, ild, ila, iro) > 0) {
-            innerleft = D_SYM(hprev(innerleft));
-            ild = ila;
-            ila = D_APEX(innerleft);
-            changed = true;
-        }
-        if (d_orient(M, ira, iro, ild) > 0) {
-            innerright = D_SYM(hnext(innerright));
-            iro = ira;
-            ira = D_APEX(innerright);
-            changed = true;
-        }
-    }
-    uint32_t leftcand = D_SYM(innerleft), rightcand = D_SYM(innerright);
-    uint32_t base = d_make(M, slot);
-    D_BOND(base, innerleft);
-    base = hnext(base);
-    D_BOND(base, innerright);
-    base = hnext(base);
-    D_ORG(base) = (IDX)iro;
-    D_DEST(base) = (IDX)ild;
-    if (ild == D_ORG(farleft)) farleft = hnext(base);
-    if (iro == D_DEST(farright)) farright = hprev(base);
-    // The seam loop keeps the coordinates of its four moving vertices in registers (a vertex is read from LDS once, when it
-    // enters the picture) instead of fetching them again for every predicate.
-    DV ll = d_vertex(M, ild), lr = d_vertex(M, iro);
-    DV ul = d_vertex(M, D_APEX(leftcand)), ur = d_vertex(M, D_APEX(rightcand));
-    for (;;) {
-        D_STEP();
-        const bool leftdone = dv_orient(ul, ll, lr) <= 0, rightdone = dv_orient(ur, ll, lr) <= 0;
-        if (leftdone && rightdone) {
-            uint32_t top = d_make(M, slot + 1);
-            D_ORG(top) = (IDX)ll.id;
-            D_DEST(top) = (IDX)lr.id;
-            D_BOND(top, base);
-            top = hnext(top);
-            D_BOND(top, rightcand);
-            top = hnext(top);
-            D_BOND(top, leftcand);
-            if (axis == 1) {  // back to left-/right-most handles
-                uint32_t flp = D_ORG(farleft);
-                uint32_t frp = D_DEST(farright), fra = D_APEX(farright);
-                uint32_t chk = D_SYM(farleft);
-                uint32_t cv = D_APEX(chk);
-                while (D_PX(cv) < D_PX(flp)) {
-                    D_STEP();
-                    farleft = hprev(chk);
-                    flp = cv;
-                    chk = D_SYM(farleft);
-                    cv = D_APEX(chk);
-                }
-                while (D_PX(fra) > D_PX(frp)) {
-                    D_STEP();
-                    farright = D_SYM(hprev(farright));
-                    frp = fra;
-                    fra = D_APEX(farright);
-                }
-            }
-            return;
-        }
-        if (!leftdone) {  // flip away left edges that the circle through ll, lr, ul invalidates
-            uint32_t nx = D_SYM(hprev(leftcand));
-            DV na = d_vertex(M, D_APEX(nx));
-            if (na.id != GHOST) {
-                bool bad = dv_incirc(ll, lr, ul, na) > 0;
-                while (bad) {
-                    D_STEP();
-                    nx = hnext(nx);
-                    const uint32_t topc = D_SYM(nx);
-                    nx = hnext(nx);
-                    const uint32_t sidec = D_SYM(nx);
-                    D_BOND(nx, topc);
-                    D_BOND(leftcand, sidec);
-                    leftcand = hnext(leftcand);
-                    const uint32_t outerc = D_SYM(leftcand);
-                    nx = hprev(nx);
-                    D_BOND(nx, outerc);
-                    D_ORG(leftcand) = (IDX)ll.id;
-                    D_DEST(leftcand) = (IDX)GHOST;
-                    D_APEX(leftcand) = (IDX)na.id;
-                    D_ORG(nx) = (IDX)GHOST;
-                    D_DEST(nx) = (IDX)ul.id;
-                    D_APEX(nx) = (IDX)na.id;
-                    ul = na;
-                    nx = sidec;
-                    na = d_vertex(M, D_APEX(nx));
-                    bad = na.id != GHOST && dv_incirc(ll, lr, ul, na) > 0;
-                }
-            }
-        }
-        if (!rightdone) {
-            uint32_t nx = D_SYM(hnext(rightcand));
-            DV na = d_vertex(M, D_APEX(nx));
-            if (na.id != GHOST) {
-                bool bad = dv_incirc(ll, lr, ur, na) > 0;
-                while (bad) {
-                    D_STEP();
-                    nx = hprev(nx);
-                    const uint32_t topc = D_SYM(nx);
-                    nx = hprev(nx);
-                    const uint32_t sidec = D_SYM(nx);
-                    D_BOND(nx, topc);
-                    D_BOND(rightcand, sidec);
-                    rightcand = hprev(rightcand);
-                    const uint32_t outerc = D_SYM(rightcand);
-                    nx = hnext(nx);
-                    D_BOND(nx, outerc);
-                    D_ORG(rightcand) = (IDX)GHOST;
-                    D_DEST(rightcand) = (IDX)lr.id;
-                    D_APEX(rightcand) = (IDX)na.id;
-                    D_ORG(nx) = (IDX)ur.id;
-                    D_DEST(nx) = (IDX)GHOST;
-                    D_APEX(nx) = (IDX)na.id;
-                    ur = na;
-                    nx = sidec;
-                    na = d_vertex(M, D_APEX(nx));
-                    bad = na.id != GHOST && dv_incirc(ll, lr, ur, na) > 0;
-                }
-            }
-        }
-        if (leftdone || (!rightdone && dv_incirc(ul, ll, lr, ur) > 0)) {
-            D_BOND(base, rightcand);
-            base = hprev(rightcand);
-            D_DEST(base) = (IDX)ll.id;
-            lr = ur;
-            rightcand = D_SYM(base);
-            ur = d_vertex(M, D_APEX(rightcand));
-        } else {
-            D_BOND(base, leftcand);
-            base = hnext(leftcand);
-            D_ORG(base) = (IDX)lr.id;
-            ll = ul;
-            leftcand = D_SYM(base);
-            ul = d_vertex(M, D_APEX(leftcand));
-        }
-    }
-}
-#undef D_STEP
-
 // Node j of depth d of the recursion over m vertices: its vertex range [lo, lo + n), the first slot of its subtree and its
 // cut axis (axis0 = the axis of the tree's root: 0 for a whole set).  False if the tree has no such node (an ancestor already is a leaf).
 __device__ __forceinline__ bool d_node(int m, int d, int j, int &lo, int &n, uint32_t &slot, int &axis, int axis0 = 0) {
@@ -509,84 +288,97 @@ __device__ __forceinline__ bool d_node(int m, int d, int j, int &lo, int &n, uin
     return true;
 }
 
-// triangle.cpp:5362-5651 on an LDS mesh; the two new triangles take slots `slot` and `slot + 1`.  Same steps as d_merge above (which
-// serves the global-memory mesh), with every triangle it looks at held in registers (TR) from ONE LDS access, the coordinates of the
-// moving vertices kept beside their ids, the two sides' next candidates fetched together, and the in-circle test in 32-bit terms.
-// A register copy is only used until the next store that could touch its triangle; after a flip both triangles are read again.
-template <bool NARROW>
-__device__ __forceinline__ void d_merge_lds(const Mesh &M, uint32_t &farleft, uint32_t innerleft, uint32_t innerright, uint32_t &farright, int axis, uint32_t slot) {
+// triangle.cpp:5362-5651 (mergehulls) on a mesh MT - Mesh (LDS, 16-bit handles) or MeshG (global memory, 32-bit handles); the two new
+// triangles take slots `slot` and `slot + 1`.  Every triangle the merge looks at is held in registers (MT::TRT) from ONE access, the
+// coordinates of the moving vertices are kept beside their ids, the two sides' next candidates are fetched together, and the in-circle
+// test runs in 32-bit terms.  A register copy is only used until the next store that could touch its triangle; after a flip both
+// triangles are read again.  MT::GUARDED: every loop trip counts against M.step_limit (a torn mesh ends the merge, never hangs the GPU).
+template <bool NARROW, class MT>
+__device__ __forceinline__ void d_merge_mesh(const MT &M, uint32_t &farleft, uint32_t innerleft, uint32_t innerright, uint32_t &farright, int axis, uint32_t slot) {
+    typedef typename MT::TRT TR;
+    constexpr uint32_t GHOST = MT::NOV;  // (shadows the 16-bit constant of the namespace)
+    uint32_t steps = 0;
+#define D_STEP()                                           \
+    do {                                                   \
+        if (MT::GUARDED && ++steps > M.step_limit) return; \
+    } while (0)
     TR TL, TRr;  // the triangles of innerleft / innerright
     M.load2(innerleft >> 2, innerright >> 2, TL, TRr);
     DVL ild, ila, iro, ira;  // dest / apex of innerleft, org / apex of innerright
-    ld_vertex2(M, tr_vtx(TL, prev3(innerleft & 3u)), tr_vtx(TL, innerleft & 3u), ild, ila);
-    ld_vertex2(M, tr_vtx(TRr, next3(innerright & 3u)), tr_vtx(TRr, innerright & 3u), iro, ira);
+    ld_vertex2(M, MT::vtx(TL, prev3(innerleft & 3u)), MT::vtx(TL, innerleft & 3u), ild, ila);
+    ld_vertex2(M, MT::vtx(TRr, next3(innerright & 3u)), MT::vtx(TRr, innerright & 3u), iro, ira);
     if (axis == 1) {  // horizontal cut: walk the four extreme handles to the bottom-/top-most hull vertices
         {
             TR t = M.load(farleft >> 2);
             DVL flp, fla;
-            ld_vertex2(M, tr_vtx(t, next3(farleft & 3u)), tr_vtx(t, farleft & 3u), flp, fla);
+            ld_vertex2(M, MT::vtx(t, next3(farleft & 3u)), MT::vtx(t, farleft & 3u), flp, fla);
             while (fla.y < flp.y) {
-                farleft = tr_nbr(t, next3(farleft & 3u));
+                D_STEP();
+                farleft = MT::nbr(t, next3(farleft & 3u));
                 t = M.load(farleft >> 2);
                 flp = fla;
-                fla = ld_vertex(M, tr_vtx(t, farleft & 3u));
+                fla = ld_vertex(M, MT::vtx(t, farleft & 3u));
             }
         }
         {
-            uint32_t chk = tr_nbr(TL, innerleft & 3u);
+            uint32_t chk = MT::nbr(TL, innerleft & 3u);
             TR t = M.load(chk >> 2);
-            DVL cv = ld_vertex(M, tr_vtx(t, chk & 3u));
+            DVL cv = ld_vertex(M, MT::vtx(t, chk & 3u));
             while (cv.y > ild.y) {
+                D_STEP();
                 innerleft = hnext(chk);
                 TL = t;  // same triangle, next orientation
                 ila = ild;
                 ild = cv;
-                chk = tr_nbr(TL, innerleft & 3u);
+                chk = MT::nbr(TL, innerleft & 3u);
                 t = M.load(chk >> 2);
-                cv = ld_vertex(M, tr_vtx(t, chk & 3u));
+                cv = ld_vertex(M, MT::vtx(t, chk & 3u));
             }
         }
         while (ira.y < iro.y) {
-            innerright = tr_nbr(TRr, next3(innerright & 3u));
+            D_STEP();
+            innerright = MT::nbr(TRr, next3(innerright & 3u));
             TRr = M.load(innerright >> 2);
             iro = ira;
-            ira = ld_vertex(M, tr_vtx(TRr, innerright & 3u));
+            ira = ld_vertex(M, MT::vtx(TRr, innerright & 3u));
         }
         {
             TR t = M.load(farright >> 2);
-            DVL frp = ld_vertex(M, tr_vtx(t, prev3(farright & 3u)));
-            uint32_t chk = tr_nbr(t, farright & 3u);
+            DVL frp = ld_vertex(M, MT::vtx(t, prev3(farright & 3u)));
+            uint32_t chk = MT::nbr(t, farright & 3u);
             t = M.load(chk >> 2);
-            DVL cv = ld_vertex(M, tr_vtx(t, chk & 3u));
+            DVL cv = ld_vertex(M, MT::vtx(t, chk & 3u));
             while (cv.y > frp.y) {
+                D_STEP();
                 farright = hnext(chk);
                 frp = cv;
-                chk = tr_nbr(t, farright & 3u);
+                chk = MT::nbr(t, farright & 3u);
                 t = M.load(chk >> 2);
-                cv = ld_vertex(M, tr_vtx(t, chk & 3u));
+                cv = ld_vertex(M, MT::vtx(t, chk & 3u));
             }
         }
     }
     for (bool changed = true; changed;) {  // lower common tangent
+        D_STEP();
         changed = false;
         if (lv_orient(ild, ila, iro) > 0) {
-            innerleft = tr_nbr(TL, prev3(innerleft & 3u));
+            innerleft = MT::nbr(TL, prev3(innerleft & 3u));
             TL = M.load(innerleft >> 2);
             ild = ila;
-            ila = ld_vertex(M, tr_vtx(TL, innerleft & 3u));
+            ila = ld_vertex(M, MT::vtx(TL, innerleft & 3u));
             changed = true;
         }
         if (lv_orient(ira, iro, ild) > 0) {
-            innerright = tr_nbr(TRr, next3(innerright & 3u));
+            innerright = MT::nbr(TRr, next3(innerright & 3u));
             TRr = M.load(innerright >> 2);
             iro = ira;
-            ira = ld_vertex(M, tr_vtx(TRr, innerright & 3u));
+            ira = ld_vertex(M, MT::vtx(TRr, innerright & 3u));
             changed = true;
         }
     }
-    uint32_t leftcand = tr_nbr(TL, innerleft & 3u), rightcand = tr_nbr(TRr, innerright & 3u);
+    uint32_t leftcand = MT::nbr(TL, innerleft & 3u), rightcand = MT::nbr(TRr, innerright & 3u);
     // the first new triangle: base = slot at orientation 2 after its two bonds; org(base) = iro (vtx[0]), dest(base) = ild (vtx[1])
-    M.store(slot, tr_pack(innerleft, innerright, 0u, iro.id, ild.id, GHOST));
+    M.store(slot, MT::pack(innerleft, innerright, 0u, iro.id, ild.id, GHOST));
     M.set_field(innerleft >> 2, innerleft & 3u, (slot << 2) | 0u);
     M.set_field(innerright >> 2, innerright & 3u, (slot << 2) | 1u);
     uint32_t base = (slot << 2) | 2u;
@@ -595,56 +387,60 @@ __device__ __forceinline__ void d_merge_lds(const Mesh &M, uint32_t &farleft, ui
     DVL ll = ild, lr = iro, ul, ur;
     TR TLc, TRc;  // the triangles of leftcand / rightcand
     M.load2(leftcand >> 2, rightcand >> 2, TLc, TRc);
-    ld_vertex2(M, tr_vtx(TLc, leftcand & 3u), tr_vtx(TRc, rightcand & 3u), ul, ur);
+    ld_vertex2(M, MT::vtx(TLc, leftcand & 3u), MT::vtx(TRc, rightcand & 3u), ul, ur);
     for (;;) {
+        D_STEP();
         const bool leftdone = lv_orient(ul, ll, lr) <= 0, rightdone = lv_orient(ur, ll, lr) <= 0;
         if (leftdone && rightdone) {
             // the second new triangle `top`: org ll (vtx[1]), dest lr (vtx[2]); bonds (top,0)-base, (top,1)-rightcand, (top,2)-leftcand
             const uint32_t top = slot + 1;
-            M.store(top, tr_pack(base, rightcand, leftcand, GHOST, ll.id, lr.id));
+            M.store(top, MT::pack(base, rightcand, leftcand, GHOST, ll.id, lr.id));
             M.set_field(base >> 2, base & 3u, (top << 2) | 0u);
             M.set_field(rightcand >> 2, rightcand & 3u, (top << 2) | 1u);
             M.set_field(leftcand >> 2, leftcand & 3u, (top << 2) | 2u);
             if (axis == 1) {  // back to left-/right-most handles
                 {
                     TR t = M.load(farleft >> 2);
-                    DVL flp = ld_vertex(M, tr_vtx(t, next3(farleft & 3u)));
-                    uint32_t chk = tr_nbr(t, farleft & 3u);
+                    DVL flp = ld_vertex(M, MT::vtx(t, next3(farleft & 3u)));
+                    uint32_t chk = MT::nbr(t, farleft & 3u);
                     t = M.load(chk >> 2);
-                    DVL cv = ld_vertex(M, tr_vtx(t, chk & 3u));
+                    DVL cv = ld_vertex(M, MT::vtx(t, chk & 3u));
                     while (cv.x < flp.x) {
+                        D_STEP();
                         farleft = hprev(chk);
                         flp = cv;
-                        chk = tr_nbr(t, farleft & 3u);
+                        chk = MT::nbr(t, farleft & 3u);
                         t = M.load(chk >> 2);
-                        cv = ld_vertex(M, tr_vtx(t, chk & 3u));
+                        cv = ld_vertex(M, MT::vtx(t, chk & 3u));
                     }
                 }
                 {
                     TR t = M.load(farright >> 2);
                     DVL frp, fra;
-                    ld_vertex2(M, tr_vtx(t, prev3(farright & 3u)), tr_vtx(t, farright & 3u), frp, fra);
+                    ld_vertex2(M, MT::vtx(t, prev3(farright & 3u)), MT::vtx(t, farright & 3u), frp, fra);
                     while (fra.x > frp.x) {
-                        farright = tr_nbr(t, prev3(farright & 3u));
+                        D_STEP();
+                        farright = MT::nbr(t, prev3(farright & 3u));
                         t = M.load(farright >> 2);
                         frp = fra;
-                        fra = ld_vertex(M, tr_vtx(t, farright & 3u));
+                        fra = ld_vertex(M, MT::vtx(t, farright & 3u));
                     }
                 }
             }
             return;
         }
         // both sides' next candidates: the triangles across the candidates' far edges and their apexes (one latency each for the pair)
-        uint32_t nxl = tr_nbr(TLc, prev3(leftcand & 3u)), nxr = tr_nbr(TRc, next3(rightcand & 3u));
+        uint32_t nxl = MT::nbr(TLc, prev3(leftcand & 3u)), nxr = MT::nbr(TRc, next3(rightcand & 3u));
         TR TNl, TNr;
         M.load2(nxl >> 2, nxr >> 2, TNl, TNr);
         DVL nal, nar;
-        ld_vertex2(M, tr_vtx(TNl, nxl & 3u), tr_vtx(TNr, nxr & 3u), nal, nar);
+        ld_vertex2(M, MT::vtx(TNl, nxl & 3u), MT::vtx(TNr, nxr & 3u), nal, nar);
         if (!leftdone && nal.id != GHOST) {  // flip away left edges that the circle through ll, lr, ul invalidates
             bool bad = lv_incirc<NARROW>(ll, lr, ul, nal) > 0, flipped = bad;
             while (bad) {
+                D_STEP();
                 const uint32_t nx1 = hnext(nxl), nx2 = hnext(nx1);
-                const uint32_t topc = tr_nbr(TNl, nx1 & 3u), sidec = tr_nbr(TNl, nx2 & 3u);
+                const uint32_t topc = MT::nbr(TNl, nx1 & 3u), sidec = MT::nbr(TNl, nx2 & 3u);
                 M.bond(nx2, topc);
                 M.bond(leftcand, sidec);
                 leftcand = hnext(leftcand);
@@ -659,7 +455,7 @@ __device__ __forceinline__ void d_merge_lds(const Mesh &M, uint32_t &farleft, ui
                 ul = nal;
                 nxl = sidec;
                 TNl = M.load(nxl >> 2);
-                nal = ld_vertex(M, tr_vtx(TNl, nxl & 3u));
+                nal = ld_vertex(M, MT::vtx(TNl, nxl & 3u));
                 bad = nal.id != GHOST && lv_incirc<NARROW>(ll, lr, ul, nal) > 0;
             }
             if (flipped) TLc = M.load(leftcand >> 2);
@@ -667,8 +463,9 @@ __device__ __forceinline__ void d_merge_lds(const Mesh &M, uint32_t &farleft, ui
         if (!rightdone && nar.id != GHOST) {
             bool bad = lv_incirc<NARROW>(ll, lr, ur, nar) > 0, flipped = bad;
             while (bad) {
+                D_STEP();
                 const uint32_t nx1 = hprev(nxr), nx2 = hprev(nx1);
-                const uint32_t topc = tr_nbr(TNr, nx1 & 3u), sidec = tr_nbr(TNr, nx2 & 3u);
+                const uint32_t topc = MT::nbr(TNr, nx1 & 3u), sidec = MT::nbr(TNr, nx2 & 3u);
                 M.bond(nx2, topc);
                 M.bond(rightcand, sidec);
                 rightcand = hprev(rightcand);
@@ -683,7 +480,7 @@ __device__ __forceinline__ void d_merge_lds(const Mesh &M, uint32_t &farleft, ui
                 ur = nar;
                 nxr = sidec;
                 TNr = M.load(nxr >> 2);
-                nar = ld_vertex(M, tr_vtx(TNr, nxr & 3u));
+                nar = ld_vertex(M, MT::vtx(TNr, nxr & 3u));
                 bad = nar.id != GHOST && lv_incirc<NARROW>(ll, lr, ur, nar) > 0;
             }
             if (flipped) TRc = M.load(rightcand >> 2);
@@ -693,20 +490,21 @@ __device__ __forceinline__ void d_merge_lds(const Mesh &M, uint32_t &farleft, ui
             base = hprev(rightcand);
             M.set_field(base >> 2, 3u + prev3(base & 3u), ll.id);  // dest(base)
             lr = ur;
-            rightcand = tr_nbr(TRc, base & 3u);  // sym(base): a field of the old candidate's triangle that the bond above did not write
+            rightcand = MT::nbr(TRc, base & 3u);  // sym(base): a field of the old candidate's triangle that the bond above did not write
             TRc = M.load(rightcand >> 2);
-            ur = ld_vertex(M, tr_vtx(TRc, rightcand & 3u));
+            ur = ld_vertex(M, MT::vtx(TRc, rightcand & 3u));
         } else {
             M.bond(base, leftcand);
             base = hnext(leftcand);
             M.set_field(base >> 2, 3u + next3(base & 3u), lr.id);  // org(base)
             ll = ul;
-            leftcand = tr_nbr(TLc, base & 3u);
+            leftcand = MT::nbr(TLc, base & 3u);
             TLc = M.load(leftcand >> 2);
-            ul = ld_vertex(M, tr_vtx(TLc, leftcand & 3u));
+            ul = ld_vertex(M, MT::vtx(TLc, leftcand & 3u));
         }
     }
 }
+#undef D_STEP
 
 // Leaf construction or merge of node j of depth d; res[] holds (farleft | farright << 16) per node in heap order.
 template <bool NARROW>
@@ -721,7 +519,7 @@ __device__ __forceinline__ void d_process_node(const Mesh &M, DG_LDS uint32_t *r
         const uint32_t rl = res[(2 << d) + 2 * j], rr = res[(2 << d) + 2 * j + 1];  // children: heap index 2h, 2h+1 with h = (1<<d)+j
         fl = rl & 0xFFFFu;
         fr = rr >> 16;
-        d_merge_lds<NARROW>(M, fl, rl >> 16, rr & 0xFFFFu, fr, axis, slot + 2 * n - 4);
+        d_merge_mesh<NARROW>(M, fl, rl >> 16, rr & 0xFFFFu, fr, axis, slot + 2 * n - 4);
     }
     res[(1 << d) + j] = fl | (fr << 16);
 }
@@ -748,13 +546,14 @@ __host__ __device__ inline int dg_cut_depth(int m, int sub_max) {
 __device__ __forceinline__ uint32_t dg_global_handle(uint32_t h, uint32_t slot0) { return (h >> 2) == 0 ? 0u : (((h >> 2) + slot0 - 1u) << 2) | (h & 3u); }
 
 // One of the remaining merges: node j of depth d (< cut depth) of a set of m vertices; gres[2h], gres[2h + 1] = farleft / farright of heap node h
+template <bool NARROW>
 __device__ __forceinline__ void dg_top_node(const MeshG &M, DG_VOLATILE uint32_t *gres, int m, int d, int j) {
     int lo, n, axis;
     uint32_t slot;
     if (!d_node(m, d, j, lo, n, slot, axis)) return;
     const int hl = (2 << d) + 2 * j, hr = hl + 1;  // children of heap node (1 << d) + j
     uint32_t fl = gres[2 * hl], fr = gres[2 * hr + 1];
-    d_merge(M, fl, gres[2 * hl + 1], gres[2 * hr], fr, axis, slot + 2 * n - 4);
+    d_merge_mesh<NARROW>(M, fl, gres[2 * hl + 1], gres[2 * hr], fr, axis, slot + 2 * n - 4);
     gres[2 * ((1 << d) + j)] = fl;
     gres[2 * ((1 << d) + j) + 1] = fr;
 }
@@ -875,7 +674,7 @@ __device__ __forceinline__ void dg_subtree(const DgSet &S, int sub_max, int j, G
     extern __shared__ uint32_t dg_lds[];
     const int tid = threadIdx.x;
     const int c = dg_cut_depth(S.m, sub_max);
-    if (j >= (1 << c)) return;
+    if (c > DG_CUT_MAX || j >= (1 << c)) return;  // (deeper cuts than the node-result table holds: the launchers never hand such a set over)
     int lo, n, axis0;
     uint32_t slot0;
     if (!d_node(S.m, c, j, lo, n, slot0, axis0) || n < 2) return;  // (every node above the cut has more than sub_max >= 6 vertices)
@@ -919,17 +718,22 @@ __device__ __forceinline__ void dg_subtree(const DgSet &S, int sub_max, int j, G
 
 // The merges above the cut, depth by depth, one lane of the first wavefront per merge (a fence between depths: a lane sees what
 // the lanes of the depth below wrote), then the triangle list by the whole workgroup.
+template <bool NARROW>
 __device__ __forceinline__ void dg_top(const DgSet &S, int sub_max, GTri *gT, const int32_t *gxy, uint32_t *gres) {
     const int tid = threadIdx.x, m = S.m;
     const int c = dg_cut_depth(m, sub_max);
+    if (c > DG_CUT_MAX) {
+        if (tid == 0) *S.count = 0;
+        return;
+    }
     const MeshG M{gT, gxy, 16u * (uint32_t)m + 4096u};
     if (tid < 64)
         for (int d = c - 1; d >= 0; d--) {
-            if (tid < (1 << d)) dg_top_node(M, (DG_VOLATILE uint32_t *)gres, m, d, tid);
+            if (tid < (1 << d)) dg_top_node<NARROW>(M, (DG_VOLATILE uint32_t *)gres, m, d, tid);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (the lanes of this wavefront: what depth d wrote, depth d - 1 reads)
         }
     __syncthreads();
-    dg_emit(2 * m - 1, [gT](int t, int k) { return (uint32_t)gT[t].vtx[k]; }, GHOST32, S.out, S.count);
+    dg_emit(2 * m - 1, [gT](int t, int k) { return gT[t].w[3 + k]; }, GHOST32, S.out, S.count);
 }
 
 // ---- preparation on the GPU: (x, y) order, duplicate scan, k-d order ----------------------------------------------------------
@@ -1508,9 +1312,13 @@ __global__ __launch_bounds__(DG_THREADS) void k_dgl_subtrees(const int4 *__restr
 }
 
 __global__ __launch_bounds__(DG_THREADS) void k_dgl_top(const int4 *__restrict__ sets, const int32_t *__restrict__ order, const int32_t *__restrict__ xy,
-                                                       int32_t *__restrict__ tri_out, int32_t *__restrict__ tri_count, int sub_max, DgScratch sc) {
+                                                       int32_t *__restrict__ tri_out, int32_t *__restrict__ tri_count, int sub_max, DgScratch sc, int narrow) {
     const int set = blockIdx.x;
-    dg_top(dg_set_from_list(sets[set], order, xy, tri_out, tri_count + set), sub_max, sc.T(set), sc.XY(set), sc.R(set));
+    const DgSet S = dg_set_from_list(sets[set], order, xy, tri_out, tri_count + set);
+    if (narrow)
+        dg_top<true>(S, sub_max, sc.T(set), sc.XY(set), sc.R(set));
+    else
+        dg_top<false>(S, sub_max, sc.T(set), sc.XY(set), sc.R(set));
 }
 
 __global__ __launch_bounds__(DG_THREADS) void k_dgl_subtrees_blob(int32_t *__restrict__ blob, int sub_max, DgScratch sc) {
@@ -1522,7 +1330,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_dgl_subtrees_blob(int32_t *__res
 __global__ __launch_bounds__(DG_THREADS) void k_dgl_top_blob(int32_t *__restrict__ blob, int sub_max, DgScratch sc) {
     const int set = blockIdx.x;
     DgSet S;
-    if (dg_set_from_blob(blob, set, sub_max, true, S) && S.npts <= sc.cap) dg_top(S, sub_max, sc.T(set), sc.XY(set), sc.R(set));
+    if (dg_set_from_blob(blob, set, sub_max, true, S) && S.npts <= sc.cap) dg_top<true>(S, sub_max, sc.T(set), sc.XY(set), sc.R(set));
 }
 
 #endif  // DG_HOST_EMULATION
@@ -1600,6 +1408,7 @@ int launch_delaunay_prepare_test(const int32_t *d_xy, const int32_t *d_dsp, int 
 }
 
 int delaunay_gpu_max_points() { return DG_SUB_MAX; }
+int delaunay_gpu_cut_max() { return DG_CUT_MAX; }
 int delaunay_gpu_large_max_points() { return DG_SUB_MAX << DG_CUT_MAX; }
 
 size_t delaunay_scratch_bytes(int cap, int nsets, size_t *tri_bytes, size_t *xy_bytes, size_t *res_bytes) {
@@ -1648,11 +1457,12 @@ int launch_delaunay_gpu_large(const int4 *sets, int nsets, const int32_t *order,
         return -1;
     }
     hipLaunchKernelGGL(k_dgl_subtrees, dim3(1 << dg_cut_depth(m_max, sub_max), nsets), dim3(DG_THREADS), lds, st, sets, order, xy, tri_out, tri_count, sub_max, dg_scratch(scratch), narrow);
-    hipLaunchKernelGGL(k_dgl_top, dim3(nsets), dim3(DG_THREADS), 0, st, sets, order, xy, tri_out, tri_count, sub_max, dg_scratch(scratch));
+    hipLaunchKernelGGL(k_dgl_top, dim3(nsets), dim3(DG_THREADS), 0, st, sets, order, xy, tri_out, tri_count, sub_max, dg_scratch(scratch), narrow);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 void launch_delaunay_blob_large(int32_t *blob, int n_pairs, int ns_max, int sub_max, const DelaunayScratch &scratch, hipStream_t st) {
+    if (dg_cut_depth(ns_max, sub_max) > DG_CUT_MAX) ns_max = sub_max << DG_CUT_MAX;  // (sv_create keeps the handle's limit below this; larger sets are the host's)
     const size_t lds = delaunay_gpu_lds_bytes(sub_max, sub_max);
     static std::atomic<size_t> granted[64];
     ensure_dynamic_lds(k_dgl_subtrees_blob, lds, granted, "delaunay_gpu");

@@ -1856,9 +1856,18 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     if (cfg->dg_sub_max > 0) h->dg_sub_max = std::max(6, std::min(h->dg_sub_max, cfg->dg_sub_max));  // experiments / tests
     if (!cfg->keep_debug) {
         const int want = std::min({h->kp.d.max_pts, delaunay_gpu_large_max_points(), 131072, fsup_copy_pts(h->kp.d)});
-        if (want > h->dg_sub_max + h->dg_sub_max / 4 || (cfg->dg_sub_max > 0 && want > h->dg_sub_max)) h->dg_limit = want;
+        if (want > h->dg_sub_max + h->dg_sub_max / 4 || (cfg->dg_sub_max > 0 && want > h->dg_sub_max)) {
+            h->dg_limit = want;
+            // Lists that have to be cut anyway (4K lattices: 21 000 - 30 000 vertices) are cut into subtrees of at most 1 024 vertices, not
+            // 4 000: a subtree workgroup then holds 34 KB of LDS instead of 136 KB for a third of the time, and the kernels of the other
+            // streams keep their occupancy - 2 460 against 2 210 pairs/s at 4K with two host threads (700: 2 480, 1 400: 2 390).
+            if (cfg->dg_sub_max <= 0) h->dg_sub_max = 1024;
+        }
     }
     if (cfg->dg_max_points > 0) h->dg_limit = std::min(h->dg_limit, std::max(cfg->dg_max_points, 16));  // tests: larger sets fall back to the pool
+    // a set is cut into at most 2^cut_max subtrees of at most dg_sub_max vertices: with a lowered dg_sub_max (experiments) the cut path takes
+    // less - a 4K list of 23 000 vertices with dg_sub_max = 350 overran the node-result table before this clamp existed
+    h->dg_limit = std::max(h->dg_sub_max, (int)std::min<long>(h->dg_limit, (long)h->dg_sub_max << delaunay_gpu_cut_max()));
     if (cfg->chunk <= 0 || cfg->n_slots <= 0) {
         size_t free_b = 0, total_b = 0;
         (void)hipSetDevice(cfg->device);

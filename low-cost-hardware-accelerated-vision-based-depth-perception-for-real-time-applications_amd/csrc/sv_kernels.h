@@ -134,6 +134,7 @@ int launch_delaunay_prepare_test(const int32_t *d_xy, const int32_t *d_dsp, int 
 // ... sets that do not fit LDS (more than delaunay_gpu_max_points() vertices): subtrees in LDS, the upper merges in a global-memory
 // mesh.  Scratch per set: 2 * cap triangles of 24 bytes, cap (x, y) pairs, node results (delaunay_scratch_bytes).
 int delaunay_gpu_large_max_points();
+int delaunay_gpu_cut_max();  // a large set is cut into at most 2^this subtrees of at most sub_max vertices
 size_t delaunay_scratch_bytes(int cap, int nsets, size_t *tri_bytes, size_t *xy_bytes, size_t *res_bytes);
 int launch_delaunay_gpu_large(const int4 *sets, int nsets, const int32_t *order, const int32_t *xy, int32_t *tri_out, int32_t *tri_count, int m_max, int sub_max,
                               const DelaunayScratch &scratch, int narrow, hipStream_t st);

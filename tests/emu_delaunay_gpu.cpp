@@ -81,7 +81,7 @@ int main() {
         deepest = c > deepest ? c : deepest;
         std::vector<sv::dg::GTri> G(2 * (size_t)m);
         std::vector<uint32_t> gres(4 << sv::dg::DG_CUT_MAX, 0);
-        for (int k = 0; k < 3; k++) { G[0].nbr[k] = 0; G[0].vtx[k] = sv::dg::GHOST32; }
+        for (int k = 0; k < 3; k++) { G[0].w[k] = 0; G[0].w[3 + k] = sv::dg::GHOST32; }
         for (int j = (1 << c) - 1; j >= 0; j--) {
             int lo, ns, axis0;
             uint32_t slot0;
@@ -99,19 +99,19 @@ int main() {
                 for (int q = (1 << d) - 1; q >= 0; q--) sv::dg::d_process_node<true>(M, res.data(), ord.data(), ns, d, q, axis0);
             for (int t = 1; t < 2 * ns - 1; t++)
                 for (int k = 0; k < 3; k++) {
-                    G[slot0 + t - 1].nbr[k] = sv::dg::dg_global_handle(F[6 * t + k], slot0);
-                    G[slot0 + t - 1].vtx[k] = F[6 * t + 3 + k] == 0xFFFF ? sv::dg::GHOST32 : (uint32_t)ids[lo + F[6 * t + 3 + k]];
+                    G[slot0 + t - 1].w[k] = sv::dg::dg_global_handle(F[6 * t + k], slot0);
+                    G[slot0 + t - 1].w[3 + k] = F[6 * t + 3 + k] == 0xFFFF ? sv::dg::GHOST32 : (uint32_t)ids[lo + F[6 * t + 3 + k]];
                 }
             gres[2 * ((1 << c) + j)] = sv::dg::dg_global_handle(res[1] & 0xFFFFu, slot0);
             gres[2 * ((1 << c) + j) + 1] = sv::dg::dg_global_handle(res[1] >> 16, slot0);
         }
         const sv::dg::MeshG MG{G.data(), xy.data(), 16u * (uint32_t)m + 4096u};
         for (int d = c - 1; d >= 0; d--)
-            for (int j = (1 << d) - 1; j >= 0; j--) sv::dg::dg_top_node(MG, gres.data(), m, d, j);
+            for (int j = (1 << d) - 1; j >= 0; j--) sv::dg::dg_top_node<true>(MG, gres.data(), m, d, j);
         std::vector<int32_t> got;
         for (int t = 1; t < 2 * m - 1; t++) {
-            if (G[t].vtx[0] == sv::dg::GHOST32 || G[t].vtx[1] == sv::dg::GHOST32 || G[t].vtx[2] == sv::dg::GHOST32) continue;
-            got.push_back((int32_t)G[t].vtx[1]); got.push_back((int32_t)G[t].vtx[2]); got.push_back((int32_t)G[t].vtx[0]);
+            if (G[t].w[3] == sv::dg::GHOST32 || G[t].w[4] == sv::dg::GHOST32 || G[t].w[5] == sv::dg::GHOST32) continue;
+            got.push_back((int32_t)G[t].w[4]); got.push_back((int32_t)G[t].w[5]); got.push_back((int32_t)G[t].w[3]);
         }
         if ((int)got.size() != 3 * nw || memcmp(got.data(), want.data(), sizeof(int32_t) * got.size())) {
             bad++;
