@@ -84,6 +84,7 @@ struct Job {
     // memory goes through the slot's page-locked staging buffers.
     bool host = false, pin_in = false, pin_out = false;
     int drained = 0;  // chunks whose maps have reached the caller (guarded by sv_handle::mu)
+    std::vector<hipEvent_t> ev_done;  // device-memory jobs: one event per chunk, recorded behind its second phase (sv_wait_batches waits on these, not on the streams)
 };
 
 enum SlotState { SLOT_FREE = 0, SLOT_BUSY = 1, SLOT_DRAINING = 2 };  // DRAINING: phase 2 issued, ev_free recorded
@@ -187,6 +188,7 @@ struct sv_handle {
     std::deque<Slot *> q4;  // host-memory jobs: maps downloaded, waiting for the deliverer (pageable callers' copy, slot release)
     std::string error;
     std::atomic<bool> failed{false};
+    std::vector<hipEvent_t> ev_pool;  // completion events of finished batches, reused (guarded by mu)
     // host pool
     std::vector<std::thread> pool;
     std::vector<HostScratch *> scratch;
@@ -1258,8 +1260,11 @@ void finisher_main(sv_handle *h) {
         bool recorded = false;
         try {
             if (!h->failed) {
-                issue_phase2(h, s, h->sP2[rr++ % h->sP2.size()]);
+                hipStream_t st = h->sP2[rr++ % h->sP2.size()];
+                issue_phase2(h, s, st);
                 recorded = true;
+                const size_t c = (size_t)(s->i0 / h->chunk);
+                if (!s->job->host && c < s->job->ev_done.size() && s->job->ev_done[c]) HIP_TRY(hipEventRecord(s->job->ev_done[c], st));
             }
         } catch (const std::exception &e) {
             note_error(h, e.what());
@@ -1372,13 +1377,13 @@ double host_cpu_share(bool *quota) {
     CPU_ZERO(&set);
     int aff = (int)std::max(1u, std::thread::hardware_concurrency());
     if (sched_getaffinity(0, sizeof(set), &set) == 0) aff = std::max(1, CPU_COUNT(&set));
-    if (!have_quota || cpus > aff) cpus = aff;
     int ranks = 1;
     if (env_int("LOCAL_WORLD_SIZE", &ranks)) ranks = std::max(1, ranks);
     if (quota) *quota = have_quota;
     // a quota is the node's budget and is shared between the node's ranks; an affinity mask narrower than that share is the rank's own
     // already (a launcher that pins its ranks) and is not divided again
-    return have_quota ? std::min((double)aff, std::max(1.0, cpus / ranks)) : cpus / ranks;
+    if (have_quota) return std::min((double)aff, std::max(1.0, cpus / ranks));
+    return (double)aff / ranks;
 }
 
 int default_pool_size() {
@@ -1547,6 +1552,8 @@ void free_handle_resources(sv_handle *h) {
     h->slots.clear();
     for (TimingCtx *t : {&h->tc_issue, &h->tc_finish})
         for (hipEvent_t e : t->pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    h->ev_pool.clear();
     if (h->sP1) (void)hipStreamDestroy(h->sP1);
     for (hipStream_t st : h->sPF)
         if (st) (void)hipStreamDestroy(st);
@@ -1601,6 +1608,19 @@ int submit_job(sv_handle *h, const uint8_t *left, const uint8_t *right, int batc
             return rc;
         }
     }
+    if (!host) {  // one completion event per chunk (from the handle's pool; created on first use)
+        (void)hipSetDevice(h->cfg.device);
+        std::lock_guard<std::mutex> lk(h->mu);
+        job->ev_done.assign((size_t)job->nchunks, nullptr);
+        for (hipEvent_t &e : job->ev_done) {
+            if (!h->ev_pool.empty()) {
+                e = h->ev_pool.back();
+                h->ev_pool.pop_back();
+            } else if (hipEventCreateWithFlags(&e, hipEventDisableTiming | (h->block_sync ? hipEventBlockingSync : 0u)) != hipSuccess) {
+                e = nullptr;  // (sv_wait_batches then falls back to the streams for this batch)
+            }
+        }
+    }
     {
         std::lock_guard<std::mutex> lk(h->mu);
         if (h->live.empty()) h->failed = false;
@@ -1632,7 +1652,11 @@ int wait_jobs(sv_handle *h) {
         collect_timing(h, &h->tc_finish);
     }
     std::lock_guard<std::mutex> lk(h->mu);
-    for (Job *j : h->live) delete j;
+    for (Job *j : h->live) {
+        for (hipEvent_t e : j->ev_done)
+            if (e) h->ev_pool.push_back(e);
+        delete j;
+    }
     h->live.clear();
     return h->failed ? SV_ERR_HIP : SV_OK;
 }
@@ -1644,7 +1668,8 @@ int wait_jobs(sv_handle *h) {
 int wait_first_jobs(sv_handle *h, int n) {
     if (!h) return SV_ERR_ARG;
     if (n <= 0) return SV_OK;
-    bool device_job = false;
+    std::vector<hipEvent_t> evs;
+    bool need_streams = false;
     {
         std::unique_lock<std::mutex> lk(h->mu);
         if ((size_t)n > h->live.size()) {
@@ -1653,14 +1678,24 @@ int wait_first_jobs(sv_handle *h, int n) {
         }
         Job *j = h->live[(size_t)n - 1];
         h->cv.wait(lk, [&] { return (j->host ? j->drained : j->issued2) == j->nchunks; });
-        device_job = !j->host;
+        // every chunk's second phase of the first n batches is enqueued and has its completion event recorded behind it: waiting on
+        // those events - not on the streams - leaves the phase-2 work of LATER batches, which the finisher may have enqueued
+        // already, out of the wait (the chunked gather of bench.py starts a chunk's collective as soon as that chunk is done)
+        for (int q = 0; q < n; q++) {
+            const Job *b = h->live[(size_t)q];
+            if (b->host) continue;  // (host-memory batches are complete once drained)
+            for (hipEvent_t e : b->ev_done) {
+                if (e) evs.push_back(e);
+                else need_streams = true;
+            }
+        }
     }
-    if (device_job) {  // every chunk's second phase is enqueued: what is left is the streams' work up to here
-        (void)hipSetDevice(h->cfg.device);
-        bool ok = true;
+    (void)hipSetDevice(h->cfg.device);
+    bool ok = true;
+    for (hipEvent_t e : evs) ok = (hipEventSynchronize(e) == hipSuccess) && ok;
+    if (need_streams)
         for (hipStream_t st : h->sP2) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
-        if (!ok) note_error(h, "stream synchronisation failed");
-    }
+    if (!ok) note_error(h, "waiting for the batches' completion events failed");
     return h->failed ? SV_ERR_HIP : SV_OK;
 }
 

@@ -1468,9 +1468,8 @@ __device__ __forceinline__ int dense_pixel(const KParams &k, int side, int u, in
     // are never set): the column-range clipping of the masks is skipped then
     const bool clip = __builtin_amdgcn_ballot_w64(a_lo != 0 || a_hi != d.D - 1) != 0;
     // the band (at most 2 * plane_radius + 1 <= 31 bits) as a 64-bit mask starting in mask word band_word
-    // (v_bfm_b32 builds the ones - at most 2 * 15 + 1 = 31 of them, none for an empty band - then ONE 64-bit shift puts them in place)
-    const int band_bits = max(d_plane_max - d_plane_min + 1, 0), band_word = d_plane_min >> 5;
-    const uint64_t band = (uint64_t)((1u << band_bits) - 1u) << (d_plane_min & 31);
+    const int band_bits = d_plane_max - d_plane_min + 1, band_word = d_plane_min >> 5;
+    const uint64_t band = band_bits > 0 ? ((1ull << band_bits) - 1ull) << (d_plane_min & 31) : 0ull;
     const uint32_t band_lo = (uint32_t)band, band_hi = (uint32_t)(band >> 32);
     uint32_t mc[DENSE_MASK_WORDS];
 #pragma unroll
@@ -1522,45 +1521,41 @@ __device__ __forceinline__ int dense_pixel(const KParams &k, int side, int u, in
     const int r = plane_radius;
     // o' = d - (d_plane - r) in [0, 2r]; the lane's valid candidates are o' in [lo_o, hi_o] (empty when lo_o > hi_o)
     const int lo_o = b_lo - (d_plane - r), hi_o = b_hi - (d_plane - r);
+    const int lo_u = __builtin_amdgcn_readfirstlane(lo_o), hi_u = __builtin_amdgcn_readfirstlane(hi_o);
 #ifndef DENSE_BAND_FAST
 #define DENSE_BAND_FAST 1
 #endif
 #ifndef DENSE_WAVES_ATTR
 #define DENSE_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
 #endif
-    // the lane has its whole band iff d_plane - r >= a_lo and d_plane + r <= a_hi: one unsigned compare (a_hi - a_lo >= 2r away from the
-    // image border, where a_lo = 0 and a_hi = D - 1; a border lane with a narrower range fails the signed guard)
-    const bool lane_full = a_hi - a_lo >= 2 * r && (uint32_t)(d_plane - r - a_lo) <= (uint32_t)(a_hi - 2 * r - a_lo);
-    if (DENSE_BAND_FAST && (RT == 3 || RT == 2) && __builtin_amdgcn_ballot_w64(!lane_full) == 0) {
-        // Fast path (89 % of the pixels of a real pair, 78 % of a synthetic one): every lane of the wavefront has its whole band, so the
-        // 2r+1 candidates are consecutive LDS slots at immediate offsets from one base, and nothing per candidate is left but the read,
-        // one v_and for the key's start value and the SAD chain.  Keys are relative here (tie-break = o'); the band bit and the band's
-        // first disparity are added once at the end (no carry: 0x8000 | d < 0x10000).
-        if (COUNT) ncand += 2 * r + 1, npath[0]++;
-        // LDS slot s of the band: pb[s], s = o' (right pixel) or 2r - o' (left pixel: its candidates run towards lower columns)
-        const uint4 *pb = side ? pu + (d_plane - r) : pu - (d_plane + r);
-        const uint32_t vmask = valid ? 0xFFFFFFFFu : 0x0000FFFFu;  // the prior counts only for a valid plane (:771)
-        const int bb = dense_band_full<RT ? RT : 3>(k, side, own, pb, vmask);
-        best = min(best, bb + (0x8000 + d_plane - r));
-    } else if (DENSE_BAND_FAST && (RT == 3 || RT == 2) &&
-               __builtin_amdgcn_ballot_w64(lo_o != __builtin_amdgcn_readfirstlane(lo_o) || hi_o != __builtin_amdgcn_readfirstlane(hi_o)) == 0) {
-        // All lanes clip the band the same way (planes at disparity 0 .. r - 1: the sky of a scene, 40 % of a synthetic pair's pixels): the
-        // bounds are scalar, the candidates still consecutive slots at immediate offsets from one base
-        const int lo_u = __builtin_amdgcn_readfirstlane(lo_o), hi_u = __builtin_amdgcn_readfirstlane(hi_o);
+    if (DENSE_BAND_FAST && r <= 3 && __builtin_amdgcn_ballot_w64(lo_o != lo_u || hi_o != hi_u) == 0) {
+        // Fast path (almost every wavefront): all lanes clip the band the same way, so the loop bounds are scalar, the seven
+        // candidates are consecutive LDS slots at immediate offsets from one base, and nothing per candidate is left but the
+        // read, one v_and_or for the key's start value and the SAD chain.  Keys are relative here (tie-break = o'); the band
+        // bit and the band's first disparity are added once at the end (no carry: 0x8000 | d < 0x10000).
         if (lo_u <= hi_u) {
-            if (COUNT) ncand += hi_u - lo_u + 1, npath[1]++;
+            if (COUNT) ncand += hi_u - lo_u + 1;
+            // LDS slot s of the band: pb[s], s = o' (right pixel) or 2r - o' (left pixel: its candidates run towards lower columns)
             const uint4 *pb = side ? pu + (d_plane - r) : pu - (d_plane + r);
-            const uint32_t vmask = valid ? 0xFFFFFFFFu : 0x0000FFFFu;
-            const int p0 = k.prior[0], p1 = k.prior[1], p2 = k.prior[2], p3 = k.prior[3];
-            int bb = KEY_NONE;
+            const uint32_t vmask = valid ? 0xFFFFFFFFu : 0x0000FFFFu;  // the prior counts only for a valid plane (:771)
+            int bb;
+            if (COUNT) npath[(lo_u == 0 && hi_u == 2 * r && (r == 3 || r == 2)) ? 0 : 1]++;
+            if (lo_u == 0 && hi_u == 2 * r && r == 3)       // the whole band (the usual case): straight-line code, reads in flight together
+                bb = dense_band_full<3>(k, side, own, pb, vmask);
+            else if (lo_u == 0 && hi_u == 2 * r && r == 2)
+                bb = dense_band_full<2>(k, side, own, pb, vmask);
+            else {
+                const int p0 = k.prior[0], p1 = k.prior[1], p2 = k.prior[2], p3 = k.prior[3];
+                bb = KEY_NONE;
 #pragma unroll
-            for (int s = 0; s <= 2 * RT; s++) {
-                const int o = side ? s : 2 * r - s;                // all scalar
-                if (o < lo_u || o > hi_u) continue;
-                const int ao = s < r ? r - s : s - r;              // |o' - r|
-                const int pa = ao == 0 ? p0 : (ao == 1 ? p1 : (ao == 2 ? p2 : p3));
-                const uint32_t start = ((uint32_t)pa << 16) | (uint32_t)o;  // scalar: (prior << 16) | o'
-                bb = min(bb, sad16_key(own, pb[s], (int)(vmask & start)));
+                for (int s = 0; s <= 6; s++) {
+                    const int o = side ? s : 2 * r - s;                // all scalar
+                    if (s > 2 * r || o < lo_u || o > hi_u) continue;
+                    const int ao = s < r ? r - s : s - r;              // |o' - r|
+                    const int pa = ao == 0 ? p0 : (ao == 1 ? p1 : (ao == 2 ? p2 : p3));
+                    const uint32_t start = ((uint32_t)pa << 16) | (uint32_t)o;  // scalar: (prior << 16) | o'
+                    bb = min(bb, sad16_key(own, pb[s], (int)(vmask & start)));
+                }
             }
             best = min(best, bb + (0x8000 + d_plane - r));
         }
@@ -1643,8 +1638,7 @@ __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const
     __syncthreads();
     // grid cell of each of the thread's columns (elas.cpp:745-746), once for both sides; word offsets fit 32 bits.  (Staging the
     // tile's cell masks in LDS instead of one global gather per pixel was measured: 10.4 against 9.2 us per pair.)
-    // (the row's cell by the same host-checked multiply-shift as the columns' - scalar - instead of an IEEE division per thread)
-    const uint32_t gy = k.cell_mul ? (((uint32_t)v * k.cell_mul) >> 16) : (uint32_t)(int)floorf((float)v / (float)d.grid_size);
+    const uint32_t gy = (uint32_t)(int)floorf((float)v / (float)d.grid_size);
     uint32_t cell_off[DENSE_TW / 256];
 #pragma unroll
     for (int j = 0; j < DENSE_TW / 256; j++) {
@@ -1715,18 +1709,10 @@ static void launch_dense_as(const KParams &k, const SlotDev &s, const dim3 &grid
 void launch_dense(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
     const size_t shmem = dense_lds_bytes(k);
     const dim3 grid((k.d.W + DENSE_TW - 1) / DENSE_TW, k.d.sub ? (k.d.H + 1) / 2 : k.d.H, n);
-    if (s.counters) {  // the counting builds: generic in the mask words, the presets' plane radii compiled in (the band paths depend on it)
-        static std::atomic<size_t> granted_c[3][64];
-        if (k.plane_radius == 3) {
-            ensure_dynamic_lds(k_dense<true, 0, 3, true>, shmem, granted_c[0], "dense_match");
-            SV_LAUNCH(K_DENSE, (k_dense<true, 0, 3, true>), grid, dim3(256), shmem, st, k, s.grad, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
-        } else if (k.plane_radius == 2) {
-            ensure_dynamic_lds(k_dense<true, 0, 2, true>, shmem, granted_c[1], "dense_match");
-            SV_LAUNCH(K_DENSE, (k_dense<true, 0, 2, true>), grid, dim3(256), shmem, st, k, s.grad, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
-        } else {
-            ensure_dynamic_lds(k_dense<true, 0, 0, true>, shmem, granted_c[2], "dense_match");
-            SV_LAUNCH(K_DENSE, (k_dense<true, 0, 0, true>), grid, dim3(256), shmem, st, k, s.grad, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
-        }
+    if (s.counters) {
+        static std::atomic<size_t> granted_c[64];
+        ensure_dynamic_lds(k_dense<true, 0, 0, true>, shmem, granted_c, "dense_match");
+        SV_LAUNCH(K_DENSE, (k_dense<true, 0, 0, true>), grid, dim3(256), shmem, st, k, s.grad, s.blob, s.tri_id, s.trirec, s.gmaskB, s.wta, s.counters);
         return;
     }
     // the usual disparity ranges (64 / 128 / 192 / 256) with the presets' plane radii (2: ROBOTICS, 3: MIDDLEBURY) get kernels

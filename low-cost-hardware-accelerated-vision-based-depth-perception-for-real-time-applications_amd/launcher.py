@@ -145,6 +145,18 @@ def gpu_numa_cpus(local_rank=0):
             cpus.update(range(int(a), int(b or a) + 1))
         return cpus
     except (OSError, ValueError, IndexError, KeyError):
+        pass
+    try:  # second source: the DRM render nodes this process may open, in minor order
+        minors = sorted(int(n[7:]) for n in os.listdir("/sys/class/drm") if n.startswith("renderD") and os.access("/dev/dri/" + n, os.R_OK | os.W_OK))
+        node = int(open("/sys/class/drm/renderD%d/device/numa_node" % minors[local_rank]).read())
+        if node < 0:
+            return set()
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        return cpus
+    except (OSError, ValueError, IndexError):
         return set()
 
 

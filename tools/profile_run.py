@@ -20,7 +20,7 @@ PKG = "low-cost-hardware-accelerated-vision-based-depth-perception-for-real-time
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--chunk", type=int, default=16)
-ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--reps", type=int, default=9, help="passes over the batch: the first is a warm-up, 8 x (batch / chunk) = 16 timed launches per kernel by default")
 ap.add_argument("--disp", type=int, default=128)
 ap.add_argument("--overlap", action="store_true", help="use the default pipelined configuration instead")
 a = ap.parse_args()

@@ -32,10 +32,23 @@ a = ap.parse_args()
 rows = collections.OrderedDict()
 if a.stats:
     f = max(glob.glob(os.path.join(a.stats, "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)  # the newest run in the directory
+    # medians from the per-dispatch trace of the same run (the stats file has average / min / max only; a cold first launch skews the average)
+    durs = collections.defaultdict(list)
+    tr = glob.glob(os.path.join(os.path.dirname(f), "*kernel_trace.csv"))
+    if tr:
+        for r in csv.DictReader(open(max(tr, key=os.path.getmtime))):
+            durs[short(r["Kernel_Name"])].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
     for r in csv.DictReader(open(f)):
         k = short(r["Name"])
-        rows[k] = {"kernel": k, "calls": int(r["Calls"]), "avg_us": round(float(r["AverageNs"]) / 1e3, 2), "min_us": round(float(r["MinNs"]) / 1e3, 2),
-                   "max_us": round(float(r["MaxNs"]) / 1e3, 2), "pct": r["Percentage"], "us_per_pair": round(float(r["AverageNs"]) / 1e3 / a.pairs_per_launch, 3)}
+        d = sorted(durs.get(k, []))
+        med = d[len(d) // 2] if len(d) % 2 else (0.5 * (d[len(d) // 2 - 1] + d[len(d) // 2]) if d else float(r["AverageNs"]) / 1e3)
+        if k in rows:  # several instantiations of one kernel (k_dense<..>): keep the one with the most time
+            if float(r["TotalDurationNs"]) <= rows[k]["_total"]:
+                continue
+        rows[k] = {"kernel": k, "calls": int(r["Calls"]), "median_us": round(med, 2), "avg_us": round(float(r["AverageNs"]) / 1e3, 2), "min_us": round(float(r["MinNs"]) / 1e3, 2),
+                   "max_us": round(float(r["MaxNs"]) / 1e3, 2), "pct": r["Percentage"], "us_per_pair": round(med / a.pairs_per_launch, 3), "_total": float(r["TotalDurationNs"])}
+    for r in rows.values():
+        r.pop("_total", None)
 for d in a.pmc:
     f = max(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
