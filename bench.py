@@ -79,7 +79,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 SAD_PEAK_BYTE_OPS = 1024 * 64 * 4 / 4 * 2.4e9
 KERNEL_TRACE_NAMES = {"descriptor": ["k_descriptor", "k_sobel"], "support_match": ["k_support"], "support_filter": ["k_filter_classify", "k_filter_resolve", "k_filter_vertical", "k_filter_horizontal", "k_filter_collect", "k_filter_corners"], "grid_mark": ["k_grid_mark"],
                       "grid_dilate": ["k_grid_dilate"], "plane_fit": ["k_planes"], "triangles_raster": ["k_raster_tiles"], "triangles_raster_fallback": ["k_raster"],
-                      "dense_match": ["k_dense"], "lr_check": ["k_lr", "k_lr2"], "delaunay_gpu": ["dg::k_delaunay_blob", "dg::k_dgl_subtrees_blob", "dg::k_dgl_top_blob"], "ccl_band": ["k_ccl_band"],
+                      "dense_match": ["k_dense"], "lr_check": ["k_lr", "k_lr2"], "delaunay_gpu": ["dg::k_delaunay_resident", "dg::k_delaunay_blob", "dg::k_dg_prepare_large_blob", "dg::k_dgl_subtrees_blob", "dg::k_dgl_top_blob"], "ccl_band": ["k_ccl_band"],
                       "ccl_finish": ["k_ccl_border", "k_ccl_total", "k_ccl_apply", "k_ccl_slow", "k_ccl_merge"], "gap_rows": ["k_gap_rows"], "gap_cols": ["k_gap_cols"],
                       "adaptive_mean": ["k_amean", "k_amean_sub"], "median": ["k_median"], "output": ["k_output"]}
 
@@ -315,15 +315,16 @@ def profile_durations(kernel, pattern):
     try:
         for r in csv.DictReader(open(f)):
             if r["kernel"] in KERNEL_TRACE_NAMES.get(kernel, []):
-                tot_us += float(r["avg_us"]) * int(r["calls"])
+                dur = float(r.get("median_us") or r["avg_us"])  # (median of the launches where the summary has it: round 4 on)
+                tot_us += dur * int(r["calls"])
                 calls = max(calls, int(r["calls"]))
-                if float(r["avg_us"]) > 0 and float(r.get("us_per_pair") or 0) > 0:
-                    ppl = round(float(r["avg_us"]) / float(r["us_per_pair"]))
+                if dur > 0 and float(r.get("us_per_pair") or 0) > 0:
+                    ppl = round(dur / float(r["us_per_pair"]))
     except (OSError, KeyError, ValueError):
         return None
     if calls == 0:
         return None
-    return {"file": os.path.relpath(f, ROOT), "avg_launch_us": round(tot_us / calls, 2), "pairs_per_launch": ppl}
+    return {"file": os.path.relpath(f, ROOT), "avg_launch_us": round(tot_us / calls, 2), "statistic": "median of the launches" if "median_us" in r else "average", "pairs_per_launch": ppl}
 
 
 def load_real_pair_for(Wx, Hx):

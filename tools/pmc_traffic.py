@@ -13,7 +13,7 @@ NAMES = {"k_filter_classify": "support_filter", "k_filter_resolve": "support_fil
          "k_amean_sub": "adaptive_mean", "k_raster_tiles": "triangles_raster", "k_lr": "lr_check", "k_lr2": "lr_check", "k_median": "median", "k_planes": "plane_fit",
          "k_ccl_band": "ccl_band", "k_gap_cols": "gap_cols", "k_gap_rows": "gap_rows", "k_grid_mark": "grid_mark", "k_grid_dilate": "grid_dilate",
          "k_raster": "triangles_raster_fallback", "k_ccl_border": "ccl_finish", "k_ccl_total": "ccl_finish", "k_ccl_apply": "ccl_finish", "k_ccl_slow": "ccl_finish",
-         "dg::k_delaunay_blob": "delaunay_gpu", "dg::k_dgl_subtrees_blob": "delaunay_gpu", "dg::k_dgl_top_blob": "delaunay_gpu"}
+         "dg::k_delaunay_blob": "delaunay_gpu", "dg::k_delaunay_resident": "delaunay_gpu", "dg::k_dg_prepare_large_blob": "delaunay_gpu", "dg::k_dgl_subtrees_blob": "delaunay_gpu", "dg::k_dgl_top_blob": "delaunay_gpu"}
 WIDE_READERS = {"k_descriptor"}  # round 1: k_dense, k_support, k_descriptor read / re-read 16-byte descriptors (dwordx4 per lane)
 ap = argparse.ArgumentParser()
 ap.add_argument("table")
