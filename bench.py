@@ -23,6 +23,8 @@ host-share figure, parity) so that a reader of the line's tail sees them.
 Also on the JSON line:
   value_at_host_share_8   the headline measured by a fresh process restricted to 1/8 of this process's CPUs with LOCAL_WORLD_SIZE=8
                   (one rank's host budget on an 8-rank node; launcher.restrict_to_host_share), before this process touches the GPU
+  host_cpu_cores_busy   CPU seconds (user + system, all threads of the process: engine threads, pool, this script) per wall second
+                  of the timed region - what a rank actually takes from the host (also inside `host_share`)
   configs         BASELINE.json's other configurations, each on its own engine behind its own parity gate: kitti_d256
                   (configs[3]) and 4k_d192 (configs[4]; with N > 1 its maps are gathered on rank 0 inside the timed region)
   roofline        the kernel with the largest total time over ALL kernels of the pipelined configuration (the one that is
@@ -523,6 +525,7 @@ def timed_region(torch, engine, left, right, bufs, steps, barrier, sync_steps=Fa
     """`steps` passes over the batch, bracketed by barrier + synchronize on both sides; returns the wall seconds of this rank."""
     B = left.shape[0]
     barrier()
+    c0 = time.process_time()
     t0 = time.perf_counter()
     if gather is not None:
         gather.start(bufs, steps)
@@ -543,7 +546,9 @@ def timed_region(torch, engine, left, right, bufs, steps, barrier, sync_steps=Fa
             engine.submit_device(left, right, bufs[0][0], bufs[0][1])
         engine.wait()
     barrier()
-    return time.perf_counter() - t0
+    el = time.perf_counter() - t0
+    timed_region.host_cpu_seconds = time.process_time() - c0  # all threads of this process (engine threads included), user + system
+    return el
 
 
 def run_config(ctx, name, steps_req, warmup, min_seconds, headline, gather):
@@ -670,7 +675,7 @@ def run_config(ctx, name, steps_req, warmup, min_seconds, headline, gather):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         per_rank = [B * steps / float(x) for x in t.tolist()]
     res.update({"pairs_per_s": round(B * world * steps / elapsed, 2), "ms_per_step": round(1e3 * elapsed / steps, 3), "steps": steps, "steps_requested": steps_req, "warmup": max(1, warmup),
-                "timed_seconds": round(elapsed, 3), "pairs_per_gpu_per_step": B, "per_rank_pairs_per_s": [round(x, 1) for x in per_rank],
+                "timed_seconds": round(elapsed, 3), "host_cpu_cores_busy": round(getattr(timed_region, "host_cpu_seconds", 0.0) / max(my_elapsed, 1e-9), 2), "pairs_per_gpu_per_step": B, "per_rank_pairs_per_s": [round(x, 1) for x in per_rank],
                 "parity_gate": {k: v for k, v in gate.items() if not k.startswith("_")}, "parity_after": after, "engine": engine_info, "valid_fraction": round(float((d1 >= 0).float().mean().item()), 4),
                 "checksum_rank0": float(d1.double().sum().item())})
     # ---- the same run with the finished left maps gathered on rank 0 (RCCL), chunk by chunk, overlapping the kernels
@@ -901,7 +906,7 @@ def main():
             "value": rate,
             "unit": "pairs/s",
             "n_gpus": world, "steps": steps, "steps_requested": args.steps, "warmup": hl["warmup"],
-            "ms_per_step": hl["ms_per_step"], "timed_seconds": hl["timed_seconds"],
+            "ms_per_step": hl["ms_per_step"], "timed_seconds": hl["timed_seconds"], "host_cpu_cores_busy": hl["host_cpu_cores_busy"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": hl["data"],
             "parity_gate": hl["parity_gate"]["status"], "parity_gate_detail": hl["parity_gate"], "parity_after": hl["parity_after"],
@@ -928,7 +933,7 @@ def main():
                 out["host_share"] = {"what": "the headline measured by a fresh process with the host budget of one rank of a %d-rank node: CPU affinity restricted to usable CPUs / %d and LOCAL_WORLD_SIZE=%d "
                                              "before anything touched the GPU (launcher.restrict_to_host_share); same engine defaults, same batch, same parity gate and parity_after" % (args.host_share, args.host_share, args.host_share),
                                      "value": host_share["value"], "ratio_to_value": round(host_share["value"] / rate, 4), "cpus": (host_share.get("host_share_child") or {}).get("cpus"),
-                                     "engine": (host_share.get("config") or {}).get("engine"), "steps": host_share.get("steps"), "timed_seconds": host_share.get("timed_seconds"),
+                                     "engine": (host_share.get("config") or {}).get("engine"), "steps": host_share.get("steps"), "timed_seconds": host_share.get("timed_seconds"), "host_cpu_cores_busy": host_share.get("host_cpu_cores_busy"),
                                      "parity_gate": host_share.get("parity_gate"), "parity_after": (host_share.get("parity_after") or {}).get("status")}
             else:
                 out[key] = None

@@ -104,7 +104,7 @@ typedef struct sv_config {
     int32_t dg_max_points;         /* > 0: largest vertex set the GPU kernels take, larger ones go to the pool (tests)       [SV_GPU_DELAUNAY_MAX] */
     int32_t affinity;              /* host threads on the CPUs of the GPU's NUMA node: 0 auto (when the node has enough allowed CPUs), 2 never [SV_NO_AFFINITY=1] */
     int32_t inline_latency_path;   /* single pairs on a chunk-1 handle driven by the calling thread: 0 auto (on), 2 off       [SV_NO_INLINE=1] */
-    int32_t event_sync;            /* how host threads wait for the GPU: 0 auto (sleep for chunk >= 4, spin below), 1 sleep, 2 spin [SV_EVENT_SYNC=block|spin] */
+    int32_t event_sync;            /* how host threads wait for the GPU: 0 auto (3 for chunk >= 4, 2 below), 1 hipEventBlockingSync, 2 spin, 3 ask the event + 40 us naps [SV_EVENT_SYNC=block|spin|poll] */
     int32_t share_sliced;          /* != 0: a balanced GPU share as a slice of every chunk instead of whole chunks (round-2 behaviour, non-resident only) [SV_GPU_DELAUNAY_SLICED=1] */
     int32_t reserved[6];           /* must be 0 */
 } sv_config;

@@ -144,6 +144,7 @@ struct sv_handle {
     int nproc = 1;  // maps per pair that get post-processed
     int chunk = 1;
     bool block_sync = false;  // host waits on events sleep (throughput mode) instead of spinning (latency mode)
+    bool poll_sync = false;   // ... by asking the event and sleeping 40 us in between (wait_event)
     bool gpu_delaunay = false;  // divide-and-conquer phase of the triangulations on the GPU (delaunay_gpu.hip); the host only orders the vertices
     int gpu_delaunay_pct = 0;   // ... for this share of the pairs (100 in the GPU mode; a part in the host mode relieves the pool)
     int dg_sub_max = 0;           // vertex sets up to this size are triangulated whole in LDS, larger ones as subtrees of at most this size
@@ -212,6 +213,8 @@ struct sv_handle {
     unsigned long long *d_counters = nullptr;  // work counters of the matching kernels (sv_debug_counters)
     uint8_t *dbg_desc = nullptr;               // keep_debug: descriptor images [cap][2][N][16] for the stage snapshot
     bool lat_trace = false;                    // SV_LAT_TRACE=1: wall-clock split of the latency path, printed by sv_destroy
+    double issue_ns[6] = {0, 0, 0, 0, 0, 0};   // lat_trace: issuer wall time in sobel+support launches / filter launches / triangulation launch / copies / event records / waiting for a slot
+    long issue_chunks = 0;
     double lat_ns[8] = {0};
     long lat_calls = 0;
     double drain_ns[3] = {0};  // drainer, per chunk: waiting for phase 2, downloading, handing pageable maps over
@@ -234,7 +237,7 @@ namespace {
 bool env_int(const char *name, int *out) {
     const char *e = getenv(name);
     if (!e || !*e) return false;
-    if (out) *out = !strcmp(e, "block") ? 1 : (!strcmp(e, "spin") ? 2 : atoi(e));
+    if (out) *out = !strcmp(e, "block") ? 1 : (!strcmp(e, "spin") ? 2 : (!strcmp(e, "poll") ? 3 : atoi(e)));
     return true;
 }
 
@@ -256,7 +259,7 @@ void apply_env_overrides(sv_config &c) {
     if (env_int("SV_RESIDENT", &v)) c.resident = v ? 0 : 2;
     if (env_int("SV_NO_AFFINITY", &v)) c.affinity = 2;
     if (env_int("SV_NO_INLINE", &v)) c.inline_latency_path = 2;
-    if (env_int("SV_EVENT_SYNC", &v)) c.event_sync = v == 1 ? 1 : 2;
+    if (env_int("SV_EVENT_SYNC", &v)) c.event_sync = v == 1 ? 1 : (v == 3 ? 3 : 2);
 }
 
 int validate(const sv_params &p, const sv_config &c, std::string &err) {
@@ -476,13 +479,32 @@ void dbg_grid(sv_handle *h, hipStream_t st, Slot *s, int j) {
     dbg_put(h, "grid_dims", gd, 3);
 }
 
+// A host thread waits for an event of the pipeline.
+hipError_t wait_event(const sv_handle *h, hipEvent_t ev) {
+    if (!h->poll_sync) return hipEventSynchronize(ev);
+    for (;;) {
+        const hipError_t r = hipEventQuery(ev);
+        if (r != hipErrorNotReady) return r;
+        const struct timespec ts = {0, 40000};
+        nanosleep(&ts, nullptr);
+    }
+}
+
 // ---- stage 1: issuer ---------------------------------------------------------------------------------------------------
 void issue_phase1(sv_handle *h, Slot *s) {
     const KParams &k = h->kp;
     const Dims &d = k.d;
     const int lat = d.Wc * d.Hc;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](int what) {  // lat_trace: where the issuing thread's time goes
+        if (!h->lat_trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        h->issue_ns[what] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(now - t_last).count();
+        t_last = now;
+    };
     launch_sobel(k, s->in_left, s->in_right, s->in_pair, s->in_stride, s->dev, s->n, h->sP1);
     launch_support(k, s->dev, s->n, h->sP1);
+    lap(0);
     hipStream_t tail = h->sP1;
     if (h->gpu_filter) {
         // the filter is one long-running workgroup per pair: on its own stream it does not hold up the next chunk's phase 1
@@ -491,6 +513,7 @@ void issue_phase1(sv_handle *h, Slot *s) {
         h->pf_turn = (h->pf_turn + 1) % h->n_pf;
         HIP_TRY(hipStreamWaitEvent(tail, s->ev_sup, 0));
         launch_support_filter(k, h->p.incon_window_size, h->p.incon_threshold, h->p.incon_min_support, s->dev, s->n, tail);
+        lap(1);
         if (s->resident) {
             // the support lists stay where they are: preparation and triangulation of both sides of every pair in one launch, straight
             // from the filter's buffers into the blob (laid out by the kernel); only the meta words come back - counts for the launch
@@ -501,6 +524,7 @@ void issue_phase1(sv_handle *h, Slot *s) {
             launch_delaunay_resident(s->dev.fsup, s->dev.fnsup, s->dev.blob, s->dev.cap, d.max_pts, blob_pair_words(d), s->n, bound, bound, d.W, d.H, d.step, d.disp_max, tail,
                                      large ? h->dg_sub_max : 0x7FFFFFFF, large ? h->dg_limit : 0);
             if (large) launch_delaunay_resident_large(s->dev.blob, s->n, h->dg_sub_max, h->dg_limit, d.W, d.H, d.step, d.disp_max, s->dev.dg.prep, s->dev.dg, tail);
+            lap(2);
             HIP_TRY(hipMemcpyAsync(s->h_blob, s->dev.blob, sizeof(int32_t) * META_WORDS * (size_t)s->n, hipMemcpyDeviceToHost, tail));
         } else {
             HIP_TRY(hipMemcpyAsync(s->h_fnsup, s->dev.fnsup, sizeof(int32_t) * (size_t)s->n, hipMemcpyDeviceToHost, tail));
@@ -511,8 +535,11 @@ void issue_phase1(sv_handle *h, Slot *s) {
     }
     if (!h->gpu_filter || h->cfg.keep_debug)
         HIP_TRY(hipMemcpyAsync(s->h_dcan, s->dev.dcan, sizeof(int16_t) * (size_t)s->n * lat, hipMemcpyDeviceToHost, tail));
+    lap(3);
     HIP_TRY(hipGetLastError());  // a rejected phase-1 launch must not leave the previous chunk's lattices to the host stage
     HIP_TRY(hipEventRecord(s->ev_p1, tail));
+    lap(4);
+    if (h->lat_trace) h->issue_chunks++;
     if (h->cfg.keep_debug) {
         const int j = s->n - 1;
         HIP_TRY(hipStreamSynchronize(tail));
@@ -763,10 +790,12 @@ void issuer_main(sv_handle *h) {
             h->ring_pos = (h->ring_pos + 1) % ns;
             bool drain = false;
             {
+                const auto w0 = std::chrono::steady_clock::now();
                 std::unique_lock<std::mutex> lk(h->mu);
                 h->cv.wait(lk, [&] { return s->state != SLOT_BUSY; });
                 drain = s->state == SLOT_DRAINING;
                 s->state = SLOT_BUSY;
+                if (h->lat_trace) h->issue_ns[5] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
             }
             s->job = job;
             s->i0 = c * h->chunk;
@@ -785,7 +814,7 @@ void issuer_main(sv_handle *h) {
                 }
             }
             try {
-                if (drain) HIP_TRY(hipEventSynchronize(s->ev_free));
+                if (drain) HIP_TRY(wait_event(h, s->ev_free));
                 if (!h->failed) {
                     if (job->host) {  // images: caller -> (page-locked mirror ->) device on the upload stream; phase 1 waits for them
                         upload_chunk(h, s, h->sIn, 3);
@@ -1040,7 +1069,7 @@ void dispatcher_main(sv_handle *h) {
         }
         bool ok = !h->failed;
         if (ok) {
-            if (hipEventSynchronize(s->ev_p1) != hipSuccess) {
+            if (wait_event(h, s->ev_p1) != hipSuccess) {
                 note_error(h, "hipEventSynchronize(phase 1) failed");
                 ok = false;
             }
@@ -1240,7 +1269,7 @@ void download_chunk(sv_handle *h, Slot *s) {
     if (!only_left) download_maps(h, s, 1, h->sOut, h->sOut2);
     HIP_TRY(hipEventRecord(s->ev_out, h->sOut));
     HIP_TRY(hipStreamSynchronize(h->sOut2));
-    HIP_TRY(hipEventSynchronize(s->ev_out));
+    HIP_TRY(wait_event(h, s->ev_out));
 }
 
 void finisher_main(sv_handle *h) {
@@ -1444,6 +1473,8 @@ bool gpu_node_cpus(int device, cpu_set_t *out) {
 void bind_thread(std::thread &t, const cpu_set_t *set) {
     if (set) (void)pthread_setaffinity_np(t.native_handle(), sizeof(cpu_set_t), set);
 }
+
+void name_thread(std::thread &t, const char *name) { (void)pthread_setname_np(t.native_handle(), name); }  // (shows in /proc/<pid>/task/*/comm: tools/thread_cpu.py)
 
 template <class T>
 void dev_alloc(T *&p, size_t count) {
@@ -1692,7 +1723,7 @@ int wait_first_jobs(sv_handle *h, int n) {
     }
     (void)hipSetDevice(h->cfg.device);
     bool ok = true;
-    for (hipEvent_t e : evs) ok = (hipEventSynchronize(e) == hipSuccess) && ok;
+    for (hipEvent_t e : evs) ok = (wait_event(h, e) == hipSuccess) && ok;
     if (need_streams)
         for (hipStream_t st : h->sP2) ok = (hipStreamSynchronize(st) == hipSuccess) && ok;
     if (!ok) note_error(h, "waiting for the batches' completion events failed");
@@ -1968,7 +1999,11 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     }
     h->ns_bound.store(std::min(h->dg_sub_max, delaunay_prep_max_points()));
     h->shared_pct.store(h->auto_pct);
-    h->block_sync = cfg->event_sync == 1 || (cfg->event_sync == 0 && h->chunk >= 4);
+    // Throughput mode (chunk >= 4): the waiting threads ask the event and nap.  hipEventSynchronize on a hipEventBlockingSync event was
+    // measured at 0.9 of a core in the dispatcher plus 0.8 in the issuer while it waits (ROCm 7.2; tools/thread_cpu.py: 2.8 cores busy
+    // against 1.1 at the same rate with one pool thread) - two of the two CPUs a rank has on a node shared by eight.
+    h->block_sync = cfg->event_sync == 1 || cfg->event_sync == 3 || (cfg->event_sync == 0 && h->chunk >= 4);
+    h->poll_sync = cfg->event_sync == 3 || (cfg->event_sync == 0 && h->chunk >= 4);
     try {
         HIP_TRY(hipSetDevice(cfg->device));
         HIP_TRY(hipStreamCreateWithFlags(&h->sP1, hipStreamNonBlocking));
@@ -2006,6 +2041,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         h->scratch.push_back(sc);
         h->pool.emplace_back(pool_main, h, sc);
         bind_thread(h->pool.back(), bind);
+        name_thread(h->pool.back(), "sv-pool");
     }
     h->inline_scratch = new HostScratch();
     h->inline_ok = cfg->inline_latency_path != 2;
@@ -2020,6 +2056,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     h->t_drain = std::thread(drainer_main, h);
     h->t_deliver = std::thread(deliverer_main, h);
     for (std::thread *t : {&h->t_issue, &h->t_dispatch, &h->t_finish, &h->t_drain, &h->t_deliver}) bind_thread(*t, bind);
+    name_thread(h->t_issue, "sv-issue"), name_thread(h->t_dispatch, "sv-dispatch"), name_thread(h->t_finish, "sv-finish"), name_thread(h->t_drain, "sv-drain"), name_thread(h->t_deliver, "sv-deliver");
     *out = h;
     return SV_OK;
 }
@@ -2027,6 +2064,10 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
 int sv_destroy(sv_handle *h) {
     if (!h) return SV_ERR_ARG;
     (void)wait_jobs(h);
+    if (h->lat_trace && h->issue_chunks > 0)
+        fprintf(stderr, "issuer, %ld chunks, ms of wall clock per chunk: sobel + support launches %.3f, filter launches %.3f, triangulation launch %.3f, copies %.3f, event record %.3f, waiting for a slot %.3f\n",
+                h->issue_chunks, 1e-6 * h->issue_ns[0] / (double)h->issue_chunks, 1e-6 * h->issue_ns[1] / (double)h->issue_chunks, 1e-6 * h->issue_ns[2] / (double)h->issue_chunks,
+                1e-6 * h->issue_ns[3] / (double)h->issue_chunks, 1e-6 * h->issue_ns[4] / (double)h->issue_chunks, 1e-6 * h->issue_ns[5] / (double)h->issue_chunks);
     if (h->lat_trace && h->drain_chunks > 0)
         fprintf(stderr, "host-memory path, %ld chunks, ms per chunk: wait for phase 2 %.3f, download %.3f, deliver %.3f\n", h->drain_chunks,
                 1e-6 * h->drain_ns[0] / (double)h->drain_chunks, 1e-6 * h->drain_ns[1] / (double)h->drain_chunks, 1e-6 * h->drain_ns[2] / (double)h->drain_chunks);

@@ -150,11 +150,12 @@ class StereoEngine:
     """
 
     def __init__(self, width, height, params=None, device=0, n_workers=0, chunk=0, keep_debug=False, n_streams=0, n_slots=0, gpu_filter=None,
-                 triangulation=None, resident=None, dg_sub_max=0, dg_max_points=0, affinity=None, inline=None, share_sliced=False):
+                 triangulation=None, resident=None, dg_sub_max=0, dg_max_points=0, affinity=None, inline=None, share_sliced=False, event_sync=None):
         """gpu_filter: None (automatic) / True / False - where the support-lattice filters run.  triangulation: None or "auto", "gpu", "host",
         "balanced" (by the pool's backlog, whatever its size) or an int 1..100 = that share of the chunks on the GPU.  resident / affinity /
         inline: None (automatic) or False to switch the resident GPU share / the NUMA binding / the calling-thread latency path off.
-        dg_sub_max, dg_max_points: limits of the GPU triangulation (tests).  See sv_config in include/stereo_vision_hip.h."""
+        dg_sub_max, dg_max_points: limits of the GPU triangulation (tests).  event_sync: None (automatic), "block", "spin" or "poll" - how the
+        handle's threads wait for the GPU.  See sv_config in include/stereo_vision_hip.h."""
         L = lib()
         self.params = params if params is not None else SvParams.driver(127)
         self.width, self.height, self.device = int(width), int(height), int(device)
@@ -171,6 +172,7 @@ class StereoEngine:
         cfg.affinity = 2 if affinity is False else 0
         cfg.inline_latency_path = 2 if inline is False else 0
         cfg.share_sliced = int(bool(share_sliced))
+        cfg.event_sync = {None: 0, "auto": 0, "block": 1, "spin": 2, "poll": 3}[event_sync]
         h = ctypes.c_void_p()
         rc = L.sv_create(ctypes.byref(self.params), ctypes.byref(cfg), ctypes.byref(h))
         if rc != 0:
