@@ -144,6 +144,8 @@ struct sv_handle {
     int nproc = 1;  // maps per pair that get post-processed
     int chunk = 1;
     bool block_sync = false;  // host waits on events sleep (throughput mode) instead of spinning (latency mode)
+    int ns_margin_pct = 12;   // head room of the resident launch's LDS request over the largest set seen (SV_DG_MARGIN; 90: -7 % pairs/s, 25 -> 5: +0.7 %;
+                              // a set beyond the request is handed to the pool, and the request grows at once)
     bool poll_sync = false;   // ... by asking the event and sleeping 40 us in between (wait_event)
     bool gpu_delaunay = false;  // divide-and-conquer phase of the triangulations on the GPU (delaunay_gpu.hip); the host only orders the vertices
     int gpu_delaunay_pct = 0;   // ... for this share of the pairs (100 in the GPU mode; a part in the host mode relieves the pool)
@@ -1105,7 +1107,7 @@ void dispatcher_main(sv_handle *h) {
             h->tri_pairs.fetch_add(s->n, std::memory_order_relaxed);
             h->gpu_tri_pairs.fetch_add(s->n, std::memory_order_relaxed);
             {  // grow at once, shrink slowly: a launch whose LDS request is too small hands its large sets to the host
-                const int target = std::min(h->dg_sub_max, seen + seen / 4 + 64), cur = h->ns_bound.load(std::memory_order_relaxed);
+                const int target = std::min(h->dg_sub_max, seen + seen * h->ns_margin_pct / 100 + 32), cur = h->ns_bound.load(std::memory_order_relaxed);
                 h->ns_bound.store(target > cur ? target : cur - (cur - target + 3) / 4, std::memory_order_relaxed);
             }
             s->gpu_pct = 0;
@@ -2049,6 +2051,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         int v = 0;
         h->lat_trace = env_int("SV_LAT_TRACE", &v);  // (also sv_debug_set "lat_trace")
         h->pool_sleep = env_int("SV_POOL_SLEEP", &v);
+        if (env_int("SV_DG_MARGIN", &v)) h->ns_margin_pct = std::max(0, v);
     }
     h->t_issue = std::thread(issuer_main, h);
     h->t_dispatch = std::thread(dispatcher_main, h);
