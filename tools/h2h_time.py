@@ -23,6 +23,9 @@ ap.add_argument("--pageable", action="store_true")
 ap.add_argument("--d2", action="store_true")
 ap.add_argument("--dmap", action="store_true")
 ap.add_argument("--trace", action="store_true")
+ap.add_argument("--slots", type=int, default=0)
+ap.add_argument("--chunk", type=int, default=0)
+ap.add_argument("--workers", type=int, default=0)
 a = ap.parse_args()
 pkg = [d for d in os.listdir(ROOT) if d.endswith("_amd")][0]
 eng = importlib.import_module(pkg + ".engine")
@@ -33,7 +36,7 @@ batch = np.concatenate([batch] * (a.batch // 32))
 alloc = (lambda shape, dt: np.zeros(shape, dt)) if a.pageable else eng.pinned_array
 L, R = alloc((a.batch, H, W), np.uint8), alloc((a.batch, H, W), np.uint8)
 L[:], R[:] = batch[:, 0], batch[:, 1]
-e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1))
+e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), n_slots=a.slots, chunk=a.chunk, n_workers=a.workers)
 if a.trace:
     e.debug_set("lat_trace", 1)
 rates = []
@@ -52,5 +55,5 @@ for _ in range(a.reps):
         sub()
     e.wait()
     rates.append(a.batch * a.steps / (time.perf_counter() - t0))
-print(os.environ.get("SV_LIB_PATH", "default"), "pageable" if a.pageable else "pinned", "dmap" if a.dmap else ("d1+d2" if a.d2 else "d1"), " ".join("%.0f" % r for r in rates), flush=True)
+print(os.environ.get("SV_LIB_PATH", "default"), "slots %d chunk %d" % (a.slots, a.chunk), "pageable" if a.pageable else "pinned", "dmap" if a.dmap else ("d1+d2" if a.d2 else "d1"), " ".join("%.0f" % r for r in rates), flush=True)
 e.close()
