@@ -168,7 +168,7 @@ struct sv_handle {
     bool gpu_filter = false;  // lattice filters on the GPU (k_support_filter) instead of the host pool
     std::vector<Slot *> slots;
     int n_pf = 2;                                             // filter streams in use: 2; 4 where the triangulation chain of a 4K chunk (8 ms) follows the filter on them
-    hipStream_t sP1 = nullptr, sPF[4] = {nullptr, nullptr, nullptr, nullptr};  // phase 1; lattice filter + its D2H (streams taken in turns:
+    hipStream_t sP1 = nullptr, sPF[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // phase 1; lattice filter + its D2H (streams taken in turns:
                                                                 // a 4K lattice keeps its one workgroup per pair busy for milliseconds)
     int pf_turn = 0;                                             // (issuer thread only)
     std::vector<hipStream_t> sP2;
@@ -2010,6 +2010,10 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         HIP_TRY(hipSetDevice(cfg->device));
         HIP_TRY(hipStreamCreateWithFlags(&h->sP1, hipStreamNonBlocking));
         h->n_pf = (h->resident_ok && h->dg_limit > h->dg_sub_max) ? 4 : 2;
+        {
+            int v = 0;
+            if (env_int("SV_PF_STREAMS", &v)) h->n_pf = std::max(1, std::min(v, 8));  // experiments
+        }
         for (int i = 0; i < h->n_pf; i++) HIP_TRY(hipStreamCreateWithFlags(&h->sPF[i], hipStreamNonBlocking));
         for (int i = 0; i < np2; i++) {
             hipStream_t st;
