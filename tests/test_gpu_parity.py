@@ -744,3 +744,30 @@ def test_policy_fields_of_the_configuration(eng):
         b.close()
     assert (qa["gpu_lattice_filter"], qa["gpu_triangulation"], qa["resident"], qa["numa_bound"]) == (0, 0, 0, 0)
     assert (qb["gpu_lattice_filter"], qb["gpu_triangulation"], qb["resident"]) == (1, 1, 1)
+
+
+@pytest.mark.parametrize("mode", ["block", "spin", "poll"])
+def test_the_ways_host_threads_wait_give_the_same_maps(eng, mode):
+    """sv_config.event_sync: hipEventBlockingSync events, spinning, or asking the event between 40 us naps (the default for chunks of
+    four pairs and more) - streamed batches through a small pipeline, device and host memory, against the automatic mode."""
+    import torch
+    B, H, W, D = 12, 120, 320, 64
+    batch = util.pkg("synth").make_batch(4200, B, H, W, D)
+    left = torch.from_numpy(np.ascontiguousarray(batch[:, 0])).cuda()
+    right = torch.from_numpy(np.ascontiguousarray(batch[:, 1])).cuda()
+    p = eng.SvParams.driver(D - 1)
+    ref = eng.StereoEngine(W, H, p, chunk=4, n_slots=2)
+    e = eng.StereoEngine(W, H, p, chunk=4, n_slots=2, event_sync=mode)
+    try:
+        r1, r2 = ref.process_device(left, right)
+        outs = [(torch.empty_like(r1), torch.empty_like(r2)) for _ in range(3)]
+        for d1, d2 in outs:  # three batches in flight
+            e.submit_device(left, right, d1, d2)
+        e.wait()
+        for d1, d2 in outs:
+            assert torch.equal(d1, r1) and torch.equal(d2, r2)
+        h1, h2, _ = e.process_host(np.ascontiguousarray(batch[:, 0]), np.ascontiguousarray(batch[:, 1]), want_d2=True)
+        assert np.array_equal(h1, r1.cpu().numpy()) and np.array_equal(h2, r2.cpu().numpy())
+    finally:
+        e.close()
+        ref.close()
