@@ -4,6 +4,7 @@ set -e
 TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 R=profile_run.py
+if [ "$2" != "configs-only" ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_kt -- python3 tools/$R --chunk 32 --batch 64 > gpurun_out/p_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/p_f -- python3 tools/$R --chunk 32 --batch 64 --reps 3 > gpurun_out/p_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/p_w -- python3 tools/$R --chunk 32 --batch 64 --reps 3 > gpurun_out/p_w.log 2>&1
@@ -16,3 +17,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_g -- python
 python tools/summarize_rocprof.py --stats gpurun_out/p_g --pairs-per-launch 64 -o gpurun_out/${TAG}_bench_pipelined_one_host_thread_kernel_stats.csv
 rm -rf gpurun_out/p_kt gpurun_out/p_f gpurun_out/p_w gpurun_out/p_sq gpurun_out/p_b gpurun_out/p_g
 tail -c 300 gpurun_out/p_b.log; tail -c 300 gpurun_out/p_g.log
+fi
+# BASELINE.json's other configurations, no-overlap passes (kernel trace only): D = 256 at KITTI size, and one 4K D = 192 chunk with the
+# triangulations resident on the GPU (the cut path's kernels) - tools/collect_profiles.sh TAG configs | configs-only
+if [ "$2" = "configs" ] || [ "$2" = "configs-only" ]; then
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_d256 -- python3 tools/$R --chunk 32 --batch 64 --disp 256 > gpurun_out/p_d256.log 2>&1
+    python tools/summarize_rocprof.py --stats gpurun_out/p_d256 --pairs-per-launch 32 -o gpurun_out/${TAG}_serial_d256_kernel_stats.csv
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p_4k -- python3 tools/profile_4k.py --reps 9 > gpurun_out/p_4k.log 2>&1
+    python tools/summarize_rocprof.py --stats gpurun_out/p_4k --pairs-per-launch 16 -o gpurun_out/${TAG}_serial_4k_d192_resident_kernel_stats.csv
+    rm -rf gpurun_out/p_d256 gpurun_out/p_4k
+fi
