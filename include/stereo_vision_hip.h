@@ -106,7 +106,8 @@ typedef struct sv_config {
     int32_t inline_latency_path;   /* single pairs on a chunk-1 handle driven by the calling thread: 0 auto (on), 2 off       [SV_NO_INLINE=1] */
     int32_t event_sync;            /* how host threads wait for the GPU: 0 auto (3 for chunk >= 4, 2 below), 1 hipEventBlockingSync, 2 spin, 3 ask the event + 40 us naps [SV_EVENT_SYNC=block|spin|poll] */
     int32_t share_sliced;          /* != 0: a balanced GPU share as a slice of every chunk instead of whole chunks (round-2 behaviour, non-resident only) [SV_GPU_DELAUNAY_SLICED=1] */
-    int32_t reserved[6];           /* must be 0 */
+    int32_t latency_split;         /* single pairs: 0 each triangulation on one thread (default), 1 halves / 2 quarters of the top-level cuts on pool threads [SV_LATENCY_SPLIT=1|2] */
+    int32_t reserved[5];           /* must be 0 */
 } sv_config;
 
 int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out);

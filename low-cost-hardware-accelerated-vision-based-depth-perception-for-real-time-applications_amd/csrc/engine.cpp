@@ -112,6 +112,9 @@ struct Slot {
     int gpu_pct = 0;            // share of this chunk's pairs whose triangulations go to the GPU kernel (set by the dispatcher)
     bool resident = false;      // this chunk's support lists stay on the device: preparation + triangulation by k_delaunay_resident in phase 1 (set by the issuer)
     bool grid_issued = false;   // latency mode: the candidate grid of this chunk was launched while the host still triangulated
+    sv_handle *grid_h = nullptr;  // ... by early_grid_launch, possibly on a pool thread: its arguments
+    size_t grid_off = 0;
+    int grid_ns = 0;
     bool delivered_ok = false;  // host-memory jobs: the download succeeded (drainer -> deliverer)
     bool out_enqueued = false;  // host-memory jobs: phase 2 was enqueued (ev_lr / ev_p2 are pending), the maps can be downloaded
     int state = SLOT_FREE;
@@ -154,9 +157,11 @@ struct sv_handle {
     bool gpu_share_auto = false;  // host mode: the dispatcher moves that share up while the pool falls behind the GPU, down while it idles
     int auto_pct = 0, auto_acc = 0;  // (dispatcher thread only)
     bool share_sliced = false;    // the GPU kernel's share as a slice of every chunk instead of whole chunks
+    int latency_split = 0;        // latency mode: depth of the triangulations' top levels shared with pool threads (0: none)
     int dbg_ccl_cap = 0, dbg_rt_cap = -1;  // sv_debug_set: overrides of the speckle stage's run-table size / the raster tile lists' size
     bool force_staging = false;            // sv_debug_set "host_force_staging"
     bool pool_sleep = false;               // sv_debug_set "pool_sleep"
+    std::atomic<int> pollers{0};           // latency mode: pool threads polling the queue length right now
     bool resident_ok = false;     // the GPU's share of the chunks is built without the support lists ever leaving the device (k_delaunay_resident)
     std::atomic<int> shared_pct{0};   // host mode with a balanced share: the dispatcher's current share, read by the issuer (who decides per chunk)
     int issue_acc = 0;                // (issuer thread only) accumulator that turns the share into whole chunks
@@ -218,6 +223,7 @@ struct sv_handle {
     double issue_ns[6] = {0, 0, 0, 0, 0, 0};   // lat_trace: issuer wall time in sobel+support launches / filter launches / triangulation launch / copies / event records / waiting for a slot
     long issue_chunks = 0;
     double lat_ns[8] = {0};
+    double lat_sub_ns[3] = {0};  // lat_trace, inside "filter + left triangulation": lattice filters, hand-over (grid upload + launch, right-side task), left triangulation
     long lat_calls = 0;
     double drain_ns[3] = {0};  // drainer, per chunk: waiting for phase 2, downloading, handing pageable maps over
     long drain_chunks = 0;
@@ -261,6 +267,7 @@ void apply_env_overrides(sv_config &c) {
     if (env_int("SV_RESIDENT", &v)) c.resident = v ? 0 : 2;
     if (env_int("SV_NO_AFFINITY", &v)) c.affinity = 2;
     if (env_int("SV_NO_INLINE", &v)) c.inline_latency_path = 2;
+    if (env_int("SV_LATENCY_SPLIT", &v)) c.latency_split = v > 0 ? (v > 1 ? 2 : 1) : 0;
     if (env_int("SV_EVENT_SYNC", &v)) c.event_sync = v == 1 ? 1 : (v == 3 ? 3 : 2);
 }
 
@@ -899,10 +906,12 @@ void triangulate_side(sv_handle *h, HostScratch *sc, Slot *s, int j, int side) {
         ord[0] = -1;
         h->gpu_tri_fallbacks.fetch_add(1, std::memory_order_relaxed);
     }
-    // latency mode: the halves of the top-level cut go to two threads (throughput mode keeps every core busy with whole pairs)
-    // (two triangulations at a time: halves need 4 threads, quarters 8, counting the calling thread)
-    const Delaunay::Spawn spawn{spawn_to_pool, h, h->pool.size() >= 7 ? 2 : 1};
-    const int nt = sc->dl.triangulate(sc->xy.data(), ns, blob + meta[3 + 2 * side], 2 * ns, (h->chunk == 1 && h->pool.size() >= 3) ? &spawn : nullptr);
+    // latency mode, on request (sv_config.latency_split): the halves (2: quarters) of the top-level cuts go to other threads.  Off by
+    // default: on the test hosts a KITTI set takes 136 us on one thread and 146 - 199 us shared (tools/latency_trace.py: the halves'
+    // triangles come back from another core's cache for the seam and for the output pass); throughput mode keeps every core busy with
+    // whole pairs anyway.  (Two triangulations at a time: halves need 4 threads, quarters 8, counting the calling thread.)
+    const Delaunay::Spawn spawn{spawn_to_pool, h, (h->latency_split >= 2 && h->pool.size() >= 7) ? 2 : 1};
+    const int nt = sc->dl.triangulate(sc->xy.data(), ns, blob + meta[3 + 2 * side], 2 * ns, (h->chunk == 1 && h->latency_split > 0 && h->pool.size() >= 3) ? &spawn : nullptr);
     if (h->timing) h->host_delaunay_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     if (nt < 0 || nt > d.max_tri) {
         note_error(h, "triangle capacity exceeded");
@@ -910,6 +919,20 @@ void triangulate_side(sv_handle *h, HostScratch *sc, Slot *s, int j, int side) {
         return;
     }
     meta[2 + 2 * side] = nt;
+}
+
+// Latency mode: meta words + support points of the slot's single pair to the device and the candidate-grid kernels behind them (phase-2
+// stream), while the triangulations are still being built.
+void early_grid_launch(Slot *s) {
+    sv_handle *h = s->grid_h;
+    try {
+        hipStream_t st = h->sP2[0];
+        HIP_TRY(hipMemcpyAsync(s->dev.blob, s->h_blob, sizeof(int32_t) * META_WORDS, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(s->dev.blob + s->grid_off, s->h_blob + s->grid_off, sizeof(int32_t) * (size_t)s->grid_ns * 3, hipMemcpyHostToDevice, st));
+        launch_grid(h->kp, s->dev, 1, s->grid_ns, st);
+    } catch (const std::exception &e) {
+        note_error(h, e.what());
+    }
 }
 
 void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
@@ -960,6 +983,7 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
         return;
     }
     if ((int)sc->sup.size() < d.max_pts * 3) sc->sup.resize((size_t)d.max_pts * 3);
+    const auto t_task0 = std::chrono::steady_clock::now();
     int ns;
     if (h->gpu_filter) {  // the lattice filters already ran on the GPU (k_support_filter): just pick up the list
         ns = s->h_fnsup[t.pair];
@@ -986,6 +1010,7 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
         }
     }
     if (h->timing) h->host_tasks += 1;
+    const auto t_filtered = std::chrono::steady_clock::now();
     if (s->job->status) s->job->status[s->i0 + t.pair] = ns;
     meta[0] = ns;
     meta[1] = meta[3] = meta[5] = 0;
@@ -1014,38 +1039,69 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
     meta[3] = (int32_t)(off + (size_t)ns * 3);
     meta[5] = (int32_t)(off + (size_t)ns * 3 + (size_t)2 * ns * 3);
     memcpy(blob + off, sc->sup.data(), sizeof(int32_t) * (size_t)ns * 3);
-    if (s->inline_mode && !meta[7]) {
-        // latency mode (this is the calling thread): the candidate grid only needs the support points - upload them and launch
-        // it now, so that it runs while the two triangulations are built
-        try {
-            hipStream_t st = h->sP2[0];
-            HIP_TRY(hipMemcpyAsync(s->dev.blob, blob, sizeof(int32_t) * META_WORDS, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(s->dev.blob + off, blob + off, sizeof(int32_t) * (size_t)ns * 3, hipMemcpyHostToDevice, st));
-            launch_grid(h->kp, s->dev, 1, ns, st);
-            s->grid_issued = true;
-        } catch (const std::exception &e) {
-            note_error(h, e.what());
-        }
+    // latency mode (this is the calling thread): the candidate grid only needs the support points - they are uploaded and the grid is
+    // launched now, so that it runs while the two triangulations are built.  With two or more pool threads one of them makes those four
+    // runtime calls (15 - 20 us) while this thread starts on the left triangulation; the chunk counts it as one more pending piece.
+    const bool early_grid = s->inline_mode && !meta[7];
+    const bool grid_on_pool = early_grid && h->pool.size() >= 2;
+    if (early_grid) {
+        s->grid_h = h, s->grid_off = off, s->grid_ns = ns;
+        s->grid_issued = true;  // (phase 2 is enqueued only after every pending piece has reported)
+        if (grid_on_pool)
+            s->pending.fetch_add(1);
+        else
+            early_grid_launch(s);
     }
     {
         std::lock_guard<std::mutex> lk(h->qmu);
+        if (grid_on_pool) {
+            Task g{nullptr, 0, 0};
+            g.fn = [](void *arg) {
+                Slot *sl = static_cast<Slot *>(arg);
+                early_grid_launch(sl);
+                pair_done(sl->grid_h, sl);
+            };
+            g.arg = s;
+            h->queue.push_front(g);
+            h->queue_len.fetch_add(1, std::memory_order_release);
+        }
         h->queue.push_front(Task{s, t.pair, 1});
         h->queue_len.fetch_add(1, std::memory_order_release);
     }
-    h->qcv.notify_one();
+    // (a poller that gives up just now still finds the queue non-empty when it takes the lock to wait: nothing is lost without a notify)
+    if (h->pollers.load(std::memory_order_acquire) < (grid_on_pool ? 2 : 1)) {
+        if (grid_on_pool)
+            h->qcv.notify_all();
+        else
+            h->qcv.notify_one();
+    }
+    const auto t_handed = std::chrono::steady_clock::now();
     triangulate_side(h, sc, s, t.pair, 0);
+    if (s->inline_mode && h->lat_trace) {
+        const auto t_end = std::chrono::steady_clock::now();
+        h->lat_sub_ns[0] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t_filtered - t_task0).count();
+        h->lat_sub_ns[1] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t_handed - t_filtered).count();
+        h->lat_sub_ns[2] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t_end - t_handed).count();
+    }
     if (__atomic_add_fetch(&meta[6], 1, __ATOMIC_ACQ_REL) == 2) pair_done(h, s);
 }
 
-void pool_main(sv_handle *h, HostScratch *sc) {
+void pool_main(sv_handle *h, HostScratch *sc, int idx) {
     (void)hipSetDevice(h->cfg.device);  // run_task may fetch a long support list from the handle's device
-    // Latency mode (chunk 1): a frame hands over pieces of its two triangulations several times within ~0.2 ms, and waking a
-    // thread that sleeps on the condition variable costs 30-50 us each time.  There the pool polls the queue length for a
-    // while (about a frame period of continuous use) before it goes to sleep; throughput handles sleep at once.
+    // Latency mode (chunk 1): a frame hands over the right triangulation and the early grid launch (and, on request, pieces of the
+    // triangulations) within ~0.2 ms, and waking a thread that sleeps on the condition variable costs 30-50 us each time.  There the
+    // first few pool threads - as many as a frame has pieces - poll the queue length for a while (about a frame period of continuous
+    // use) before they go to sleep; the others, and throughput handles, sleep at once.  (All 14 polling: 15 busy threads on a 16-CPU
+    // quota, and a notify_all that costs the calling thread 19 us.)  A producer that finds enough pollers does not notify at all.
+    const int hot = 2 + (h->latency_split >= 2 ? 6 : (h->latency_split == 1 ? 2 : 0));
     for (;;) {
         Task t;
-        const int spin_rounds = h->chunk == 1 && !h->pool_sleep ? 400000 : 0;
-        for (int i = 0; i < spin_rounds && h->queue_len.load(std::memory_order_acquire) == 0; i++) __builtin_ia32_pause();
+        const int spin_rounds = h->chunk == 1 && idx < hot && !h->pool_sleep ? 400000 : 0;
+        if (spin_rounds) {
+            h->pollers.fetch_add(1, std::memory_order_acq_rel);
+            for (int i = 0; i < spin_rounds && h->queue_len.load(std::memory_order_acquire) == 0; i++) __builtin_ia32_pause();
+            h->pollers.fetch_sub(1, std::memory_order_acq_rel);
+        }
         {
             std::unique_lock<std::mutex> lk(h->qmu);
             h->qcv.wait(lk, [&] { return h->pool_quit || !h->queue.empty(); });
@@ -1979,6 +2035,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     // no fixed share: it follows the pool's backlog (42 600 against 40 100 pairs/s with 14 threads in round 2)
     h->gpu_share_auto = !h->gpu_delaunay && (mode == 0 || mode == 4) && gpu_capable;
     h->share_sliced = cfg->share_sliced != 0;
+    h->latency_split = std::max(0, std::min(cfg->latency_split, 2));
     // start where the balance was measured to settle (4 ... 14 threads); a handle with fewer than four slots cannot build up a backlog
     if (h->gpu_share_auto && nslots >= 4) h->auto_pct = std::max(0, std::min(95, 117 - 7 * npool));
     if (!(h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0)) h->dg_limit = h->dg_sub_max;  // the pool triangulates everything: no scratch
@@ -2045,7 +2102,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     for (int i = 0; i < npool; i++) {
         HostScratch *sc = new HostScratch();
         h->scratch.push_back(sc);
-        h->pool.emplace_back(pool_main, h, sc);
+        h->pool.emplace_back(pool_main, h, sc, i);
         bind_thread(h->pool.back(), bind);
         name_thread(h->pool.back(), "sv-pool");
     }
@@ -2082,6 +2139,8 @@ int sv_destroy(sv_handle *h) {
         static const char *names[6] = {"enqueue phase 1", "wait phase 1", "filter + left triangulation", "wait right triangulation", "enqueue phase 2", "wait phase 2 (+ downloads)"};
         fprintf(stderr, "latency path, %ld calls, us per call:", h->lat_calls);
         for (int i = 0; i < 6; i++) fprintf(stderr, "  %s %.1f", names[i], 1e-3 * h->lat_ns[i] / (double)h->lat_calls);
+        fprintf(stderr, "  (of the third: lattice filters %.1f, hand-over %.1f, left triangulation %.1f)", 1e-3 * h->lat_sub_ns[0] / (double)h->lat_calls, 1e-3 * h->lat_sub_ns[1] / (double)h->lat_calls,
+                1e-3 * h->lat_sub_ns[2] / (double)h->lat_calls);
         fprintf(stderr, "\n");
     }
     {

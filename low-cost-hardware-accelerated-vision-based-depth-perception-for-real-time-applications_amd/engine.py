@@ -56,7 +56,7 @@ class SvConfig(ctypes.Structure):
                 ("chunk", ctypes.c_int32), ("keep_debug", ctypes.c_int32), ("n_streams", ctypes.c_int32), ("n_slots", ctypes.c_int32),
                 ("gpu_lattice_filter", ctypes.c_int32), ("gpu_triangulation", ctypes.c_int32), ("gpu_triangulation_pct", ctypes.c_int32),
                 ("resident", ctypes.c_int32), ("dg_sub_max", ctypes.c_int32), ("dg_max_points", ctypes.c_int32), ("affinity", ctypes.c_int32),
-                ("inline_latency_path", ctypes.c_int32), ("event_sync", ctypes.c_int32), ("share_sliced", ctypes.c_int32), ("reserved", ctypes.c_int32 * 6)]
+                ("inline_latency_path", ctypes.c_int32), ("event_sync", ctypes.c_int32), ("share_sliced", ctypes.c_int32), ("latency_split", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5)]
 
 
 _TRIANGULATION_MODES = {None: 0, "auto": 0, "gpu": 1, "host": 2, "balanced": 4}
@@ -150,7 +150,7 @@ class StereoEngine:
     """
 
     def __init__(self, width, height, params=None, device=0, n_workers=0, chunk=0, keep_debug=False, n_streams=0, n_slots=0, gpu_filter=None,
-                 triangulation=None, resident=None, dg_sub_max=0, dg_max_points=0, affinity=None, inline=None, share_sliced=False, event_sync=None):
+                 triangulation=None, resident=None, dg_sub_max=0, dg_max_points=0, affinity=None, inline=None, share_sliced=False, event_sync=None, latency_split=0):
         """gpu_filter: None (automatic) / True / False - where the support-lattice filters run.  triangulation: None or "auto", "gpu", "host",
         "balanced" (by the pool's backlog, whatever its size) or an int 1..100 = that share of the chunks on the GPU.  resident / affinity /
         inline: None (automatic) or False to switch the resident GPU share / the NUMA binding / the calling-thread latency path off.
@@ -173,6 +173,7 @@ class StereoEngine:
         cfg.inline_latency_path = 2 if inline is False else 0
         cfg.share_sliced = int(bool(share_sliced))
         cfg.event_sync = {None: 0, "auto": 0, "block": 1, "spin": 2, "poll": 3}[event_sync]
+        cfg.latency_split = int(latency_split)
         h = ctypes.c_void_p()
         rc = L.sv_create(ctypes.byref(self.params), ctypes.byref(cfg), ctypes.byref(h))
         if rc != 0:

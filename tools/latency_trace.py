@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Where a single frame's time goes (batch 1, device memory): the handle's own wall-clock split (sv_debug_set "lat_trace"), printed when the
+handle closes.   python tools/latency_trace.py [--disp 128] [--calls 300]"""
+import argparse
+import importlib
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--disp", type=int, default=128)
+ap.add_argument("--calls", type=int, default=300)
+ap.add_argument("--workers", type=int, default=0)
+a = ap.parse_args()
+import util
+pkg = [d for d in os.listdir(ROOT) if d.endswith("_amd")][0]
+eng = importlib.import_module(pkg + ".engine")
+l, r = util.load_png("kitti0_left.png"), util.load_png("kitti0_right.png")
+H, W = l.shape
+L, R = torch.from_numpy(l[None].copy()).cuda(), torch.from_numpy(r[None].copy()).cuda()
+d1 = torch.empty((1, H, W), dtype=torch.float32, device="cuda")
+d2 = torch.empty_like(d1)
+e = eng.StereoEngine(W, H, eng.SvParams.driver(a.disp - 1), chunk=1, n_slots=2, n_streams=1, n_workers=a.workers)
+for _ in range(20):
+    e.process_device(L, R, d1, d2)
+e.debug_set("lat_trace", 1)
+ts = []
+for _ in range(a.calls):
+    t0 = time.perf_counter()
+    e.process_device(L, R, d1, d2)
+    ts.append(time.perf_counter() - t0)
+ts = np.array(ts) * 1e3
+print("D=%d: median %.3f ms, p99 %.3f ms over %d calls; engine %s" % (a.disp, np.median(ts), np.percentile(ts, 99), a.calls, e.query()), flush=True)
+e.close()
