@@ -59,6 +59,17 @@ __device__ __forceinline__ uint32_t texture16(const uint4 &a) {
 
 __device__ __forceinline__ uint4 ld16(const uint8_t *p) { return *reinterpret_cast<const uint4 *>(p); }
 
+// Element `idx` of a map whose base pointer is uniform over the workgroup: a 32-bit BYTE offset beside the base (a map is far below
+// 4 GB) lets the compiler address with the scalar base + one 32-bit VGPR (global_load ... v, s[base]) instead of building a 64-bit
+// address per access with v_mad_u64_u32 / v_lshl_add_u64.  Used where the SQ_INSTS_VALU pass showed fewer instructions (tools/pmc_ab.sh:
+// adaptive mean -4 %, median -4 %, L/R check -9 %, gap rows, Sobel, raster -2 %); the matching kernels' staging loads, the speckle bands and
+// the gap columns issued MORE with it (+1 - 8 %) and keep their 64-bit arithmetic.
+template <class T>
+__device__ __forceinline__ T map_ld(const T *base, uint32_t idx) { return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + idx * (uint32_t)sizeof(T)); }
+template <class T>
+__device__ __forceinline__ void map_st(T *base, uint32_t idx, T v) { *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + idx * (uint32_t)sizeof(T)) = v; }
+
+
 // work counters (sv_debug_counters): one atomic per wavefront, only in the COUNT instantiations of the matching kernels
 __device__ __forceinline__ void count_add(unsigned long long *slot, int mine) {
 #pragma unroll
@@ -175,8 +186,9 @@ __global__ __launch_bounds__(256) void k_sobel(const uint8_t *__restrict__ left,
         const uint32_t dv01 = sat_pk_u8(((T[0] + (s2)(Q0 << 1) + T[1]) >> 2) + k128), dv23 = sat_pk_u8(((T[1] + (s2)(Q1 << 1) + T[2]) >> 2) + k128);
         const uint32_t du_w = __builtin_amdgcn_perm(du23, du01, 0x05040100u), dv_w = __builtin_amdgcn_perm(dv23, dv01, 0x05040100u);
         if (y < d.H && x < ((d.W + 3) & ~3)) {  // whole words: the bytes beyond W land in the row's right margin and are never used
-            *reinterpret_cast<uint32_t *>(DU + (size_t)y * P + x) = du_w;
-            *reinterpret_cast<uint32_t *>(DV + (size_t)y * P + x) = dv_w;
+            const uint32_t q = (uint32_t)(y * P + x);  // (byte offset inside the plane; the plane pointers are uniform)
+            *reinterpret_cast<uint32_t *>(DU + q) = du_w;
+            *reinterpret_cast<uint32_t *>(DV + q) = dv_w;
         }
     }
 }
@@ -1394,7 +1406,7 @@ __global__ __launch_bounds__(256) void k_raster_tiles(KParams k, const int32_t *
     int32_t *ids = tri_id + (size_t)(pair * 2 + side) * d.N;
     for (int i = threadIdx.x; i < RT_H * RT_W; i += 256) {
         const int r = i / RT_W, c = i - r * RT_W;
-        if (ty0 + r < d.H && tx0 + c < d.W) ids[(size_t)(ty0 + r) * d.W + tx0 + c] = tile[r][c];
+        if (ty0 + r < d.H && tx0 + c < d.W) map_st(ids, (uint32_t)((ty0 + r) * d.W + tx0 + c), tile[r][c]);
     }
 }
 
@@ -1765,9 +1777,9 @@ __global__ __launch_bounds__(256) void k_lr2(KParams k, const int32_t *__restric
     if (blob[pair * META_WORDS] < 3) return;
     const int u = 2 * (blockIdx.x * 256 + threadIdx.x), v = blockIdx.y;
     if (u >= d.W) return;
-    const int16_t *W1 = wta + (size_t)(pair * 2) * d.N, *W2 = W1 + d.N;
-    const size_t row = (size_t)v * d.W;
-    const short2 a = *reinterpret_cast<const short2 *>(W1 + row + u), b = *reinterpret_cast<const short2 *>(W2 + row + u);
+    const size_t row = (size_t)v * d.W;  // (uniform: the row's pointers are scalar, the columns 32-bit offsets - map_ld)
+    const int16_t *W1 = wta + (size_t)(pair * 2) * d.N + row, *W2 = W1 + d.N;
+    const short2 a = map_ld(reinterpret_cast<const short2 *>(W1), (uint32_t)u >> 1), b = map_ld(reinterpret_cast<const short2 *>(W2), (uint32_t)u >> 1);
     const float thr = (float)k.lr_threshold;
     float o1[2], o2[2];
 #pragma unroll
@@ -1777,12 +1789,13 @@ __global__ __launch_bounds__(256) void k_lr2(KParams k, const int32_t *__restric
         o1[j] = o2[j] = -10.0f;
         // half resolution (elas.cpp:972-975): the map is half size, the disparities are still full-resolution pixels
         const float uw1 = d.sub ? (float)uj - d1 / 2 : (float)uj - d1, uw2 = d.sub ? (float)uj + d2 / 2 : (float)uj + d2;
-        if (d1 >= 0 && uw1 >= 0 && uw1 < (float)d.W) o1[j] = (fabsf((float)W2[row + (int)uw1] - d1) > thr) ? -10.0f : d1;
-        if (d2 >= 0 && uw2 >= 0 && uw2 < (float)d.W) o2[j] = (fabsf((float)W1[row + (int)uw2] - d2) > thr) ? -10.0f : d2;
+        if (d1 >= 0 && uw1 >= 0 && uw1 < (float)d.W) o1[j] = (fabsf((float)map_ld(W2, (uint32_t)(int)uw1) - d1) > thr) ? -10.0f : d1;
+        if (d2 >= 0 && uw2 >= 0 && uw2 < (float)d.W) o2[j] = (fabsf((float)map_ld(W1, (uint32_t)(int)uw2) - d2) > thr) ? -10.0f : d2;
     }
-    *reinterpret_cast<float2 *>(disp + (size_t)(pair * 2) * d.N + row + u) = make_float2(o1[0], o1[1]);
-    if (keep_right) *reinterpret_cast<float2 *>(disp + (size_t)(pair * 2 + 1) * d.N + row + u) = make_float2(o2[0], o2[1]);
-    if (user_d2) *reinterpret_cast<float2 *>(user_d2 + (size_t)pair * d.N + row + u) = make_float2(o2[0], o2[1]);
+    float *D1r = disp + (size_t)(pair * 2) * d.N + row;
+    map_st(reinterpret_cast<float2 *>(D1r), (uint32_t)u >> 1, make_float2(o1[0], o1[1]));
+    if (keep_right) map_st(reinterpret_cast<float2 *>(D1r + d.N), (uint32_t)u >> 1, make_float2(o2[0], o2[1]));
+    if (user_d2) map_st(reinterpret_cast<float2 *>(user_d2 + (size_t)pair * d.N + row), (uint32_t)u >> 1, make_float2(o2[0], o2[1]));
 }
 
 void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st, float *user_d2, bool keep_right) {
@@ -2312,7 +2325,7 @@ __global__ __launch_bounds__(GAPR_THREADS) void k_gap_rows(KParams k, int nproc,
     __shared__ int prevb[SV_MAX_LINE_WORDS], nextb[SV_MAX_LINE_WORDS];
     for (int c = wave; c < nch; c += nw) {
         const int u = c * 64 + lane;
-        const float val = u < d.W ? D[u] : -1.0f;
+        const float val = u < d.W ? map_ld(D, (uint32_t)u) : -1.0f;
         const unsigned long long b = __ballot(val >= 0);
         if (lane == 0) mw[c] = b;
     }
@@ -2363,12 +2376,12 @@ __global__ __launch_bounds__(GAPR_THREADS) void k_gap_rows(KParams k, int nproc,
         const int pl = below ? c * 64 + 63 - __clzll((long long)below) : prevb[c];
         const int nr = above ? u + __ffsll((long long)above) : nextb[c];
         if (pl >= 0 && nr >= 0) {
-            if (nr - pl - 1 <= gw) D[u] = gap_value(D[pl], D[nr]);  // :1158-1176
+            if (nr - pl - 1 <= gw) map_st(D, (uint32_t)u, gap_value(map_ld(D, (uint32_t)pl), map_ld(D, (uint32_t)nr)));  // :1158-1176
         } else if (k.add_corners) {
             if (pl < 0 && nr >= 0) {
-                if (u >= nr - gw) D[u] = D[nr];  // :1191-1201
+                if (u >= nr - gw) map_st(D, (uint32_t)u, map_ld(D, (uint32_t)nr));  // :1191-1201
             } else if (nr < 0 && pl >= 0) {
-                if (u <= pl + gw) D[u] = D[pl];  // :1204-1214
+                if (u <= pl + gw) map_st(D, (uint32_t)u, map_ld(D, (uint32_t)pl));  // :1204-1214
             }
         }
     }
@@ -2604,7 +2617,7 @@ __global__ __launch_bounds__(256) void k_amean(KParams k, int nproc, const int32
             const int r = i / DCOLS, c = i - r * DCOLS;
             const int y = y0 - 4 + r, x = x0 - 4 + c;
             const bool in = i < ROWS * DCOLS && y >= 0 && y < d.H && x >= 0 && x < d.W;
-            val[t] = in ? S[(size_t)y * d.W + x] : -10.0f;
+            val[t] = in ? map_ld(S, (uint32_t)(y * d.W + x)) : -10.0f;
         }
 #pragma unroll
         for (int t = 0; t < NLD; t++) {
@@ -2653,7 +2666,7 @@ __global__ __launch_bounds__(256) void k_amean(KParams k, int nproc, const int32
             // map holds a negative value other than -10, and every stage in front of this one (L/R check, speckle, gap) writes -10 for invalid
             float val = sD[AM_NC * g + c + 4][cx + 4];
             if (xin && y >= 4 && y <= d.H - 4 && ok[c]) val = res[c];
-            dst[off + (size_t)y * d.W + x] = val;
+            map_st(dst + off, (uint32_t)(y * d.W + x), val);
         }
     }
 }
@@ -2780,7 +2793,7 @@ __global__ __launch_bounds__(256) void k_median(KParams k, int nproc, const int3
             const int i = threadIdx.x + t * 256;
             const int r = i / (PF_TW + 6), c = i - r * (PF_TW + 6);
             const int y = y0 - 3 + r, x = x0 - 3 + c;
-            val[t] = (i < (PF_TH + 6) * (PF_TW + 6) && y >= 0 && y < d.H && x >= 0 && x < d.W) ? S[(size_t)y * d.W + x] : 0.0f;
+            val[t] = (i < (PF_TH + 6) * (PF_TW + 6) && y >= 0 && y < d.H && x >= 0 && x < d.W) ? map_ld(S, (uint32_t)(y * d.W + x)) : 0.0f;
         }
 #pragma unroll
         for (int t = 0; t < NLD; t++) {
@@ -2834,12 +2847,12 @@ __global__ __launch_bounds__(256) void k_median(KParams k, int nproc, const int3
             float v0 = sD[ry + 3][cx + 3], v1 = sD[ry + 4][cx + 3];
             if (xin && y >= 3 && y < d.H - 3 && v0 >= 0) v0 = m0;
             if (xin && y + 1 >= 3 && y + 1 < d.H - 3 && v1 >= 0) v1 = m1;
-            const size_t q = (size_t)y * d.W + x;
-            if (dst) dst[off + q] = v0;
-            if (user) user[(size_t)pair * d.N + q] = v0;
+            const uint32_t q = (uint32_t)(y * d.W + x);
+            if (dst) map_st(dst + off, q, v0);
+            if (user) map_st(user + (size_t)pair * d.N, q, v0);
             if (y + 1 < d.H) {
-                if (dst) dst[off + q + d.W] = v1;
-                if (user) user[(size_t)pair * d.N + q + d.W] = v1;
+                if (dst) map_st(dst + off, q + (uint32_t)d.W, v1);
+                if (user) map_st(user + (size_t)pair * d.N, q + (uint32_t)d.W, v1);
             }
         }
     }
