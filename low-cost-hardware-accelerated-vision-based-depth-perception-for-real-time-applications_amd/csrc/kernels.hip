@@ -1480,8 +1480,9 @@ __device__ __forceinline__ int dense_pixel(const KParams &k, int side, int u, in
     // are never set): the column-range clipping of the masks is skipped then
     const bool clip = __builtin_amdgcn_ballot_w64(a_lo != 0 || a_hi != d.D - 1) != 0;
     // the band (at most 2 * plane_radius + 1 <= 31 bits) as a 64-bit mask starting in mask word band_word
-    const int band_bits = d_plane_max - d_plane_min + 1, band_word = d_plane_min >> 5;
-    const uint64_t band = band_bits > 0 ? ((1ull << band_bits) - 1ull) << (d_plane_min & 31) : 0ull;
+    // (the ones - at most 2 * 15 + 1 = 31 of them, none for an empty band - in 32 bits, then ONE 64-bit shift puts them in place)
+    const int band_bits = max(d_plane_max - d_plane_min + 1, 0), band_word = d_plane_min >> 5;
+    const uint64_t band = (uint64_t)((1u << band_bits) - 1u) << (d_plane_min & 31);
     const uint32_t band_lo = (uint32_t)band, band_hi = (uint32_t)(band >> 32);
     uint32_t mc[DENSE_MASK_WORDS];
 #pragma unroll
@@ -1650,7 +1651,8 @@ __global__ __launch_bounds__(256) DENSE_WAVES_ATTR void k_dense(KParams k, const
     __syncthreads();
     // grid cell of each of the thread's columns (elas.cpp:745-746), once for both sides; word offsets fit 32 bits.  (Staging the
     // tile's cell masks in LDS instead of one global gather per pixel was measured: 10.4 against 9.2 us per pair.)
-    const uint32_t gy = (uint32_t)(int)floorf((float)v / (float)d.grid_size);
+    // (the row's cell by the same host-checked multiply-shift as the columns' - scalar - instead of an IEEE division per thread)
+    const uint32_t gy = k.cell_mul ? (((uint32_t)v * k.cell_mul) >> 16) : (uint32_t)(int)floorf((float)v / (float)d.grid_size);
     uint32_t cell_off[DENSE_TW / 256];
 #pragma unroll
     for (int j = 0; j < DENSE_TW / 256; j++) {
@@ -2608,21 +2610,32 @@ __global__ __launch_bounds__(256) void k_amean(KParams k, int nproc, const int32
     constexpr int ROWS = AM_TH + 7, DCOLS = AM_TW + 8, NV = AM_NC + 7;
     __shared__ __attribute__((aligned(16))) float sD[ROWS][DCOLS];  // D_copy (:1307-1318): rows y0-4.., columns x0-4..; invalid -> -10
     __shared__ __attribute__((aligned(16))) float sT[ROWS][AM_TW];  // D_tmp after the horizontal pass: rows y0-4.., columns x0..
-    {  // all of a thread's tile loads are requested before the first one is used (one load per loop trip is a chain of latencies)
-        constexpr int NLD = (ROWS * DCOLS + 255) / 256;
-        float val[NLD];
+    {  // all of a thread's tile loads are requested before the first one is used (one load per loop trip is a chain of latencies).
+       // A thread owns one column PAIR of the tile (x0 - 4 is even) and every 7th row: its column tests and offsets are computed once.
+        constexpr int PAIRS = DCOLS / 2, RPP = 256 / PAIRS, NLD = (ROWS + RPP - 1) / RPP;  // 36 pairs, 7 rows per pass, 6 passes
+        const int cp = threadIdx.x % PAIRS, rp = threadIdx.x / PAIRS;
+        const int x = x0 - 4 + 2 * cp;
+        const bool live = rp < RPP, in0 = x >= 0 && x < d.W, in1 = x + 1 >= 0 && x + 1 < d.W;
+        const bool wide = (d.W & 1) == 0 && in0 && in1;  // both columns inside and the pair 8-byte aligned in every row
+        float2 val[NLD];
 #pragma unroll
         for (int t = 0; t < NLD; t++) {
-            const int i = threadIdx.x + t * 256;
-            const int r = i / DCOLS, c = i - r * DCOLS;
-            const int y = y0 - 4 + r, x = x0 - 4 + c;
-            const bool in = i < ROWS * DCOLS && y >= 0 && y < d.H && x >= 0 && x < d.W;
-            val[t] = in ? map_ld(S, (uint32_t)(y * d.W + x)) : -10.0f;
+            const int r = rp + t * RPP, y = y0 - 4 + r;
+            val[t] = make_float2(-10.0f, -10.0f);
+            if (live && r < ROWS && y >= 0 && y < d.H) {
+                const uint32_t q = (uint32_t)(y * d.W + x);
+                if (wide) {
+                    val[t] = map_ld(reinterpret_cast<const float2 *>(S), q >> 1);
+                } else {
+                    if (in0) val[t].x = map_ld(S, q);
+                    if (in1) val[t].y = map_ld(S, q + 1u);
+                }
+            }
         }
 #pragma unroll
         for (int t = 0; t < NLD; t++) {
-            const int i = threadIdx.x + t * 256;
-            if (i < ROWS * DCOLS) (&sD[0][0])[i] = val[t] < 0 ? -10.0f : val[t];
+            const int r = rp + t * RPP;
+            if (live && r < ROWS) *reinterpret_cast<float2 *>(&sD[r][2 * cp]) = make_float2(val[t].x < 0 ? -10.0f : val[t].x, val[t].y < 0 ? -10.0f : val[t].y);
         }
     }
     __syncthreads();
