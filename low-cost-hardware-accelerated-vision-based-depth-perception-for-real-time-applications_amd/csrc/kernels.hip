@@ -445,11 +445,16 @@ __global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, const uint8_
     // left -> right
     const int dmax1 = uc < uc1 ? support_range<false>(d, u, v) : -1;
     uint32_t texture = 0;  // of the centre descriptor (elas.cpp:296-300)
-    if (dmax1 >= 0) texture = texture_at(g1, v, u);  // used after the search: its latency hides behind it
+    __shared__ uint32_t s_tex[SUP_POINTS];  // one of the four wavefronts of a point fetches its sixteen bytes, the others read the sum after the barrier
+    if (part == 0) {
+        if (dmax1 >= 0) texture = texture_at(g1, v, u);  // used after the search: its latency hides behind it
+        s_tex[point] = texture;
+    }
     uint32_t k1 = SUP_KEY_NONE, k2 = SUP_KEY_NONE;
     if (d_lo <= dmax1) support_scan<false>(L, R, u, d_lo, min(dmax1, d_lo + qlen - 1), k1, k2);
     rec[threadIdx.x] = make_uint2(k1, k2);
     __syncthreads();
+    texture = s_tex[point];
     const int dd = dmax1 >= 0 ? support_decide(k, texture, support_merge(rec, point)) : -1;
     // right -> left from the match (elas.cpp:404-409)
     const int u2 = u - dd;
