@@ -128,23 +128,34 @@ __global__ __launch_bounds__(256) void k_sobel(const uint8_t *__restrict__ left,
     __shared__ uint32_t g[(SOB_TH + 2) * SOB_GW];
     const int tid = threadIdx.x;
     // gray tile, one word (4 pixels) per item; pixels outside the image read as 0 (they never reach a valid descriptor)
-    for (int i = tid; i < (SOB_TH + 2) * SOB_GW; i += 256) {
-        const int r = i / SOB_GW, cw = i - r * SOB_GW;
-        const int y = y0 - 1 + r, xb = x0 - 4 + 4 * cw;
-        uint32_t w = 0;
-        if (y >= 0 && y < d.H) {
-            const uint8_t *row = I + (size_t)y * stride;
-            if (xb >= 0 && xb + 3 < d.W) {
-                w = reinterpret_cast<const UnalignedWord *>(row + xb)->v;
-            } else {
+    {  // a thread owns one word column of the tile and every third row: the column tests once, all its loads in flight together
+        constexpr int RPP = 256 / SOB_GW, NLD = (SOB_TH + 2 + RPP - 1) / RPP;  // 3 rows per pass, 6 passes
+        const int cw = tid % SOB_GW, rp = tid / SOB_GW;
+        const int xb = x0 - 4 + 4 * cw;
+        const bool live = rp < RPP, whole = xb >= 0 && xb + 3 < d.W;
+        uint32_t w[NLD];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int x = xb + j;
-                    if (x >= 0 && x < d.W) w |= (uint32_t)row[x] << (8 * j);
+        for (int t = 0; t < NLD; t++) {
+            const int r = rp + t * RPP, y = y0 - 1 + r;
+            w[t] = 0;
+            if (live && r < SOB_TH + 2 && y >= 0 && y < d.H) {
+                const uint32_t q = (uint32_t)(y * stride + xb);
+                if (whole) {
+                    w[t] = reinterpret_cast<const UnalignedWord *>(reinterpret_cast<const char *>(I) + q)->v;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int x = xb + j;
+                        if (x >= 0 && x < d.W) w[t] |= (uint32_t)map_ld(I, q + (uint32_t)j) << (8 * j);
+                    }
                 }
             }
         }
-        g[i] = w;
+#pragma unroll
+        for (int t = 0; t < NLD; t++) {
+            const int r = rp + t * RPP;
+            if (live && r < SOB_TH + 2) g[r * SOB_GW + cw] = w[t];
+        }
     }
     __syncthreads();
     // one thread = 4 pixels (one word) of a row: gray rows r, r+1, r+2 of the tile (y-1, y, y+1), gray columns c-1 .. c+4
@@ -2801,23 +2812,34 @@ __global__ __launch_bounds__(256) void k_median(KParams k, int nproc, const int3
     const size_t off = map_offset(d, m, nproc);
     const float *S = src + off;
     const int x0 = blockIdx.x * PF_TW, y0 = blockIdx.y * PF_TH;
-    __shared__ float sD[PF_TH + 6][PF_TW + 8];  // rows y0-3.., columns x0-3.. (70 used)
+    constexpr int XO = 4;  // the tile starts at the even column x0 - 4: a thread stages one column pair (float2 loads, the column tests once)
+    __shared__ __attribute__((aligned(16))) float sD[PF_TH + 6][PF_TW + 8];  // rows y0-3.., columns x0-4..
     __shared__ float sT[PF_TH + 6][PF_TW];      // D_temp after the horizontal pass (:1515-1534): rows y0-3.., columns x0..
     {  // all of a thread's tile loads are requested before the first one is used
-        constexpr int NLD = ((PF_TH + 6) * (PF_TW + 6) + 255) / 256;
-        float val[NLD];
+        constexpr int ROWS = PF_TH + 6, PAIRS = (PF_TW + 8) / 2, RPP = 256 / PAIRS, NLD = (ROWS + RPP - 1) / RPP;  // 36 pairs, 7 rows per pass, 6 passes
+        const int cp = threadIdx.x % PAIRS, rp = threadIdx.x / PAIRS;
+        const int x = x0 - XO + 2 * cp;
+        const bool live = rp < RPP, in0 = x >= 0 && x < d.W, in1 = x + 1 >= 0 && x + 1 < d.W;
+        const bool wide = (d.W & 1) == 0 && in0 && in1;
+        float2 val[NLD];
 #pragma unroll
         for (int t = 0; t < NLD; t++) {
-            const int i = threadIdx.x + t * 256;
-            const int r = i / (PF_TW + 6), c = i - r * (PF_TW + 6);
-            const int y = y0 - 3 + r, x = x0 - 3 + c;
-            val[t] = (i < (PF_TH + 6) * (PF_TW + 6) && y >= 0 && y < d.H && x >= 0 && x < d.W) ? map_ld(S, (uint32_t)(y * d.W + x)) : 0.0f;
+            const int r = rp + t * RPP, y = y0 - 3 + r;
+            val[t] = make_float2(0.0f, 0.0f);
+            if (live && r < ROWS && y >= 0 && y < d.H) {
+                const uint32_t q = (uint32_t)(y * d.W + x);
+                if (wide) {
+                    val[t] = map_ld(reinterpret_cast<const float2 *>(S), q >> 1);
+                } else {
+                    if (in0) val[t].x = map_ld(S, q);
+                    if (in1) val[t].y = map_ld(S, q + 1u);
+                }
+            }
         }
 #pragma unroll
         for (int t = 0; t < NLD; t++) {
-            const int i = threadIdx.x + t * 256;
-            const int r = i / (PF_TW + 6), c = i - r * (PF_TW + 6);
-            if (i < (PF_TH + 6) * (PF_TW + 6)) sD[r][c] = val[t];
+            const int r = rp + t * RPP;
+            if (live && r < ROWS) *reinterpret_cast<float2 *>(&sD[r][2 * cp]) = val[t];
         }
     }
     __syncthreads();
@@ -2832,11 +2854,15 @@ __global__ __launch_bounds__(256) void k_median(KParams k, int nproc, const int3
             if (r >= PF_TH + 6) break;
             const int y = y0 - 3 + r;
             float a[8];
+            {  // columns x - 3 .. x + 4 = tile columns c2 + 1 .. c2 + 8: five aligned pairs, the outer halves of the first and the last unused
+                const float2 p0 = *reinterpret_cast<const float2 *>(&sD[r][c2]), p4 = *reinterpret_cast<const float2 *>(&sD[r][c2 + 8]);
+                a[0] = p0.y, a[7] = p4.x;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float2 v = *reinterpret_cast<const float2 *>(&sD[r][c2 + 2 * j]);
-                a[2 * j] = v.x;
-                a[2 * j + 1] = v.y;
+                for (int j = 1; j < 4; j++) {
+                    const float2 v = *reinterpret_cast<const float2 *>(&sD[r][c2 + 2 * j]);
+                    a[2 * j - 1] = v.x;
+                    a[2 * j] = v.y;
+                }
             }
             float m0, m1;
             median7_pair(a, m0, m1);
@@ -2862,7 +2888,7 @@ __global__ __launch_bounds__(256) void k_median(KParams k, int nproc, const int3
             for (int j = 0; j < 8; j++) a[j] = sT[ry + j][cx];
             float m0, m1;
             median7_pair(a, m0, m1);
-            float v0 = sD[ry + 3][cx + 3], v1 = sD[ry + 4][cx + 3];
+            float v0 = sD[ry + 3][cx + XO], v1 = sD[ry + 4][cx + XO];
             if (xin && y >= 3 && y < d.H - 3 && v0 >= 0) v0 = m0;
             if (xin && y + 1 >= 3 && y + 1 < d.H - 3 && v1 >= 0) v1 = m1;
             const uint32_t q = (uint32_t)(y * d.W + x);
