@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """DESIGN.md section 4's kernel table, regenerated from a committed profile:
 
-    python tools/design_table.py profiles/r04e_serial_kernel_stats_pmc.csv [--pairs-per-launch 32]
+    python tools/design_table.py profiles/r04f_serial_kernel_stats_pmc.csv [--pairs-per-launch 32]
 
 Columns: median launch duration of the no-overlap pass (rocprofv3 --kernel-trace, >= 16 launches per kernel), HBM traffic from the
 FETCH_SIZE / WRITE_SIZE passes (KB per launch as rocprofv3 reports them, no correction: no kernel of the path streams 16 bytes per lane),
