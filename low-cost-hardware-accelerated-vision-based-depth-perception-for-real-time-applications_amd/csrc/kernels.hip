@@ -1788,6 +1788,7 @@ __global__ __launch_bounds__(256) void k_lr(KParams k, const int32_t *__restrict
 
 // Two pixels per thread for even map widths (every row then starts on a 4-byte boundary of the int16 maps and an 8-byte
 // boundary of the float maps): half the load / store instructions of this pure map kernel
+template <bool SUB>  // half resolution compiled in: the full-resolution kernel does not compute both warps and select
 __global__ __launch_bounds__(256) void k_lr2(KParams k, const int32_t *__restrict__ blob, const int16_t *__restrict__ wta, float *__restrict__ disp,
                                              float *__restrict__ user_d2, int keep_right) {
     const Dims &d = k.d;
@@ -1806,7 +1807,7 @@ __global__ __launch_bounds__(256) void k_lr2(KParams k, const int32_t *__restric
         const int uj = u + j;
         o1[j] = o2[j] = -10.0f;
         // half resolution (elas.cpp:972-975): the map is half size, the disparities are still full-resolution pixels
-        const float uw1 = d.sub ? (float)uj - d1 / 2 : (float)uj - d1, uw2 = d.sub ? (float)uj + d2 / 2 : (float)uj + d2;
+        const float uw1 = SUB ? (float)uj - d1 / 2 : (float)uj - d1, uw2 = SUB ? (float)uj + d2 / 2 : (float)uj + d2;
         if (d1 >= 0 && uw1 >= 0 && uw1 < (float)d.W) o1[j] = (fabsf((float)map_ld(W2, (uint32_t)(int)uw1) - d1) > thr) ? -10.0f : d1;
         if (d2 >= 0 && uw2 >= 0 && uw2 < (float)d.W) o2[j] = (fabsf((float)map_ld(W1, (uint32_t)(int)uw2) - d2) > thr) ? -10.0f : d2;
     }
@@ -1817,8 +1818,10 @@ __global__ __launch_bounds__(256) void k_lr2(KParams k, const int32_t *__restric
 }
 
 void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st, float *user_d2, bool keep_right) {
-    if ((k.d.W & 1) == 0 && (reinterpret_cast<uintptr_t>(user_d2) & 7) == 0)
-        SV_LAUNCH(K_LR, k_lr2, dim3((k.d.W / 2 + 255) / 256, k.d.H, n), dim3(256), 0, st, k, s.blob, s.wta, s.disp, user_d2, keep_right ? 1 : 0);
+    if ((k.d.W & 1) == 0 && (reinterpret_cast<uintptr_t>(user_d2) & 7) == 0 && k.d.sub)
+        SV_LAUNCH(K_LR, k_lr2<true>, dim3((k.d.W / 2 + 255) / 256, k.d.H, n), dim3(256), 0, st, k, s.blob, s.wta, s.disp, user_d2, keep_right ? 1 : 0);
+    else if ((k.d.W & 1) == 0 && (reinterpret_cast<uintptr_t>(user_d2) & 7) == 0)
+        SV_LAUNCH(K_LR, k_lr2<false>, dim3((k.d.W / 2 + 255) / 256, k.d.H, n), dim3(256), 0, st, k, s.blob, s.wta, s.disp, user_d2, keep_right ? 1 : 0);
     else
         SV_LAUNCH(K_LR, k_lr, dim3((k.d.W + 255) / 256, k.d.H, n), dim3(256), 0, st, k, s.blob, s.wta, s.disp, user_d2, keep_right ? 1 : 0);
 }

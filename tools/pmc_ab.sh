@@ -14,7 +14,8 @@ for lib in sys.argv[1:]:
     acc, cnt = collections.defaultdict(float), collections.Counter()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == "SQ_INSTS_VALU":
-            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sv::", "")[:28]
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sv::", "")
+            k = k[:k.index("<false")] if "<false" in k else k[:28]  # (instantiations of the product kernels under one name)
             acc[k] += float(r["Counter_Value"]); cnt[k] += 1
     tabs.append({k: acc[k] / cnt[k] / 32 for k in acc})
 keys = sorted(tabs[0], key=lambda k: -tabs[0][k])
