@@ -771,3 +771,26 @@ def test_the_ways_host_threads_wait_give_the_same_maps(eng, mode):
     finally:
         e.close()
         ref.close()
+
+
+@pytest.mark.parametrize("split", [0, 1, 2])
+def test_single_pairs_with_shared_triangulations_give_the_same_maps(eng, split):
+    """Latency mode (one pair per call on a chunk-1 handle): each triangulation on one thread (the default), or its top-level cuts shared
+    with pool threads (sv_config.latency_split = 1: halves, 2: quarters) - same maps as a throughput handle; the real frame and a synthetic one."""
+    import torch
+    l, r = util.load_png("kitti0_left.png"), util.load_png("kitti0_right.png")
+    H, W = l.shape
+    p = eng.SvParams.driver(127)
+    syn = util.pkg("synth").make_batch(77, 1, H, W, 128)[0]
+    ref = eng.StereoEngine(W, H, p, chunk=4, n_slots=2)
+    e = eng.StereoEngine(W, H, p, chunk=1, n_slots=2, n_streams=1, n_workers=8, latency_split=split)
+    try:
+        for a, b in ((l, r), (syn[0], syn[1])):
+            L, R = torch.from_numpy(np.ascontiguousarray(a[None])).cuda(), torch.from_numpy(np.ascontiguousarray(b[None])).cuda()
+            r1, r2 = ref.process_device(L, R)
+            for _ in range(3):  # (repeated: the pool's pollers pick the pieces up in varying order)
+                d1, d2 = e.process_device(L, R)
+                assert torch.equal(d1, r1) and torch.equal(d2, r2)
+    finally:
+        e.close()
+        ref.close()
