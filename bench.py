@@ -850,9 +850,9 @@ def main():
     # cycled through the batch (real maps are far more fragmented than synthetic ones); afterwards every distinct frame's maps
     # must hash to the reference's digests
     real_rate = None
-    if rank == 0 and world == 1 and real is not None and not args.no_real and not args.real_pair:
+    rp = load_real_pairs(W, H, D) if (rank == 0 and world == 1 and real is not None and not args.no_real and not args.real_pair) else []
+    if rp:  # (empty without PIL, or when no committed frame has a digest for this disparity range: the region is skipped, not a crash after the headline)
         import hashlib
-        rp = load_real_pairs(W, H, D)
         idx = [i % len(rp) for i in range(B)]
         rl = torch.from_numpy(np.stack([rp[i][1] for i in idx])).cuda()
         rr = torch.from_numpy(np.stack([rp[i][2] for i in idx])).cuda()

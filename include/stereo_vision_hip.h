@@ -97,7 +97,8 @@ typedef struct sv_config {
     /* ---- policy (0 = automatic) */
     int32_t gpu_lattice_filter;    /* support-lattice filters: 0 auto (GPU for chunk >= 4), 1 GPU, 2 host pool             [SV_GPU_FILTER=1 / SV_HOST_FILTER=1] */
     int32_t gpu_triangulation;     /* who triangulates: 0 auto (pool and GPU balanced by the pool's backlog; GPU alone with < 3 host threads),
-                                      1 GPU, 2 host pool, 3 a fixed share of gpu_triangulation_pct percent on the GPU    [SV_GPU_DELAUNAY=1/0, SV_GPU_DELAUNAY_PCT=n, SV_GPU_DELAUNAY_AUTO=0] */
+                                      1 GPU, 2 host pool, 3 a fixed share of gpu_triangulation_pct percent on the GPU, 4 balanced by the pool's
+                                      backlog whatever the number of host threads                                        [SV_GPU_DELAUNAY=1/0, SV_GPU_DELAUNAY_PCT=n, SV_GPU_DELAUNAY_AUTO=0] */
     int32_t gpu_triangulation_pct; /* the share for mode 3 (1..100) */
     int32_t resident;              /* the GPU's share without the support lists ever leaving the device: 0 auto (on), 2 off  [SV_RESIDENT=0] */
     int32_t dg_sub_max;            /* > 0: vertices a set may have to be triangulated whole in LDS (default 4000; experiments, tests) [SV_DG_SUBMAX] */
@@ -107,7 +108,11 @@ typedef struct sv_config {
     int32_t event_sync;            /* how host threads wait for the GPU: 0 auto (3 for chunk >= 4, 2 below), 1 hipEventBlockingSync, 2 spin, 3 ask the event + 40 us naps [SV_EVENT_SYNC=block|spin|poll] */
     int32_t share_sliced;          /* != 0: a balanced GPU share as a slice of every chunk instead of whole chunks (round-2 behaviour, non-resident only) [SV_GPU_DELAUNAY_SLICED=1] */
     int32_t latency_split;         /* single pairs: 0 each triangulation on one thread (default), 1 halves / 2 quarters of the top-level cuts on pool threads [SV_LATENCY_SPLIT=1|2] */
-    int32_t reserved[5];           /* must be 0 */
+    int32_t host_copies;           /* host-memory batches (sv_submit_batch_host...): who moves images and maps over PCIe.  0 auto = 2 where the runtime
+                                      allows it, 1 hipMemcpyAsync (the runtime picks an SDMA engine per copy - the directions can end up sharing
+                                      one), 2 engine-addressed copies (csrc/dma_lanes.cpp): uploads and downloads on SDMA engines of their own,
+                                      queued ahead of the kernels                                                          [SV_HOST_COPIES=1|2] */
+    int32_t reserved[4];           /* must be 0 (sv_create checks) */
 } sv_config;
 
 int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out);
@@ -124,6 +129,8 @@ enum sv_query_key {
     SV_Q_NUMA_BOUND = 7,         /* 1: the handle's host threads are bound to the CPUs of the GPU's NUMA node (SV_NO_AFFINITY=1 disables) */
     SV_Q_RESIDENT = 8,           /* 1: the GPU's share of the chunks is built "resident" - the support lists never leave the device: sort, duplicate scan,
                                     k-d order and triangulation in one kernel after the lattice filter; the host only reads 8 meta words per pair */
+    SV_Q_HOST_COPIES = 9,        /* who moves host-memory batches over PCIe: 0 not decided yet (no such batch so far), 1 hipMemcpyAsync,
+                                    2 engine-addressed SDMA copies (sv_config.host_copies) */
     SV_Q_GPU_TRIANGULATION_SHARE = 5 /* per mille of the pairs so far whose triangulations the GPU kernel built (in the host mode the
                                         dispatcher hands it a share of a chunk while the pool is behind; results are identical) */
 };
@@ -224,6 +231,11 @@ int sv_host_delaunay_par(const int32_t *xy, int n, int32_t *tri_out, int cap, in
  * ordering on the host), `reps` copies of the set in one launch, kernel time in *kernel_ms (may be NULL).  n <= 4000: one workgroup per set, mesh in LDS;
  * larger sets (<= 256 000): subtrees in LDS, upper merges in a global-memory mesh (SV_DG_SUBMAX lowers the 4000 for tests). */
 int sv_gpu_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap, int reps, double *kernel_ms);
+
+/* Test hook (no GPU needed): the size of the host pool a handle gets by default in this process (cgroup CPU quota or affinity mask,
+ * shared between LOCAL_WORLD_SIZE ranks; a mask already as narrow as one rank's share is not divided again).  ignore_quota != 0: as
+ * on a host without a CPU quota. */
+int sv_default_host_threads(int ignore_quota);
 
 /* Test hooks: the preparation of a vertex set for the triangulation - (x, y) sort, duplicate scan, k-d order (reference:
  * triangle.cpp:5183-5360, 5889-5903) - on the host and on the GPU (csrc/delaunay_gpu.hip: dg_prepare; vertices on the support lattice

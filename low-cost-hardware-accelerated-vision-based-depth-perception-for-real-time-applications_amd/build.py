@@ -13,8 +13,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libstereo_vision_hip.so")
-SOURCES = ["kernels.hip", "delaunay_gpu.hip", "legacy_kernels.hip", "engine.cpp", "host_stage.cpp", "legacy.cpp", "calib.cpp"]
-HEADERS = ["sv_kernels.h", "host_stage.h", "calib.h", os.path.join("..", "..", "include", "stereo_vision_hip.h")]
+SOURCES = ["kernels.hip", "delaunay_gpu.hip", "legacy_kernels.hip", "engine.cpp", "host_stage.cpp", "legacy.cpp", "calib.cpp", "dma_lanes.cpp"]
+HEADERS = ["sv_kernels.h", "host_stage.h", "calib.h", "dma_lanes.h", os.path.join("..", "..", "include", "stereo_vision_hip.h")]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
 HOST = ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"]
 DEVICE = ["--offload-arch=gfx950", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-gpu-rdc"]
@@ -50,7 +50,7 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lpthread"]
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -816,10 +816,13 @@ __device__ __forceinline__ int dg_prepare(const DgLds &L, int npts, const DgPrep
     DG_LDS uint32_t *X = bm + pp.bm_words + (pp.bm_words + 1) / 2, *Y = X + m;
     DG_LDS uint16_t *idx = (DG_LDS uint16_t *)(Y + m), *xr = idx + m + (m & 1);
     DG_LDS uint32_t *chunk = (DG_LDS uint32_t *)(xr + m + (m & 1));  // per thread: prefix of its chunk's flags | flag bits << 16
-    DG_LDS int *cells = (DG_LDS int *)(chunk + DG_THREADS);           // [0..3] wavefront totals, [4] "unusable" flag, [5] coincident vertices seen, [6] vertices dropped
+    DG_LDS int *cells = (DG_LDS int *)(chunk + DG_THREADS);           // [0..3] wavefront totals, [4] "unusable" flag, [5] coincident vertices seen, [6] vertices dropped,
+                                                                      // [7] "coincident vertices with different disparities" (a word of its own: a flag that is tested after barrier N
+                                                                      //     is never written between barrier N and barrier N + 1, so every test is uniform)
     DG_LDS int *dup_id = cells + 16, *dup_min = dup_id + DG_DUP_MAX;   // the vertices that found their cell taken; lowest id of each one's cell
     DG_LDS uint32_t *dropped = (DG_LDS uint32_t *)(dup_min + DG_DUP_MAX);  // bit i: vertex i is a coincident point that does not survive
-    if (tid == 0) cells[4] = (m > DG_PREP_MAX || m > 0xFFFF) ? 1 : 0, cells[5] = 0, cells[6] = 0;
+    if (m > DG_PREP_MAX || m > 0xFFFF) return -1;  // (uniform: an argument)
+    if (tid == 0) cells[4] = 0, cells[5] = 0, cells[6] = 0, cells[7] = 0;
     for (int w = tid; w < (m + 31) / 32; w += DG_THREADS) dropped[w] = 0u;
     // ---- (x, y) ranks: column-major bit map
     for (int w = tid; w < pp.bm_words; w += DG_THREADS) bm[w] = 0u;
@@ -841,7 +844,7 @@ __device__ __forceinline__ int dg_prepare(const DgLds &L, int npts, const DgPrep
         }
     }
     __syncthreads();
-    if (cells[4]) return -1;  // (uniform: read after the barrier)
+    if (cells[4]) return -1;  // (uniform: read after the barrier, not written again)
     const int ndup = cells[5];
     if (ndup > 0) {
         // every vertex that shares a cell with one of the listed vertices is a member of that coincident group: the group's lowest id
@@ -850,12 +853,12 @@ __device__ __forceinline__ int dg_prepare(const DgLds &L, int npts, const DgPrep
             for (int q = 0; q < ndup; q++) {
                 const int c = dup_id[q];
                 if (L.pxy[i] == L.pxy[c]) {
-                    if (dsp[(size_t)i * dstride] != dsp[(size_t)c * dstride]) cells[4] = 1;
+                    if (dsp[(size_t)i * dstride] != dsp[(size_t)c * dstride]) cells[7] = 1;
                     __hip_atomic_fetch_min(&dup_min[q], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         __syncthreads();
-        if (cells[4]) return -1;
+        if (cells[7]) return -1;
         for (int i = tid; i < m; i += DG_THREADS)
             for (int q = 0; q < ndup; q++) {
                 const int c = dup_id[q];
@@ -1013,11 +1016,16 @@ __device__ __forceinline__ void dgp_word_prefix(const uint32_t *bm, uint32_t *pm
 // ids in k-d order, or ord_out[0] = -1 (coincident points that are not interchangeable, vertices outside the bit maps).  All
 // DGP_THREADS threads call it; returns m or -1 uniformly.
 __device__ __forceinline__ int dg_prepare_global(const int32_t *__restrict__ sup, int npts, int side, const DgPrep &pp, uint32_t *scr, int cap, int bm_words, int32_t *ord_out) {
-    __shared__ int cells[24];            // [0..15] wavefront totals, [16] unusable, [17] coincident vertices seen, [18] dropped
+    __shared__ int cells[24];            // [0..15] wavefront totals, [16] unusable, [17] coincident vertices seen, [18] dropped, [19] coincident vertices with different
+                                         // disparities (its own word: no flag is written between the barrier it is tested after and the next one)
     __shared__ int dup_id[DG_DUP_MAX], dup_min[DG_DUP_MAX];
     const int tid = threadIdx.x;
     uint32_t *bm = scr, *pm = bm + bm_words, *X = pm + bm_words, *Y = X + cap, *Z = Y + cap, *idx = Z + cap, *xr = idx + cap, *pref = xr + cap;
-    if (tid == 0) cells[16] = (npts > cap || npts > 0xFFFF) ? 1 : 0, cells[17] = 0, cells[18] = 0;
+    if (npts > cap || npts > 0xFFFF) {  // (uniform: arguments)
+        if (tid == 0) ord_out[0] = -1;
+        return -1;
+    }
+    if (tid == 0) cells[16] = 0, cells[17] = 0, cells[18] = 0, cells[19] = 0;
     auto vx = [&](int i) { return sup[3 * i] - (side ? sup[3 * i + 2] : 0) - pp.xmin; };
     auto vrow = [&](int i) {
         const int y = sup[3 * i + 1];
@@ -1026,10 +1034,6 @@ __device__ __forceinline__ int dg_prepare_global(const int32_t *__restrict__ sup
     for (int w = tid; w < bm_words; w += DGP_THREADS) gst(bm + w, 0u);
     for (int i = tid; i < npts; i += DGP_THREADS) gst(pref + i, 0u);  // doubles as the "dropped" flags until the first pass
     __syncthreads();
-    if (cells[16]) {
-        if (tid == 0) ord_out[0] = -1;
-        return -1;
-    }
     // ---- (x, y) ranks: column-major bit map; coincident vertices
     for (int i = tid; i < npts; i += DGP_THREADS) {
         const int x = vx(i), row = vrow(i);
@@ -1053,7 +1057,7 @@ __device__ __forceinline__ int dg_prepare_global(const int32_t *__restrict__ sup
             for (int q = 0; q < ndup; q++) {
                 const int c = dup_id[q];
                 if (vx(i) == vx(c) && sup[3 * i + 1] == sup[3 * c + 1]) {
-                    if (sup[3 * i + 2] != sup[3 * c + 2]) cells[16] = 1;
+                    if (sup[3 * i + 2] != sup[3 * c + 2]) cells[19] = 1;
                     atomicMin(&dup_min[q], i);
                 }
             }
@@ -1068,7 +1072,7 @@ __device__ __forceinline__ int dg_prepare_global(const int32_t *__restrict__ sup
             }
     }
     __syncthreads();
-    if (cells[16]) {
+    if (cells[16] || cells[19]) {
         if (tid == 0) ord_out[0] = -1;
         return -1;
     }
@@ -1388,10 +1392,21 @@ size_t delaunay_prep_large_bytes(int W, int H, int step, int disp_max, int cap) 
     return sizeof(uint32_t) * (2 * (size_t)pp.bm_words + 6 * (size_t)cap);
 }
 
+// A set of more than sub_max << DG_CUT_MAX vertices needs more subtrees than a set's node-result table holds (round 4: a 23 000-vertex
+// 4K list with sub_max = 350 overran it).  sv_create keeps the handle's limit below that and the kernels leave deeper sets alone;
+// a caller that asks for more gets an error, not a silently smaller launch.
+static void dg_check_cut(int ns_max, int sub_max, const DelaunayScratch &scratch) {
+    if (sub_max < 6 || sub_max > DG_SUB_MAX || dg_cut_depth(ns_max, sub_max) > DG_CUT_MAX)
+        throw std::invalid_argument("delaunay_gpu: sets of " + std::to_string(ns_max) + " vertices cannot be cut into " + std::to_string(1 << DG_CUT_MAX) + " subtrees of " +
+                                    std::to_string(sub_max));
+    if (ns_max > scratch.cap) throw std::invalid_argument("delaunay_gpu: the scratch holds sets of " + std::to_string(scratch.cap) + " vertices, asked for " + std::to_string(ns_max));
+}
+
 // The sets of a resident chunk that are beyond LDS (sub_max < vertices <= large_cap): preparation, then the cut path's two kernels.
 // prep_scratch: 2 * n_pairs sets of delaunay_prep_large_bytes(.., scratch.cap).
 void launch_delaunay_resident_large(int32_t *blob, int n_pairs, int sub_max, int large_cap, int W, int H, int step, int disp_max, void *prep_scratch, const DelaunayScratch &scratch,
                                     hipStream_t st) {
+    dg_check_cut(large_cap < scratch.cap ? large_cap : scratch.cap, sub_max, scratch);
     const DgPrep pp = dg_prep_dims(W, H, step, disp_max);
     const DgPrepScratch ps{static_cast<uint32_t *>(prep_scratch), scratch.cap, pp.bm_words};
     SV_LAUNCH(K_DELAUNAY, k_dg_prepare_large_blob, dim3(2 * n_pairs), dim3(DGP_THREADS), 0, st, blob, sub_max, large_cap < scratch.cap ? large_cap : scratch.cap, pp, ps);
@@ -1462,7 +1477,7 @@ int launch_delaunay_gpu_large(const int4 *sets, int nsets, const int32_t *order,
 }
 
 void launch_delaunay_blob_large(int32_t *blob, int n_pairs, int ns_max, int sub_max, const DelaunayScratch &scratch, hipStream_t st) {
-    if (dg_cut_depth(ns_max, sub_max) > DG_CUT_MAX) ns_max = sub_max << DG_CUT_MAX;  // (sv_create keeps the handle's limit below this; larger sets are the host's)
+    dg_check_cut(ns_max, sub_max, scratch);
     const size_t lds = delaunay_gpu_lds_bytes(sub_max, sub_max);
     static std::atomic<size_t> granted[64];
     ensure_dynamic_lds(k_dgl_subtrees_blob, lds, granted, "delaunay_gpu");

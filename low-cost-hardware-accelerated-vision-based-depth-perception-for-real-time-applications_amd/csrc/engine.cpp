@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -36,6 +37,7 @@
 #include <vector>
 
 #include "../../include/stereo_vision_hip.h"
+#include "dma_lanes.h"
 #include "host_stage.h"
 #include "sv_kernels.h"
 
@@ -116,6 +118,7 @@ struct Slot {
     size_t grid_off = 0;
     int grid_ns = 0;
     bool delivered_ok = false;  // host-memory jobs: the download succeeded (drainer -> deliverer)
+    int up_ticket = -1, down_ticket = -1;  // DMA lanes: the chunk's image upload / map download in flight (DmaLanes tickets)
     bool out_enqueued = false;  // host-memory jobs: phase 2 was enqueued (ev_lr / ev_p2 are pending), the maps can be downloaded
     int state = SLOT_FREE;
     // chunk in flight
@@ -181,6 +184,8 @@ struct sv_handle {
     bool host_dev_ready = false, host_pin_in_ready = false, host_pin_out_ready = false;  // lazily allocated staging (guarded by host_mu)
     bool host_dev8_ready = false, host_pin_out8_ready = false;
     std::mutex host_mu;
+    DmaLanes *dma = nullptr;   // engine-addressed SDMA copies of the host-memory path (dma_lanes.h); nullptr: hipMemcpyAsync on sIn / sOut / sOut2
+    int host_copies_mode = 0;  // 0 not decided yet, 1 hipMemcpyAsync, 2 DMA lanes (SV_Q_HOST_COPIES)
     // control threads + queues
     std::thread t_issue, t_dispatch, t_finish, t_drain, t_deliver;
     std::mutex mu;  // guards: job queue + counters, quit, slot states, q1, q2, error
@@ -227,6 +232,16 @@ struct sv_handle {
     long lat_calls = 0;
     double drain_ns[3] = {0};  // drainer, per chunk: waiting for phase 2, downloading, handing pageable maps over
     long drain_chunks = 0;
+    // SV_CHUNK_TRACE=<file>: wall-clock time of every pipeline stage of every chunk (tools/chunk_trace.py reads it), written by sv_destroy
+    struct TraceRec {
+        int slot, stage;
+        int64_t ns;
+    };
+    bool chunk_trace_on = false;
+    std::string chunk_trace_path;
+    std::mutex trace_mu;
+    std::vector<TraceRec> chunk_trace;
+    std::chrono::steady_clock::time_point t_created = std::chrono::steady_clock::now();
 };
 
 namespace {
@@ -240,6 +255,17 @@ namespace {
             throw std::runtime_error(buf_);                                                                   \
         }                                                                                                     \
     } while (0)
+
+enum TraceStage { TR_SLOT = 0, TR_UP_QUEUED, TR_UP_DONE, TR_P1_QUEUED, TR_P1_DONE, TR_HOST_DONE, TR_P2_QUEUED, TR_P2_DONE, TR_DOWN_QUEUED, TR_DOWN_DONE, TR_FREE, TR_COUNT };
+const char *const kTraceStageNames[TR_COUNT] = {"slot", "upload_queued", "upload_done", "phase1_queued", "phase1_done", "host_done", "phase2_queued", "phase2_done", "download_queued",
+                                                "download_done", "free"};
+
+inline void trace_mark(sv_handle *h, const Slot *s, int stage) {
+    if (!h->chunk_trace_on) return;
+    const int64_t ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - h->t_created).count();
+    std::lock_guard<std::mutex> lk(h->trace_mu);
+    h->chunk_trace.push_back({s->id, stage, ns});
+}
 
 // The only place this file reads the environment.
 bool env_int(const char *name, int *out) {
@@ -269,6 +295,7 @@ void apply_env_overrides(sv_config &c) {
     if (env_int("SV_NO_INLINE", &v)) c.inline_latency_path = 2;
     if (env_int("SV_LATENCY_SPLIT", &v)) c.latency_split = v > 0 ? (v > 1 ? 2 : 1) : 0;
     if (env_int("SV_EVENT_SYNC", &v)) c.event_sync = v == 1 ? 1 : (v == 3 ? 3 : 2);
+    if (env_int("SV_HOST_COPIES", &v)) c.host_copies = v == 1 ? 1 : (v == 2 ? 2 : 0);
 }
 
 int validate(const sv_params &p, const sv_config &c, std::string &err) {
@@ -295,6 +322,27 @@ int validate(const sv_params &p, const sv_config &c, std::string &err) {
         err = "image too large";
         return SV_ERR_ARG;
     }
+    // policy words: a caller built against an older, shorter sv_config hands over garbage here - refuse it instead of acting on it
+    const struct {
+        const char *name;
+        int32_t v, lo, hi;
+    } fields[] = {{"device", c.device, 0, 1023}, {"n_workers", c.n_workers, 0, 1024}, {"chunk", c.chunk, 0, 4096}, {"n_streams", c.n_streams, 0, 64}, {"n_slots", c.n_slots, 0, 64},
+                  {"gpu_lattice_filter", c.gpu_lattice_filter, 0, 2}, {"gpu_triangulation", c.gpu_triangulation, 0, 4}, {"gpu_triangulation_pct", c.gpu_triangulation_pct, 0, 100},
+                  {"resident", c.resident, 0, 2}, {"dg_sub_max", c.dg_sub_max, 0, 1 << 20}, {"dg_max_points", c.dg_max_points, 0, 1 << 24}, {"affinity", c.affinity, 0, 2},
+                  {"inline_latency_path", c.inline_latency_path, 0, 2}, {"event_sync", c.event_sync, 0, 3}, {"share_sliced", c.share_sliced, 0, 1}, {"latency_split", c.latency_split, 0, 2},
+                  {"host_copies", c.host_copies, 0, 2}};
+    for (const auto &f : fields)
+        if (f.v < f.lo || f.v > f.hi) {
+            snprintf(b, sizeof(b), "sv_config.%s = %d is outside [%d, %d] (is the caller built against this header's sv_config: %d int32 words?)", f.name, (int)f.v, (int)f.lo, (int)f.hi,
+                     (int)(sizeof(sv_config) / sizeof(int32_t)));
+            err = b;
+            return SV_ERR_ARG;
+        }
+    for (int32_t r : c.reserved)
+        if (r != 0) {
+            err = "sv_config.reserved must be 0";
+            return SV_ERR_ARG;
+        }
     return SV_OK;
 }
 
@@ -657,6 +705,18 @@ void ensure_host_staging(sv_handle *h, bool need_pin_in, bool need_pin_out, bool
             HIP_TRY(hipEventCreateWithFlags(&sl->ev_p2, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&sl->ev_out, evf));
         }
+        // Who moves the chunks over PCIe in the pipeline: SDMA engines of our own choice - one for the image uploads, another for the
+        // map downloads - where the runtime offers engine-addressed copies, else hipMemcpyAsync on the three copy streams (which picks
+        // "the first engine that is free" per copy: the directions end up on one engine every few chunks and serialise).  Single pairs
+        // on a chunk-1 handle (run_inline) copy in stream order on the kernels' own streams either way.
+        h->host_copies_mode = 1;
+        if (h->cfg.host_copies != 1) {
+            std::string why;
+            int v = 0;
+            h->dma = DmaLanes::create(h->slots[0]->d_in, h->slots[0]->h_blob, &why, env_int("SV_DMA_ENGINES", &v) ? (uint32_t)v : 0u);
+            if (h->dma) h->host_copies_mode = 2;
+            else if (h->cfg.host_copies == 2) throw std::runtime_error("sv_config.host_copies = 2, but " + why);
+        }
         h->host_dev_ready = true;
     }
     if (need_pin_in && !h->host_pin_in_ready) {
@@ -679,13 +739,37 @@ void ensure_host_staging(sv_handle *h, bool need_pin_in, bool need_pin_out, bool
 
 // Upload of a chunk's images on `st` (stream sIn in the pipeline, the phase-1 stream itself in latency mode).  Device layout:
 // rows packed to W bytes, all left images of the chunk, then all right images.
-void upload_chunk(sv_handle *h, Slot *s, hipStream_t st, int copy_helpers) {
+// lanes (pipeline only): the copies go to the upload engine of h->dma instead of `st` and s->up_ticket names them - whoever launches
+// phase 1 waits for the ticket on the host first (the issuer keeps the next chunks' uploads queued on the engine meanwhile).
+void upload_chunk(sv_handle *h, Slot *s, hipStream_t st, int copy_helpers, bool lanes = false) {
     const Dims &d = h->kp.d;
     const Job &job = *s->job;
     const size_t cap = (size_t)s->dev.cap, img = (size_t)d.N, src_pair = (size_t)d.H * job.stride;
     const uint8_t *src[2] = {job.left + (size_t)s->i0 * src_pair, job.right + (size_t)s->i0 * src_pair};
+    s->up_ticket = -1;
+    if (lanes && h->dma && !(job.pin_in && job.stride != d.W)) {  // (strided page-locked rows stay with the runtime's 2-D copy)
+        s->up_ticket = h->dma->begin(2);
+        if (s->up_ticket < 0) throw std::runtime_error("DMA lanes: no completion signal");
+    }
     for (int side = 0; side < 2; side++) {
         uint8_t *dev = s->d_in + side * cap * img;
+        if (s->up_ticket >= 0) {
+            const uint8_t *from = src[side];
+            if (!job.pin_in) {  // pageable: pack into the page-locked mirror first (the left images travel while the right ones are packed)
+                uint8_t *stage = s->h_in + side * cap * img;
+                CopyList cl;
+                if (job.stride == d.W) {
+                    cl.add(stage, src[side], (size_t)s->n * img);
+                } else {
+                    for (int j = 0; j < s->n; j++)
+                        for (int y = 0; y < d.H; y++) cl.job->pieces.push_back({stage + (size_t)j * img + (size_t)y * d.W, src[side] + (size_t)j * src_pair + (size_t)y * job.stride, (size_t)d.W});
+                }
+                cl.run(h, copy_helpers);
+                from = stage;
+            }
+            if (!h->dma->add(s->up_ticket, DmaLanes::UP, dev, from, (size_t)s->n * img, true)) note_error(h, "DMA lanes: an image upload was refused");
+            continue;
+        }
         if (job.pin_in) {  // DMA straight from the caller's page-locked memory
             if (job.stride == d.W)
                 HIP_TRY(hipMemcpyAsync(dev, src[side], (size_t)s->n * img, hipMemcpyHostToDevice, st));
@@ -710,9 +794,17 @@ void upload_chunk(sv_handle *h, Slot *s, hipStream_t st, int copy_helpers) {
     s->in_stride = d.W;
 }
 
-// Download of one finished map block (side 0: left maps, 1: right maps) of a chunk on `st`.  Pairs with fewer than 3 support
-// points are skipped: the reference leaves the caller's maps untouched for them (elas.cpp:63-69).
-void download_maps(sv_handle *h, Slot *s, int side, hipStream_t st, hipStream_t st2 = nullptr) {
+// Downloads of one finished map block (side 0: left maps, 1: right maps) of a chunk, as a list of copies.  Pairs with fewer than 3
+// support points are skipped: the reference leaves the caller's maps untouched for them (elas.cpp:63-69).  `second`: the copy may go
+// to the second download stream / engine (long runs go down as two halves).
+struct DlCopy {
+    void *dst;
+    const void *src;
+    size_t bytes;
+    bool second;
+};
+
+void plan_downloads(sv_handle *h, Slot *s, int side, bool split, std::vector<DlCopy> &out) {
     const Dims &d = h->kp.d;
     const Job &job = *s->job;
     const size_t cap = (size_t)s->dev.cap, Nm = (size_t)d.Nm;
@@ -726,7 +818,7 @@ void download_maps(sv_handle *h, Slot *s, int side, hipStream_t st, hipStream_t 
             }
             int e = j + 1;
             while (e < s->n && s->h_blob[(size_t)e * META_WORDS] >= 3) e++;
-            HIP_TRY(hipMemcpyAsync(dst8 + (size_t)j * Nm, s->d_out8 + (size_t)j * Nm, (size_t)(e - j) * Nm, hipMemcpyDeviceToHost, st));
+            out.push_back({dst8 + (size_t)j * Nm, s->d_out8 + (size_t)j * Nm, (size_t)(e - j) * Nm, false});
             j = e;
         }
         return;
@@ -742,12 +834,18 @@ void download_maps(sv_handle *h, Slot *s, int side, hipStream_t st, hipStream_t 
         }
         int e = j + 1;
         while (e < s->n && s->h_blob[(size_t)e * META_WORDS] >= 3) e++;
-        // long runs go down as two halves on two streams: one DMA engine moves ~41 GB/s beside the uploads, two share the link better
-        const int half = (st2 && e - j >= 8) ? j + (e - j) / 2 : e;
-        HIP_TRY(hipMemcpyAsync(dst + (size_t)j * Nm, dev + (size_t)j * Nm, (size_t)(half - j) * Nm * sizeof(float), hipMemcpyDeviceToHost, st));
-        if (half < e) HIP_TRY(hipMemcpyAsync(dst + (size_t)half * Nm, dev + (size_t)half * Nm, (size_t)(e - half) * Nm * sizeof(float), hipMemcpyDeviceToHost, st2));
+        // the runtime's copies: long runs go down as two halves on two streams (one DMA engine moved ~41 GB/s beside the uploads)
+        const int half = (split && e - j >= 8) ? j + (e - j) / 2 : e;
+        out.push_back({dst + (size_t)j * Nm, dev + (size_t)j * Nm, (size_t)(half - j) * Nm * sizeof(float), false});
+        if (half < e) out.push_back({dst + (size_t)half * Nm, dev + (size_t)half * Nm, (size_t)(e - half) * Nm * sizeof(float), true});
         j = e;
     }
+}
+
+void download_maps(sv_handle *h, Slot *s, int side, hipStream_t st, hipStream_t st2 = nullptr) {
+    std::vector<DlCopy> plan;
+    plan_downloads(h, s, side, st2 != nullptr, plan);
+    for (const DlCopy &c : plan) HIP_TRY(hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToHost, c.second ? st2 : st));
 }
 
 // Pageable callers: the maps of a chunk from the page-locked mirror into the caller's arrays (after ev_out)
@@ -780,39 +878,62 @@ void set_chunk_inputs(sv_handle *h, Slot *s) {  // device-memory jobs read the c
     s->in_stride = job.stride;
 }
 
+// Stage 1.  The issuer takes the chunks of the submitted batches in order, gives each the next slot of the ring, and launches its first
+// GPU phase.  Host-memory batches on DMA lanes: a chunk's images have to be in HBM before its kernels are LAUNCHED (the upload engine
+// and the HIP streams share no device-side dependency), so the issuer keeps the uploads of the next chunks queued on the engine -
+// `ahead` chunks are prepared (slot taken, upload enqueued) before the oldest of them is waited for and launched.  The engine never
+// runs dry and the host wait costs the kernels nothing: they are launched one upload behind.
 void issuer_main(sv_handle *h) {
     (void)hipSetDevice(h->cfg.device);
+    const int ns = (int)h->slots.size();
+    std::deque<Slot *> ready;  // prepared chunks, oldest first
+    Job *job = nullptr;        // the batch whose chunks are being prepared
+    int next_c = 0;
     for (;;) {
-        Job *job = nullptr;
-        {
-            std::unique_lock<std::mutex> lk(h->mu);
-            h->cv.wait(lk, [&] { return h->quit || !h->jobs.empty(); });
-            if (h->quit) return;
-            job = h->jobs.front();
-            h->jobs.pop_front();
-        }
-        g_launch_hook.fn = h->timing ? timing_hook : nullptr;
-        g_launch_hook.ctx = &h->tc_issue;
-        const int ns = (int)h->slots.size();
-        for (int c = 0; c < job->nchunks; c++) {
+        // (1) prepare: blocking while nothing is prepared, opportunistic (never waiting) beyond that
+        for (;;) {
+            const bool may_block = ready.empty();
+            const size_t ahead = (job && next_c < job->nchunks && job->host && h->dma) ? (size_t)std::max(1, std::min(3, ns / 2)) : 1;
+            if (!may_block && ready.size() >= ahead) break;
+            if (!job || next_c >= job->nchunks) {
+                std::unique_lock<std::mutex> lk(h->mu);
+                if (may_block) h->cv.wait(lk, [&] { return h->quit || !h->jobs.empty(); });
+                if (h->quit) return;
+                if (h->jobs.empty()) break;
+                if (!may_block && !(h->jobs.front()->host && h->dma)) break;  // (only uploads are worth preparing ahead)
+                job = h->jobs.front();
+                h->jobs.pop_front();
+                next_c = 0;
+                continue;
+            }
             Slot *s = h->slots[h->ring_pos];
-            h->ring_pos = (h->ring_pos + 1) % ns;
             bool drain = false;
             {
                 const auto w0 = std::chrono::steady_clock::now();
                 std::unique_lock<std::mutex> lk(h->mu);
-                h->cv.wait(lk, [&] { return s->state != SLOT_BUSY; });
+                if (may_block) h->cv.wait(lk, [&] { return s->state != SLOT_BUSY; });
+                else if (s->state == SLOT_BUSY) break;
                 drain = s->state == SLOT_DRAINING;
+                if (drain && !may_block && hipEventQuery(s->ev_free) != hipSuccess) break;  // its previous chunk is still in phase 2
                 s->state = SLOT_BUSY;
                 if (h->lat_trace) h->issue_ns[5] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - w0).count();
             }
+            h->ring_pos = (h->ring_pos + 1) % ns;
+            trace_mark(h, s, TR_SLOT);
             s->job = job;
-            s->i0 = c * h->chunk;
+            s->i0 = next_c * h->chunk;
             s->n = std::min(h->chunk, job->batch - s->i0);
+            s->up_ticket = -1;
+            next_c++;
             // who triangulates this chunk: the GPU mode keeps every chunk resident; with a balanced share every 1 / share-th chunk
             s->resident = false;
             if (h->resident_ok) {
-                if (h->gpu_delaunay_pct >= 100) {
+                // Host-memory batches under the automatic policy are resident throughout: a chunk the pool triangulates moves its support
+                // lists down and its blob (~120 KB per pair) up with the runtime's own copies, which take whichever SDMA engine looks free
+                // when they are enqueued and then sit behind a 2 ms map download on it - phase 2 of such a chunk took 7.9 ms instead of 3
+                // (tools/chunk_trace.py).  Measured with 14 pool threads / everything resident: f32 maps 22 100 - 24 600 / 27 500 pairs/s,
+                // 8-bit maps 37 000 / 44 000 (profiles/HISTORY.md, round 5); the link is the limit either way, the pool has nothing to add.
+                if (h->gpu_delaunay_pct >= 100 || (job->host && h->gpu_share_auto)) {
                     s->resident = true;
                 } else {
                     h->issue_acc += h->gpu_share_auto ? h->shared_pct.load(std::memory_order_relaxed) : h->gpu_delaunay_pct;
@@ -825,29 +946,51 @@ void issuer_main(sv_handle *h) {
             try {
                 if (drain) HIP_TRY(wait_event(h, s->ev_free));
                 if (!h->failed) {
-                    if (job->host) {  // images: caller -> (page-locked mirror ->) device on the upload stream; phase 1 waits for them
-                        upload_chunk(h, s, h->sIn, 3);
-                        HIP_TRY(hipEventRecord(s->ev_in, h->sIn));
-                        HIP_TRY(hipStreamWaitEvent(h->sP1, s->ev_in, 0));
+                    if (job->host) {  // images: caller -> (page-locked mirror ->) device; phase 1 waits for them
+                        upload_chunk(h, s, h->sIn, 3, true);
+                        trace_mark(h, s, TR_UP_QUEUED);
+                        if (s->up_ticket < 0) {  // the runtime's copies on the upload stream: a device-side dependency
+                            HIP_TRY(hipEventRecord(s->ev_in, h->sIn));
+                            HIP_TRY(hipStreamWaitEvent(h->sP1, s->ev_in, 0));
+                        }
                     } else {
                         set_chunk_inputs(h, s);
                     }
-                    issue_phase1(h, s);
                 }
             } catch (const std::exception &e) {
                 note_error(h, e.what());
             }
-            {
-                std::lock_guard<std::mutex> lk(h->mu);
-                h->q1.push_back(s);
-            }
-            h->cv.notify_all();
+            ready.push_back(s);
         }
+        if (ready.empty()) continue;
+        // (2) launch the oldest prepared chunk
+        Slot *s = ready.front();
+        ready.pop_front();
+        g_launch_hook.fn = h->timing ? timing_hook : nullptr;
+        g_launch_hook.ctx = &h->tc_issue;
+        try {
+            if (s->up_ticket >= 0) {
+                const bool ok = h->dma->wait(s->up_ticket, h->poll_sync);
+                s->up_ticket = -1;
+                if (!ok) throw std::runtime_error("DMA lanes: an image upload failed");
+                trace_mark(h, s, TR_UP_DONE);
+            }
+            if (!h->failed) issue_phase1(h, s);
+            trace_mark(h, s, TR_P1_QUEUED);
+        } catch (const std::exception &e) {
+            note_error(h, e.what());
+        }
+        {
+            std::lock_guard<std::mutex> lk(h->mu);
+            h->q1.push_back(s);
+        }
+        h->cv.notify_all();
     }
 }
 
 // ---- stage 2: dispatcher + host pool ---------------------------------------------------------------------------------
 void chunk_host_done(sv_handle *h, Slot *s) {
+    trace_mark(h, s, TR_HOST_DONE);
     if (s->inline_mode) {
         s->inline_done.store(1, std::memory_order_release);
         return;
@@ -1132,6 +1275,7 @@ void dispatcher_main(sv_handle *h) {
                 ok = false;
             }
         }
+        trace_mark(h, s, TR_P1_DONE);
         if (!ok) {  // keep the pipeline moving: mark every pair as skipped
             for (int j = 0; j < s->n; j++) {
                 int32_t *meta = s->h_blob + (size_t)j * META_WORDS;
@@ -1330,6 +1474,29 @@ void download_chunk(sv_handle *h, Slot *s) {
     HIP_TRY(wait_event(h, s->ev_out));
 }
 
+// The same on DMA lanes: the host waits for phase 2 (nothing sits in an engine's queue behind a wait), the copies go to the download
+// engines - left maps / 8-bit images on one, right maps on the other - and s->down_ticket names them: the deliverer waits for the
+// ticket, so the drainer can queue the next chunk's copies while these run.
+void download_chunk_lanes(sv_handle *h, Slot *s) {
+    const Job &job = *s->job;
+    s->down_ticket = -1;
+    HIP_TRY(wait_event(h, s->ev_p2));
+    trace_mark(h, s, TR_P2_DONE);
+    std::vector<DlCopy> plan;
+    size_t n1 = 0;
+    if (job.d2 && !job.dmap) plan_downloads(h, s, 1, false, plan);
+    n1 = plan.size();
+    plan_downloads(h, s, 0, false, plan);
+    if (plan.empty()) return;
+    s->down_ticket = h->dma->begin((int)plan.size());
+    if (s->down_ticket < 0) throw std::runtime_error("DMA lanes: no completion signal");
+    bool ok = true;
+    for (size_t i = 0; i < plan.size(); i++)
+        ok = h->dma->add(s->down_ticket, i < n1 ? DmaLanes::DOWN2 : DmaLanes::DOWN, plan[i].dst, plan[i].src, plan[i].bytes, false) && ok;
+    if (!ok) note_error(h, "DMA lanes: a map download was refused");
+    trace_mark(h, s, TR_DOWN_QUEUED);
+}
+
 void finisher_main(sv_handle *h) {
     (void)hipSetDevice(h->cfg.device);
     size_t rr = 0;
@@ -1349,6 +1516,7 @@ void finisher_main(sv_handle *h) {
             if (!h->failed) {
                 hipStream_t st = h->sP2[rr++ % h->sP2.size()];
                 issue_phase2(h, s, st);
+                trace_mark(h, s, TR_P2_QUEUED);
                 recorded = true;
                 const size_t c = (size_t)(s->i0 / h->chunk);
                 if (!s->job->host && c < s->job->ev_done.size() && s->job->ev_done[c]) HIP_TRY(hipEventRecord(s->job->ev_done[c], st));
@@ -1385,12 +1553,14 @@ void drainer_main(sv_handle *h) {
             h->q3.pop_front();
         }
         s->delivered_ok = false;
+        s->down_ticket = -1;
         if (s->out_enqueued && !h->failed) {
             try {
                 const auto t0 = std::chrono::steady_clock::now();
                 if (h->lat_trace) (void)hipEventSynchronize(s->ev_p2);  // trace only: separates "waiting for phase 2" from the copy
                 const auto t1 = std::chrono::steady_clock::now();
-                download_chunk(h, s);
+                if (h->dma) download_chunk_lanes(h, s);
+                else download_chunk(h, s);
                 s->delivered_ok = true;
                 if (h->lat_trace) {
                     h->drain_ns[0] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
@@ -1422,6 +1592,14 @@ void deliverer_main(sv_handle *h) {
             s = h->q4.front();
             h->q4.pop_front();
         }
+        if (s->down_ticket >= 0) {  // DMA lanes: the chunk's downloads are in flight (or queued behind the previous chunk's)
+            if (!h->dma->wait(s->down_ticket, h->poll_sync)) {
+                note_error(h, "DMA lanes: a map download failed");
+                s->delivered_ok = false;
+            }
+            s->down_ticket = -1;
+        }
+        trace_mark(h, s, TR_DOWN_DONE);
         if (s->delivered_ok && !h->failed) {
             const auto t0 = std::chrono::steady_clock::now();
             deliver_maps(h, s, 3);
@@ -1430,6 +1608,7 @@ void deliverer_main(sv_handle *h) {
         {
             std::lock_guard<std::mutex> lk(h->mu);
             s->state = SLOT_FREE;
+            trace_mark(h, s, TR_FREE);
             if (++s->job->drained == s->job->nchunks) h->jobs_finished++;
         }
         h->cv.notify_all();
@@ -1439,15 +1618,15 @@ void deliverer_main(sv_handle *h) {
 // Host cores this process may use: the cgroup CPU quota when there is one, else the affinity mask; shared evenly between
 // the ranks of one node (LOCAL_WORLD_SIZE, set by torch.distributed.run).  Without a visible quota the pool stays at 16.
 // cores this rank may use (cgroup quota or affinity mask, divided by the ranks of the node); *quota = a cgroup quota is set
-double host_cpu_share(bool *quota) {
+double host_cpu_share(bool *quota, bool ignore_quota = false) {
     double cpus = 0.0;
-    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
+    if (FILE *f = ignore_quota ? nullptr : fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota> <period>" or "max <period>"
         char q[64];
         double period = 0.0;
         if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0.0) cpus = atof(q) / period;
         fclose(f);
     }
-    if (cpus <= 0.0) {  // cgroup v1
+    if (cpus <= 0.0 && !ignore_quota) {  // cgroup v1
         double quota = -1.0, period = 0.0;
         if (FILE *f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
             if (fscanf(f, "%lf", &quota) != 1) quota = -1.0;
@@ -1470,12 +1649,16 @@ double host_cpu_share(bool *quota) {
     // a quota is the node's budget and is shared between the node's ranks; an affinity mask narrower than that share is the rank's own
     // already (a launcher that pins its ranks) and is not divided again
     if (have_quota) return std::min((double)aff, std::max(1.0, cpus / ranks));
+    // no quota: a mask that is already no wider than one rank's share of the machine (launcher.restrict_to_host_share, torchrun ranks
+    // pinned per rank) is not divided a second time - the pool would be sized for 1 / ranks^2 of the CPUs
+    const long hw = std::max(1L, sysconf(_SC_NPROCESSORS_CONF));  // the machine's CPUs, whatever this process's mask
+    if (ranks > 1 && (long)aff * ranks <= hw) return (double)aff;
     return (double)aff / ranks;
 }
 
-int default_pool_size() {
+int default_pool_size(bool ignore_quota = false) {
     bool have_quota = false;
-    const int share = std::max(1, (int)host_cpu_share(&have_quota));
+    const int share = std::max(1, (int)host_cpu_share(&have_quota, ignore_quota));
     // under a CPU quota the pool leaves two cores to the control threads and the caller: a pool that fills the quota gets the whole
     // process throttled in bursts (sustained over 20 000 pairs: 37 300 - 38 600 pairs/s with 16 threads of a 16-CPU quota,
     // 40 100 - 40 400 with 14)
@@ -1652,6 +1835,8 @@ void free_handle_resources(sv_handle *h) {
     if (h->sIn) (void)hipStreamDestroy(h->sIn);
     if (h->sOut) (void)hipStreamDestroy(h->sOut);
     if (h->sOut2) (void)hipStreamDestroy(h->sOut2);
+    delete h->dma;
+    h->dma = nullptr;
 }
 
 // host-memory jobs: classify the caller's memory and make sure the staging buffers exist
@@ -2111,6 +2296,10 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     {
         int v = 0;
         h->lat_trace = env_int("SV_LAT_TRACE", &v);  // (also sv_debug_set "lat_trace")
+        if (const char *path = getenv("SV_CHUNK_TRACE")) {
+            h->chunk_trace_on = *path != 0;
+            h->chunk_trace_path = path;
+        }
         h->pool_sleep = env_int("SV_POOL_SLEEP", &v);
         if (env_int("SV_DG_MARGIN", &v)) h->ns_margin_pct = std::max(0, v);
     }
@@ -2128,6 +2317,13 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
 int sv_destroy(sv_handle *h) {
     if (!h) return SV_ERR_ARG;
     (void)wait_jobs(h);
+    if (h->chunk_trace_on && !h->chunk_trace.empty()) {
+        if (FILE *f = fopen(h->chunk_trace_path.c_str(), "a")) {
+            fprintf(f, "# handle %p: slot stage ns\n", (void *)h);
+            for (const sv_handle::TraceRec &r : h->chunk_trace) fprintf(f, "%d %s %lld\n", r.slot, kTraceStageNames[r.stage], (long long)r.ns);
+            fclose(f);
+        }
+    }
     if (h->lat_trace && h->issue_chunks > 0)
         fprintf(stderr, "issuer, %ld chunks, ms of wall clock per chunk: sobel + support launches %.3f, filter launches %.3f, triangulation launch %.3f, copies %.3f, event record %.3f, waiting for a slot %.3f\n",
                 h->issue_chunks, 1e-6 * h->issue_ns[0] / (double)h->issue_chunks, 1e-6 * h->issue_ns[1] / (double)h->issue_chunks, 1e-6 * h->issue_ns[2] / (double)h->issue_chunks,
@@ -2188,6 +2384,7 @@ int sv_query(const sv_handle *h, int what) {
         case SV_Q_GPU_TRIANGULATION: return h->gpu_delaunay ? 1 : 0;
         case SV_Q_NUMA_BOUND: return h->node_bound ? 1 : 0;
         case SV_Q_RESIDENT: return h->resident_ok ? 1 : 0;
+        case SV_Q_HOST_COPIES: return h->host_copies_mode;
         case SV_Q_GPU_TRIANGULATION_FALLBACKS: return (int)std::min<int64_t>(h->gpu_tri_fallbacks.load(), 0x7FFFFFFF);
         case SV_Q_GPU_TRIANGULATION_SHARE: {
             const int64_t all = h->tri_pairs.load(), g = h->gpu_tri_pairs.load();
@@ -2368,6 +2565,10 @@ int sv_kernel_timing_select(sv_handle *h, const char *names) {
     h->timing_mask.store(mask);
     return SV_OK;
 }
+
+// Test hook (no GPU needed): the host pool a handle would get by default in this process - CPU quota / affinity mask / LOCAL_WORLD_SIZE;
+// ignore_quota != 0 takes the branch of a host without a cgroup quota whatever this one has.
+int sv_default_host_threads(int ignore_quota) { return default_pool_size(ignore_quota != 0); }
 
 int sv_host_support_filter(const sv_params *p, int16_t *dcan, int width, int height, int32_t *support, int cap) {
     if (!p || !dcan || !support) return SV_ERR_ARG;

@@ -56,7 +56,7 @@ class SvConfig(ctypes.Structure):
                 ("chunk", ctypes.c_int32), ("keep_debug", ctypes.c_int32), ("n_streams", ctypes.c_int32), ("n_slots", ctypes.c_int32),
                 ("gpu_lattice_filter", ctypes.c_int32), ("gpu_triangulation", ctypes.c_int32), ("gpu_triangulation_pct", ctypes.c_int32),
                 ("resident", ctypes.c_int32), ("dg_sub_max", ctypes.c_int32), ("dg_max_points", ctypes.c_int32), ("affinity", ctypes.c_int32),
-                ("inline_latency_path", ctypes.c_int32), ("event_sync", ctypes.c_int32), ("share_sliced", ctypes.c_int32), ("latency_split", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5)]
+                ("inline_latency_path", ctypes.c_int32), ("event_sync", ctypes.c_int32), ("share_sliced", ctypes.c_int32), ("latency_split", ctypes.c_int32), ("host_copies", ctypes.c_int32), ("reserved", ctypes.c_int32 * 4)]
 
 
 _TRIANGULATION_MODES = {None: 0, "auto": 0, "gpu": 1, "host": 2, "balanced": 4}
@@ -150,12 +150,13 @@ class StereoEngine:
     """
 
     def __init__(self, width, height, params=None, device=0, n_workers=0, chunk=0, keep_debug=False, n_streams=0, n_slots=0, gpu_filter=None,
-                 triangulation=None, resident=None, dg_sub_max=0, dg_max_points=0, affinity=None, inline=None, share_sliced=False, event_sync=None, latency_split=0):
+                 triangulation=None, resident=None, dg_sub_max=0, dg_max_points=0, affinity=None, inline=None, share_sliced=False, event_sync=None, latency_split=0, host_copies=None):
         """gpu_filter: None (automatic) / True / False - where the support-lattice filters run.  triangulation: None or "auto", "gpu", "host",
         "balanced" (by the pool's backlog, whatever its size) or an int 1..100 = that share of the chunks on the GPU.  resident / affinity /
         inline: None (automatic) or False to switch the resident GPU share / the NUMA binding / the calling-thread latency path off.
         dg_sub_max, dg_max_points: limits of the GPU triangulation (tests).  event_sync: None (automatic), "block", "spin" or "poll" - how the
-        handle's threads wait for the GPU.  See sv_config in include/stereo_vision_hip.h."""
+        handle's threads wait for the GPU.  host_copies: None (automatic), "runtime" (hipMemcpyAsync) or "lanes" (engine-addressed SDMA copies) -
+        who moves host-memory batches over PCIe.  See sv_config in include/stereo_vision_hip.h."""
         L = lib()
         self.params = params if params is not None else SvParams.driver(127)
         self.width, self.height, self.device = int(width), int(height), int(device)
@@ -174,6 +175,7 @@ class StereoEngine:
         cfg.share_sliced = int(bool(share_sliced))
         cfg.event_sync = {None: 0, "auto": 0, "block": 1, "spin": 2, "poll": 3}[event_sync]
         cfg.latency_split = int(latency_split)
+        cfg.host_copies = {None: 0, "auto": 0, "runtime": 1, "lanes": 2}[host_copies]
         h = ctypes.c_void_p()
         rc = L.sv_create(ctypes.byref(self.params), ctypes.byref(cfg), ctypes.byref(h))
         if rc != 0:
@@ -349,6 +351,7 @@ class StereoEngine:
         out = {k: int(L.sv_query(self._h, i)) for i, k in enumerate(keys)}
         out["numa_bound"] = int(L.sv_query(self._h, 7))
         out["resident"] = int(L.sv_query(self._h, 8))
+        out["host_copies"] = int(L.sv_query(self._h, 9))  # 0 not decided yet (no host-memory batch so far), 1 hipMemcpyAsync, 2 DMA lanes
         return out
 
     def gpu_triangulation_share(self):

@@ -311,6 +311,41 @@ def test_gpu_triangulation_falls_back_per_set(eng, oracle, monkeypatch):
         assert util.sha(d1[i]) == entry["stages"]["final1"] and util.sha(d2[i]) == entry["stages"]["final2"]
 
 
+@pytest.mark.parametrize("resident", [True, False])
+def test_sets_beyond_the_cut_table_go_to_the_host(eng, resident):
+    """Round 4's fault, pinned: a set of more than dg_sub_max << 6 vertices needs a deeper cut than a set's node-result table holds
+    (delaunay_gpu.hip: DG_CUT_MAX).  With dg_sub_max = 100 the 4K strip's 7 528-vertex sets (limit 6 400) must be handed to the host -
+    by the handle's clamp (engine.cpp: dg_limit), the launchers' check and the kernels' own skip - and every map must still be the
+    reference's.  Asked for with and without resident chunks."""
+    entry = DIG["synth5000_4kstrip_d192"]
+    assert entry["n_support"] > 100 << 6
+    L, R = util.case_images(entry)
+    e = eng.StereoEngine(L.shape[1], L.shape[0], util.case_params(entry, eng.SvParams), chunk=4, n_slots=2, n_streams=2, n_workers=3, triangulation="gpu", dg_sub_max=100,
+                         resident=None if resident else False)
+    try:
+        # (a handle whose GPU limit is below the lists its bulk copy can hold does not go resident at all: sv_create's own rule)
+        assert e.query()["gpu_triangulation"] == 1 and e.query()["resident"] == 0
+        d1, d2, st = e.process_host(np.stack([L] * 5), np.stack([R] * 5))
+        assert e.gpu_triangulation_fallbacks() == 10  # both sides of the five pairs went to the pool, none into the node-result table
+    finally:
+        e.close()
+    assert (st == entry["n_support"]).all()
+    for i in range(5):
+        assert util.sha(d1[i]) == entry["stages"]["final1"] and util.sha(d2[i]) == entry["stages"]["final2"]
+
+
+def test_cut_launcher_refuses_sets_it_cannot_cut(eng, monkeypatch):
+    """The launchers themselves return an error for a set that needs more than 2^6 subtrees instead of launching a smaller grid."""
+    rng = np.random.default_rng(5)
+    monkeypatch.setenv("SV_DG_SUBMAX", "100")
+    lat = rng.permutation(120 * 75)[:7000]
+    pts = np.stack([(lat % 120) * 5, (lat // 120) * 5], 1)  # 7 000 distinct lattice points > 100 << 6
+    with pytest.raises(eng.StereoError):
+        eng.gpu_delaunay(pts)
+    got, _ = eng.gpu_delaunay(pts[:6400])  # exactly at the limit: depth 6
+    assert np.array_equal(got, eng.host_delaunay(pts[:6400]))
+
+
 def test_pipeline_with_mixed_triangulation(eng, oracle, monkeypatch):
     """SV_GPU_DELAUNAY_PCT=40: inside one chunk some pairs are triangulated by the pool, the others by the GPU kernel (per-pair
     flag in the blob's meta words); every pair still equals its own oracle result."""

@@ -63,6 +63,24 @@ def test_host_share_restriction_before_any_gpu_call():
     assert len(kept) == max(1, before // 4) and kept == now and lws == "4" and torch_loaded is False
 
 
+def test_pool_size_of_a_pinned_rank_without_a_cpu_quota():
+    """A rank whose mask is already its share of the machine (restrict_to_host_share, torchrun ranks pinned per rank) keeps that share
+    on a host without a CPU quota: the mask is not divided by LOCAL_WORLD_SIZE a second time (engine.cpp: host_cpu_share)."""
+    ncpu = os.cpu_count()
+    usable = sorted(os.sched_getaffinity(0))
+    if ncpu < 4 or len(usable) < 2:
+        pytest.skip("needs a mask of two CPUs on a machine with at least four")
+    code = ("import os, sys, ctypes; os.sched_setaffinity(0, %r); os.environ['LOCAL_WORLD_SIZE'] = %r; "
+            "L = ctypes.CDLL(%r); L.sv_default_host_threads.argtypes = [ctypes.c_int]; print(L.sv_default_host_threads(1))")
+    lib = os.path.join(util.ROOT, util.PKG, "libstereo_vision_hip.so")
+    ranks = ncpu // 2  # a 2-CPU mask is exactly one rank's share
+    pinned = int(subprocess.check_output([sys.executable, "-c", code % (set(usable[:2]), str(ranks), lib)], text=True))
+    assert pinned == 2
+    # a mask wider than the share IS the node's budget and is divided between the ranks
+    wide = int(subprocess.check_output([sys.executable, "-c", code % (set(usable), "2", lib)], text=True))
+    assert wide == min(16, len(usable) // 2 if len(usable) * 2 > ncpu else len(usable))  # (16: the pool's cap without a quota)
+
+
 def test_launcher_module_is_stdlib_only():
     """The parent of a multi-GPU run must not initialise HIP: the launcher imports neither torch nor the engine."""
     code = "import sys, importlib; importlib.import_module(%r + '.launcher'); print(int('torch' in sys.modules), int('numpy' in sys.modules))" % util.PKG

@@ -39,6 +39,15 @@ L[:], R[:] = batch[:, 0], batch[:, 1]
 e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), n_slots=a.slots, chunk=a.chunk, n_workers=a.workers)
 if a.trace:
     e.debug_set("lat_trace", 1)
+def throttled():
+    """(periods throttled, ms throttled) of this cgroup so far: a pool that fills the CPU quota gets every thread stopped in bursts"""
+    try:
+        st = dict(l.split() for l in open("/sys/fs/cgroup/cpu.stat"))
+        return int(st.get("nr_throttled", 0)), int(st.get("throttled_usec", 0)) / 1e3
+    except (OSError, ValueError):
+        return 0, 0.0
+
+
 rates = []
 if a.dmap:
     dm = alloc((a.batch, H, W), np.uint8)
@@ -49,11 +58,16 @@ else:
     d2 = alloc((a.batch, H, W), np.float32) if a.d2 else None
     e.process_host(L, R, want_d2=a.d2, d1=d1, d2=d2)
     sub = lambda: e.submit_host(L, R, d1, d2)
+th0 = throttled()
+c0 = time.process_time()
+w0 = time.perf_counter()
 for _ in range(a.reps):
     t0 = time.perf_counter()
     for _ in range(a.steps):
         sub()
     e.wait()
     rates.append(a.batch * a.steps / (time.perf_counter() - t0))
+th1 = throttled()
+print("cores busy %.1f, cgroup throttled %d periods / %.0f ms, host threads %d;" % ((time.process_time() - c0) / (time.perf_counter() - w0), th1[0] - th0[0], th1[1] - th0[1], e.query()["host_threads"]), end=" ")
 print(os.environ.get("SV_LIB_PATH", "default"), "slots %d chunk %d" % (a.slots, a.chunk), "pageable" if a.pageable else "pinned", "dmap" if a.dmap else ("d1+d2" if a.d2 else "d1"), " ".join("%.0f" % r for r in rates), flush=True)
 e.close()
