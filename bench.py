@@ -302,6 +302,16 @@ def host_to_host(eng, e, params, batch, steps, lat_pair, reps=3):
                      "pairs_per_s_d1": round(r1, 1), "pairs_per_s_d1_runs": [round(x, 1) for x in runs1], "pairs_per_s_d1_d2": round(r2, 1), "pairs_per_s_d1_d2_runs": [round(x, 1) for x in runs2],
                      "pcie_GBps_d1": {"h2d": round(r1 * in_b / 1e9, 2), "d2h": round(r1 * map_b / 1e9, 2)},
                      "pcie_GBps_d1_d2": {"h2d": round(r2 * in_b / 1e9, 2), "d2h": round(r2 * 2 * map_b / 1e9, 2)}}
+    # who moved the chunks (sv_config.host_copies: 2 = SDMA engines the engine addresses itself, csrc/dma_lanes.cpp; 1 = hipMemcpyAsync) and
+    # what the page-locked f32 rate is of the link's own rate for that download (>= 0.9)
+    out["copies"] = {2: "dma_lanes", 1: "hipMemcpyAsync"}.get(e.query().get("host_copies"), "undecided")
+    ceil_pairs = out["pcie_ceiling_GBps"]["each_direction_when_both_run"] * 1e9 / map_b
+    out["pinned"]["d1_over_link_ceiling"] = round(out["pinned"]["pairs_per_s_d1"] / ceil_pairs, 3)
+    out["pinned"]["link_ceiling_pairs_per_s_d1"] = round(ceil_pairs, 1)
+    for kind in ("pinned", "pageable"):
+        for key in ("pairs_per_s_dmap_u8", "pairs_per_s_d1", "pairs_per_s_d1_d2"):
+            runs = out[kind][key + "_runs"]
+            out[kind][key + "_spread"] = round((max(runs) - min(runs)) / max(runs), 3)
     out["latency_ms_batch1_host"] = {k: host_latency(eng, params, lat_pair[0], lat_pair[1], k == "pinned") for k in ("pinned", "pageable")}
     return out
 
@@ -834,6 +844,22 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    # N ranks must be N ranks on N distinct GPUs: a launcher that started fewer, or two ranks that ended up on one
+    # device (a LOCAL_RANK that was not passed on), would still print a plausible line
+    rank_devices = None
+    if world > 1:
+        if dist.get_world_size() != args.gpus:
+            print("the process group has %d ranks, --gpus says %d" % (dist.get_world_size(), args.gpus), file=sys.stderr)
+            raise SystemExit(4)
+        props = torch.cuda.get_device_properties(local_rank)
+        ident = "%s/%s" % (os.uname().nodename, getattr(props, "uuid", None) or "%s:%s:%s" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", local_rank), getattr(props, "pci_device_id", 0)))
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, str(ident))
+        if backend == "nccl" and len(set(rank_devices)) != world:  # (the gloo rehearsal shares devices on purpose)
+            if rank == 0:
+                print("ranks share a GPU: %s" % rank_devices, file=sys.stderr)
+            raise SystemExit(4)
+
     eng = importlib.import_module(PKG + ".engine")
     synth = importlib.import_module(PKG + ".synth")
     par = importlib.import_module(PKG + ".parallel")
@@ -1049,7 +1075,17 @@ def main():
         # the keys a reader of the line's tail needs, last (the line is ~15 KB; a tail keeps its end)
         out["trailer"] = {
             "value": rate, "parity_gate": hl["parity_gate"]["status"], "parity_after": hl["parity_after"]["status"],
-            "value_host_to_host": out.get("value_host_to_host"), "value_real_frames": (real_rate or {}).get("value"),
+            "value_host_to_host": out.get("value_host_to_host"), "host_to_host_dmap_u8": ((h2h or {}).get("pinned") or {}).get("pairs_per_s_dmap_u8"),
+            "host_to_host_d1_over_link_ceiling": ((h2h or {}).get("pinned") or {}).get("d1_over_link_ceiling"), "host_copies": (h2h or {}).get("copies"),
+            "latency_ms_batch1_host_pinned": (((h2h or {}).get("latency_ms_batch1_host") or {}).get("pinned") or {}).get("median"),
+            "value_real_frames": (real_rate or {}).get("value"),
+            # N > 1: what makes the line self-validating - ranks, backend, every rank's own rate and their mean (the figure to hold against an
+            # N = 1 run's value), the root's blocks of the gathered maps checked against the ranks' checksums
+            "n_ranks": world, "collective_backend": backend if world > 1 else None, "rccl_ranks": (dist.get_world_size() if world > 1 and backend == "nccl" else None),
+            "distinct_devices": (len(set(rank_devices)) if rank_devices else None),
+            "per_rank_pairs_per_s": hl["per_rank_pairs_per_s"] if world > 1 else None, "per_rank_mean_pairs_per_s": round(rate / world, 1),
+            "root_blocks_match_rank_checksums": {k: (v.get(g) or {}).get("root_blocks_match_rank_checksums") for k, v in [("headline", hl)] + list(configs.items())
+                                                 for g in ("with_gather",) if world > 1 and v.get(g)} or None,
             "value_at_host_share_%d" % args.host_share: out.get("value_at_host_share_%d" % args.host_share),
             "kitti_d256_pairs_per_s": (configs.get("kitti_d256") or {}).get("pairs_per_s"), "4k_d192_pairs_per_s": (configs.get("4k_d192") or {}).get("pairs_per_s"),
             "configs_parity": {k: [v["parity_gate"]["status"], v["parity_after"]["status"]] for k, v in configs.items()},

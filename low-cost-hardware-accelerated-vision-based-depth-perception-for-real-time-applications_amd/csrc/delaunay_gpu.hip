@@ -27,6 +27,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
+// The workgroup-cooperative code (the on-GPU preparation of a vertex set) is compiled for the device and - DG_SIMT_EMULATION, on top of
+// DG_HOST_EMULATION - for CPU threads that play one workgroup under the sanitizers: tests/emu_dg_prepare.cpp supplies threadIdx,
+// __syncthreads, __shfl_up and the atomics.
+#if !defined(DG_HOST_EMULATION) || defined(DG_SIMT_EMULATION)
+#define DG_COOP 1
+#endif
+
 namespace sv {
 
 namespace dg {
@@ -575,6 +582,9 @@ struct DgSet {
     __device__ __forceinline__ int y(int i) const { return yb[(size_t)i * stride]; }
 };
 
+#endif  // DG_HOST_EMULATION
+
+#ifdef DG_COOP
 // LDS carve-up for a tree of n vertices with np coordinate entries: coordinates, k-d ordered ids, node results (heap order), triangles.
 // The coordinates and the order come first: the on-GPU preparation (dg_prepare) produces the order in place and uses the region behind
 // it - node results and triangles, not yet in use then - as its scratch.
@@ -597,6 +607,9 @@ __device__ __forceinline__ DgLds dg_carve(DG_LDS uint32_t *base, int n, int np) 
     L.W = L.res + (2 << depth);
     return L;
 }
+#endif  // DG_COOP
+
+#ifndef DG_HOST_EMULATION
 
 // Triangle list of a finished mesh, in pool order without the bounding triangles: corners org / dest / apex at orientation 0.
 // vtx(t, k) reads corner k of slot t.  All DG_THREADS threads of the workgroup call it.
@@ -736,6 +749,9 @@ __device__ __forceinline__ void dg_top(const DgSet &S, int sub_max, GTri *gT, co
     dg_emit(2 * m - 1, [gT](int t, int k) { return gT[t].w[3 + k]; }, GHOST32, S.out, S.count);
 }
 
+#endif  // DG_HOST_EMULATION
+
+#ifdef DG_COOP
 // ---- preparation on the GPU: (x, y) order, duplicate scan, k-d order ----------------------------------------------------------
 // What Delaunay::prepare (host_stage.cpp) does for the host triangulation - and what the reference does with a randomised quicksort,
 // a duplicate scan and randomised quickselects (triangle.cpp:5183-5360, 5889-5903) - for a vertex set that lives on the support
@@ -1173,6 +1189,9 @@ __device__ __forceinline__ int dg_prepare_global(const int32_t *__restrict__ sup
     if (tid == 0) ord_out[0] = m;
     return m;
 }
+#endif  // DG_COOP
+
+#ifndef DG_HOST_EMULATION
 
 // Pipeline form for resident chunks: the sets of more than sub_max vertices (up to large_cap) of a chunk whose blob k_delaunay_resident
 // has laid out; leaves [m, ids ...] where the host stage would have left them, for k_dgl_subtrees_blob / k_dgl_top_blob.
@@ -1349,6 +1368,9 @@ size_t delaunay_gpu_lds_bytes(int m, int npts) {
     return sizeof(uint32_t) * (dg_head_words(m, npts) + (2 << dg_depth(m))) + sizeof(DTri) * nslots + 16;
 }
 
+#endif  // DG_HOST_EMULATION
+
+#ifdef DG_COOP
 // Lattice geometry of the on-GPU preparation for images of W x H with lattice step `step` and disparities up to disp_max.
 static DgPrep dg_prep_dims(int W, int H, int step, int disp_max) {
     DgPrep pp;
@@ -1373,6 +1395,9 @@ size_t delaunay_resident_lds_bytes(int W, int H, int step, int disp_max, int m) 
     return sizeof(uint32_t) * dg_head_words(m, m) + (tri > prep ? tri : prep) + 16;
 }
 int delaunay_prep_max_points() { return DG_PREP_MAX; }
+#endif  // DG_COOP
+
+#ifndef DG_HOST_EMULATION
 
 // Both triangulations of every pair of a chunk from the lattice filter's lists on the device (k_delaunay_resident).  ns_max: an upper
 // bound of the chunk's support counts that take the LDS path (sizes the LDS request).

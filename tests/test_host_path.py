@@ -38,9 +38,12 @@ def _check(d1, d2, want):
             assert np.array_equal(d2[i].view(np.uint8), o2.view(np.uint8)), "pair %d D2" % i
 
 
+@pytest.mark.parametrize("copies", ["lanes", "runtime"])
 @pytest.mark.parametrize("memory", ["pageable", "pinned", "pinned_forced_staging"])
-def test_host_batch_streams_through_several_chunks(eng, batch13, memory, monkeypatch):
-    """13 pairs, chunk 2, 4 slots: >= 3 chunks in flight, the last chunk is ragged; twice on the same handle."""
+def test_host_batch_streams_through_several_chunks(eng, batch13, memory, copies, monkeypatch):
+    """13 pairs, chunk 2, 4 slots: >= 3 chunks in flight, the last chunk is ragged; twice on the same handle.  copies: who moves the
+    chunks over PCIe - SDMA engines the engine addresses itself (csrc/dma_lanes.cpp; what a handle picks by default on this runtime) or
+    hipMemcpyAsync on the copy streams (sv_config.host_copies)."""
     batch, want = batch13
     B = batch.shape[0]
     if memory == "pageable":
@@ -50,8 +53,9 @@ def test_host_batch_streams_through_several_chunks(eng, batch13, memory, monkeyp
         L, R = eng.pinned_array((B, H, W), np.uint8), eng.pinned_array((B, H, W), np.uint8)
         L[:], R[:] = batch[:, 0], batch[:, 1]
         d1, d2 = eng.pinned_array((B, H, W), np.float32), eng.pinned_array((B, H, W), np.float32)
-    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), n_workers=3, chunk=2, n_streams=2, n_slots=4)
+    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), n_workers=3, chunk=2, n_streams=2, n_slots=4, host_copies=copies)
     try:
+        assert e.query()["host_copies"] == 0  # decided at the first host-memory batch
         if memory == "pinned_forced_staging":
             e.debug_set("host_force_staging", 1)
         for _ in range(2):
@@ -59,6 +63,7 @@ def test_host_batch_streams_through_several_chunks(eng, batch13, memory, monkeyp
             o1, o2, status = e.process_host(L, R, d1=d1, d2=d2)
             assert o1 is d1 and o2 is d2 and (status >= 3).all()
             _check(d1, d2, want)
+            assert e.query()["host_copies"] == (2 if copies == "lanes" else 1)
         d1[:] = 7.0
         e.process_host(L, R, want_d2=False, d1=d1)  # D2 == NULL
         _check(d1, None, want)

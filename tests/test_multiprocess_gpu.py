@@ -91,3 +91,9 @@ def test_bench_launches_its_own_ranks(tmp_path):
     g8 = r["with_gather_u8"]  # the same gather with the driver's 8-bit disparity images: a quarter of the bytes
     assert g8["root_block0_equals_own_maps"] is True and g8["bytes_into_root_per_step"] * 4 == g["bytes_into_root_per_step"]
     assert r["roofline"]["kernel"] and "cpu_baseline" not in r  # the CPU baseline is a rank-0, N=1 measurement
+    # the line's tail validates an N-rank run by itself (the nccl = RCCL branch has the same keys; there `rccl_ranks` = N and the ranks'
+    # devices must be distinct - here the two gloo ranks share the box's one GPU on purpose)
+    t = r["trailer"]
+    assert t["n_ranks"] == 2 and t["collective_backend"] == "gloo" and t["rccl_ranks"] is None and t["distinct_devices"] == 1
+    assert len(t["per_rank_pairs_per_s"]) == 2 and abs(t["per_rank_mean_pairs_per_s"] - r["value"] / 2) < 1.0
+    assert t["root_blocks_match_rank_checksums"] == {"headline": [True, True]}
