@@ -85,6 +85,10 @@ struct Job {
     // staging buffers, maps come back from them.  Page-locked caller memory is the DMA source / target itself, pageable
     // memory goes through the slot's page-locked staging buffers.
     bool host = false, pin_in = false, pin_out = false;
+    // single pairs in latency mode (run_inline) with page-locked memory: no copies at all - k_sobel reads the gray rows and the last
+    // kernels write the maps over PCIe themselves (device-side addresses of the caller's buffers; nullptr: staged copies)
+    const uint8_t *zc_left = nullptr, *zc_right = nullptr;
+    float *zc_d1 = nullptr, *zc_d2 = nullptr;
     int drained = 0;  // chunks whose maps have reached the caller (guarded by sv_handle::mu)
     std::vector<hipEvent_t> ev_done;  // device-memory jobs: one event per chunk, recorded behind its second phase (sv_wait_batches waits on these, not on the streams)
 };
@@ -873,8 +877,8 @@ void deliver_maps(sv_handle *h, Slot *s, int copy_helpers) {
 void set_chunk_inputs(sv_handle *h, Slot *s) {  // device-memory jobs read the caller's tensors in place
     const Job &job = *s->job;
     s->in_pair = (size_t)h->kp.d.H * job.stride;
-    s->in_left = job.left + (size_t)s->i0 * s->in_pair;
-    s->in_right = job.right + (size_t)s->i0 * s->in_pair;
+    s->in_left = (job.zc_left ? job.zc_left : job.left) + (size_t)s->i0 * s->in_pair;
+    s->in_right = (job.zc_right ? job.zc_right : job.right) + (size_t)s->i0 * s->in_pair;
     s->in_stride = job.stride;
 }
 
@@ -1409,7 +1413,10 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
     launch_triangles(k, s->dev, n, max_points, st);
     launch_dense(k, s->dev, n, st);
     float *u1 = job.d1 ? job.d1 + (size_t)s->i0 * d.Nm : nullptr, *u2 = job.d2 ? job.d2 + (size_t)s->i0 * d.Nm : nullptr;  // the caller's maps are [batch][Hm][Wm]
-    if (job.host) {  // host-memory job: the maps are written to the slot's device staging and downloaded from there
+    if (job.host && job.zc_d1) {  // a single pair, page-locked maps: the kernels write them over PCIe themselves
+        u1 = job.zc_d1;
+        u2 = job.zc_d2;
+    } else if (job.host) {  // host-memory job: the maps are written to the slot's device staging and downloaded from there
         u1 = s->d_out;
         u2 = job.d2 ? s->d_out + (size_t)s->dev.cap * d.Nm : nullptr;
     }
@@ -1989,6 +1996,24 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
     if (host) {
         const int rc = prepare_host_job(h, &job);
         if (rc != SV_OK) return rc;
+        // One pair at a time has no use for staged copies: with page-locked memory the kernels address the caller's buffers themselves
+        // (0.93 MB of gray rows in, 1.86 MB per map out: the link's time hides inside the kernels, and two copies with their
+        // hand-overs go away).  Streamed batches do NOT do this - the matching kernels would sit on their LDS while the link
+        // trickles (tools/zc_probe.py: 11 900 against 27 500 pairs/s).
+        void *dp = nullptr;
+        if (h->cfg.host_copies != 1 && job.pin_in && hipHostGetDevicePointer(&dp, const_cast<uint8_t *>(left), 0) == hipSuccess) {
+            job.zc_left = static_cast<const uint8_t *>(dp);
+            if (hipHostGetDevicePointer(&dp, const_cast<uint8_t *>(right), 0) == hipSuccess) job.zc_right = static_cast<const uint8_t *>(dp);
+            else job.zc_left = nullptr;
+        }
+        if (h->cfg.host_copies != 1 && job.pin_out && hipHostGetDevicePointer(&dp, d1, 0) == hipSuccess) {
+            job.zc_d1 = static_cast<float *>(dp);
+            if (d2) {
+                if (hipHostGetDevicePointer(&dp, d2, 0) == hipSuccess) job.zc_d2 = static_cast<float *>(dp);
+                else job.zc_d1 = nullptr;
+            }
+        }
+        (void)hipGetLastError();
     }
     Slot *s = h->slots[0];
     h->failed = false;
@@ -2006,7 +2031,7 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
         using clk = std::chrono::steady_clock;
         clk::time_point tp[7];
         tp[0] = clk::now();
-        if (host)
+        if (host && !job.zc_left)
             upload_chunk(h, s, h->sP1, 2);  // on the phase-1 stream itself: in order, no event
         else
             set_chunk_inputs(h, s);
@@ -2024,11 +2049,11 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
         g_launch_hook.ctx = &h->tc_finish;
         issue_phase2(h, s, h->sP2[0]);
         tp[5] = clk::now();
-        if (host) {
+        if (host && !job.zc_d1) {
             download_chunk(h, s);
             deliver_maps(h, s, 3);
         } else {
-            HIP_TRY(hipStreamSynchronize(h->sP2[0]));
+            HIP_TRY(hipStreamSynchronize(h->sP2[0]));  // (maps written straight into page-locked host memory are visible now as well)
         }
         tp[6] = clk::now();
         if (h->lat_trace) {
