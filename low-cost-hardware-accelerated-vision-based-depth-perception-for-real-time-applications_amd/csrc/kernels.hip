@@ -1519,6 +1519,10 @@ __device__ __forceinline__ int dense_pixel(const KParams &k, int side, int u, in
 #pragma unroll
     for (int w = 0; w < DENSE_MASK_WORDS; w++) {  // grid candidates outside the band (:759-767 / :778-786), ascending d
         if (w >= MW) break;
+        // no lane of the wavefront has a candidate in this word (a cell's support disparities sit in one or two of the words): nothing to
+        // remove, test or merge - one compare and a scalar branch instead of ~12 instructions (round 5: -4.4 % wave instructions, -2.3 % time at
+        // D = 128, -4.4 % at D = 256; the same test on "does a band touch this word" issued MORE, scalar start keys for all-valid wavefronts the same)
+        if (__builtin_amdgcn_ballot_w64(mc[w] != 0u) == 0) continue;
         uint32_t m = mc[w] & ~(w == band_word ? band_lo : (w == band_word + 1 ? band_hi : 0u));  // drop [d_plane_min, d_plane_max]
         if (COUNT) ncand += __popc(m);
         int best_w = KEY_NONE;  // keys of this word carry the bit index only; 32 * w is added once per word
