@@ -181,7 +181,7 @@ bool DmaLanes::done(int ticket) const {
     return a.signal_load(sig) < 1;
 }
 
-bool DmaLanes::wait(int ticket, bool nap) {
+bool DmaLanes::wait(int ticket, bool nap, int timeout_ms) {
     const HsaApi &a = api();
     hsa_signal_t sig;
     {
@@ -189,7 +189,14 @@ bool DmaLanes::wait(int ticket, bool nap) {
         sig = impl_->signals[ticket];
     }
     hsa_signal_value_t v;
+    struct timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     while ((v = a.signal_load(sig)) >= 1) {
+        if (timeout_ms > 0) {
+            struct timespec t1;
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000L + (t1.tv_nsec - t0.tv_nsec) / 1000000L > timeout_ms) return false;  // (the ticket stays taken)
+        }
         if (nap) {
             const struct timespec ts = {0, 30000};
             nanosleep(&ts, nullptr);

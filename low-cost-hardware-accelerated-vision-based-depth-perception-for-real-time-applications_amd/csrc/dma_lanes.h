@@ -33,7 +33,7 @@ class DmaLanes {
     // ticket (false: the runtime reported a failed copy).  nap: sleep between polls (throughput mode) instead of spinning.
     int begin(int ncopies);
     bool add(int ticket, Lane lane, void *dst, const void *src, size_t bytes, bool to_device);
-    bool wait(int ticket, bool nap);
+    bool wait(int ticket, bool nap, int timeout_ms = 0);  // timeout_ms > 0: give up after that long (false; the ticket is NOT reused: its copies may still land)
     bool done(int ticket) const;  // all copies of the group have landed (does not release the ticket)
 
     uint32_t engine(Lane lane) const { return engine_[lane]; }

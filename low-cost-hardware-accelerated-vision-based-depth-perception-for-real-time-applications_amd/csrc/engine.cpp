@@ -718,6 +718,29 @@ void ensure_host_staging(sv_handle *h, bool need_pin_in, bool need_pin_out, bool
             std::string why;
             int v = 0;
             h->dma = DmaLanes::create(h->slots[0]->d_in, h->slots[0]->h_blob, &why, env_int("SV_DMA_ENGINES", &v) ? (uint32_t)v : 0u);
+            if (h->dma) {
+                // every lane moves a few bytes both ways before a batch depends on it (an engine id the runtime takes at creation but
+                // refuses - or never completes - for this pair of agents would otherwise fail the first batch): the slot's page-locked
+                // blob and its image staging are idle here
+                Slot *s0 = h->slots[0];
+                int32_t *hb = s0->h_blob;
+                const int32_t keep[2] = {hb[0], hb[1]};
+                hb[0] = 0x5356444D, hb[1] = 0x414C414E;  // "SVDM" "ALAN"
+                bool ok = true;
+                for (DmaLanes::Lane lane : {DmaLanes::DOWN, DmaLanes::DOWN2}) {
+                    const int t = h->dma->begin(1);
+                    ok = ok && t >= 0 && h->dma->add(t, DmaLanes::UP, s0->d_in, hb, 8, true) && h->dma->wait(t, false, 2000);
+                    hb[0] = hb[1] = 0;
+                    const int t2 = ok ? h->dma->begin(1) : -1;
+                    ok = ok && t2 >= 0 && h->dma->add(t2, lane, hb, s0->d_in, 8, false) && h->dma->wait(t2, false, 2000) && hb[0] == 0x5356444D && hb[1] == 0x414C414E;
+                }
+                hb[0] = keep[0], hb[1] = keep[1];
+                if (!ok) {
+                    why = "the SDMA lanes failed their self-test (" + h->dma->describe() + ")";
+                    delete h->dma;
+                    h->dma = nullptr;
+                }
+            }
             if (h->dma) h->host_copies_mode = 2;
             else if (h->cfg.host_copies == 2) throw std::runtime_error("sv_config.host_copies = 2, but " + why);
         }
