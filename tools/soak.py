@@ -39,3 +39,39 @@ for name, env in (("auto", {}), ("gpu", {"SV_GPU_DELAUNAY": "1"}), ("pct35", {"S
     h, share, rate = run(env, NS)
     bad = sum(1 for x in h if x != ref[0])
     print(name, "steps", len(h), "share", share, "rate %.0f" % rate, "mismatching steps", bad, flush=True)
+
+
+def run_host(steps, copies):
+    """Host-memory batches (page-locked f32, 8-bit, pageable f32) and device batches interleaved on ONE handle for `steps` rounds: every
+    output of every round must equal the first round's (DMA lanes / the runtime's copies: `copies`)."""
+    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), host_copies=copies)
+    L, R = eng.pinned_array((B, H, W), np.uint8), eng.pinned_array((B, H, W), np.uint8)
+    L[:], R[:] = b[:, 0], b[:, 1]
+    Lp, Rp = np.ascontiguousarray(b[:, 0]), np.ascontiguousarray(b[:, 1])
+    h1, h8, hp = eng.pinned_array((B, H, W), np.float32), eng.pinned_array((B, H, W), np.uint8), np.zeros((B, H, W), np.float32)
+    dd1 = torch.empty((B, H, W), dtype=torch.float32, device="cuda")
+    first, bad = None, 0
+    t0 = time.perf_counter()
+    for s in range(steps):
+        h1[:1] = 0; h8[:1] = 0; hp[:1] = 0  # (cheap: the first pair of every output must be rewritten each round)
+        e.submit_host(L, R, h1)
+        e.submit_host_dmap(L, R, h8)
+        e.submit_device(l, r, dd1)
+        e.submit_host(Lp, Rp, hp)
+        e.wait(); torch.cuda.synchronize()
+        sig = (hashlib.sha256(h1.tobytes()).hexdigest(), hashlib.sha256(h8.tobytes()).hexdigest(), hashlib.sha256(hp.tobytes()).hexdigest(), float(dd1.double().sum().item()))
+        if first is None:
+            first = sig
+            ok8 = np.array_equal(h8, np.clip(np.rint(h1 * np.float32(4.0)), 0, 255).astype(np.uint8))
+            print("  first round: pinned == pageable == device: %s, 8-bit == convert(f32): %s" % (bool(np.array_equal(h1, hp) and np.array_equal(h1, dd1.cpu().numpy())), bool(ok8)), flush=True)
+        bad += sig != first
+    dt = time.perf_counter() - t0
+    mode = e.query()["host_copies"]
+    e.close()
+    return bad, 4 * B * steps / dt, mode
+
+
+if os.environ.get("HOST_STEPS"):
+    for copies in ("lanes", "runtime"):
+        bad, rate, mode = run_host(int(os.environ["HOST_STEPS"]), copies)
+        print("host soak, copies %s (mode %d): mismatching rounds %d, %.0f pairs/s over all four kinds" % (copies, mode, bad, rate), flush=True)
