@@ -167,6 +167,7 @@ struct sv_handle {
     int latency_split = 0;        // latency mode: depth of the triangulations' top levels shared with pool threads (0: none)
     int dbg_ccl_cap = 0, dbg_rt_cap = -1;  // sv_debug_set: overrides of the speckle stage's run-table size / the raster tile lists' size
     bool force_staging = false;            // sv_debug_set "host_force_staging"
+    bool dbg_dma_fail = false;             // sv_debug_set "dma_selftest_fail"
     bool pool_sleep = false;               // sv_debug_set "pool_sleep"
     std::atomic<int> pollers{0};           // latency mode: pool threads polling the queue length right now
     bool resident_ok = false;     // the GPU's share of the chunks is built without the support lists ever leaving the device (k_delaunay_resident)
@@ -735,6 +736,7 @@ void ensure_host_staging(sv_handle *h, bool need_pin_in, bool need_pin_out, bool
                     ok = ok && t2 >= 0 && h->dma->add(t2, lane, hb, s0->d_in, 8, false) && h->dma->wait(t2, false, 2000) && hb[0] == 0x5356444D && hb[1] == 0x414C414E;
                 }
                 hb[0] = keep[0], hb[1] = keep[1];
+                if (h->dbg_dma_fail) ok = false;
                 if (!ok) {
                     why = "the SDMA lanes failed their self-test (" + h->dma->describe() + ")";
                     delete h->dma;
@@ -2511,6 +2513,8 @@ int sv_debug_set(sv_handle *h, const char *key, int value) {
         h->gpu_filter = gpu_filter;
     } else if (k == "host_force_staging") {
         h->force_staging = value != 0;
+    } else if (k == "dma_selftest_fail") {  // (before the first host-memory batch) the lanes' self-test is taken as failed: the fallback to the runtime's copies
+        h->dbg_dma_fail = value != 0;
     } else if (k == "ns_bound") {
         h->ns_bound.store(std::max(3, std::min(value, h->dg_sub_max)));
     } else if (k == "pool_sleep") {

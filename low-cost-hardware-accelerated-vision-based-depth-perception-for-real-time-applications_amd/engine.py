@@ -194,7 +194,7 @@ class StereoEngine:
             pass
 
     def debug_set(self, key, value):
-        """Test hooks on a live handle (sv_debug_set): "ccl_cap", "rt_cap", "host_force_staging", "ns_bound", "pool_sleep", "lat_trace"."""
+        """Test hooks on a live handle (sv_debug_set): "ccl_cap", "rt_cap", "host_force_staging", "ns_bound", "pool_sleep", "lat_trace", "dma_selftest_fail"."""
         L = lib()
         L.sv_debug_set.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         self._check(L.sv_debug_set(self._h, key.encode(), int(value)))

@@ -215,3 +215,25 @@ def test_host_batch_with_the_drivers_8bit_output(eng, batch13, memory):
         assert (got[0] == 99).all() and (got[2] == 99).all() and not (got[1] == 99).all()  # elas.cpp:63-69: untouched outputs
     finally:
         e.close()
+
+
+def test_dma_lanes_that_fail_their_self_test_fall_back_to_the_runtime(eng, batch13):
+    """Before a batch depends on them the SDMA lanes move a few bytes both ways; when that fails (forced here) a handle with the automatic
+    policy uses hipMemcpyAsync instead - same maps - and a handle that was told to use lanes reports it instead of falling back silently."""
+    batch, want = batch13
+    L, R = np.ascontiguousarray(batch[:, 0]), np.ascontiguousarray(batch[:, 1])
+    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), n_workers=3, chunk=4, n_slots=3)
+    try:
+        e.debug_set("dma_selftest_fail", 1)
+        d1, d2, status = e.process_host(L, R)
+        assert e.query()["host_copies"] == 1 and (status >= 3).all()
+        _check(d1, d2, want)
+    finally:
+        e.close()
+    e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), n_workers=3, chunk=4, n_slots=3, host_copies="lanes")
+    try:
+        e.debug_set("dma_selftest_fail", 1)
+        with pytest.raises(eng.StereoError, match="self-test"):
+            e.process_host(L, R)
+    finally:
+        e.close()
