@@ -541,7 +541,7 @@ void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
 #define FST_DROP 2
 #define FST_UNC 3
 
-#define FLT_THREADS 1024  // lattice points per collect block
+#define FLT_THREADS 256   // lattice points per collect block (1 024 until round 5: a 16-wavefront workgroup waits for a CU with four free wavefront slots per SIMD - 12 x its own duration inside the pipeline)
 #define RSV_THREADS 256   // threads of the resolve workgroup
 
 // exclusive prefix sum over the workgroup (NT threads): wavefront scans by shuffles, one barrier pair for the wavefront totals
@@ -1854,7 +1854,7 @@ __device__ __forceinline__ size_t map_offset(const Dims &d, int m, int nproc) { 
 }
 
 constexpr int CCL_R = 8;         // rows per band
-constexpr int CCL_THREADS = 512;
+constexpr int CCL_THREADS = 256;  // (512 until round 5: inside the pipeline an 8-wavefront workgroup with ~55 KB of LDS waited 5 x its own duration for a CU; 256: serial 50 -> 67 us per 32 pairs, pipelined 530 -> 378 us per 64, +0.7 % pairs/s)
 
 // Run records of a map are bump-allocated (a band takes as many as it has runs), `rcap` per map: real disparity maps are far
 // more fragmented than smooth synthetic ones (kitti_mini pair 0: 49 000 runs, up to 170 per row), worst case one run per pixel.
@@ -2418,7 +2418,8 @@ void launch_gap_rows(const KParams &k, const SlotDev &s, int n, int nproc, hipSt
 
 // Columns: a workgroup owns 64 columns; its 4 wavefronts split the rows.  Pass 1 builds the per-column validity
 // bit masks in LDS (coalesced row reads), pass 2 resolves every invalid pixel on its own from the masks.
-#define GAPC_THREADS 512  // 8 wavefronts: one 64-row word each for maps up to 512 rows
+#define GAPC_THREADS 256  // (512 until round 5; pipelined 166 -> 62 us per 64-pair launch)
+// // 8 wavefronts: one 64-row word each for maps up to 512 rows
 __global__ __launch_bounds__(GAPC_THREADS) void k_gap_cols(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp) {
     const Dims &d = k.d;
     const int m = blockIdx.y;
