@@ -2418,8 +2418,7 @@ void launch_gap_rows(const KParams &k, const SlotDev &s, int n, int nproc, hipSt
 
 // Columns: a workgroup owns 64 columns; its 4 wavefronts split the rows.  Pass 1 builds the per-column validity
 // bit masks in LDS (coalesced row reads), pass 2 resolves every invalid pixel on its own from the masks.
-#define GAPC_THREADS 256  // (512 until round 5; pipelined 166 -> 62 us per 64-pair launch)
-// // 8 wavefronts: one 64-row word each for maps up to 512 rows
+#define GAPC_THREADS 256  // a wavefront takes 64-row words of the column masks in turns (512 threads until round 5: pipelined 166 -> 62 us per 64-pair launch)
 __global__ __launch_bounds__(GAPC_THREADS) void k_gap_cols(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp) {
     const Dims &d = k.d;
     const int m = blockIdx.y;
