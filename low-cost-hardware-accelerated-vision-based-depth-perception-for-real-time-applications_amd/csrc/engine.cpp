@@ -168,6 +168,7 @@ struct sv_handle {
     int dbg_ccl_cap = 0, dbg_rt_cap = -1;  // sv_debug_set: overrides of the speckle stage's run-table size / the raster tile lists' size
     bool force_staging = false;            // sv_debug_set "host_force_staging"
     bool dbg_dma_fail = false;             // sv_debug_set "dma_selftest_fail"
+    uint32_t dma_engines_override = 0;     // SV_DMA_ENGINES (experiments): engine of the upload lane | download lane << 8 | second download lane << 16, each as log2 + 1
     bool pool_sleep = false;               // sv_debug_set "pool_sleep"
     std::atomic<int> pollers{0};           // latency mode: pool threads polling the queue length right now
     bool resident_ok = false;     // the GPU's share of the chunks is built without the support lists ever leaving the device (k_delaunay_resident)
@@ -717,8 +718,7 @@ void ensure_host_staging(sv_handle *h, bool need_pin_in, bool need_pin_out, bool
         h->host_copies_mode = 1;
         if (h->cfg.host_copies != 1) {
             std::string why;
-            int v = 0;
-            h->dma = DmaLanes::create(h->slots[0]->d_in, h->slots[0]->h_blob, &why, env_int("SV_DMA_ENGINES", &v) ? (uint32_t)v : 0u);
+            h->dma = DmaLanes::create(h->slots[0]->d_in, h->slots[0]->h_blob, &why, h->dma_engines_override);
             if (h->dma) {
                 // every lane moves a few bytes both ways before a batch depends on it (an engine id the runtime takes at creation but
                 // refuses - or never completes - for this pair of agents would otherwise fail the first batch): the slot's page-locked
@@ -2356,6 +2356,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     {
         int v = 0;
         h->lat_trace = env_int("SV_LAT_TRACE", &v);  // (also sv_debug_set "lat_trace")
+        if (env_int("SV_DMA_ENGINES", &v)) h->dma_engines_override = (uint32_t)v;
         if (const char *path = getenv("SV_CHUNK_TRACE")) {
             h->chunk_trace_on = *path != 0;
             h->chunk_trace_path = path;
