@@ -396,7 +396,7 @@ void fill_kparams(sv_handle *h) {
     k.ccl_cap = std::max(4096, std::min(8192, ((d.W * 2 + 1023) / 1024) * 1024));
     if (h->dbg_ccl_cap > 0) k.ccl_cap = h->dbg_ccl_cap;  // tests (sv_debug_set "ccl_cap"): force the per-pixel slow path
     {
-        const long room = (144L * 1024 - 256 - 8L * ((d.W + 63) / 64) * 28) / 12;
+        const long room = (144L * 1024 - 256 - 8L * ((d.W + 63) / 64) * 28) / 8;  // (two words of LDS per run: kernels.hip ccl_lds_bytes)
         k.ccl_cap = (int)std::max(1L, std::min((long)k.ccl_cap, room));
     }
     {  // multiply-shift for the grid column and row of a pixel (k_dense): valid only if it reproduces the division for every column and row

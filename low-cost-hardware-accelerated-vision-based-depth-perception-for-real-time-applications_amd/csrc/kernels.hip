@@ -1911,7 +1911,7 @@ size_t ccl_ws_bytes(const KParams &k, int maps_cap) {
 }
 
 // LDS of k_ccl_band: three bit masks and one run-number prefix per 64-pixel word of the band, 12 B per run
-size_t ccl_lds_bytes(const KParams &k) { return (size_t)CCL_R * ((k.d.W + 63) / 64) * (3 * 8 + 4) + (size_t)k.ccl_cap * 3 * 4; }
+size_t ccl_lds_bytes(const KParams &k) { return (size_t)CCL_R * ((k.d.W + 63) / 64) * (3 * 8 + 4) + (size_t)k.ccl_cap * 2 * 4; }
 
 // union-find with the smaller index as root; works on LDS and on global memory
 __device__ __forceinline__ int ccl_find(const int32_t *L, int x) {
@@ -2007,7 +2007,7 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
     const int v0 = band * CCL_R, rows = min(CCL_R, d.H - v0);
     uint64_t *Sm = ccl_lds, *Vm = Sm + CCL_R * nch, *Lm = Vm + CCL_R * nch;  // [CCL_R][nch] run-start / valid / up-link masks
     int32_t *base = reinterpret_cast<int32_t *>(Lm + CCL_R * nch);           // [CCL_R][nch] run starts of the row before the word
-    int32_t *parent = base + CCL_R * nch, *len = parent + cap, *start = len + cap;
+    int32_t *parent = base + CCL_R * nch, *len = parent + cap;  // (a run's first pixel goes straight into its record: 16 KB of LDS less than a table of them)
     __shared__ int32_t rowbase[CCL_R + 1];
     __shared__ int32_t rec0;  // first run record of this band
     const float *D = disp + map_offset(d, m, nproc);
@@ -2080,6 +2080,7 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
     // run records (first pixel, length) and vertical unions: one THREAD per quarter of a mask word (16 pixels), walking its set
     // bits.  (One thread per word left 160 of the 512 threads with up to 64 dependent LDS atomics / union-find walks each: 11 of
     // the kernel's 20 us on a real map.)
+    int4 *R = ws.runs + (size_t)m * ws.rcap + off;
     for (int task = tid; task < rows * nch * 4; task += CCL_THREADS) {
         const int rc = task >> 2, q = task & 3;
         const uint64_t qmask = 0xFFFFull << (16 * q), qbelow = (1ull << (16 * q)) - 1ull;
@@ -2097,7 +2098,7 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
             const int pos = ctz64(sb);
             const uint64_t bk = brk & ~bits_upto(pos);
             atomicAdd(&len[j], (bk ? ctz64(bk) : 64) - pos);
-            start[j] = pix0 + pos;
+            R[j].x = pix0 + pos;
         }
         if (r >= 1) {
             const uint64_t Vu = Vm[rc - nch], Su = Sm[rc - nch];
@@ -2112,12 +2113,11 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
     __syncthreads();
     // flatten; the records take (first pixel, length, root); then the lengths of the non-roots are folded into their root's slot
     // (a non-root's own slot is never a target), which leaves the component sizes at the roots
-    int4 *R = ws.runs + (size_t)m * ws.rcap + off;
     int32_t *GP = ws.gparent + (size_t)m * ws.rcap + off, *TOT = ws.total + (size_t)m * ws.rcap + off;
     for (int i = tid; i < T; i += CCL_THREADS) {
         const int root = ccl_find(parent, i);
         parent[i] = root;
-        R[i] = make_int4(start[i], len[i], off + root, 0);
+        R[i].y = len[i], R[i].z = off + root, R[i].w = 0;
         GP[i] = off + root;
         TOT[i] = 0;
     }
