@@ -2212,9 +2212,11 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     cfg = &h->cfg;  // from here on: the caller's configuration with the environment's overrides
     fill_kparams(h);
     int npool = cfg->n_workers > 0 ? cfg->n_workers : default_pool_size();
-    // defaults: 64 pairs per launch, 8 slots, 4 phase-2 streams, scaled down so that the slots stay within a memory budget
+    // defaults: 64 pairs per launch, 8 slots, 5 phase-2 streams, scaled down so that the slots stay within a memory budget
     // (about 66 bytes per pixel per pair in flight: 31 MB at KITTI size, 0.55 GB at 4K)
-    int np2 = cfg->n_streams > 0 ? cfg->n_streams : 4;
+    // (five: with the latency-chain kernels in 256-thread workgroups since round 5, 3 / 4 / 5 / 6 / 7 streams measure 47 300 / 48 000 / 48 750 / 48 700 / 48 200 pairs/s;
+    //  four were the optimum until then - HISTORY.md)
+    int np2 = cfg->n_streams > 0 ? cfg->n_streams : 5;
     int nslots = cfg->n_slots > 0 ? cfg->n_slots : 8;
     h->chunk = cfg->chunk > 0 ? cfg->chunk : 64;
     // Vertex sets the GPU triangulation takes: up to dg_sub_max whole in LDS; larger ones (4K lattices) through a mesh in the slots'
