@@ -92,7 +92,7 @@ typedef struct sv_config {
                          * affinity mask, shared between the ranks of a node, at most 16 without a quota) */
     int32_t chunk;      /* pairs per GPU launch = pairs per pipeline slot (0 = default 64, less for large images) */
     int32_t keep_debug; /* != 0: keep per-stage intermediates of the LAST processed pair for sv_debug_get */
-    int32_t n_streams;  /* HIP streams the second GPU phase alternates over (0 = default 5); phase 1 has its own streams */
+    int32_t n_streams;  /* HIP streams the second GPU phase alternates over (0 = default 5; 4 for images of 2 M pixels and more); phase 1 has its own streams */
     int32_t n_slots;    /* buffer slots (chunks in flight) of the 3-stage pipeline (0 = default 8, within a quarter of the free HBM / 64 GB) */
     /* ---- policy (0 = automatic) */
     int32_t gpu_lattice_filter;    /* support-lattice filters: 0 auto (GPU for chunk >= 4), 1 GPU, 2 host pool             [SV_GPU_FILTER=1 / SV_HOST_FILTER=1] */

@@ -2216,7 +2216,8 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     // (about 66 bytes per pixel per pair in flight: 31 MB at KITTI size, 0.55 GB at 4K)
     // (five: with the latency-chain kernels in 256-thread workgroups since round 5, 3 / 4 / 5 / 6 / 7 streams measure 47 300 / 48 000 / 48 750 / 48 700 / 48 200 pairs/s;
     //  four were the optimum until then - HISTORY.md)
-    int np2 = cfg->n_streams > 0 ? cfg->n_streams : 5;
+    //  (4K, D = 192: 4 streams 2 900 - 2 930, 5 streams 2 760 - 2 790: large images keep four)
+    int np2 = cfg->n_streams > 0 ? cfg->n_streams : ((size_t)cfg->width * cfg->height >= ((size_t)2 << 20) ? 4 : 5);
     int nslots = cfg->n_slots > 0 ? cfg->n_slots : 8;
     h->chunk = cfg->chunk > 0 ? cfg->chunk : 64;
     // Vertex sets the GPU triangulation takes: up to dg_sub_max whole in LDS; larger ones (4K lattices) through a mesh in the slots'
