@@ -237,3 +237,36 @@ def test_dma_lanes_that_fail_their_self_test_fall_back_to_the_runtime(eng, batch
             e.process_host(L, R)
     finally:
         e.close()
+
+
+def test_registered_host_memory_is_page_locked_memory(eng, batch13):
+    """Caller memory that was page-locked after the fact (hipHostRegister - what an OpenCV / numpy user has) takes the same paths as
+    hipHostMalloc'ed memory: DMA lanes for a streamed batch, no copies at all for single pairs on a latency handle (the kernels use the
+    device-side address of the registration)."""
+    import torch
+    rt = torch.cuda.cudart()
+    batch, want = batch13
+    B = batch.shape[0]
+    bufs = [np.ascontiguousarray(batch[:, 0]), np.ascontiguousarray(batch[:, 1]), np.full((B, H, W), 5.0, np.float32), np.full((B, H, W), 5.0, np.float32)]
+    for a in bufs:
+        assert int(rt.cudaHostRegister(a.ctypes.data, a.nbytes, 0)) == 0
+    try:
+        L, R, d1, d2 = bufs
+        e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), n_workers=3, chunk=4, n_slots=3)
+        try:
+            e.process_host(L, R, d1=d1, d2=d2)
+            assert e.query()["host_copies"] == 2
+            _check(d1, d2, want)
+        finally:
+            e.close()
+        d1[:], d2[:] = 5.0, 5.0
+        e = eng.StereoEngine(W, H, eng.SvParams.driver(D - 1), n_workers=2, chunk=1, n_streams=1, n_slots=2)
+        try:
+            for i in range(3):
+                o1, o2, st = e.process_host(L[i], R[i], d1=d1[i:i + 1], d2=d2[i:i + 1])
+            _check(d1[:3], d2[:3], want[:3])
+        finally:
+            e.close()
+    finally:
+        for a in bufs:
+            rt.cudaHostUnregister(a.ctypes.data)
