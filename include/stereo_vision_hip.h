@@ -107,7 +107,9 @@ typedef struct sv_config {
     int32_t inline_latency_path;   /* single pairs on a chunk-1 handle driven by the calling thread: 0 auto (on), 2 off       [SV_NO_INLINE=1] */
     int32_t event_sync;            /* how host threads wait for the GPU: 0 auto (3 for chunk >= 4, 2 below), 1 hipEventBlockingSync, 2 spin, 3 ask the event + 40 us naps [SV_EVENT_SYNC=block|spin|poll] */
     int32_t share_sliced;          /* != 0: a balanced GPU share as a slice of every chunk instead of whole chunks (round-2 behaviour, non-resident only) [SV_GPU_DELAUNAY_SLICED=1] */
-    int32_t latency_split;         /* single pairs: 0 each triangulation on one thread (default), 1 halves / 2 quarters of the top-level cuts on pool threads [SV_LATENCY_SPLIT=1|2] */
+    int32_t latency_split;         /* single pairs: 0 automatic - each triangulation in halves, the second half on a pool thread pinned to a core that shares the calling
+                                      thread's L3 cache, when the host has such cores within the process's mask (and affinity != 2), otherwise as 3;
+                                      1 halves / 2 quarters of the top-level cuts on pool threads in any case; 3 each triangulation on one thread [SV_LATENCY_SPLIT=0..3] */
     int32_t host_copies;           /* host-memory batches (sv_submit_batch_host...): who moves images and maps over PCIe.  0 auto = 2 where the runtime
                                       allows it, 1 hipMemcpyAsync (the runtime picks an SDMA engine per copy - the directions can end up sharing
                                       one), 2 engine-addressed copies (csrc/dma_lanes.cpp): uploads and downloads on SDMA engines of their own,
@@ -131,6 +133,7 @@ enum sv_query_key {
                                     k-d order and triangulation in one kernel after the lattice filter; the host only reads 8 meta words per pair */
     SV_Q_HOST_COPIES = 9,        /* who moves host-memory batches over PCIe: 0 not decided yet (no such batch so far), 1 hipMemcpyAsync,
                                     2 engine-addressed SDMA copies (sv_config.host_copies) */
+    SV_Q_LATENCY_SPLIT = 10,     /* single pairs: 0 each triangulation on one thread, 1 in halves, 2 in quarters (sv_config.latency_split as resolved at creation) */
     SV_Q_GPU_TRIANGULATION_SHARE = 5 /* per mille of the pairs so far whose triangulations the GPU kernel built (in the host mode the
                                         dispatcher hands it a share of a chunk while the pool is behind; results are identical) */
 };

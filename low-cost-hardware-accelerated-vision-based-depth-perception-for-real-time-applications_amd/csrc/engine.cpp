@@ -102,6 +102,8 @@ struct Slot {
     int32_t *h_fsup = nullptr;  // pinned [cap][fsup_copy_pts][3]: head of the GPU-filtered support lists
     int32_t *h_fnsup = nullptr; // pinned [cap]
     int32_t *h_blob = nullptr;  // pinned
+    int16_t *h_dcan_dev = nullptr;  // the two page-locked buffers as the device addresses them (latency mode: copies by kernel)
+    int32_t *h_blob_dev = nullptr;
     size_t blob_words = 0;
     hipEvent_t ev_p1 = nullptr, ev_free = nullptr, ev_sup = nullptr;
     // host-memory jobs: device staging (images in, maps out), page-locked staging for pageable callers, copy events
@@ -170,6 +172,10 @@ struct sv_handle {
     bool dbg_dma_fail = false;             // sv_debug_set "dma_selftest_fail"
     uint32_t dma_engines_override = 0;     // SV_DMA_ENGINES (experiments): engine of the upload lane | download lane << 8 | second download lane << 16, each as log2 + 1
     bool pool_sleep = false;               // sv_debug_set "pool_sleep"
+    bool lat_runtime_copies = false;       // latency mode: the lattice / blob copies through hipMemcpyAsync as in the streamed path (sv_debug_set "lat_runtime_copies")
+    int lat_pin = 0;                       // latency mode: keep the polling pool threads on the calling thread's L3 (sv_debug_set "latency_pin", SV_LATENCY_PIN)
+    int lat_pin_l3 = -2;                   // the L3 domain they are pinned to right now (-2: never pinned)
+    cpu_set_t pool_cpus;                   // where the pool threads run otherwise (the GPU's NUMA node or the process's mask)
     std::atomic<int> pollers{0};           // latency mode: pool threads polling the queue length right now
     bool resident_ok = false;     // the GPU's share of the chunks is built without the support lists ever leaving the device (k_delaunay_resident)
     std::atomic<int> shared_pct{0};   // host mode with a balanced share: the dispatcher's current share, read by the issuer (who decides per chunk)
@@ -299,7 +305,7 @@ void apply_env_overrides(sv_config &c) {
     if (env_int("SV_RESIDENT", &v)) c.resident = v ? 0 : 2;
     if (env_int("SV_NO_AFFINITY", &v)) c.affinity = 2;
     if (env_int("SV_NO_INLINE", &v)) c.inline_latency_path = 2;
-    if (env_int("SV_LATENCY_SPLIT", &v)) c.latency_split = v > 0 ? (v > 1 ? 2 : 1) : 0;
+    if (env_int("SV_LATENCY_SPLIT", &v)) c.latency_split = v >= 0 && v <= 3 ? v : 0;
     if (env_int("SV_EVENT_SYNC", &v)) c.event_sync = v == 1 ? 1 : (v == 3 ? 3 : 2);
     if (env_int("SV_HOST_COPIES", &v)) c.host_copies = v == 1 ? 1 : (v == 2 ? 2 : 0);
 }
@@ -335,7 +341,7 @@ int validate(const sv_params &p, const sv_config &c, std::string &err) {
     } fields[] = {{"device", c.device, 0, 1023}, {"n_workers", c.n_workers, 0, 1024}, {"chunk", c.chunk, 0, 4096}, {"n_streams", c.n_streams, 0, 64}, {"n_slots", c.n_slots, 0, 64},
                   {"gpu_lattice_filter", c.gpu_lattice_filter, 0, 2}, {"gpu_triangulation", c.gpu_triangulation, 0, 4}, {"gpu_triangulation_pct", c.gpu_triangulation_pct, 0, 100},
                   {"resident", c.resident, 0, 2}, {"dg_sub_max", c.dg_sub_max, 0, 1 << 20}, {"dg_max_points", c.dg_max_points, 0, 1 << 24}, {"affinity", c.affinity, 0, 2},
-                  {"inline_latency_path", c.inline_latency_path, 0, 2}, {"event_sync", c.event_sync, 0, 3}, {"share_sliced", c.share_sliced, 0, 1}, {"latency_split", c.latency_split, 0, 2},
+                  {"inline_latency_path", c.inline_latency_path, 0, 2}, {"event_sync", c.event_sync, 0, 3}, {"share_sliced", c.share_sliced, 0, 1}, {"latency_split", c.latency_split, 0, 3},
                   {"host_copies", c.host_copies, 0, 2}};
     for (const auto &f : fields)
         if (f.v < f.lo || f.v > f.hi) {
@@ -596,8 +602,12 @@ void issue_phase1(sv_handle *h, Slot *s) {
                                      hipMemcpyDeviceToHost, tail));
         }
     }
-    if (!h->gpu_filter || h->cfg.keep_debug)
-        HIP_TRY(hipMemcpyAsync(s->h_dcan, s->dev.dcan, sizeof(int16_t) * (size_t)s->n * lat, hipMemcpyDeviceToHost, tail));
+    if (!h->gpu_filter || h->cfg.keep_debug) {
+        if (s->inline_mode && s->h_dcan_dev && !h->lat_runtime_copies)
+            launch_copy_block(s->h_dcan_dev, s->dev.dcan, sizeof(int16_t) * (size_t)s->n * lat, tail);  // single pair: in stream order, by a kernel
+        else
+            HIP_TRY(hipMemcpyAsync(s->h_dcan, s->dev.dcan, sizeof(int16_t) * (size_t)s->n * lat, hipMemcpyDeviceToHost, tail));
+    }
     lap(3);
     HIP_TRY(hipGetLastError());  // a rejected phase-1 launch must not leave the previous chunk's lattices to the host stage
     HIP_TRY(hipEventRecord(s->ev_p1, tail));
@@ -1043,9 +1053,9 @@ void spawn_to_pool(void *ctx, void (*fn)(void *), void *arg) {
         t.fn = fn;
         t.arg = arg;
         h->queue.push_front(t);
-        h->queue_len.fetch_add(1, std::memory_order_release);
     }
-    h->qcv.notify_one();
+    h->queue_len.fetch_add(1, std::memory_order_release);  // (after the lock is free again: the pollers go for it the moment they see this)
+    if (h->pollers.load(std::memory_order_acquire) < 1) h->qcv.notify_one();  // a polling thread needs no wake-up (a system call on this thread)
 }
 
 // one Delaunay triangulation of a pair's support points; errors are recorded, never thrown (the completion accounting of
@@ -1099,8 +1109,12 @@ void early_grid_launch(Slot *s) {
     sv_handle *h = s->grid_h;
     try {
         hipStream_t st = h->sP2[0];
-        HIP_TRY(hipMemcpyAsync(s->dev.blob, s->h_blob, sizeof(int32_t) * META_WORDS, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(s->dev.blob + s->grid_off, s->h_blob + s->grid_off, sizeof(int32_t) * (size_t)s->grid_ns * 3, hipMemcpyHostToDevice, st));
+        if (s->h_blob_dev && !h->lat_runtime_copies && s->grid_off * sizeof(int32_t) <= 256) {  // (one pair: the points follow the meta words)
+            launch_copy_block(s->dev.blob, s->h_blob_dev, sizeof(int32_t) * (s->grid_off + (size_t)s->grid_ns * 3), st);
+        } else {
+            HIP_TRY(hipMemcpyAsync(s->dev.blob, s->h_blob, sizeof(int32_t) * META_WORDS, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(s->dev.blob + s->grid_off, s->h_blob + s->grid_off, sizeof(int32_t) * (size_t)s->grid_ns * 3, hipMemcpyHostToDevice, st));
+        }
         launch_grid(h->kp, s->dev, 1, s->grid_ns, st);
     } catch (const std::exception &e) {
         note_error(h, e.what());
@@ -1235,11 +1249,10 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
             };
             g.arg = s;
             h->queue.push_front(g);
-            h->queue_len.fetch_add(1, std::memory_order_release);
         }
         h->queue.push_front(Task{s, t.pair, 1});
-        h->queue_len.fetch_add(1, std::memory_order_release);
     }
+    h->queue_len.fetch_add(grid_on_pool ? 2 : 1, std::memory_order_release);  // published once, with the lock free again: pollers go for it at once
     // (a poller that gives up just now still finds the queue non-empty when it takes the lock to wait: nothing is lost without a notify)
     if (h->pollers.load(std::memory_order_acquire) < (grid_on_pool ? 2 : 1)) {
         if (grid_on_pool)
@@ -1258,6 +1271,10 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
     if (__atomic_add_fetch(&meta[6], 1, __ATOMIC_ACQ_REL) == 2) pair_done(h, s);
 }
 
+// pool threads that poll for a frame's pieces in latency mode: the right triangulation and the early grid launch, plus the halves
+// (quarters) of the two triangulations when those are shared
+int latency_pollers(const sv_handle *h) { return 2 + (h->latency_split >= 2 ? 6 : (h->latency_split == 1 ? 2 : 0)); }
+
 void pool_main(sv_handle *h, HostScratch *sc, int idx) {
     (void)hipSetDevice(h->cfg.device);  // run_task may fetch a long support list from the handle's device
     // Latency mode (chunk 1): a frame hands over the right triangulation and the early grid launch (and, on request, pieces of the
@@ -1265,16 +1282,29 @@ void pool_main(sv_handle *h, HostScratch *sc, int idx) {
     // first few pool threads - as many as a frame has pieces - poll the queue length for a while (about a frame period of continuous
     // use) before they go to sleep; the others, and throughput handles, sleep at once.  (All 14 polling: 15 busy threads on a 16-CPU
     // quota, and a notify_all that costs the calling thread 19 us.)  A producer that finds enough pollers does not notify at all.
-    const int hot = 2 + (h->latency_split >= 2 ? 6 : (h->latency_split == 1 ? 2 : 0));
+    const int hot = latency_pollers(h);
     for (;;) {
         Task t;
+        bool have = false;
         const int spin_rounds = h->chunk == 1 && idx < hot && !h->pool_sleep ? 400000 : 0;
         if (spin_rounds) {
+            // a poller never sleeps on the queue's mutex (try_lock): nobody then has to wake it with a system call when the lock is released
             h->pollers.fetch_add(1, std::memory_order_acq_rel);
-            for (int i = 0; i < spin_rounds && h->queue_len.load(std::memory_order_acquire) == 0; i++) __builtin_ia32_pause();
+            for (int i = 0; i < spin_rounds && !have; i++) {
+                if (h->queue_len.load(std::memory_order_acquire) > 0 && h->qmu.try_lock()) {
+                    if (!h->queue.empty()) {
+                        t = h->queue.front();
+                        h->queue.pop_front();
+                        h->queue_len.fetch_sub(1, std::memory_order_relaxed);
+                        have = true;
+                    }
+                    h->qmu.unlock();
+                }
+                if (!have) __builtin_ia32_pause();
+            }
             h->pollers.fetch_sub(1, std::memory_order_acq_rel);
         }
-        {
+        if (!have) {
             std::unique_lock<std::mutex> lk(h->qmu);
             h->qcv.wait(lk, [&] { return h->pool_quit || !h->queue.empty(); });
             if (h->pool_quit && h->queue.empty()) return;
@@ -1417,6 +1447,8 @@ void issue_phase2(sv_handle *h, Slot *s, hipStream_t st) {
                     HIP_TRY(hipMemcpyAsync(s->dev.blob + meta[3 + 2 * side], blob + meta[3 + 2 * side], sizeof(int32_t) * 3 * (size_t)meta[2 + 2 * side], hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(s->dev.blob + (size_t)j * META_WORDS, meta, sizeof(int32_t) * META_WORDS, hipMemcpyHostToDevice, st));
         }
+    } else if (s->inline_mode && s->h_blob_dev && !h->lat_runtime_copies) {
+        launch_copy_block(s->dev.blob, s->h_blob_dev, off * sizeof(int32_t), st);  // single pair: ~0.13 MB in stream order, by a kernel
     } else {
         HIP_TRY(hipMemcpyAsync(s->dev.blob, blob, off * sizeof(int32_t), hipMemcpyHostToDevice, st));
     }
@@ -1752,6 +1784,97 @@ void bind_thread(std::thread &t, const cpu_set_t *set) {
 
 void name_thread(std::thread &t, const char *name) { (void)pthread_setname_np(t.native_handle(), name); }  // (shows in /proc/<pid>/task/*/comm: tools/thread_cpu.py)
 
+// "0-7,128-135" -> CPUs
+static void parse_cpu_list(const char *buf, cpu_set_t *out) {
+    CPU_ZERO(out);
+    for (const char *p = buf; *p;) {
+        char *end;
+        const long a = strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+            if (c >= 0) CPU_SET((int)c, out);
+        while (*p == ',' || *p == '\n' || *p == ' ') p++;
+    }
+}
+
+static bool read_cpu_list(const char *fmt, int cpu, cpu_set_t *out) {
+    char path[160], buf[1024];
+    snprintf(path, sizeof(path), fmt, cpu);
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    const bool got = fgets(buf, sizeof(buf), f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    parse_cpu_list(buf, out);
+    return CPU_COUNT(out) > 0;
+}
+
+// Latency mode with shared triangulations: the pieces a frame hands to pool threads come back through the caches (the halves' triangles
+// are read by the seam merge and the output pass of the calling thread).  From another core complex that costs more than the second
+// thread saves (EPYC 9575F, a KITTI set: 134 us on one thread, 181 - 195 us in halves on threads anywhere on the socket, 106 - 112 us
+// with the helper on a core that shares the caller's L3), so the polling pool threads are kept on the calling thread's L3 domain.
+//
+// One CPU per core of `cpu`'s L3 domain within the process's mask, the core of `cpu` itself left out; l3_first = the domain's first CPU.
+static bool l3_helper_cores(int cpu, int want, std::vector<int> *cores, int *l3_first) {
+    cpu_set_t l3, allowed, taken;
+    if (cpu < 0 || !read_cpu_list("/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu, &l3)) return false;
+    CPU_ZERO(&allowed);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+    if (!read_cpu_list("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu, &taken)) {
+        CPU_ZERO(&taken);
+        CPU_SET(cpu, &taken);
+    }
+    *l3_first = -1;
+    cores->clear();
+    for (int c = 0; c < CPU_SETSIZE; c++) {
+        if (!CPU_ISSET(c, &l3)) continue;
+        if (*l3_first < 0) *l3_first = c;
+        if (!CPU_ISSET(c, &allowed) || CPU_ISSET(c, &taken)) continue;
+        cores->push_back(c);
+        cpu_set_t sib;
+        if (read_cpu_list("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c, &sib)) CPU_OR(&taken, &taken, &sib);
+    }
+    return (int)cores->size() >= want;
+}
+
+// Called at the start of every single-pair call: re-pins the polling threads when the caller has moved to another L3 domain (one
+// sched_getcpu and a table look-up otherwise).  A domain without room for them: they go back to where the pool runs.
+void pin_pollers_to_callers_l3(sv_handle *h, int hot) {
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return;
+    static std::mutex mu;
+    static std::vector<int> l3_of;  // first CPU of the L3 domain of each CPU asked about so far (-3: not yet, -1: unknown)
+    std::lock_guard<std::mutex> lk(mu);
+    if ((int)l3_of.size() <= cpu) l3_of.resize(cpu + 1, -3);
+    std::vector<int> cores;
+    bool room = false, looked = false;
+    if (l3_of[cpu] == -3) {
+        int first = -1;
+        room = l3_helper_cores(cpu, hot, &cores, &first);
+        looked = true;
+        l3_of[cpu] = first;
+    }
+    if (l3_of[cpu] < 0 || l3_of[cpu] == h->lat_pin_l3) return;
+    if (!looked) {
+        int first = -1;
+        room = l3_helper_cores(cpu, hot, &cores, &first);
+    }
+    const int n = std::min(hot, (int)h->pool.size());
+    for (int i = 0; i < n; i++) {
+        cpu_set_t one;
+        CPU_ZERO(&one);
+        if (room) CPU_SET(cores[i], &one);
+        (void)pthread_setaffinity_np(h->pool[i].native_handle(), sizeof(cpu_set_t), room ? &one : &h->pool_cpus);
+    }
+    h->lat_pin_l3 = l3_of[cpu];
+}
+
 template <class T>
 void dev_alloc(T *&p, size_t count) {
     HIP_TRY(hipMalloc((void **)&p, count * sizeof(T)));
@@ -1821,6 +1944,12 @@ void alloc_slot(sv_handle *h, Slot *sl) {
     }
     HIP_TRY(hipHostMalloc((void **)&sl->h_dcan, sizeof(int16_t) * (cap * d.Wc * d.Hc + LATTICE_PAD), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void **)&sl->h_blob, sizeof(int32_t) * sl->blob_words, hipHostMallocDefault));
+    {
+        void *dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, sl->h_dcan, 0) == hipSuccess) sl->h_dcan_dev = static_cast<int16_t *>(dp);
+        if (hipHostGetDevicePointer(&dp, sl->h_blob, 0) == hipSuccess) sl->h_blob_dev = static_cast<int32_t *>(dp);
+        (void)hipGetLastError();
+    }
     // throughput mode: waiting threads sleep on the event instead of spinning, so the cores go to the Delaunay pool
     const unsigned evf = hipEventDisableTiming | (h->block_sync ? hipEventBlockingSync : 0u);
     HIP_TRY(hipEventCreateWithFlags(&sl->ev_p1, evf));
@@ -2044,6 +2173,7 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
         }
         (void)hipGetLastError();
     }
+    if (h->lat_pin) pin_pollers_to_callers_l3(h, latency_pollers(h));
     Slot *s = h->slots[0];
     h->failed = false;
     s->job = &job;
@@ -2283,7 +2413,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
     // no fixed share: it follows the pool's backlog (42 600 against 40 100 pairs/s with 14 threads in round 2)
     h->gpu_share_auto = !h->gpu_delaunay && (mode == 0 || mode == 4) && gpu_capable;
     h->share_sliced = cfg->share_sliced != 0;
-    h->latency_split = std::max(0, std::min(cfg->latency_split, 2));
+    h->latency_split = cfg->latency_split == 3 ? 0 : std::max(0, std::min(cfg->latency_split, 2));  // (0 = automatic: resolved below, once the pool's size is known)
     // start where the balance was measured to settle (4 ... 14 threads); a handle with fewer than four slots cannot build up a backlog
     if (h->gpu_share_auto && nslots >= 4) h->auto_pct = std::max(0, std::min(95, 117 - 7 * npool));
     if (!(h->gpu_delaunay || h->gpu_share_auto || h->gpu_delaunay_pct > 0)) h->dg_limit = h->dg_sub_max;  // the pool triangulates everything: no scratch
@@ -2347,6 +2477,26 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         if (CPU_COUNT(&node_cpus) >= std::min(npool + 2, share)) bind = &node_cpus;
     }
     h->node_bound = bind != nullptr;
+    if (bind) {
+        h->pool_cpus = node_cpus;
+    } else {
+        CPU_ZERO(&h->pool_cpus);
+        if (sched_getaffinity(0, sizeof(cpu_set_t), &h->pool_cpus) != 0)
+            for (int c = 0; c < CPU_SETSIZE; c++) CPU_SET(c, &h->pool_cpus);
+    }
+    if (h->chunk == 1) {
+        // single pairs: the two triangulations in halves when the helpers can sit next to the calling thread (see l3_helper_cores)
+        std::vector<int> cores;
+        int first = -1;
+        const int policy = cfg->latency_split;
+        h->lat_pin = cfg->affinity != 2 && policy != 3;
+        if (policy == 0) {
+            h->latency_split = (h->lat_pin && npool >= 4 && l3_helper_cores(sched_getcpu(), 4, &cores, &first)) ? 1 : 0;
+            if (!h->latency_split) h->lat_pin = 0;
+        } else {
+            h->latency_split = policy == 3 ? 0 : policy;
+        }
+    }
     for (int i = 0; i < npool; i++) {
         HostScratch *sc = new HostScratch();
         h->scratch.push_back(sc);
@@ -2365,6 +2515,8 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
             h->chunk_trace_path = path;
         }
         h->pool_sleep = env_int("SV_POOL_SLEEP", &v);
+        h->lat_runtime_copies = env_int("SV_LAT_RUNTIME_COPIES", &v) && v;
+        if (env_int("SV_LATENCY_PIN", &v)) h->lat_pin = v;  // (experiments: shared triangulations without / with the helpers next to the caller)
         if (env_int("SV_DG_MARGIN", &v)) h->ns_margin_pct = std::max(0, v);
     }
     h->t_issue = std::thread(issuer_main, h);
@@ -2450,6 +2602,7 @@ int sv_query(const sv_handle *h, int what) {
         case SV_Q_NUMA_BOUND: return h->node_bound ? 1 : 0;
         case SV_Q_RESIDENT: return h->resident_ok ? 1 : 0;
         case SV_Q_HOST_COPIES: return h->host_copies_mode;
+        case SV_Q_LATENCY_SPLIT: return h->chunk == 1 ? h->latency_split : 0;
         case SV_Q_GPU_TRIANGULATION_FALLBACKS: return (int)std::min<int64_t>(h->gpu_tri_fallbacks.load(), 0x7FFFFFFF);
         case SV_Q_GPU_TRIANGULATION_SHARE: {
             const int64_t all = h->tri_pairs.load(), g = h->gpu_tri_pairs.load();
@@ -2523,6 +2676,10 @@ int sv_debug_set(sv_handle *h, const char *key, int value) {
         h->ns_bound.store(std::max(3, std::min(value, h->dg_sub_max)));
     } else if (k == "pool_sleep") {
         h->pool_sleep = value != 0;
+    } else if (k == "lat_runtime_copies") {
+        h->lat_runtime_copies = value != 0;
+    } else if (k == "latency_pin") {
+        h->lat_pin = value != 0;
     } else if (k == "lat_trace") {
         h->lat_trace = value != 0;
     } else {

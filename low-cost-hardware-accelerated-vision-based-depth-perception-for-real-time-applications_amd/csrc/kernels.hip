@@ -307,6 +307,24 @@ __global__ __launch_bounds__(256) void k_expand_all(const uint8_t *__restrict__ 
         if (4 * q + j < d.W) out[4 * q + j] = o[j];
 }
 
+// A small block of words between page-locked host memory and HBM, moved by a kernel on the stream of the kernels that produce / consume
+// it (latency mode only: single pairs).  The runtime's hipMemcpyAsync puts such a copy on an SDMA engine or on a blit kernel in a queue of
+// its own, and the dependency between that and the stream's kernels costs 10 - 12 us each way (tools/latency_trace.py under rocprofv3:
+// k_support -> 12 us -> copy; copy -> 12 us -> k_planes); a kernel in the same queue starts when its predecessor ends.  Streamed batches
+// keep the DMA engines: there the copies overlap other chunks' kernels and the CUs have better things to do.
+__global__ __launch_bounds__(256) void k_copy_block(uint4 *__restrict__ dst, const uint4 *__restrict__ src, size_t n16, size_t tail_bytes) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+    if (blockIdx.x == 0 && threadIdx.x < tail_bytes) reinterpret_cast<uint8_t *>(dst + n16)[threadIdx.x] = reinterpret_cast<const uint8_t *>(src + n16)[threadIdx.x];
+}
+
+void launch_copy_block(void *dst, const void *src, size_t bytes, hipStream_t st) {  // both 16-byte aligned, device-visible
+    if (!bytes) return;
+    if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15u) throw std::invalid_argument("launch_copy_block: unaligned block");
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(k_copy_block, dim3((unsigned)std::max<size_t>(1, (n16 + 255) / 256)), dim3(256), 0, st, static_cast<uint4 *>(dst), static_cast<const uint4 *>(src), n16, bytes - n16 * 16);
+}
+
 void launch_expand_debug(const KParams &k, const SlotDev &s, int n, uint8_t *desc, hipStream_t st) {
     hipLaunchKernelGGL(k_expand_all, dim3((k.d.W / 4 + 256) / 256, k.d.H, n * 2), dim3(256), 0, st, s.grad, desc, k.d);
 }

@@ -91,6 +91,7 @@ enum CounterId { CNT_DENSE_CANDIDATES = 0, CNT_DENSE_PIXELS, CNT_SUPPORT_ENERGIE
 void launch_sobel(const KParams &k, const uint8_t *left, const uint8_t *right, size_t in_pair_stride, int stride, const SlotDev &s, int n, hipStream_t st);
 size_t grad_bytes_per_pair(const KParams &k);
 int launch_check_amean_div(unsigned long long *d_mism, hipStream_t st);  // exhaustive check of the adaptive mean's division shortcut (kernels.hip: amean_div)
+void launch_copy_block(void *dst, const void *src, size_t bytes, hipStream_t st);  // latency mode: small host <-> device blocks in stream order, by a kernel
 void launch_expand_debug(const KParams &k, const SlotDev &s, int n, uint8_t *desc, hipStream_t st);  // debug: the descriptor images for the stage snapshot
 void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st);
 size_t support_filter_ws_bytes(const KParams &k, int cap);

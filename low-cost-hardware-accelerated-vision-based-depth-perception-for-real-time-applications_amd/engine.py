@@ -352,6 +352,7 @@ class StereoEngine:
         out["numa_bound"] = int(L.sv_query(self._h, 7))
         out["resident"] = int(L.sv_query(self._h, 8))
         out["host_copies"] = int(L.sv_query(self._h, 9))  # 0 not decided yet (no host-memory batch so far), 1 hipMemcpyAsync, 2 DMA lanes
+        out["latency_split"] = int(L.sv_query(self._h, 10))  # single pairs: triangulations on one thread each (0), in halves (1), in quarters (2)
         return out
 
     def gpu_triangulation_share(self):

@@ -808,10 +808,11 @@ def test_the_ways_host_threads_wait_give_the_same_maps(eng, mode):
         ref.close()
 
 
-@pytest.mark.parametrize("split", [0, 1, 2])
+@pytest.mark.parametrize("split", [0, 1, 2, 3])
 def test_single_pairs_with_shared_triangulations_give_the_same_maps(eng, split):
-    """Latency mode (one pair per call on a chunk-1 handle): each triangulation on one thread (the default), or its top-level cuts shared
-    with pool threads (sv_config.latency_split = 1: halves, 2: quarters) - same maps as a throughput handle; the real frame and a synthetic one."""
+    """Latency mode (one pair per call on a chunk-1 handle): each triangulation on one thread (3), or its top-level cuts shared with pool
+    threads (sv_config.latency_split = 1: halves, 2: quarters; 0: halves when the helpers can sit on the caller's L3, the default) - same maps
+    as a throughput handle; the real frame and a synthetic one."""
     import torch
     l, r = util.load_png("kitti0_left.png"), util.load_png("kitti0_right.png")
     H, W = l.shape
@@ -820,6 +821,7 @@ def test_single_pairs_with_shared_triangulations_give_the_same_maps(eng, split):
     ref = eng.StereoEngine(W, H, p, chunk=4, n_slots=2)
     e = eng.StereoEngine(W, H, p, chunk=1, n_slots=2, n_streams=1, n_workers=8, latency_split=split)
     try:
+        assert e.query()["latency_split"] == ({1: 1, 2: 2, 3: 0}[split] if split else e.query()["latency_split"]) and e.query()["latency_split"] in (0, 1, 2)
         for a, b in ((l, r), (syn[0], syn[1])):
             L, R = torch.from_numpy(np.ascontiguousarray(a[None])).cuda(), torch.from_numpy(np.ascontiguousarray(b[None])).cuda()
             r1, r2 = ref.process_device(L, R)
