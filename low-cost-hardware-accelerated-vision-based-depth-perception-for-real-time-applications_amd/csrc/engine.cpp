@@ -1939,7 +1939,7 @@ void alloc_slot(sv_handle *h, Slot *sl) {
         uint8_t *w = nullptr;
         const size_t bytes = ccl_ws_bytes(h->kp, (int)cap * 2);
         dev_alloc(w, bytes);
-        HIP_TRY(hipMemset(w, 0, bytes));  // the overflow flags start cleared; k_ccl_slow clears the ones it consumes
+        HIP_TRY(hipMemset(w, 0, bytes));  // the overflow marks start cleared (no launch has epoch 0)
         s.ccl_ws = w;
     }
     HIP_TRY(hipHostMalloc((void **)&sl->h_dcan, sizeof(int16_t) * (cap * d.Wc * d.Hc + LATTICE_PAD), hipHostMallocDefault));

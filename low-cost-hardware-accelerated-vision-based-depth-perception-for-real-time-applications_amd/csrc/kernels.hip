@@ -1863,7 +1863,7 @@ void launch_lr(const KParams &k, const SlotDev &s, int n, hipStream_t st, float 
 //                     run records - unions across band borders (global union-find over run records), component sizes
 //                     summed at the global roots, runs of components smaller than speckle_size overwritten with -10.
 //                     Only those pixels are written; no per-pixel label map exists.
-//     A band with more than ccl_cap runs flags its map; k_ccl_slow then labels that map with the slower per-pixel
+//     A band with more than ccl_cap runs flags its map; the last workgroup of k_ccl_apply's grid row then labels that map with the slower per-pixel
 //     union-find on global memory (ccl_legacy_map, one workgroup per flagged map), so any input is handled.
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ size_t map_offset(const Dims &d, int m, int nproc) {  // m = pair*nproc + side
@@ -1872,6 +1872,7 @@ __device__ __forceinline__ size_t map_offset(const Dims &d, int m, int nproc) { 
 }
 
 constexpr int CCL_R = 8;         // rows per band
+constexpr int CCL_THREADS_ALONE = 1024;
 constexpr int CCL_THREADS = 256;  // (512 until round 5: inside the pipeline an 8-wavefront workgroup with ~55 KB of LDS waited 5 x its own duration for a CU; 256: serial 50 -> 67 us per 32 pairs, pipelined 530 -> 378 us per 64, +0.7 % pairs/s)
 
 // Run records of a map are bump-allocated (a band takes as many as it has runs), `rcap` per map: real disparity maps are far
@@ -1880,10 +1881,10 @@ struct CclWs {  // workspace views of one launch (ccl_views lays them out)
     int4 *runs;          // [maps][rcap]     (first pixel, length, root as map-wide run index, component size if band-local root)
     int32_t *gparent;    // [maps][rcap]     union-find over the run records
     int32_t *total;      // [maps][rcap]     component size, accumulated at global roots
-    int32_t *nruns;      // [maps]           records handed out so far (bump allocator); cleared by k_ccl_slow
+    int32_t *nruns;      // [maps]           records handed out so far (bump allocator); cleared by k_ccl_apply's last workgroup
     int32_t *boff;       // [maps][nb]       first record of each band
     int32_t *tcount;     // [maps][nb]       runs per band
-    int32_t *flag;       // [maps]           1 = some band overflowed; cleared by k_ccl_slow
+    int32_t *flag;       // [maps]           == the launch's epoch: some band overflowed (never cleared: the next launch has another epoch)
     uint64_t *bwords;    // [maps][nb][5][nch]  first row: start, valid, up-link masks; last row: start, valid masks
     int32_t *bbase;      // [maps][nb][2][nch]  run number before each 64-pixel word of the first / last row
     int cap, rcap, nb, nch;
@@ -2016,7 +2017,9 @@ __device__ __forceinline__ int ctz64(uint64_t x) { return __ffsll((long long)x) 
 // last pixel of the previous word.
 __device__ __forceinline__ uint64_t ccl_new_links(uint64_t L, uint64_t H, uint64_t Hu, uint64_t carry) { return L & ~(H & Hu & ((L << 1) | carry)); }
 
-__global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, const int32_t *__restrict__ blob, const float *__restrict__ disp, CclWs ws) {
+template <int NT>  // CCL_THREADS inside the pipeline; CCL_THREADS_ALONE when the launch is too small to fill the GPU anyway (single pairs): the band's phases are
+// chains of dependent loads and barriers, and sixteen wavefronts walk them in a third of the rounds (28 -> ~15 us for one KITTI pair)
+__global__ __launch_bounds__(NT) void k_ccl_band(KParams k, int nproc, int epoch, const int32_t *__restrict__ blob, const float *__restrict__ disp, CclWs ws) {
     const Dims &d = k.d;
     extern __shared__ uint64_t ccl_lds[];
     const int m = blockIdx.y, band = blockIdx.x;
@@ -2030,8 +2033,8 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
     __shared__ int32_t rec0;  // first run record of this band
     const float *D = disp + map_offset(d, m, nproc);
     const float thr = k.speckle_sim;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = CCL_THREADS / 64;
-    for (int i = tid; i < cap; i += CCL_THREADS) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = NT / 64;
+    for (int i = tid; i < cap; i += NT) {
         parent[i] = i;
         len[i] = 0;
     }
@@ -2090,7 +2093,7 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
     const int off = rec0;
     if (T > cap || off + T > ws.rcap) {  // too many runs for the LDS tables / the map's record pool: the whole map goes the slow way
         if (tid == 0) {
-            ws.flag[m] = 1;
+            ws.flag[m] = epoch;
             *tc = 0;
         }
         return;
@@ -2099,7 +2102,7 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
     // bits.  (One thread per word left 160 of the 512 threads with up to 64 dependent LDS atomics / union-find walks each: 11 of
     // the kernel's 20 us on a real map.)
     int4 *R = ws.runs + (size_t)m * ws.rcap + off;
-    for (int task = tid; task < rows * nch * 4; task += CCL_THREADS) {
+    for (int task = tid; task < rows * nch * 4; task += NT) {
         const int rc = task >> 2, q = task & 3;
         const uint64_t qmask = 0xFFFFull << (16 * q), qbelow = (1ull << (16 * q)) - 1ull;
         const int r = rc / nch, c = rc - r * nch;
@@ -2132,7 +2135,7 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
     // flatten; the records take (first pixel, length, root); then the lengths of the non-roots are folded into their root's slot
     // (a non-root's own slot is never a target), which leaves the component sizes at the roots
     int32_t *GP = ws.gparent + (size_t)m * ws.rcap + off, *TOT = ws.total + (size_t)m * ws.rcap + off;
-    for (int i = tid; i < T; i += CCL_THREADS) {
+    for (int i = tid; i < T; i += NT) {
         const int root = ccl_find(parent, i);
         parent[i] = root;
         R[i].y = len[i], R[i].z = off + root, R[i].w = 0;
@@ -2140,10 +2143,10 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
         TOT[i] = 0;
     }
     __syncthreads();
-    for (int i = tid; i < T; i += CCL_THREADS)
+    for (int i = tid; i < T; i += NT)
         if (parent[i] != i) atomicAdd(&len[parent[i]], len[i]);
     __syncthreads();
-    for (int i = tid; i < T; i += CCL_THREADS) {
+    for (int i = tid; i < T; i += NT) {
         if (parent[i] == i) R[i].w = len[i];
         if (len[parent[i]] >= k.speckle_size) GP[i] = CCL_LARGE;  // a band-local component of that size: large whatever it joins
     }
@@ -2153,7 +2156,7 @@ __global__ __launch_bounds__(CCL_THREADS) void k_ccl_band(KParams k, int nproc, 
     }
     uint64_t *bw = ws.bwords + ((size_t)m * ws.nb + band) * 5 * nch;
     int32_t *bb = ws.bbase + ((size_t)m * ws.nb + band) * 2 * nch;
-    for (int c = tid; c < nch; c += CCL_THREADS) {
+    for (int c = tid; c < nch; c += NT) {
         const int rl = (rows - 1) * nch + c;
         bw[c] = Sm[c];
         bw[nch + c] = Vm[c];
@@ -2245,9 +2248,9 @@ __device__ void ccl_legacy_map(const KParams &k, float *D, int32_t *label, int32
 // (a) unions across band borders: first row of band b against the last row of band b-1.  One WAVEFRONT per 64-pixel mask word,
 // one lane per pixel: every union is a chain of dependent L2 accesses, so the links of a word are joined side by side, not one
 // after the other (a word of a real map has up to ten of them)
-__global__ __launch_bounds__(256) void k_ccl_border(int nproc, const int32_t *__restrict__ blob, CclWs ws) {
+__global__ __launch_bounds__(256) void k_ccl_border(int nproc, int epoch, const int32_t *__restrict__ blob, CclWs ws) {
     const int m = blockIdx.y;
-    if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m]) return;
+    if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m] == epoch) return;
     const int nch = ws.nch, nb = ws.nb;
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;  // wave-uniform word index
     if (idx >= (nb - 1) * nch) return;
@@ -2270,9 +2273,9 @@ __global__ __launch_bounds__(256) void k_ccl_border(int nproc, const int32_t *__
 // (b) component sizes at the global roots: every band-local root adds its component's pixel count.  CCL_SPLIT workgroups per
 // band: the walk to a root is a chain of dependent loads, so a thread should not have to do more than one or two of them
 constexpr int CCL_SPLIT = 4;
-__global__ __launch_bounds__(256) void k_ccl_total(int nproc, int speckle_size, const int32_t *__restrict__ blob, CclWs ws) {
+__global__ __launch_bounds__(256) void k_ccl_total(int nproc, int epoch, int speckle_size, const int32_t *__restrict__ blob, CclWs ws) {
     const int m = blockIdx.y, b = blockIdx.x / CCL_SPLIT, part = blockIdx.x - b * CCL_SPLIT;
-    if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m]) return;
+    if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m] == epoch) return;
     const int T = ws.tcount[(size_t)m * ws.nb + b], off = ws.boff[(size_t)m * ws.nb + b];
     int32_t *GP = ws.gparent + (size_t)m * ws.rcap;
     int32_t *TOT = ws.total + (size_t)m * ws.rcap;
@@ -2294,11 +2297,24 @@ __global__ __launch_bounds__(256) void k_ccl_total(int nproc, int speckle_size, 
     }
 }
 
-// (c) runs of components smaller than speckle_size are wiped (elas.cpp:1109-1114); nothing else is written
-__global__ __launch_bounds__(256) void k_ccl_apply(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp, CclWs ws) {
+// (c) runs of components smaller than speckle_size are wiped (elas.cpp:1109-1114); nothing else is written.
+// (d) The LAST workgroup of every map's row of the grid (blockIdx.x == nb * CCL_SPLIT) is the slow path for maps whose bands overflowed
+// the run tables: per-pixel union-find, one workgroup per flagged map (normally none - it returns at once).  It used to be a launch of its
+// own (one more 5 us link in a single pair's chain, and up to 78 us per chunk beside the other streams' kernels); that the two can share a
+// launch is what the epoch is for: a band marks its map with the number of the launch, nobody has to clear the mark while others still read it.
+__global__ __launch_bounds__(256) void k_ccl_apply(KParams k, int nproc, int epoch, const int32_t *__restrict__ blob, float *__restrict__ disp, CclWs ws, int32_t *__restrict__ label,
+                                                   int32_t *__restrict__ csize, int32_t *__restrict__ cnt) {
     const Dims &d = k.d;
-    const int m = blockIdx.y, b = blockIdx.x / CCL_SPLIT, part = blockIdx.x - b * CCL_SPLIT;
-    if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m]) return;
+    const int m = blockIdx.y;
+    if ((int)blockIdx.x == ws.nb * CCL_SPLIT) {
+        if (threadIdx.x == 0) ws.nruns[m] = 0;  // the record pool is free again for the slot's next launch (nobody allocates after k_ccl_band)
+        if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m] != epoch) return;
+        const size_t off = map_offset(d, m, nproc);
+        ccl_legacy_map(k, disp + off, label + off, csize + off, cnt + off);
+        return;
+    }
+    const int b = blockIdx.x / CCL_SPLIT, part = blockIdx.x - b * CCL_SPLIT;
+    if (blob[(m / nproc) * META_WORDS] < 3 || ws.flag[m] == epoch) return;
     const int T = ws.tcount[(size_t)m * ws.nb + b], off = ws.boff[(size_t)m * ws.nb + b];
     const int32_t *GP = ws.gparent + (size_t)m * ws.rcap, *TOT = ws.total + (size_t)m * ws.rcap;
     const int4 *RUNS = ws.runs + (size_t)m * ws.rcap;
@@ -2312,34 +2328,24 @@ __global__ __launch_bounds__(256) void k_ccl_apply(KParams k, int nproc, const i
     }
 }
 
-// (d) maps whose bands overflowed the run tables: per-pixel union-find, one workgroup per flagged map (normally none).  Four
-// wavefronts only: the launch is made for every chunk and normally returns at once, but a 16-wavefront workgroup has to wait for
-// half a CU to drain before it can do even that (78 us per launch beside the other streams' kernels, 5 us alone).
-#define CCL_SLOW_THREADS 256
-__global__ __launch_bounds__(CCL_SLOW_THREADS) void k_ccl_slow(KParams k, int nproc, const int32_t *__restrict__ blob, float *__restrict__ disp, CclWs ws,
-                                                   int32_t *__restrict__ label, int32_t *__restrict__ csize, int32_t *__restrict__ cnt) {
-    const int m = blockIdx.x;
-    if (threadIdx.x == 0) ws.nruns[m] = 0;  // the record pool is free again for the slot's next launch
-    if (blob[(m / nproc) * META_WORDS] < 3 || !ws.flag[m]) return;
-    const size_t off = map_offset(k.d, m, nproc);
-    ccl_legacy_map(k, disp + off, label + off, csize + off, cnt + off);
-    __syncthreads();
-    if (threadIdx.x == 0) ws.flag[m] = 0;
-}
-
 void launch_speckle(const KParams &k, const SlotDev &s, int n, int nproc, hipStream_t st) {
     const int maps = n * nproc;
     CclWs ws;
     ccl_views(k, s.ccl_ws, s.cap * 2, ws);
     const size_t lds = ccl_lds_bytes(k);
-    static std::atomic<size_t> granted[64];
-    ensure_dynamic_lds(k_ccl_band, lds, granted, "ccl_band");  // wide images: larger run tables than the default dynamic-LDS limit allows
-    SV_LAUNCH(K_CCL_BAND, k_ccl_band, dim3(ws.nb, maps), dim3(CCL_THREADS), lds, st, k, nproc, s.blob, s.disp, ws);
-    if (ws.nb > 1) SV_LAUNCH(K_CCL_FINISH, k_ccl_border, dim3(((ws.nb - 1) * ws.nch + 3) / 4, maps), dim3(256), 0, st, nproc, s.blob, ws);
-    SV_LAUNCH(K_CCL_FINISH, k_ccl_total, dim3(ws.nb * CCL_SPLIT, maps), dim3(256), 0, st, nproc, k.speckle_size, s.blob, ws);
-    SV_LAUNCH(K_CCL_FINISH, k_ccl_apply, dim3(ws.nb * CCL_SPLIT, maps), dim3(256), 0, st, k, nproc, s.blob, s.disp, ws);
+    const int epoch = (int)(++s.ccl_epoch & 0x3FFFFFFFu) + 1;  // > 0: the workspace's marks start cleared
+    static std::atomic<size_t> granted[64], granted_alone[64];
+    if ((size_t)ws.nb * maps <= 256) {  // less than one workgroup per CU: the bands' own latency is all there is
+        ensure_dynamic_lds(k_ccl_band<CCL_THREADS_ALONE>, lds, granted_alone, "ccl_band");
+        SV_LAUNCH(K_CCL_BAND, k_ccl_band<CCL_THREADS_ALONE>, dim3(ws.nb, maps), dim3(CCL_THREADS_ALONE), lds, st, k, nproc, epoch, s.blob, s.disp, ws);
+    } else {
+        ensure_dynamic_lds(k_ccl_band<CCL_THREADS>, lds, granted, "ccl_band");  // wide images: larger run tables than the default dynamic-LDS limit allows
+        SV_LAUNCH(K_CCL_BAND, k_ccl_band<CCL_THREADS>, dim3(ws.nb, maps), dim3(CCL_THREADS), lds, st, k, nproc, epoch, s.blob, s.disp, ws);
+    }
+    if (ws.nb > 1) SV_LAUNCH(K_CCL_FINISH, k_ccl_border, dim3(((ws.nb - 1) * ws.nch + 3) / 4, maps), dim3(256), 0, st, nproc, epoch, s.blob, ws);
+    SV_LAUNCH(K_CCL_FINISH, k_ccl_total, dim3(ws.nb * CCL_SPLIT, maps), dim3(256), 0, st, nproc, epoch, k.speckle_size, s.blob, ws);
     int32_t *cnt = reinterpret_cast<int32_t *>(s.tmp);  // slow path only: the filters' scratch map is free during speckle removal
-    SV_LAUNCH(K_CCL_FINISH, k_ccl_slow, dim3(maps), dim3(CCL_SLOW_THREADS), 0, st, k, nproc, s.blob, s.disp, ws, s.tri_id, s.csize, cnt);
+    SV_LAUNCH(K_CCL_FINISH, k_ccl_apply, dim3(ws.nb * CCL_SPLIT + 1, maps), dim3(256), 0, st, k, nproc, epoch, s.blob, s.disp, ws, s.tri_id, s.csize, cnt);
 }
 
 // ------------------------------------------------------------------------------------------------------------

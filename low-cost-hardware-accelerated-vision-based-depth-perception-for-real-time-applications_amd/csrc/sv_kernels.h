@@ -82,6 +82,7 @@ struct SlotDev {
     float *tmp;         // [cap][2][N]  second map buffer: the fused filters ping-pong disp <-> tmp (CCL counters before that)
     int32_t *csize;     // [cap][2][N]  slow-path CCL only: run lengths (at run-start pixels); component sizes accumulate in `tmp`
     void *ccl_ws;       // run records, union-find and border masks of the speckle stage (ccl_ws_bytes)
+    mutable uint32_t ccl_epoch = 0;  // launches of the speckle stage on this workspace so far: the overflow marks of one launch mean nothing to the next
     unsigned long long *counters;  // work counters of the matching kernels (CounterId), nullptr = not counting (the normal case)
 };
 
