@@ -107,9 +107,10 @@ typedef struct sv_config {
     int32_t inline_latency_path;   /* single pairs on a chunk-1 handle driven by the calling thread: 0 auto (on), 2 off       [SV_NO_INLINE=1] */
     int32_t event_sync;            /* how host threads wait for the GPU: 0 auto (3 for chunk >= 4, 2 below), 1 hipEventBlockingSync, 2 spin, 3 ask the event + 40 us naps [SV_EVENT_SYNC=block|spin|poll] */
     int32_t share_sliced;          /* != 0: a balanced GPU share as a slice of every chunk instead of whole chunks (round-2 behaviour, non-resident only) [SV_GPU_DELAUNAY_SLICED=1] */
-    int32_t latency_split;         /* single pairs: 0 automatic - each triangulation in halves, the second half on a pool thread pinned to a core that shares the calling
-                                      thread's L3 cache, when the host has such cores within the process's mask (and affinity != 2), otherwise as 3;
-                                      1 halves / 2 quarters of the top-level cuts on pool threads in any case; 3 each triangulation on one thread [SV_LATENCY_SPLIT=0..3] */
+    int32_t latency_split;         /* single pairs: 0 automatic - each triangulation in quarters (seven helper cores) or halves (four) on pool threads pinned to
+                                      cores that share the calling thread's L3 cache, when the host has such cores within the process's mask (and affinity != 2),
+                                      otherwise as 3; 1 halves / 2 quarters of the top-level cuts on pool threads in any case; 3 each triangulation on one thread
+                                      [SV_LATENCY_SPLIT=0..3] */
     int32_t host_copies;           /* host-memory batches (sv_submit_batch_host...): who moves images and maps over PCIe.  0 auto = 2 where the runtime
                                       allows it, 1 hipMemcpyAsync (the runtime picks an SDMA engine per copy - the directions can end up sharing
                                       one), 2 engine-addressed copies (csrc/dma_lanes.cpp): uploads and downloads on SDMA engines of their own,

@@ -1273,7 +1273,7 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
 
 // pool threads that poll for a frame's pieces in latency mode: the right triangulation and the early grid launch, plus the halves
 // (quarters) of the two triangulations when those are shared
-int latency_pollers(const sv_handle *h) { return 2 + (h->latency_split >= 2 ? 6 : (h->latency_split == 1 ? 2 : 0)); }
+int latency_pollers(const sv_handle *h) { return 2 + (h->latency_split >= 2 ? 5 : (h->latency_split == 1 ? 2 : 0)); }  // (quarters: 1 + 1 + 3 + 3 pieces - the grid launch is over before the quarters are cut, and an L3 domain of 8 cores has 7 beside the caller's)
 
 void pool_main(sv_handle *h, HostScratch *sc, int idx) {
     (void)hipSetDevice(h->cfg.device);  // run_task may fetch a long support list from the handle's device
@@ -2490,8 +2490,9 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         int first = -1;
         const int policy = cfg->latency_split;
         h->lat_pin = cfg->affinity != 2 && policy != 3;
-        if (policy == 0) {
-            h->latency_split = (h->lat_pin && npool >= 4 && l3_helper_cores(sched_getcpu(), 4, &cores, &first)) ? 1 : 0;
+        if (policy == 0) {  // quarters need seven helpers beside the caller's core, halves four
+            h->latency_split = 0;
+            if (h->lat_pin && npool >= 4 && l3_helper_cores(sched_getcpu(), 4, &cores, &first)) h->latency_split = (npool >= 7 && cores.size() >= 7) ? 2 : 1;
             if (!h->latency_split) h->lat_pin = 0;
         } else {
             h->latency_split = policy == 3 ? 0 : policy;
