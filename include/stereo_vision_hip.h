@@ -219,6 +219,9 @@ int sv_kernel_timing_select(sv_handle *h, const char *names);
  * the in-place support-point filters + corner points (elas.cpp:152-264, 413-433) and the Delaunay
  * triangulation (elas.cpp:442-501 -> Triangle "zQB"). */
 int sv_host_support_filter(const sv_params *p, int16_t *dcan, int width, int height, int32_t *support, int cap);
+/* The same filters with the lattice shared between `threads` threads, as single-pair calls do with the pool threads that sit next to the
+ * calling thread (csrc/host_stage.cpp: the order-dependent filter splits into a parallel classification and a short serial pass). */
+int sv_host_support_filter_threads(const sv_params *p, int16_t *dcan, int width, int height, int32_t *support, int cap, int threads);
 int sv_host_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap);
 /* Test hook: exhaustive comparison, on the current device, of the adaptive-mean kernel's division shortcut (v_rcp_f32 + one FMA
  * correction; kernels.hip: amean_div) with the IEEE division: every float mantissa, both signs, 31 exponents, the sixteen divisors

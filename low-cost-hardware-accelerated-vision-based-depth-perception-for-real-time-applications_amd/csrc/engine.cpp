@@ -65,6 +65,7 @@ struct HostScratch {  // per pool thread
     std::vector<int32_t> xy;
     std::vector<int32_t> sup;
     std::vector<int16_t> lattice;
+    FilterScratch filter;  // latency mode: the lattice filters shared with the polling pool threads
 };
 
 // words of a pair's part of the device blob when the device lays it out itself (resident chunks): support points, two triangle lists, two vertex orders
@@ -172,10 +173,17 @@ struct sv_handle {
     bool dbg_dma_fail = false;             // sv_debug_set "dma_selftest_fail"
     uint32_t dma_engines_override = 0;     // SV_DMA_ENGINES (experiments): engine of the upload lane | download lane << 8 | second download lane << 16, each as log2 + 1
     bool pool_sleep = false;               // sv_debug_set "pool_sleep"
+    bool lat_filter_alone = false;         // latency mode: the lattice filters on the calling thread alone (sv_debug_set "lat_filter_alone")
     bool lat_runtime_copies = false;       // latency mode: the lattice / blob copies through hipMemcpyAsync as in the streamed path (sv_debug_set "lat_runtime_copies")
     int lat_pin = 0;                       // latency mode: keep the polling pool threads on the calling thread's L3 (sv_debug_set "latency_pin", SV_LATENCY_PIN)
     int lat_pin_l3 = -2;                   // the L3 domain they are pinned to right now (-2: never pinned)
     cpu_set_t pool_cpus;                   // where the pool threads run otherwise (the GPU's NUMA node or the process's mask)
+    // latency mode: a team call of the calling thread (team_run)
+    std::atomic<int> team_open{0}, team_active{0}, team_next{0}, team_done{0};  // team_open: 0 or the number of the open call
+    void (*team_fn)(void *, int) = nullptr;
+    void *team_arg = nullptr;
+    int team_parts = 0;
+    int team_calls = 0;
     std::atomic<int> pollers{0};           // latency mode: pool threads polling the queue length right now
     bool resident_ok = false;     // the GPU's share of the chunks is built without the support lists ever leaving the device (k_delaunay_resident)
     std::atomic<int> shared_pct{0};   // host mode with a balanced share: the dispatcher's current share, read by the issuer (who decides per chunk)
@@ -635,6 +643,7 @@ void issue_phase1(sv_handle *h, Slot *s) {
 
 // ---- host-memory jobs: staging and copies ------------------------------------------------------------------------------
 void spawn_to_pool(void *ctx, void (*fn)(void *), void *arg);
+int latency_pollers(const sv_handle *h);
 
 // A large host-side copy shared between the calling thread and idle pool threads: pieces are claimed from an atomic counter,
 // so the caller never waits for a helper that is busy with a triangulation (it just ends up copying more itself).
@@ -1058,6 +1067,38 @@ void spawn_to_pool(void *ctx, void (*fn)(void *), void *arg) {
     if (h->pollers.load(std::memory_order_acquire) < 1) h->qcv.notify_one();  // a polling thread needs no wake-up (a system call on this thread)
 }
 
+// Latency mode: the lattice filters of the single pair as a team of the calling thread and the polling pool threads (idle until the
+// filters are done: the triangulations start from their result).  The pollers watch one word of the handle beside the queue length; a
+// team call opens it, whoever is polling joins and claims parts from a counter together with the caller, which does not depend on
+// anybody showing up.  No lock, no allocation: a filter pass is a few microseconds and the queue's mutex would cost as much again
+// (measured: ~2 us per call through the queue with seven pollers).  The caller closes the call and waits until everybody who got in
+// has left before it returns - fn, arg and the counters are then free for the next call.
+void team_work(sv_handle *h) {
+    const int parts = h->team_parts;
+    for (int q = h->team_next.fetch_add(1); q < parts; q = h->team_next.fetch_add(1)) {
+        h->team_fn(h->team_arg, q);
+        h->team_done.fetch_add(1);
+    }
+}
+
+void team_join(sv_handle *h) {  // a polling pool thread that has seen team_open != 0
+    h->team_active.fetch_add(1);
+    if (h->team_open.load()) team_work(h);  // (still open after we are counted: the caller waits for us before it reuses anything)
+    h->team_active.fetch_sub(1);
+}
+
+void team_run(void *ctx, int parts, void (*fn)(void *, int), void *arg) {
+    sv_handle *h = static_cast<sv_handle *>(ctx);
+    h->team_fn = fn, h->team_arg = arg, h->team_parts = parts;
+    h->team_next.store(0);
+    h->team_done.store(0);
+    h->team_open.store(++h->team_calls ? h->team_calls : ++h->team_calls);
+    team_work(h);
+    while (h->team_done.load() < parts) __builtin_ia32_pause();
+    h->team_open.store(0);
+    while (h->team_active.load() != 0) __builtin_ia32_pause();
+}
+
 // one Delaunay triangulation of a pair's support points; errors are recorded, never thrown (the completion accounting of
 // the caller must run in any case)
 void triangulate_side(sv_handle *h, HostScratch *sc, Slot *s, int j, int side) {
@@ -1186,9 +1227,18 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
     } else {
         const auto tf0 = std::chrono::steady_clock::now();
         // work on a private copy: the filters rewrite the lattice in place and the pinned buffer is DMA-visible memory
-        if ((int)sc->lattice.size() < lat + LATTICE_PAD) sc->lattice.assign((size_t)lat + LATTICE_PAD, 0);
-        memcpy(sc->lattice.data(), s->h_dcan + (size_t)t.pair * lat, sizeof(int16_t) * (size_t)lat);
-        ns = support_filter_t(h->p, sc->lattice.data(), d.W, d.H, sc->sup.data(), d.max_pts);
+        const FilterTeam team{team_run, h, 1 + h->pollers.load(std::memory_order_acquire)};
+        const bool shared = s->inline_mode && h->latency_split > 0 && h->lat_pin && !h->lat_filter_alone && team.threads > 1 && support_filter_team_usable(h->p);
+        if (shared) {
+            // the pollers sit next to this thread: the filters as a team.  The team reads the lattice where the device left it (its first
+            // pass only reads, every thread its own columns) and writes the result over it at the end; the slot has one pair, so the
+            // sixteen entries the vector loads may touch behind the lattice are the buffer's padding.
+            ns = support_filter_t(h->p, s->h_dcan + (size_t)t.pair * lat, d.W, d.H, sc->sup.data(), d.max_pts, &team, &sc->filter);
+        } else {
+            if ((int)sc->lattice.size() < lat + LATTICE_PAD) sc->lattice.assign((size_t)lat + LATTICE_PAD, 0);
+            memcpy(sc->lattice.data(), s->h_dcan + (size_t)t.pair * lat, sizeof(int16_t) * (size_t)lat);
+            ns = support_filter_t(h->p, sc->lattice.data(), d.W, d.H, sc->sup.data(), d.max_pts);
+        }
         if (h->timing) h->host_filter_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - tf0).count();
         if (ns < 0) {
             note_error(h, "support point capacity exceeded");
@@ -1283,6 +1333,7 @@ void pool_main(sv_handle *h, HostScratch *sc, int idx) {
     // use) before they go to sleep; the others, and throughput handles, sleep at once.  (All 14 polling: 15 busy threads on a 16-CPU
     // quota, and a notify_all that costs the calling thread 19 us.)  A producer that finds enough pollers does not notify at all.
     const int hot = latency_pollers(h);
+    int team_seen = 0;
     for (;;) {
         Task t;
         bool have = false;
@@ -1291,6 +1342,11 @@ void pool_main(sv_handle *h, HostScratch *sc, int idx) {
             // a poller never sleeps on the queue's mutex (try_lock): nobody then has to wake it with a system call when the lock is released
             h->pollers.fetch_add(1, std::memory_order_acq_rel);
             for (int i = 0; i < spin_rounds && !have; i++) {
+                if (const int call = h->team_open.load(std::memory_order_acquire); call && call != team_seen) {
+                    team_join(h);
+                    team_seen = call;  // (once per call: no parts are left when team_join returns)
+                    i = 0;             // in use: keep polling
+                }
                 if (h->queue_len.load(std::memory_order_acquire) > 0 && h->qmu.try_lock()) {
                     if (!h->queue.empty()) {
                         t = h->queue.front();
@@ -2517,6 +2573,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         }
         h->pool_sleep = env_int("SV_POOL_SLEEP", &v);
         h->lat_runtime_copies = env_int("SV_LAT_RUNTIME_COPIES", &v) && v;
+        h->lat_filter_alone = env_int("SV_LAT_FILTER_ALONE", &v) && v;
         if (env_int("SV_LATENCY_PIN", &v)) h->lat_pin = v;  // (experiments: shared triangulations without / with the helpers next to the caller)
         if (env_int("SV_DG_MARGIN", &v)) h->ns_margin_pct = std::max(0, v);
     }
@@ -2677,6 +2734,8 @@ int sv_debug_set(sv_handle *h, const char *key, int value) {
         h->ns_bound.store(std::max(3, std::min(value, h->dg_sub_max)));
     } else if (k == "pool_sleep") {
         h->pool_sleep = value != 0;
+    } else if (k == "lat_filter_alone") {
+        h->lat_filter_alone = value != 0;
     } else if (k == "lat_runtime_copies") {
         h->lat_runtime_copies = value != 0;
     } else if (k == "latency_pin") {
@@ -2798,6 +2857,11 @@ int sv_default_host_threads(int ignore_quota) { return default_pool_size(ignore_
 int sv_host_support_filter(const sv_params *p, int16_t *dcan, int width, int height, int32_t *support, int cap) {
     if (!p || !dcan || !support) return SV_ERR_ARG;
     return support_filter(*p, dcan, width, height, support, cap);
+}
+
+int sv_host_support_filter_threads(const sv_params *p, int16_t *dcan, int width, int height, int32_t *support, int cap, int threads) {
+    if (!p || !dcan || !support || threads < 1) return SV_ERR_ARG;
+    return support_filter_threads(*p, dcan, width, height, support, cap, threads);
 }
 
 int sv_host_delaunay(const int32_t *xy, int n, int32_t *tri_out, int cap) {

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <thread>
 
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -137,11 +138,11 @@ static void drop_redundant_scalar(int16_t *T, int Wc, int Hc, int max_dist, int 
 // still visited in order, but its +-max_dist neighbourhood is one 16-lane window load: lanes 0..max_dist-1 are the points
 // below, lane max_dist the point itself, the next max_dist lanes the points above.  Points closer than max_dist to a column
 // end take the scalar path.  Requires max_dist <= 7.
-__attribute__((target("avx2"))) static void drop_redundant_v_avx2(int16_t *T, int Wc, int Hc, int max_dist, int thr) {
+__attribute__((target("avx2"))) static void drop_redundant_v_avx2(int16_t *T, int uc0, int uc1, int Hc, int max_dist, int thr) {  // columns [uc0, uc1)
     const __m256i vthr = _mm256_set1_epi16((short)thr), vneg1 = _mm256_set1_epi16(-1);
     const uint32_t lo_bits = (1u << (2 * max_dist)) - 1u;                              // movemask: 2 bits per int16 lane
     const uint32_t hi_bits = ((1u << (2 * max_dist)) - 1u) << (2 * (max_dist + 1));
-    for (int uc = 0; uc < Wc; uc++) {
+    for (int uc = uc0; uc < uc1; uc++) {
         int16_t *col = T + (size_t)uc * Hc;
         for (int v0 = 0; v0 < Hc; v0 += 16)
             for (uint32_t vm = valid_lanes(col, v0, Hc); vm; vm &= vm - 1) {
@@ -166,7 +167,7 @@ __attribute__((target("avx2"))) static void drop_redundant_v_avx2(int16_t *T, in
 
 // Pass along u: a point only looks at points of its own row v, so the 16 rows of a vector are independent of each other and
 // the column loop (u ascending) already is the reference's visiting order for each of them.
-__attribute__((target("avx2"))) static void drop_redundant_u_avx2(int16_t *T, int Wc, int Hc, int max_dist, int thr) {
+__attribute__((target("avx2"))) static void drop_redundant_u_avx2(int16_t *T, int Wc, int Hc, int max_dist, int thr, int vb0 = 0, int vb1 = 1 << 30) {  // rows [vb0, vb1), vb0 a multiple of 16
     const __m256i vthr = _mm256_set1_epi16((short)thr), vneg1 = _mm256_set1_epi16(-1);
     alignas(32) int16_t lane_id[16];
     for (int i = 0; i < 16; i++) lane_id[i] = (int16_t)i;
@@ -174,7 +175,7 @@ __attribute__((target("avx2"))) static void drop_redundant_u_avx2(int16_t *T, in
     for (int uc = 0; uc < Wc; uc++) {
         const int n_lo = std::min(max_dist, uc), n_hi = std::min(max_dist, Wc - 1 - uc);
         int16_t *col = T + (size_t)uc * Hc;
-        for (int v0 = 0; v0 < Hc; v0 += 16) {
+        for (int v0 = vb0; v0 < std::min(Hc, vb1); v0 += 16) {
             const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(col + v0));
             const __m256i valid = _mm256_cmpgt_epi16(x, vneg1);
             __m256i flo = _mm256_setzero_si256(), fhi = _mm256_setzero_si256();
@@ -191,7 +192,14 @@ __attribute__((target("avx2"))) static void drop_redundant_u_avx2(int16_t *T, in
             // rows beyond the column's end belong to the next column: leave them alone
             const __m256i inside = _mm256_cmpgt_epi16(_mm256_set1_epi16((short)std::min(Hc - v0, 16)), vlane);
             const __m256i drop = _mm256_and_si256(_mm256_and_si256(valid, inside), _mm256_and_si256(flo, fhi));
-            _mm256_storeu_si256(reinterpret_cast<__m256i *>(col + v0), _mm256_blendv_epi8(x, vneg1, drop));
+            const __m256i res = _mm256_blendv_epi8(x, vneg1, drop);
+            if (Hc - v0 >= 16) {
+                _mm256_storeu_si256(reinterpret_cast<__m256i *>(col + v0), res);
+            } else {  // the column's last rows only: the entries behind them are the next column's first rows, which another thread of a team may be rewriting
+                alignas(32) int16_t tmp[16];
+                _mm256_store_si256(reinterpret_cast<__m256i *>(tmp), res);
+                memcpy(col + v0, tmp, sizeof(int16_t) * (size_t)(Hc - v0));
+            }
         }
     }
 }
@@ -203,7 +211,7 @@ static void drop_redundant(int16_t *T, int Wc, int Hc, int max_dist, int thr, bo
     static const bool have_avx2 = __builtin_cpu_supports("avx2");
     if (have_avx2 && max_dist >= 1 && max_dist <= 7 && thr >= 0 && thr < 16384) {
         if (vertical)
-            drop_redundant_v_avx2(T, Wc, Hc, max_dist, thr);
+            drop_redundant_v_avx2(T, 0, Wc, Hc, max_dist, thr);
         else
             drop_redundant_u_avx2(T, Wc, Hc, max_dist, thr);
         return;
@@ -261,12 +269,172 @@ static int collect_points(const int16_t *T, int Wc, int Hc, int step, int32_t *o
     return collect_points_scalar(T, Wc, Hc, step, out, cap);
 }
 
-int support_filter_t(const sv_params &p, int16_t *T, int W, int H, int32_t *out, int cap) {
+#if defined(__x86_64__)
+// ---- the same filters with the lattice shared between the threads of a team (latency mode: one pair, several idle cores) ----
+//
+// removeInconsistentSupportPoints is order dependent, but only one way: when a point is visited, the points AFTER it in the scan
+// (u outer, v inner) still have their original values and the points BEFORE it have their final ones.  So
+//     support(p) = L(p) + E(p),   L = similar valid points of the window at or after p (itself included) - known from the input alone,
+//                                 E = similar points of the window before p that were KEPT,  0 <= E <= Emax = those valid in the input.
+// Pass 1 (any order, any number of threads, reads the input only): L >= need: kept for certain; L + Emax < need: dropped for certain;
+// otherwise undecided (with its L).  Pass 2 (one thread, scan order, undecided points only): E counted in the lattice of kept points.
+// On a KITTI lattice 6 400 of 18 675 entries are valid and a few hundred stay undecided.
+// similar valid entries among the `rows` entries from `col` (bit pairs of movemask; rows <= 16)
+__attribute__((target("avx2"))) static inline uint32_t similar_lanes(const int16_t *col, __m256i vd, __m256i vthr, __m256i vneg1, uint32_t lanes) {
+    const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(col));
+    const __m256i diff = _mm256_abs_epi16(_mm256_sub_epi16(x, vd));
+    const __m256i ok = _mm256_andnot_si256(_mm256_cmpgt_epi16(diff, vthr), _mm256_cmpgt_epi16(x, vneg1));
+    return (uint32_t)_mm256_movemask_epi8(ok) & lanes;
+}
+
+// pass 1 for the columns [uc0, uc1): K[pos] = d for points kept for certain, -1 for everything else; undecided points appended in scan order
+__attribute__((target("avx2"))) static void classify_inconsistent_avx2(const sv_params &p, const int16_t *T, int16_t *K, int Wc, int Hc, int uc0, int uc1, std::vector<Undecided> &und) {
+    const int win = p.incon_window_size, need = p.incon_min_support;
+    const __m256i vthr = _mm256_set1_epi16((short)p.incon_threshold), vneg1 = _mm256_set1_epi16(-1);
+    for (int uc = uc0; uc < uc1; uc++) {
+        const int u_lo = std::max(uc - win, 0), u_hi = std::min(uc + win, Wc - 1);
+        const int16_t *col = T + (size_t)uc * Hc;
+        int16_t *kcol = K + (size_t)uc * Hc;
+        std::fill_n(kcol, Hc, (int16_t)-1);  // (exactly this column: the next one may belong to another thread)
+        for (int v0 = 0; v0 < Hc; v0 += 16) {
+            for (uint32_t vm = valid_lanes(col, v0, Hc); vm; vm &= vm - 1) {
+                const int vc = v0 + (__builtin_ctz(vm) >> 1);
+                const int d = col[vc];
+                const int v_lo = std::max(vc - win, 0), v_hi = std::min(vc + win, Hc - 1);
+                const uint32_t lanes = (uint32_t)((1ull << (2 * (v_hi - v_lo + 1))) - 1ull);
+                const uint32_t before = (1u << (2 * (vc - v_lo))) - 1u;  // the rows of a column that come before row vc
+                const __m256i vd = _mm256_set1_epi16((short)d);
+                const uint32_t own = similar_lanes(col + v_lo, vd, vthr, vneg1, lanes);
+                int later = __builtin_popcount(own & ~before) >> 1;  // (the point itself is one of them)
+                for (int u2 = uc + 1; u2 <= u_hi && later < need; u2++) later += __builtin_popcount(similar_lanes(T + (size_t)u2 * Hc + v_lo, vd, vthr, vneg1, lanes)) >> 1;
+                if (later >= need) {
+                    kcol[vc] = (int16_t)d;
+                    continue;
+                }
+                int sup = later + (__builtin_popcount(own & before) >> 1);
+                for (int u2 = uc - 1; u2 >= u_lo && sup < need; u2--) sup += __builtin_popcount(similar_lanes(T + (size_t)u2 * Hc + v_lo, vd, vthr, vneg1, lanes)) >> 1;
+                if (sup >= need) und.push_back(Undecided{uc * Hc + vc, later});
+            }
+        }
+    }
+}
+
+// pass 2: the undecided points in scan order against the kept points before them
+__attribute__((target("avx2"))) static void resolve_inconsistent_avx2(const sv_params &p, const int16_t *T, int16_t *K, int Wc, int Hc, const Undecided *und, size_t n) {
+    const int win = p.incon_window_size, need = p.incon_min_support;
+    const __m256i vthr = _mm256_set1_epi16((short)p.incon_threshold), vneg1 = _mm256_set1_epi16(-1);
+    for (size_t i = 0; i < n; i++) {
+        const int uc = und[i].pos / Hc, vc = und[i].pos - uc * Hc;
+        const int d = T[und[i].pos];
+        const int u_lo = std::max(uc - win, 0);
+        const int v_lo = std::max(vc - win, 0), v_hi = std::min(vc + win, Hc - 1);
+        const uint32_t lanes = (uint32_t)((1ull << (2 * (v_hi - v_lo + 1))) - 1ull);
+        const uint32_t before = (1u << (2 * (vc - v_lo))) - 1u;
+        const __m256i vd = _mm256_set1_epi16((short)d);
+        int sup = und[i].later + (__builtin_popcount(similar_lanes(K + (size_t)uc * Hc + v_lo, vd, vthr, vneg1, lanes & before)) >> 1);
+        for (int u2 = uc - 1; u2 >= u_lo && sup < need; u2--) sup += __builtin_popcount(similar_lanes(K + (size_t)u2 * Hc + v_lo, vd, vthr, vneg1, lanes)) >> 1;
+        if (sup >= need) K[und[i].pos] = (int16_t)d;
+    }
+}
+
+// The pass along u for the rows [v0, v0 + 16) by one thread of a team, on a private copy of those rows ([Wc][16], contiguous): in the
+// shared lattice the row blocks of a column lie side by side in the same cache lines, and five threads rewriting them in place spend
+// their time passing those lines around (measured: 11 us for the pass on five threads, 8 on one).  Only changed entries go back.
+__attribute__((target("avx2"))) static void drop_redundant_u_block_avx2(int16_t *K, int Wc, int Hc, int max_dist, int thr, int v0, std::vector<int16_t> &blk) {
+    const int rows = std::min(Hc - v0, 16);
+    if (rows <= 0) return;
+    if (blk.size() < (size_t)Wc * 16) blk.resize((size_t)Wc * 16);
+    int16_t *B = blk.data();
+    for (int uc = 0; uc < Wc; uc++)  // (the last block reads into the next column / the padding: those lanes are never stored)
+        _mm256_storeu_si256(reinterpret_cast<__m256i *>(B + (size_t)uc * 16), _mm256_loadu_si256(reinterpret_cast<const __m256i *>(K + (size_t)uc * Hc + v0)));
+    const __m256i vthr = _mm256_set1_epi16((short)thr), vneg1 = _mm256_set1_epi16(-1);
+    alignas(32) int16_t lane_id[16];
+    for (int i = 0; i < 16; i++) lane_id[i] = (int16_t)i;
+    const __m256i inside = _mm256_cmpgt_epi16(_mm256_set1_epi16((short)rows), _mm256_load_si256(reinterpret_cast<const __m256i *>(lane_id)));
+    for (int uc = 0; uc < Wc; uc++) {
+        const int n_lo = std::min(max_dist, uc), n_hi = std::min(max_dist, Wc - 1 - uc);
+        int16_t *col = B + (size_t)uc * 16;
+        const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(col));
+        const __m256i valid = _mm256_and_si256(_mm256_cmpgt_epi16(x, vneg1), inside);
+        if (_mm256_testz_si256(valid, valid)) continue;
+        __m256i flo = _mm256_setzero_si256(), fhi = _mm256_setzero_si256();
+        for (int j = 1; j <= n_lo; j++) {
+            const __m256i y = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(col - (size_t)j * 16));
+            flo = _mm256_or_si256(flo, _mm256_andnot_si256(_mm256_cmpgt_epi16(_mm256_abs_epi16(_mm256_sub_epi16(x, y)), vthr), _mm256_cmpgt_epi16(y, vneg1)));
+        }
+        for (int j = 1; j <= n_hi; j++) {
+            const __m256i y = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(col + (size_t)j * 16));
+            fhi = _mm256_or_si256(fhi, _mm256_andnot_si256(_mm256_cmpgt_epi16(_mm256_abs_epi16(_mm256_sub_epi16(x, y)), vthr), _mm256_cmpgt_epi16(y, vneg1)));
+        }
+        const __m256i drop = _mm256_and_si256(valid, _mm256_and_si256(flo, fhi));
+        if (_mm256_testz_si256(drop, drop)) continue;
+        _mm256_storeu_si256(reinterpret_cast<__m256i *>(col), _mm256_blendv_epi8(x, vneg1, drop));
+        memcpy(K + (size_t)uc * Hc + v0, col, sizeof(int16_t) * (size_t)rows);  // (this thread's rows of the column: nobody else reads or writes them)
+    }
+}
+
+namespace {
+struct TeamJob {
+    const sv_params *p;
+    const int16_t *T;
+    int16_t *K;
+    int Wc, Hc, parts;
+    std::vector<Undecided> *und;  // [parts]
+    int stage;
+};
+}  // namespace
+
+__attribute__((target("avx2"))) static void team_piece(void *arg, int part) {
+    const TeamJob &j = *static_cast<const TeamJob *>(arg);
+    const int c0 = (int)((long)j.Wc * part / j.parts), c1 = (int)((long)j.Wc * (part + 1) / j.parts);
+    if (j.stage == 0) {
+        j.und[part].clear();
+        classify_inconsistent_avx2(*j.p, j.T, j.K, j.Wc, j.Hc, c0, c1, j.und[part]);
+    } else if (j.stage == 1) {
+        drop_redundant_v_avx2(j.K, c0, c1, j.Hc, 5, 1);
+    } else {
+        static thread_local std::vector<int16_t> blk;
+        drop_redundant_u_block_avx2(j.K, j.Wc, j.Hc, 5, 1, 16 * part, blk);
+    }
+}
+
+bool support_filter_team_usable(const sv_params &p) {
+    static const bool have_avx2 = __builtin_cpu_supports("avx2");
+    return have_avx2 && p.incon_window_size >= 0 && p.incon_window_size <= 7 && p.incon_threshold >= 0 && p.incon_threshold < 16384 && p.incon_min_support >= 1;
+}
+
+// The three filters of support_filter_t by a team; the filtered lattice ends up in T again.
+static void filter_lattice_team(const sv_params &p, int16_t *T, int Wc, int Hc, const FilterTeam &team, FilterScratch &sc) {
+    const size_t lat = (size_t)Wc * Hc;
+    if (sc.kept.size() < lat + LATTICE_PAD) sc.kept.assign(lat + LATTICE_PAD, -1);
+    const int parts = std::max(1, std::min(Wc, 16));
+    if ((int)sc.undecided.size() < parts) sc.undecided.resize(parts);
+    TeamJob job{&p, T, sc.kept.data(), Wc, Hc, parts, sc.undecided.data(), 0};
+    team.run(team.ctx, parts, team_piece, &job);
+    for (int q = 0; q < parts; q++) resolve_inconsistent_avx2(p, T, job.K, Wc, Hc, job.und[q].data(), job.und[q].size());
+    job.stage = 1;
+    team.run(team.ctx, parts, team_piece, &job);
+    job.stage = 2;
+    team.run(team.ctx, (Hc + 15) / 16, team_piece, &job);
+    memcpy(T, job.K, sizeof(int16_t) * lat);
+}
+#else
+bool support_filter_team_usable(const sv_params &) { return false; }
+#endif
+
+int support_filter_t(const sv_params &p, int16_t *T, int W, int H, int32_t *out, int cap, const FilterTeam *team, FilterScratch *scratch) {
     int Wc, Hc;
     lattice_dims(p, W, H, Wc, Hc);
-    drop_inconsistent(p, T, Wc, Hc);
-    drop_redundant(T, Wc, Hc, 5, 1, true);
-    drop_redundant(T, Wc, Hc, 5, 1, false);
+#if defined(__x86_64__)
+    if (team && scratch && team->threads > 1 && support_filter_team_usable(p)) {
+        filter_lattice_team(p, T, Wc, Hc, *team, *scratch);
+    } else
+#endif
+    {
+        drop_inconsistent(p, T, Wc, Hc);
+        drop_redundant(T, Wc, Hc, 5, 1, true);
+        drop_redundant(T, Wc, Hc, 5, 1, false);
+    }
     const int step = lattice_step(p);
     int n = 0;
 #ifdef SV_FILTER_PROFILE
@@ -320,6 +488,37 @@ int support_filter(const sv_params &p, int16_t *dcan, int W, int H, int32_t *out
     for (int vc = 0; vc < Hc; vc++)
         for (int uc = 0; uc < Wc; uc++) T[(size_t)uc * Hc + vc] = dcan[(size_t)vc * Wc + uc];
     const int n = support_filter_t(p, T.data(), W, H, out, cap);
+    for (int vc = 0; vc < Hc; vc++)
+        for (int uc = 0; uc < Wc; uc++) dcan[(size_t)vc * Wc + uc] = T[(size_t)uc * Hc + vc];
+    return n;
+}
+
+// test hook: the team made of std::threads started per call (slow to start, same arithmetic)
+int support_filter_threads(const sv_params &p, int16_t *dcan, int W, int H, int32_t *out, int cap, int threads) {
+    int Wc, Hc;
+    lattice_dims(p, W, H, Wc, Hc);
+    std::vector<int16_t> T((size_t)Wc * Hc + LATTICE_PAD, 0);
+    for (int vc = 0; vc < Hc; vc++)
+        for (int uc = 0; uc < Wc; uc++) T[(size_t)uc * Hc + vc] = dcan[(size_t)vc * Wc + uc];
+    struct Ctx {
+        int threads;
+    } ctx{std::max(1, threads)};
+    FilterTeam team;
+    team.ctx = &ctx;
+    team.threads = ctx.threads;
+    team.run = [](void *c, int parts, void (*fn)(void *, int), void *arg) {
+        const int nt = static_cast<Ctx *>(c)->threads;
+        std::atomic<int> next{0};
+        auto work = [&] {
+            for (int q = next.fetch_add(1); q < parts; q = next.fetch_add(1)) fn(arg, q);
+        };
+        std::vector<std::thread> th;
+        for (int i = 1; i < nt; i++) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+    };
+    FilterScratch sc;
+    const int n = support_filter_t(p, T.data(), W, H, out, cap, &team, &sc);
     for (int vc = 0; vc < Hc; vc++)
         for (int uc = 0; uc < Wc; uc++) dcan[(size_t)vc * Wc + uc] = T[(size_t)uc * Hc + vc];
     return n;

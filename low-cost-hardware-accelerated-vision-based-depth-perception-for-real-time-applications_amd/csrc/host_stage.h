@@ -21,7 +21,27 @@ int support_filter(const sv_params &p, int16_t *dcan, int W, int H, int32_t *out
 // The transposed-lattice entry point may read (never write) up to LATTICE_PAD int16 elements past the end of T.
 constexpr int LATTICE_PAD = 16;
 // Same on the transposed lattice T[uc * Hc + vc] (the layout the GPU writes and the filters scan contiguously).
-int support_filter_t(const sv_params &p, int16_t *T, int W, int H, int32_t *out, int cap);
+//
+// With a team (latency mode: one pair at a time and idle cores next to the calling thread) the lattice is filtered by several threads:
+// run(ctx, parts, fn, arg) calls fn(arg, part) for every part in [0, parts) - on any threads, the caller included - and returns when
+// all of them have returned.  Same result, entry for entry (host_stage.cpp explains why the order-dependent filter allows it).
+struct FilterTeam {
+    void (*run)(void *ctx, int parts, void (*fn)(void *arg, int part), void *arg);
+    void *ctx;
+    int threads;  // threads the team can count on (1: not worth it)
+};
+struct Undecided {   // a point whose fate depends on which of the points before it were kept
+    int32_t pos;     // uc * Hc + vc
+    int32_t later;   // its support from itself and the points after it
+};
+struct FilterScratch {
+    std::vector<int16_t> kept;                        // the lattice of the points kept so far
+    std::vector<std::vector<Undecided>> undecided;    // per part, in scan order
+};
+bool support_filter_team_usable(const sv_params &p);  // AVX2 and parameters in the vector code's range
+int support_filter_t(const sv_params &p, int16_t *T, int W, int H, int32_t *out, int cap, const FilterTeam *team = nullptr, FilterScratch *scratch = nullptr);
+// Test hook: support_filter with a team of `threads` std::threads.
+int support_filter_threads(const sv_params &p, int16_t *dcan, int W, int H, int32_t *out, int cap, int threads);
 
 // Divide-and-conquer Delaunay triangulation with alternating cuts that reproduces, triangle for triangle and
 // corner for corner, what the reference obtains from Triangle 1.6 with switches "zQB" (elas.cpp:483-484;

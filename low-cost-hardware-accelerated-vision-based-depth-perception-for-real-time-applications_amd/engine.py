@@ -132,6 +132,8 @@ def lib():
     L.sv_kernel_timing_select.restype = ctypes.c_int
     L.sv_host_support_filter.argtypes = [ctypes.POINTER(SvParams), ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     L.sv_host_support_filter.restype = ctypes.c_int
+    L.sv_host_support_filter_threads.argtypes = [ctypes.POINTER(SvParams), ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    L.sv_host_support_filter_threads.restype = ctypes.c_int
     L.sv_host_delaunay.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
     L.sv_host_delaunay.restype = ctypes.c_int
     _lib = L
@@ -458,15 +460,19 @@ def disparity_to_u8(disp, out=None):
     return out
 
 
-def host_support_filter(params, dcan, width, height):
-    """Product host stage: lattice filters + corner points (CPU by design; see csrc/host_stage.h)."""
+def host_support_filter(params, dcan, width, height, threads=0, lattice=False):
+    """Product host stage: lattice filters + corner points (CPU by design; see csrc/host_stage.h).  threads > 0: the lattice shared between
+    that many threads (what single-pair calls do); lattice=True: also return the filtered lattice."""
     d = np.ascontiguousarray(dcan, dtype=np.int16).copy()
     cap = d.size + 6
     out = np.empty((cap, 3), np.int32)
-    n = lib().sv_host_support_filter(ctypes.byref(params), d.ctypes.data, width, height, out.ctypes.data, cap)
+    if threads > 0:
+        n = lib().sv_host_support_filter_threads(ctypes.byref(params), d.ctypes.data, width, height, out.ctypes.data, cap, threads)
+    else:
+        n = lib().sv_host_support_filter(ctypes.byref(params), d.ctypes.data, width, height, out.ctypes.data, cap)
     if n < 0:
         raise StereoError("support capacity")
-    return out[:n].copy()
+    return (out[:n].copy(), d) if lattice else out[:n].copy()
 
 
 def gpu_delaunay(xy, reps=1):

@@ -63,6 +63,8 @@ def test_host_stage_matches_oracle(eng, oracle, name):
     oracle.run_stages(util.case_params(e, ElasParams), L, R)
     s = eng.host_support_filter(util.case_params(e, eng.SvParams), oracle.stage("dcan_raw"), L.shape[1], L.shape[0])
     assert np.array_equal(s.ravel(), oracle.stage("support"))
+    s3 = eng.host_support_filter(util.case_params(e, eng.SvParams), oracle.stage("dcan_raw"), L.shape[1], L.shape[0], threads=3)
+    assert np.array_equal(s3, s)
     tl = eng.host_delaunay(np.stack([s[:, 0], s[:, 1]], 1))
     tr = eng.host_delaunay(np.stack([s[:, 0] - s[:, 2], s[:, 1]], 1))
     assert np.array_equal(tl.ravel(), oracle.stage("tri1")) and np.array_equal(tr.ravel(), oracle.stage("tri2"))
@@ -115,6 +117,10 @@ def test_host_filter_random_lattices(eng, oracle):
         n = L.orc_support_filter(ctypes.byref(po), a.ctypes.data, W, H, want.ctypes.data, want.shape[0])
         got = eng.host_support_filter(pe, d.copy(), W, H)
         assert n == got.shape[0] and np.array_equal(got, want[:n]), (it, W, H, step)
+        # the same lattice shared between the threads of a team (what single-pair calls do): same list, same filtered lattice
+        for threads in (2, 5):
+            shared, lat = eng.host_support_filter(pe, d.copy(), W, H, threads=threads, lattice=True)
+            assert np.array_equal(shared, want[:n]) and np.array_equal(lat, a), (it, W, H, step, threads)
 
 
 def test_host_delaunay_split_halves(eng):
