@@ -745,9 +745,11 @@ def run_config(ctx, name, steps_req, warmup, min_seconds, headline, gather):
             e1.process_device(l1, r1, o1, o2)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - a)
+        split = e1.query().get("latency_split")
         e1.close()
         lat_ms = {"median": round(1e3 * float(np.median(ts)), 3), "p99": round(1e3 * float(np.percentile(ts, 99)), 3),
                   "pair": "kitti_mini pair 0" if real is not None else "first pair of the batch", "calls": ncalls,
+                  "host_threads_per_triangulation": {0: 1, 1: 2, 2: 4}.get(split),  # (2 / 4: pool threads pinned to the calling thread's L3 domain share the host stage)
                   "memory": "device in / device out" + (" (host memory: host_to_host.latency_ms_batch1_host)" if headline else "")}
     res["latency_ms_batch1"] = lat_ms
     if headline:
