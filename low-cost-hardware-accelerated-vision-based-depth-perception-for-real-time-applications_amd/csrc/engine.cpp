@@ -173,6 +173,10 @@ struct sv_handle {
     bool dbg_dma_fail = false;             // sv_debug_set "dma_selftest_fail"
     uint32_t dma_engines_override = 0;     // SV_DMA_ENGINES (experiments): engine of the upload lane | download lane << 8 | second download lane << 16, each as log2 + 1
     bool pool_sleep = false;               // sv_debug_set "pool_sleep"
+    // latency mode, frames at a regular pace (a camera): the polling pool threads sleep between frames and are back shortly before the next one is due
+    int64_t lat_last_start_ns = 0, lat_period_ns = 0;   // calling thread only
+    std::atomic<int64_t> lat_next_expected_ns{0}, lat_period_ns_pub{0};
+    int64_t lat_wake_lead_ns = 0;                        // 0: period / 16 within [0.3, 2] ms (SV_LAT_WAKE_LEAD_US)
     bool lat_filter_alone = false;         // latency mode: the lattice filters on the calling thread alone (sv_debug_set "lat_filter_alone")
     bool lat_runtime_copies = false;       // latency mode: the lattice / blob copies through hipMemcpyAsync as in the streamed path (sv_debug_set "lat_runtime_copies")
     int lat_pin = 0;                       // latency mode: keep the polling pool threads on the calling thread's L3 (sv_debug_set "latency_pin", SV_LATENCY_PIN)
@@ -1362,7 +1366,22 @@ void pool_main(sv_handle *h, HostScratch *sc, int idx) {
         }
         if (!have) {
             std::unique_lock<std::mutex> lk(h->qmu);
-            h->qcv.wait(lk, [&] { return h->pool_quit || !h->queue.empty(); });
+            const auto ready = [&] { return h->pool_quit || !h->queue.empty(); };
+            bool timed = false;
+            if (spin_rounds) {
+                // A poller that has run out of patience.  Frames at a regular pace (a camera at 30 Hz: one call every 33 ms, far beyond the
+                // polling window): sleep towards the next one and be polling again shortly before it is due - a frame that finds the pollers
+                // asleep pays 30 - 50 us per wake-up and runs its host stage mostly alone (measured at one frame per 33 ms: 0.51 ms instead of 0.28).
+                using clk = std::chrono::steady_clock;
+                const int64_t next = h->lat_next_expected_ns.load(std::memory_order_relaxed), period = next ? h->lat_period_ns_pub.load(std::memory_order_relaxed) : 0;
+                const int64_t lead = h->lat_wake_lead_ns > 0 ? h->lat_wake_lead_ns : std::max<int64_t>(300000, std::min<int64_t>(2000000, period / 16));
+                const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now().time_since_epoch()).count();
+                if (next - lead > now + 100000) {
+                    timed = true;
+                    if (!h->qcv.wait_until(lk, clk::time_point(std::chrono::duration_cast<clk::duration>(std::chrono::nanoseconds(next - lead))), ready)) continue;  // time to poll again
+                }
+            }
+            if (!timed) h->qcv.wait(lk, ready);
             if (h->pool_quit && h->queue.empty()) return;
             t = h->queue.front();
             h->queue.pop_front();
@@ -2230,6 +2249,17 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
         (void)hipGetLastError();
     }
     if (h->lat_pin) pin_pollers_to_callers_l3(h, latency_pollers(h));
+    {  // the pace of the calls, for the pollers' sleep between frames (pool_main)
+        const int64_t now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+        const int64_t last = h->lat_last_start_ns;
+        h->lat_last_start_ns = now;
+        if (last) {
+            const int64_t dt = now - last, p = h->lat_period_ns;
+            h->lat_period_ns = (p > 0 && dt > p / 2 && dt < 2 * p) ? (3 * p + dt) / 4 : dt;
+            h->lat_period_ns_pub.store(h->lat_period_ns, std::memory_order_relaxed);
+            h->lat_next_expected_ns.store(now + h->lat_period_ns, std::memory_order_relaxed);
+        }
+    }
     Slot *s = h->slots[0];
     h->failed = false;
     s->job = &job;
@@ -2574,6 +2604,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         h->pool_sleep = env_int("SV_POOL_SLEEP", &v);
         h->lat_runtime_copies = env_int("SV_LAT_RUNTIME_COPIES", &v) && v;
         h->lat_filter_alone = env_int("SV_LAT_FILTER_ALONE", &v) && v;
+        if (env_int("SV_LAT_WAKE_LEAD_US", &v) && v > 0) h->lat_wake_lead_ns = (int64_t)v * 1000;
         if (env_int("SV_LATENCY_PIN", &v)) h->lat_pin = v;  // (experiments: shared triangulations without / with the helpers next to the caller)
         if (env_int("SV_DG_MARGIN", &v)) h->ns_margin_pct = std::max(0, v);
     }

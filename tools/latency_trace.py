@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--disp", type=int, default=128)
 ap.add_argument("--calls", type=int, default=300)
 ap.add_argument("--workers", type=int, default=0)
+ap.add_argument("--period-ms", type=float, default=0.0, help="a frame every so many milliseconds (a camera) instead of back to back")
 ap.add_argument("--host", choices=["pinned", "pageable"], default=None, help="sv_elas_process with host pointers (the reference's seam) instead of device tensors")
 a = ap.parse_args()
 import util
@@ -57,6 +58,10 @@ for _ in range(a.calls):
     t0 = time.perf_counter()
     e.process_device(L, R, d1, d2)
     ts.append(time.perf_counter() - t0)
+    if a.period_ms > 0:
+        time.sleep(max(0.0, a.period_ms * 1e-3 - (time.perf_counter() - t0)))
 ts = np.array(ts) * 1e3
+if a.period_ms > 0:
+    print("one frame every %.1f ms:" % a.period_ms, end=" ")
 print("D=%d: median %.3f ms, p99 %.3f ms over %d calls; engine %s" % (a.disp, np.median(ts), np.percentile(ts, 99), a.calls, e.query()), flush=True)
 e.close()
