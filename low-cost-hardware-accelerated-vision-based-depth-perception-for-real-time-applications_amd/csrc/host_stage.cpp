@@ -148,7 +148,9 @@ __attribute__((target("avx2"))) static void drop_redundant_v_avx2(int16_t *T, in
             for (uint32_t vm = valid_lanes(col, v0, Hc); vm; vm &= vm - 1) {
                 const int vc = v0 + (__builtin_ctz(vm) >> 1);
                 const int d = col[vc];
-                if (vc < max_dist || vc + max_dist >= Hc) {  // near a column end
+                // near a column end; in the last column of the range also wherever the 16-lane window would reach into the next column, which
+                // may be another thread's (its lanes would be ignored, but the read itself would race with that thread's writes)
+                if (vc < max_dist || vc + max_dist >= Hc || (uc == uc1 - 1 && vc - max_dist + 16 > Hc)) {
                     const int n_lo = std::min(max_dist, vc), n_hi = std::min(max_dist, Hc - 1 - vc);
                     int found_lo = 0, found_hi = 0;
                     for (int j = 1; j <= n_lo; j++) found_lo |= (col[vc - j] >= 0) & (abs(d - col[vc - j]) <= thr);
@@ -345,8 +347,16 @@ __attribute__((target("avx2"))) static void drop_redundant_u_block_avx2(int16_t 
     if (rows <= 0) return;
     if (blk.size() < (size_t)Wc * 16) blk.resize((size_t)Wc * 16);
     int16_t *B = blk.data();
-    for (int uc = 0; uc < Wc; uc++)  // (the last block reads into the next column / the padding: those lanes are never stored)
-        _mm256_storeu_si256(reinterpret_cast<__m256i *>(B + (size_t)uc * 16), _mm256_loadu_si256(reinterpret_cast<const __m256i *>(K + (size_t)uc * Hc + v0)));
+    if (rows == 16) {
+        for (int uc = 0; uc < Wc; uc++)
+            _mm256_storeu_si256(reinterpret_cast<__m256i *>(B + (size_t)uc * 16), _mm256_loadu_si256(reinterpret_cast<const __m256i *>(K + (size_t)uc * Hc + v0)));
+    } else {  // the column's last rows: exactly those (the entries behind them are the next column's first rows - another thread's)
+        for (int uc = 0; uc < Wc; uc++) {
+            int16_t *col = B + (size_t)uc * 16;
+            for (int i = rows; i < 16; i++) col[i] = -1;
+            memcpy(col, K + (size_t)uc * Hc + v0, sizeof(int16_t) * (size_t)rows);
+        }
+    }
     const __m256i vthr = _mm256_set1_epi16((short)thr), vneg1 = _mm256_set1_epi16(-1);
     alignas(32) int16_t lane_id[16];
     for (int i = 0; i < 16; i++) lane_id[i] = (int16_t)i;

@@ -56,8 +56,17 @@ int main() {
         std::vector<int16_t> T((size_t)Wc * Hc + LATTICE_PAD, 0);
         for (int i = 0; i < Wc * Hc; i++) T[i] = (rng() % 3) ? (int16_t)(rng() % 60) : (int16_t)-1;
         std::vector<int32_t> out(3 * ((size_t)Wc * Hc + 6));
+        // the same lattice (row-major copy) through a team of threads: same list, same lattice - and no thread reads what another writes
+        std::vector<int16_t> rm((size_t)Wc * Hc), rm2;
+        for (int vc = 0; vc < Hc; vc++)
+            for (int uc = 0; uc < Wc; uc++) rm[(size_t)vc * Wc + uc] = T[(size_t)uc * Hc + vc];
+        rm2 = rm;
+        std::vector<int32_t> out_a(out.size()), out_b(out.size());
+        const int na = support_filter(p, rm.data(), W, H, out_a.data(), Wc * Hc + 6);
+        const int nb = support_filter_threads(p, rm2.data(), W, H, out_b.data(), Wc * Hc + 6, 2 + it % 4);
+        if (na != nb || (na > 0 && memcmp(out_a.data(), out_b.data(), sizeof(int32_t) * 3 * na)) || rm != rm2) bad++;
         support_filter_t(p, T.data(), W, H, out.data(), Wc * Hc + 6);
     }
-    printf("sanitizer run done, delaunay mismatches: %d\n", bad);
+    printf("sanitizer run done, delaunay / filter-team mismatches: %d\n", bad);
     return bad != 0;
 }
