@@ -118,7 +118,7 @@ bool legacy_init(int width, int height, float scale, const char *yaml, bool subs
     cfg.width = width;
     cfg.height = height;
     cfg.device = g.device = g_want_device;
-    cfg.n_workers = 4;  // latency mode: two triangulations, each split over two threads
+    cfg.n_workers = 7;  // latency mode: the frame's host stage shared with up to seven polling threads next to the calling one (sv_config.latency_split)
     cfg.n_streams = 1;
     cfg.n_slots = 2;
     cfg.chunk = 1;
