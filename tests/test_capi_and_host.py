@@ -46,6 +46,16 @@ def test_create_rejects_unsupported(eng):
     assert L.sv_create(ctypes.byref(p), ctypes.byref(cfg), ctypes.byref(h)) == -1 and not h.value
     assert b"disp_max" in L.sv_last_error(None)
     assert L.sv_create(None, None, None) == -1
+    # policy words are range-checked before anything touches a device: one past the last policy of some of them, a reserved word
+    p = eng.SvParams.driver(127)
+    for field, bad in (("latency_split", 4), ("gpu_triangulation", 5), ("host_copies", 3), ("event_sync", 4), ("gpu_triangulation_pct", 101), ("affinity", 3), ("latency_split", -1)):
+        cfg = eng.SvConfig(1242, 375, 0, 1, 1, 0)
+        setattr(cfg, field, bad)
+        assert L.sv_create(ctypes.byref(p), ctypes.byref(cfg), ctypes.byref(h)) == -1 and not h.value, field
+        assert field.encode() in L.sv_last_error(None), (field, L.sv_last_error(None))
+    cfg = eng.SvConfig(1242, 375, 0, 1, 1, 0)
+    cfg.reserved[3] = 1
+    assert L.sv_create(ctypes.byref(p), ctypes.byref(cfg), ctypes.byref(h)) == -1 and b"reserved" in L.sv_last_error(None)
 
 
 def test_no_gpu_fails_loudly(eng):
