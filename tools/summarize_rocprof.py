@@ -8,6 +8,7 @@ import collections
 import csv
 import glob
 import os
+import re
 
 
 def short(name):
@@ -19,6 +20,7 @@ def short(name):
         name = name[5:]
     if "<false" in name:  # "k_dense<false, 4, 3>" (not counting, 4 mask words, plane radius 3) -> "k_dense"
         name = name[:name.index("<false")]
+    name = re.sub(r"<\d+>$", "", name)  # "k_ccl_band<256>" / "<1024>" (workgroup size of the launch) -> "k_ccl_band"
     return name
 
 
