@@ -22,7 +22,7 @@ GROUPS = [  # (name in the bench line, rocprof kernel names, what it replaces, S
     ("triangles_raster", ["k_raster_tiles", "k_raster"], "scan conversion of `computeDisparity`", 0),
     ("dense_match", ["k_dense"], "`findMatch`, both sides", 10 * N),
     ("lr_check", ["k_lr2", "k_lr"], "`leftRightConsistencyCheck`", 12 * N),
-    ("ccl_band + ccl_finish", ["k_ccl_band", "k_ccl_border", "k_ccl_total", "k_ccl_apply", "k_ccl_slow"]  # (k_ccl_slow: a launch of its own until r05c), "`removeSmallSegments`", 16 * N),
+    ("ccl_band + ccl_finish", ["k_ccl_band", "k_ccl_border", "k_ccl_total", "k_ccl_apply", "k_ccl_slow"], "`removeSmallSegments`", 16 * N),
     ("gap_rows + gap_cols", ["k_gap_rows", "k_gap_cols"], "`gapInterpolation`", 16 * N),
     ("adaptive_mean", ["k_amean", "k_amean_sub"], "`adaptiveMean`", 16 * N),
     ("median", ["k_median"], "`median`", 16 * N),
