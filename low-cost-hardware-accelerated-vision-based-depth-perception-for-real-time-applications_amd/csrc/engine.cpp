@@ -181,6 +181,8 @@ struct sv_handle {
     bool lat_runtime_copies = false;       // latency mode: the lattice / blob copies through hipMemcpyAsync as in the streamed path (sv_debug_set "lat_runtime_copies")
     int lat_pin = 0;                       // latency mode: keep the polling pool threads on the calling thread's L3 (sv_debug_set "latency_pin", SV_LATENCY_PIN)
     int lat_pin_l3 = -2;                   // the L3 domain they are pinned to right now (-2: never pinned)
+    std::atomic<bool> lat_near{false};     // ... and they could be pinned there
+    bool lat_auto = false;                 // sv_config.latency_split was 0: share the host stage only while lat_near
     cpu_set_t pool_cpus;                   // where the pool threads run otherwise (the GPU's NUMA node or the process's mask)
     // latency mode: a team call of the calling thread (team_run)
     std::atomic<int> team_open{0}, team_active{0}, team_next{0}, team_done{0};  // team_open: 0 or the number of the open call
@@ -1138,7 +1140,7 @@ void triangulate_side(sv_handle *h, HostScratch *sc, Slot *s, int j, int side) {
     // triangles come back from another core's cache for the seam and for the output pass); throughput mode keeps every core busy with
     // whole pairs anyway.  (Two triangulations at a time: halves need 4 threads, quarters 8, counting the calling thread.)
     const Delaunay::Spawn spawn{spawn_to_pool, h, (h->latency_split >= 2 && h->pool.size() >= 7) ? 2 : 1};
-    const int nt = sc->dl.triangulate(sc->xy.data(), ns, blob + meta[3 + 2 * side], 2 * ns, (h->chunk == 1 && h->latency_split > 0 && h->pool.size() >= 3) ? &spawn : nullptr);
+    const int nt = sc->dl.triangulate(sc->xy.data(), ns, blob + meta[3 + 2 * side], 2 * ns, (h->chunk == 1 && h->latency_split > 0 && h->pool.size() >= 3 && (!h->lat_auto || h->lat_near.load(std::memory_order_acquire))) ? &spawn : nullptr);
     if (h->timing) h->host_delaunay_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     if (nt < 0 || nt > d.max_tri) {
         note_error(h, "triangle capacity exceeded");
@@ -1232,7 +1234,7 @@ void run_task(sv_handle *h, HostScratch *sc, const Task &t) {
         const auto tf0 = std::chrono::steady_clock::now();
         // work on a private copy: the filters rewrite the lattice in place and the pinned buffer is DMA-visible memory
         const FilterTeam team{team_run, h, 1 + h->pollers.load(std::memory_order_acquire)};
-        const bool shared = s->inline_mode && h->latency_split > 0 && h->lat_pin && !h->lat_filter_alone && team.threads > 1 && support_filter_team_usable(h->p);
+        const bool shared = s->inline_mode && h->latency_split > 0 && h->lat_pin && h->lat_near.load(std::memory_order_acquire) && !h->lat_filter_alone && team.threads > 1 && support_filter_team_usable(h->p);
         if (shared) {
             // the pollers sit next to this thread: the filters as a team.  The team reads the lattice where the device left it (its first
             // pass only reads, every thread its own columns) and writes the result over it at the end; the slot has one pair, so the
@@ -1941,12 +1943,17 @@ void pin_pollers_to_callers_l3(sv_handle *h, int hot) {
         room = l3_helper_cores(cpu, hot, &cores, &first);
     }
     const int n = std::min(hot, (int)h->pool.size());
-    for (int i = 0; i < n; i++) {
+    bool near = room;
+    for (int i = 0; i < n && near; i++) {
         cpu_set_t one;
         CPU_ZERO(&one);
-        if (room) CPU_SET(cores[i], &one);
-        (void)pthread_setaffinity_np(h->pool[i].native_handle(), sizeof(cpu_set_t), room ? &one : &h->pool_cpus);
+        CPU_SET(cores[i], &one);
+        near = pthread_setaffinity_np(h->pool[i].native_handle(), sizeof(cpu_set_t), &one) == 0;  // (a cpuset may refuse)
     }
+    if (!near)
+        for (int i = 0; i < n; i++) (void)pthread_setaffinity_np(h->pool[i].native_handle(), sizeof(cpu_set_t), &h->pool_cpus);
+    // under the automatic policy the host stage is only shared with helpers that sit next to the caller (anywhere else it costs more than it saves)
+    h->lat_near.store(near, std::memory_order_release);
     h->lat_pin_l3 = l3_of[cpu];
 }
 
@@ -2575,6 +2582,7 @@ int sv_create(const sv_params *params, const sv_config *cfg, sv_handle **out) {
         std::vector<int> cores;
         int first = -1;
         const int policy = cfg->latency_split;
+        h->lat_auto = policy == 0;
         h->lat_pin = cfg->affinity != 2 && policy != 3;
         if (policy == 0) {  // quarters need seven helpers beside the caller's core, halves four
             h->latency_split = 0;
