@@ -144,8 +144,16 @@ __attribute__((target("avx2"))) static void drop_redundant_v_avx2(int16_t *T, in
     const uint32_t hi_bits = ((1u << (2 * max_dist)) - 1u) << (2 * (max_dist + 1));
     for (int uc = uc0; uc < uc1; uc++) {
         int16_t *col = T + (size_t)uc * Hc;
-        for (int v0 = 0; v0 < Hc; v0 += 16)
-            for (uint32_t vm = valid_lanes(col, v0, Hc); vm; vm &= vm - 1) {
+        for (int v0 = 0; v0 < Hc; v0 += 16) {
+            uint32_t vm;
+            if (uc == uc1 - 1 && Hc - v0 < 16) {  // the range's last column, its last rows: not a 16-lane load that runs into the next column (another thread's, perhaps)
+                alignas(32) int16_t tmp[16];
+                for (int i = 0; i < 16; i++) tmp[i] = i < Hc - v0 ? col[v0 + i] : (int16_t)-1;
+                vm = valid_lanes(tmp, 0, 16);
+            } else {
+                vm = valid_lanes(col, v0, Hc);
+            }
+            for (; vm; vm &= vm - 1) {
                 const int vc = v0 + (__builtin_ctz(vm) >> 1);
                 const int d = col[vc];
                 // near a column end; in the last column of the range also wherever the 16-lane window would reach into the next column, which
@@ -164,6 +172,7 @@ __attribute__((target("avx2"))) static void drop_redundant_v_avx2(int16_t *T, in
                 const uint32_t m = (uint32_t)_mm256_movemask_epi8(ok);
                 if ((m & lo_bits) && (m & hi_bits)) col[vc] = -1;
             }
+        }
     }
 }
 
