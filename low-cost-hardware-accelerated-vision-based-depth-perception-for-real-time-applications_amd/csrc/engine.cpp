@@ -2699,7 +2699,8 @@ int sv_query(const sv_handle *h, int what) {
         case SV_Q_NUMA_BOUND: return h->node_bound ? 1 : 0;
         case SV_Q_RESIDENT: return h->resident_ok ? 1 : 0;
         case SV_Q_HOST_COPIES: return h->host_copies_mode;
-        case SV_Q_LATENCY_SPLIT: return h->chunk == 1 ? h->latency_split : 0;
+        case SV_Q_LATENCY_SPLIT:  // (automatic policy: what the last single-pair call could do - no sharing while the helpers cannot sit next to the caller)
+            return h->chunk != 1 ? 0 : (h->lat_auto && h->lat_pin_l3 != -2 && !h->lat_near.load()) ? 0 : h->latency_split;
         case SV_Q_GPU_TRIANGULATION_FALLBACKS: return (int)std::min<int64_t>(h->gpu_tri_fallbacks.load(), 0x7FFFFFFF);
         case SV_Q_GPU_TRIANGULATION_SHARE: {
             const int64_t all = h->tri_pairs.load(), g = h->gpu_tri_pairs.load();
