@@ -349,6 +349,7 @@ void launch_expand_debug(const KParams &k, const SlotDev &s, int n, uint8_t *des
 #define SUP_THREADS 256
 #define SUP_POINTS 64
 #define SUP_SPLIT (SUP_THREADS / SUP_POINTS)
+#define SUP_SPLIT_ALONE 8
 
 struct SupRows {            // one staged image: rows v-2 and v+2, columns [c0, c0+n)
     const uint4 *r0, *r1;
@@ -415,10 +416,11 @@ __device__ __forceinline__ void support_scan(const SupRows &A, const SupRows &B,
 }
 
 // the four partial records of a point -> (best, runner-up) of the whole range
+template <int SPLIT>
 __device__ __forceinline__ uint2 support_merge(const uint2 *rec, int point) {
     uint2 m = rec[point];
 #pragma unroll
-    for (int g = 1; g < SUP_SPLIT; ++g) {
+    for (int g = 1; g < SPLIT; ++g) {
         const uint2 o = rec[g * SUP_POINTS + point];
         m.y = min(min(m.y, o.y), max(m.x, o.x));
         m.x = min(m.x, o.x);
@@ -442,8 +444,13 @@ __device__ __forceinline__ int support_decide(const KParams &k, uint32_t texture
     return E1 < k.support_threshold * E2 ? (int)(m.x & 0xFFFFu) : -1;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, const uint8_t *__restrict__ grad, int16_t *__restrict__ dcan, unsigned long long *__restrict__ counters) {
+// SPLIT wavefronts per workgroup, each with a SPLIT-th of the disparity range: SUP_SPLIT (4) inside the pipeline; SUP_SPLIT_ALONE (8) when the
+// launch cannot fill the GPU anyway (a single pair: 290 workgroups on 256 CUs) - a lane's scan is then half as long.
+// (The lattice of a single pair copied to the host by this kernel's last workgroup instead of by a copy kernel behind it - one launch
+// boundary less - was measured: one workgroup moving 37 KB is five rounds of dependent accesses, 67 instead of 20 us of waiting.)
+template <bool COUNT, int SPLIT>
+__global__ __launch_bounds__(64 * SPLIT) void k_support(KParams k, const uint8_t *__restrict__ grad, int16_t *__restrict__ dcan, unsigned long long *__restrict__ counters) {
+    constexpr int SUP_THREADS_T = 64 * SPLIT;
     const Dims &d = k.d;
     extern __shared__ uint4 sup_lds[];
     const int pair = blockIdx.z, vc = blockIdx.y + 1;
@@ -457,9 +464,9 @@ __global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, const uint8_
     const int qR = (r_c1 - r_c0 + 4) >> 2, qL = (l_c1 - l_c0 + 4) >> 2;  // quads per staged row
     const int nR = 4 * qR, nL = 4 * qL;
     uint2 *rec = reinterpret_cast<uint2 *>(sup_lds);  // [2 passes][SUP_SPLIT][SUP_POINTS]
-    uint4 *sR0 = sup_lds + 2 * SUP_THREADS * sizeof(uint2) / sizeof(uint4), *sR1 = sR0 + nR, *sL0 = sR1 + nR, *sL1 = sL0 + nL;
+    uint4 *sR0 = sup_lds + 2 * SUP_THREADS_T * sizeof(uint2) / sizeof(uint4), *sR1 = sR0 + nR, *sL0 = sR1 + nR, *sL1 = sL0 + nL;
     // rows v-2 and v+2 of both descriptor images, assembled from the gradient planes (rows without descriptors come out as zeros)
-    for (int i = threadIdx.x; i < 2 * (qR + qL); i += SUP_THREADS) {
+    for (int i = threadIdx.x; i < 2 * (qR + qL); i += SUP_THREADS_T) {
         const int row = i & 1, q = i >> 1;  // consecutive lanes alternate between the two rows of one quad column
         if (q < qR)
             expand_quad(g2, d, row ? v + 2 : v - 2, r_c0 + 4 * q, (row ? sR1 : sR0) + 4 * q);
@@ -470,7 +477,7 @@ __global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, const uint8_
     const SupRows L{sL0, sL1, l_c0}, R{sR0, sR1, r_c0};
     const int point = threadIdx.x & (SUP_POINTS - 1), part = __builtin_amdgcn_readfirstlane(threadIdx.x / SUP_POINTS);  // wave-uniform
     const int uc = uc0 + point, u = uc * d.step;
-    const int qlen = (d.disp_max - d.disp_min + SUP_SPLIT) / SUP_SPLIT, d_lo = d.disp_min + part * qlen;  // this wavefront's share of [disp_min, disp_max]
+    const int qlen = (d.disp_max - d.disp_min + SPLIT) / SPLIT, d_lo = d.disp_min + part * qlen;  // this wavefront's share of [disp_min, disp_max]
     // left -> right
     const int dmax1 = uc < uc1 ? support_range<false>(d, u, v) : -1;
     uint32_t texture = 0;  // of the centre descriptor (elas.cpp:296-300)
@@ -484,19 +491,19 @@ __global__ __launch_bounds__(SUP_THREADS) void k_support(KParams k, const uint8_
     rec[threadIdx.x] = make_uint2(k1, k2);
     __syncthreads();
     texture = s_tex[point];
-    const int dd = dmax1 >= 0 ? support_decide(k, texture, support_merge(rec, point)) : -1;
+    const int dd = dmax1 >= 0 ? support_decide(k, texture, support_merge<SPLIT>(rec, point)) : -1;
     // right -> left from the match (elas.cpp:404-409)
     const int u2 = u - dd;
     const int dmax2 = dd >= 0 ? support_range<true>(d, u2, v) : -1;
     if (dmax2 >= 0 && part == 0) texture = texture_at(g2, v, u2);
     k1 = k2 = SUP_KEY_NONE;
     if (d_lo <= dmax2) support_scan<true>(R, L, u2, d_lo, min(dmax2, d_lo + qlen - 1), k1, k2);
-    rec[SUP_THREADS + threadIdx.x] = make_uint2(k1, k2);
+    rec[SUP_THREADS_T + threadIdx.x] = make_uint2(k1, k2);
     if (COUNT)  // 64-byte energies evaluated by this lane: its share of [0, dmax] in both directions
         count_add(counters + CNT_SUPPORT_ENERGIES, (d_lo <= dmax1 ? min(dmax1, d_lo + qlen - 1) - d_lo + 1 : 0) + (d_lo <= dmax2 ? min(dmax2, d_lo + qlen - 1) - d_lo + 1 : 0));
     __syncthreads();
     if (part == 0 && uc < uc1) {
-        const int d2v = dmax2 >= 0 ? support_decide(k, texture, support_merge(rec + SUP_THREADS, point)) : -1;
+        const int d2v = dmax2 >= 0 ? support_decide(k, texture, support_merge<SPLIT>(rec + SUP_THREADS_T, point)) : -1;
         const int res = (d2v >= 0 && abs(dd - d2v) <= k.lr_threshold) ? dd : -1;
         int16_t *lat = dcan + (size_t)pair * d.Wc * d.Hc;
         lat[(size_t)uc * d.Hc + vc] = (int16_t)res;  // transposed: the host filters scan u outer / v inner
@@ -514,17 +521,24 @@ void launch_support(const KParams &k, const SlotDev &s, int n, hipStream_t st) {
         return;
     }
     const int span = (SUP_POINTS - 1) * k.d.step;
-    // two rows per image; each staged range starts up to 3 columns early and ends on a whole quad
-    const size_t shmem = 2 * SUP_THREADS * sizeof(uint2) + sizeof(uint4) * 2 * ((size_t)(span + k.d.disp_max + 5 + 6) + (size_t)(span + 2 * k.d.disp_max + 5 + 6));
-    static std::atomic<size_t> granted[64], granted_c[64];
     dim3 grid((k.d.Wc - 1 + SUP_POINTS - 1) / SUP_POINTS, k.d.Hc - 1, n);
+    const bool alone = !s.counters && (size_t)grid.x * grid.y * grid.z <= 512;  // fewer than two workgroups per CU
+    const int threads = 64 * (alone ? SUP_SPLIT_ALONE : SUP_SPLIT);
+    // two rows per image; each staged range starts up to 3 columns early and ends on a whole quad
+    const size_t shmem = 2 * threads * sizeof(uint2) + sizeof(uint4) * 2 * ((size_t)(span + k.d.disp_max + 5 + 6) + (size_t)(span + 2 * k.d.disp_max + 5 + 6));
+    static std::atomic<size_t> granted[64], granted_c[64], granted_a[64];
     if (s.counters) {
-        ensure_dynamic_lds(k_support<true>, shmem, granted_c, "support_match");
-        SV_LAUNCH(K_SUPPORT, k_support<true>, grid, dim3(SUP_THREADS), shmem, st, k, s.grad, s.dcan, s.counters);
+        ensure_dynamic_lds(k_support<true, SUP_SPLIT>, shmem, granted_c, "support_match");
+        SV_LAUNCH(K_SUPPORT, (k_support<true, SUP_SPLIT>), grid, dim3(threads), shmem, st, k, s.grad, s.dcan, s.counters);
         return;
     }
-    ensure_dynamic_lds(k_support<false>, shmem, granted, "support_match");  // large disparity ranges: more than the default dynamic LDS limit
-    SV_LAUNCH(K_SUPPORT, k_support<false>, grid, dim3(SUP_THREADS), shmem, st, k, s.grad, s.dcan, s.counters);
+    if (alone) {
+        ensure_dynamic_lds(k_support<false, SUP_SPLIT_ALONE>, shmem, granted_a, "support_match");
+        SV_LAUNCH(K_SUPPORT, (k_support<false, SUP_SPLIT_ALONE>), grid, dim3(threads), shmem, st, k, s.grad, s.dcan, s.counters);
+        return;
+    }
+    ensure_dynamic_lds(k_support<false, SUP_SPLIT>, shmem, granted, "support_match");  // large disparity ranges: more than the default dynamic LDS limit
+    SV_LAUNCH(K_SUPPORT, (k_support<false, SUP_SPLIT>), grid, dim3(threads), shmem, st, k, s.grad, s.dcan, s.counters);
 }
 
 // ------------------------------------------------------------------------------------------------------------
