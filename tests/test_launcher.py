@@ -63,6 +63,21 @@ def test_host_share_restriction_before_any_gpu_call():
     assert len(kept) == max(1, before // 4) and kept == now and lws == "4" and torch_loaded is False
 
 
+def test_host_share_slices_of_different_ranks_are_disjoint():
+    """launcher.restrict_to_host_share(share, local_rank): rank r takes slice r + 1 (mod share) of the CPU list, so the ranks of a node get
+    distinct CPUs and a single sampled rank 0 does not sit on the list's first CPUs (CPU 0: interrupts, housekeeping)."""
+    code = ("import os, sys, json, importlib; sys.path.insert(0, %r); l = importlib.import_module(%r + '.launcher'); "
+            "allowed = sorted(os.sched_getaffinity(0)); out = []\n"
+            "for r in range(2):\n"
+            "    os.sched_setaffinity(0, allowed); out.append(l.restrict_to_host_share(2, r))\n"
+            "print(json.dumps([allowed, out]))" % (util.ROOT, util.PKG))
+    allowed, kept = json.loads(subprocess.check_output([sys.executable, "-c", code], text=True))
+    if len(allowed) < 4:
+        pytest.skip("fewer than four CPUs")
+    assert not set(kept[0]) & set(kept[1]) and len(kept[0]) == len(kept[1]) >= 1
+    assert set(kept[0]) | set(kept[1]) <= set(allowed)
+
+
 def test_pool_size_of_a_pinned_rank_without_a_cpu_quota():
     """A rank whose mask is already its share of the machine (restrict_to_host_share, torchrun ranks pinned per rank) keeps that share
     on a host without a CPU quota: the mask is not divided by LOCAL_WORLD_SIZE a second time (engine.cpp: host_cpu_share)."""
