@@ -142,8 +142,23 @@ __attribute__((target("avx2"))) static void drop_redundant_v_avx2(int16_t *T, in
     const __m256i vthr = _mm256_set1_epi16((short)thr), vneg1 = _mm256_set1_epi16(-1);
     const uint32_t lo_bits = (1u << (2 * max_dist)) - 1u;                              // movemask: 2 bits per int16 lane
     const uint32_t hi_bits = ((1u << (2 * max_dist)) - 1u) << (2 * (max_dist + 1));
+    // A dropped point is NOT written while its column is being scanned: a 2-byte store followed by 32-byte loads that cover it (the
+    // windows of the next points) cannot be forwarded from the store buffer and stalls every one of them - and this filter drops five
+    // points of six (a 4K lattice: 370 - 510 us for this pass, more than the whole parallel classification of the first filter).  The rows
+    // dropped so far travel in a register instead (hist: bit j = row vc - 1 - j was dropped), the stores follow when the column is done.
+    uint32_t lane_clear[128];  // movemask bits of the window lanes 0 .. max_dist - 1 that hist's low bits take out (lane i = row vc - max_dist + i)
+    for (int h = 0; h < (1 << max_dist); h++) {
+        uint32_t m = 0;
+        for (int jj = 0; jj < max_dist; jj++)
+            if ((h >> jj) & 1) m |= 3u << (2 * (max_dist - 1 - jj));
+        lane_clear[h] = m;
+    }
+    static thread_local std::vector<int16_t> drops;
+    if ((int)drops.size() < Hc) drops.resize(Hc);
     for (int uc = uc0; uc < uc1; uc++) {
         int16_t *col = T + (size_t)uc * Hc;
+        uint64_t hist = 0;
+        int hist_row = 0, ndrop = 0;  // bit j of hist: row hist_row - 1 - j
         for (int v0 = 0; v0 < Hc; v0 += 16) {
             uint32_t vm;
             if (uc == uc1 - 1 && Hc - v0 < 16) {  // the range's last column, its last rows: not a 16-lane load that runs into the next column (another thread's, perhaps)
@@ -156,23 +171,31 @@ __attribute__((target("avx2"))) static void drop_redundant_v_avx2(int16_t *T, in
             for (; vm; vm &= vm - 1) {
                 const int vc = v0 + (__builtin_ctz(vm) >> 1);
                 const int d = col[vc];
+                const int sh = vc - hist_row;
+                hist = sh >= 64 ? 0 : hist << sh;
+                hist_row = vc;
+                bool drop;
                 // near a column end; in the last column of the range also wherever the 16-lane window would reach into the next column, which
                 // may be another thread's (its lanes would be ignored, but the read itself would race with that thread's writes)
                 if (vc < max_dist || vc + max_dist >= Hc || (uc == uc1 - 1 && vc - max_dist + 16 > Hc)) {
                     const int n_lo = std::min(max_dist, vc), n_hi = std::min(max_dist, Hc - 1 - vc);
                     int found_lo = 0, found_hi = 0;
-                    for (int j = 1; j <= n_lo; j++) found_lo |= (col[vc - j] >= 0) & (abs(d - col[vc - j]) <= thr);
-                    for (int j = 1; j <= n_hi; j++) found_hi |= (col[vc + j] >= 0) & (abs(d - col[vc + j]) <= thr);
-                    if (found_lo & found_hi) col[vc] = -1;
-                    continue;
+                    for (int jj = 1; jj <= n_lo; jj++) found_lo |= (col[vc - jj] >= 0) & (abs(d - col[vc - jj]) <= thr) & (int)(~(hist >> (jj - 1)) & 1u);
+                    for (int jj = 1; jj <= n_hi; jj++) found_hi |= (col[vc + jj] >= 0) & (abs(d - col[vc + jj]) <= thr);
+                    drop = (found_lo & found_hi) != 0;
+                } else {
+                    const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(col + vc - max_dist));
+                    const __m256i diff = _mm256_abs_epi16(_mm256_sub_epi16(x, _mm256_set1_epi16((short)d)));
+                    const __m256i ok = _mm256_andnot_si256(_mm256_cmpgt_epi16(diff, vthr), _mm256_cmpgt_epi16(x, vneg1));
+                    const uint32_t m = (uint32_t)_mm256_movemask_epi8(ok) & ~lane_clear[hist & ((1u << max_dist) - 1u)];
+                    drop = (m & lo_bits) && (m & hi_bits);
                 }
-                const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(col + vc - max_dist));
-                const __m256i diff = _mm256_abs_epi16(_mm256_sub_epi16(x, _mm256_set1_epi16((short)d)));
-                const __m256i ok = _mm256_andnot_si256(_mm256_cmpgt_epi16(diff, vthr), _mm256_cmpgt_epi16(x, vneg1));
-                const uint32_t m = (uint32_t)_mm256_movemask_epi8(ok);
-                if ((m & lo_bits) && (m & hi_bits)) col[vc] = -1;
+                hist = (hist << 1) | (drop ? 1u : 0u);
+                hist_row = vc + 1;
+                if (drop) drops[ndrop++] = (int16_t)vc;
             }
         }
+        for (int i = 0; i < ndrop; i++) col[drops[i]] = -1;
     }
 }
 

@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--disp", type=int, default=128)
 ap.add_argument("--calls", type=int, default=300)
 ap.add_argument("--workers", type=int, default=0)
+ap.add_argument("--size", choices=["kitti", "4k"], default="kitti", help="kitti_mini pair 0 (1242x375) or a synthetic 3840x2160 pair")
 ap.add_argument("--period-ms", type=float, default=0.0, help="a frame every so many milliseconds (a camera) instead of back to back")
 ap.add_argument("--host", choices=["pinned", "pageable"], default=None, help="sv_elas_process with host pointers (the reference's seam) instead of device tensors")
 a = ap.parse_args()
@@ -24,6 +25,9 @@ import util
 pkg = [d for d in os.listdir(ROOT) if d.endswith("_amd")][0]
 eng = importlib.import_module(pkg + ".engine")
 l, r = util.load_png("kitti0_left.png"), util.load_png("kitti0_right.png")
+if a.size == "4k":
+    b4 = util.pkg("synth").make_batch(5000, 1, 2160, 3840, a.disp)
+    l, r = b4[0, 0], b4[0, 1]
 H, W = l.shape
 if a.host:
     import ctypes
