@@ -63,6 +63,9 @@ def block(d, src):
     add("... pageable caller memory: D1 / 8-bit", "%s / %s" % (f(pag.get("pairs_per_s_d1")), f(pag.get("pairs_per_s_dmap_u8"))), "host_to_host.pageable")
     add("who moves the chunks over PCIe", str(h2h.get("copies")), "host_to_host.copies")
     add("ms/frame, one pair per call, device memory: median / p99", "**%s** / %s" % (f(lat.get("median"), 3), f(lat.get("p99"), 3)), "latency_ms_batch1")
+    paced = lat.get("at_30_frames_per_s") or {}
+    if paced:
+        add("... one frame every 33 ms (a camera's pace; the helper threads sleep in between): median / p99", "%s / %s" % (f(paced.get("median"), 3), f(paced.get("p99"), 3)), "latency_ms_batch1.at_30_frames_per_s")
     add("ms/frame through `sv_elas_process` (host pointers): page-locked / pageable, median", "%s / %s" % (f((lath.get("pinned") or {}).get("median"), 3), f((lath.get("pageable") or {}).get("median"), 3)),
         "host_to_host.latency_ms_batch1_host")
     add("the seven committed real frames cycled through the batch", f((d.get("value_real_pair") or {}).get("value")), "value_real_pair.value")
