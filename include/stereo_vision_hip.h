@@ -190,7 +190,11 @@ int sv_elas_process(sv_handle *h, const uint8_t *I1, const uint8_t *I2, float *D
  * map takes the per-pixel path), "rt_cap" (triangles a raster tile list may hold), "host_force_staging" (host-memory jobs take the
  * pageable route whatever the caller's memory is), "ns_bound" (vertices the next resident launches request LDS for: smaller sets than
  * the chunk has are handed to the host stage), "pool_sleep" (latency handles: pool threads sleep instead of polling), "lat_trace"
- * (wall-clock split of the latency path, printed by sv_destroy).  Returns SV_OK or SV_ERR_ARG for an unknown key. */
+ * (wall-clock split of the latency path, printed by sv_destroy), "dma_selftest_fail" (the DMA lanes' self-test reports a failure: the
+ * runtime's copies take over); single pairs: "latency_pin" (0: the polling pool threads stay where the pool runs) [SV_LATENCY_PIN],
+ * "lat_runtime_copies" (lattice / blob copies through hipMemcpyAsync instead of the copy kernel) [SV_LAT_RUNTIME_COPIES],
+ * "lat_filter_alone" (the lattice filters on the calling thread alone) [SV_LAT_FILTER_ALONE]; SV_LAT_WAKE_LEAD_US: how long before a
+ * frame that is due the sleeping helpers poll again (default: period / 16 within 0.3 - 2 ms).  Returns SV_OK or SV_ERR_ARG for an unknown key. */
 int sv_debug_set(sv_handle *h, const char *key, int value);
 
 /* Per-stage intermediates of the last pair processed (cfg.keep_debug != 0).  Names and layouts follow

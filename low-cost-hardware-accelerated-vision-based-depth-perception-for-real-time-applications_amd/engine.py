@@ -196,7 +196,7 @@ class StereoEngine:
             pass
 
     def debug_set(self, key, value):
-        """Test hooks on a live handle (sv_debug_set): "ccl_cap", "rt_cap", "host_force_staging", "ns_bound", "pool_sleep", "lat_trace", "dma_selftest_fail"."""
+        """Test hooks on a live handle (sv_debug_set): "ccl_cap", "rt_cap", "host_force_staging", "ns_bound", "pool_sleep", "lat_trace", "dma_selftest_fail", "latency_pin", "lat_runtime_copies", "lat_filter_alone" (include/stereo_vision_hip.h)."""
         L = lib()
         L.sv_debug_set.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int]
         self._check(L.sv_debug_set(self._h, key.encode(), int(value)))
