@@ -1,6 +1,8 @@
 """GPU (MI355X): the HIP path, called through the C ABI, against the CPU oracle on the same inputs and against the
 golden vectors the compiled reference produced.  Bit-exact at every stage (integer WTA index AND the float maps
 after gap interpolation / adaptive mean / median — tolerance 0)."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -803,6 +805,36 @@ def test_the_ways_host_threads_wait_give_the_same_maps(eng, mode):
             assert torch.equal(d1, r1) and torch.equal(d2, r2)
         h1, h2, _ = e.process_host(np.ascontiguousarray(batch[:, 0]), np.ascontiguousarray(batch[:, 1]), want_d2=True)
         assert np.array_equal(h1, r1.cpu().numpy()) and np.array_equal(h2, r2.cpu().numpy())
+    finally:
+        e.close()
+        ref.close()
+
+
+@pytest.mark.parametrize("hook", ["lat_runtime_copies", "lat_filter_alone", "latency_pin_off"])
+def test_single_pair_paths_behind_the_test_hooks_give_the_same_maps(eng, hook):
+    """The single-pair path has alternatives the round measured against each other and kept reachable: the lattice / blob copies through
+    hipMemcpyAsync instead of the copy kernel, the lattice filters on the calling thread alone instead of as a team, the polling threads
+    left where the pool runs.  Same maps either way, device and page-locked host memory."""
+    import torch
+    l, r = util.load_png("kitti0_left.png"), util.load_png("kitti0_right.png")
+    H, W = l.shape
+    p = eng.SvParams.driver(127)
+    ref = eng.StereoEngine(W, H, p, chunk=4, n_slots=2)
+    e = eng.StereoEngine(W, H, p, chunk=1, n_slots=2, n_streams=1, n_workers=7)
+    try:
+        L, R = torch.from_numpy(np.ascontiguousarray(l[None])).cuda(), torch.from_numpy(np.ascontiguousarray(r[None])).cuda()
+        r1, r2 = ref.process_device(L, R)
+        e.process_device(L, R)
+        e.debug_set("latency_pin" if hook == "latency_pin_off" else hook, 0 if hook == "latency_pin_off" else 1)
+        for _ in range(3):
+            d1, d2 = e.process_device(L, R)
+            assert torch.equal(d1, r1) and torch.equal(d2, r2)
+        hl, hr = eng.pinned_array((H, W), np.uint8), eng.pinned_array((H, W), np.uint8)
+        h1, h2 = eng.pinned_array((H, W), np.float32), eng.pinned_array((H, W), np.float32)
+        hl[:], hr[:] = l, r
+        dims = (ctypes.c_int32 * 3)(W, H, W)
+        assert eng.lib().sv_elas_process(e._h, hl.ctypes.data, hr.ctypes.data, h1.ctypes.data, h2.ctypes.data, dims) == 0
+        assert np.array_equal(h1, r1[0].cpu().numpy()) and np.array_equal(h2, r2[0].cpu().numpy())
     finally:
         e.close()
         ref.close()
