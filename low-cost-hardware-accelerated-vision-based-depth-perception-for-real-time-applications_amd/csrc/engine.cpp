@@ -679,11 +679,12 @@ struct CopyJob {
 
 constexpr size_t COPY_PIECE = (size_t)512 << 10;
 
-struct CopyList {  // collects (dst, src, bytes) ranges, cut into pieces of at most COPY_PIECE
+struct CopyList {  // collects (dst, src, bytes) ranges, cut into pieces of at most `piece` bytes
     CopyJob *job = new CopyJob();
+    size_t piece = COPY_PIECE;
     void add(void *dst, const void *src, size_t bytes) {
-        for (size_t o = 0; o < bytes; o += COPY_PIECE)
-            job->pieces.push_back({static_cast<uint8_t *>(dst) + o, static_cast<const uint8_t *>(src) + o, std::min(COPY_PIECE, bytes - o)});
+        for (size_t o = 0; o < bytes; o += piece)
+            job->pieces.push_back({static_cast<uint8_t *>(dst) + o, static_cast<const uint8_t *>(src) + o, std::min(piece, bytes - o)});
     }
     // runs the copies; returns when every byte has landed
     void run(sv_handle *h, int max_helpers) {
@@ -795,6 +796,26 @@ void ensure_host_staging(sv_handle *h, bool need_pin_in, bool need_pin_out, bool
 // rows packed to W bytes, all left images of the chunk, then all right images.
 // lanes (pipeline only): the copies go to the upload engine of h->dma instead of `st` and s->up_ticket names them - whoever launches
 // phase 1 waits for the ticket on the host first (the issuer keeps the next chunks' uploads queued on the engine meanwhile).
+// Pageable images of a chunk packed into the slot's page-locked mirror (both sides), by this thread and `copy_helpers` pool threads
+void pack_images(sv_handle *h, Slot *s, int copy_helpers, size_t piece) {
+    const Dims &d = h->kp.d;
+    const Job &job = *s->job;
+    const size_t cap = (size_t)s->dev.cap, img = (size_t)d.N, src_pair = (size_t)d.H * job.stride;
+    CopyList cl;
+    cl.piece = piece;
+    for (int side = 0; side < 2; side++) {
+        const uint8_t *src = (side ? job.right : job.left) + (size_t)s->i0 * src_pair;
+        uint8_t *stage = s->h_in + side * cap * img;
+        if (job.stride == d.W) {
+            cl.add(stage, src, (size_t)s->n * img);
+        } else {
+            for (int j = 0; j < s->n; j++)
+                for (int y = 0; y < d.H; y++) cl.job->pieces.push_back({stage + (size_t)j * img + (size_t)y * d.W, src + (size_t)j * src_pair + (size_t)y * job.stride, (size_t)d.W});
+        }
+    }
+    cl.run(h, copy_helpers);
+}
+
 void upload_chunk(sv_handle *h, Slot *s, hipStream_t st, int copy_helpers, bool lanes = false) {
     const Dims &d = h->kp.d;
     const Job &job = *s->job;
@@ -903,12 +924,13 @@ void download_maps(sv_handle *h, Slot *s, int side, hipStream_t st, hipStream_t 
 }
 
 // Pageable callers: the maps of a chunk from the page-locked mirror into the caller's arrays (after ev_out)
-void deliver_maps(sv_handle *h, Slot *s, int copy_helpers) {
+void deliver_maps(sv_handle *h, Slot *s, int copy_helpers, int sides = 3) {  // sides: bit 0 the left maps, bit 1 the right maps
     const Dims &d = h->kp.d;
     const Job &job = *s->job;
     if (job.pin_out) return;
     const size_t cap = (size_t)s->dev.cap, Nm = (size_t)d.Nm;
     CopyList cl;
+    if (s->inline_mode) cl.piece = COPY_PIECE / 4;  // a single pair's maps: enough pieces for everybody who polls
     if (job.dmap) {
         for (int j = 0; j < s->n; j++)
             if (s->h_blob[(size_t)j * META_WORDS] >= 3) cl.add(job.dmap + (size_t)(s->i0 + j) * Nm, s->h_out8 + (size_t)j * Nm, Nm);
@@ -917,7 +939,7 @@ void deliver_maps(sv_handle *h, Slot *s, int copy_helpers) {
     }
     for (int side = 0; side < 2; side++) {
         float *user = side ? job.d2 : job.d1;
-        if (!user) continue;
+        if (!user || !((sides >> side) & 1)) continue;
         for (int j = 0; j < s->n; j++)
             if (s->h_blob[(size_t)j * META_WORDS] >= 3) cl.add(user + (size_t)(s->i0 + j) * Nm, s->h_out + side * cap * Nm + (size_t)j * Nm, Nm * sizeof(float));
     }
@@ -2232,6 +2254,7 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
     job.d2 = d2;
     job.status = status;
     job.nchunks = 1;
+    const uint8_t *mirror_in = nullptr;  // pageable images: the device's view of the slot's page-locked mirror
     const auto t_prep = std::chrono::steady_clock::now();
     if (host) {
         const int rc = prepare_host_job(h, &job);
@@ -2252,6 +2275,15 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
                 if (hipHostGetDevicePointer(&dp, d2, 0) == hipSuccess) job.zc_d2 = static_cast<float *>(dp);
                 else job.zc_d1 = nullptr;
             }
+        }
+        // Pageable buffers (what the reference's cv::Mat hands over): the same without copies by the runtime - the images are packed into
+        // the slot's page-locked mirror and read from there by k_sobel, the kernels write the maps into the page-locked mirror of the
+        // outputs, and the pool's pollers help with the two memcpys.  (Staged DMA copies in front of and behind the kernels: +0.25 ms.)
+        Slot *s0 = h->slots[0];
+        if (h->cfg.host_copies != 1 && !job.pin_in && s0->h_in && hipHostGetDevicePointer(&dp, s0->h_in, 0) == hipSuccess) mirror_in = static_cast<const uint8_t *>(dp);
+        if (h->cfg.host_copies != 1 && !job.pin_out && !job.dmap && s0->h_out && hipHostGetDevicePointer(&dp, s0->h_out, 0) == hipSuccess) {
+            job.zc_d1 = static_cast<float *>(dp);
+            if (d2) job.zc_d2 = job.zc_d1 + (size_t)s0->dev.cap * h->kp.d.Nm;
         }
         (void)hipGetLastError();
     }
@@ -2283,10 +2315,17 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
         using clk = std::chrono::steady_clock;
         clk::time_point tp[7];
         tp[0] = clk::now();
-        if (host && !job.zc_left)
+        if (host && mirror_in && !job.zc_left) {
+            pack_images(h, s, std::max(2, h->pollers.load(std::memory_order_acquire)), COPY_PIECE / 8);
+            s->in_left = mirror_in;
+            s->in_right = mirror_in + (size_t)s->dev.cap * h->kp.d.N;
+            s->in_pair = (size_t)h->kp.d.N;
+            s->in_stride = h->kp.d.W;
+        } else if (host && !job.zc_left) {
             upload_chunk(h, s, h->sP1, 2);  // on the phase-1 stream itself: in order, no event
-        else
+        } else {
             set_chunk_inputs(h, s);
+        }
         issue_phase1(h, s);
         tp[1] = clk::now();
         HIP_TRY(hipEventSynchronize(s->ev_p1));
@@ -2301,17 +2340,24 @@ int run_inline(sv_handle *h, const uint8_t *left, const uint8_t *right, int stri
         g_launch_hook.ctx = &h->tc_finish;
         issue_phase2(h, s, h->sP2[0]);
         tp[5] = clk::now();
+        int delivered = 0;  // sides the caller's pageable maps have already
         if (host && !job.zc_d1) {
             download_chunk(h, s);
             deliver_maps(h, s, 3);
         } else if (host && h->nproc == 1 && job.d2) {  // zero-copy left map; the right map's DMA runs beside the post-processing kernels
             HIP_TRY(hipStreamWaitEvent(h->sOut, s->ev_lr, 0));
             download_maps(h, s, 1, h->sOut);
+            if (!job.pin_out) {  // pageable: the right map goes from the mirror to the caller while the left one is still being post-processed
+                HIP_TRY(hipStreamSynchronize(h->sOut));
+                deliver_maps(h, s, std::max(3, h->pollers.load(std::memory_order_acquire)), 2);
+                delivered = 2;
+            }
             HIP_TRY(hipStreamSynchronize(h->sP2[0]));
             HIP_TRY(hipStreamSynchronize(h->sOut));
         } else {
             HIP_TRY(hipStreamSynchronize(h->sP2[0]));  // (maps written straight into page-locked host memory are visible now as well)
         }
+        if (host && job.zc_d1 && !job.pin_out) deliver_maps(h, s, std::max(3, h->pollers.load(std::memory_order_acquire)), 3 & ~delivered);  // mirror -> the caller's pageable maps
         tp[6] = clk::now();
         if (h->lat_trace) {
             for (int i = 0; i < 6; i++) h->lat_ns[i] += (double)std::chrono::duration_cast<std::chrono::nanoseconds>(tp[i + 1] - tp[i]).count();
